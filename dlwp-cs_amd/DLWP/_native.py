@@ -1,0 +1,163 @@
+"""
+ctypes binding of libdlwpcs.so (the C ABI declared in include/dlwpcs.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a tensor is not on a HIP device, the ops raise.
+torch is used for device memory, streams and autograd glue only; no torch type crosses the ABI (raw device pointers,
+sizes and a hipStream_t handle do).
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+import torch   # must be imported before the library so that one HIP runtime (torch's) serves both
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libdlwpcs.so')
+
+F32 = 0
+ACT_NONE = 0
+ACT_LEAKY_CLIP = 1
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+class ConvDesc(ctypes.Structure):
+    """struct dlwpcs_conv_desc (include/dlwpcs.h)"""
+    _fields_ = [('B', ctypes.c_int32), ('N', ctypes.c_int32), ('C0', ctypes.c_int32), ('C1', ctypes.c_int32),
+                ('Cout', ctypes.c_int32), ('ksize', ctypes.c_int32), ('halo', ctypes.c_int32),
+                ('up0', ctypes.c_int32), ('flip_north_pole', ctypes.c_int32), ('act', ctypes.c_int32),
+                ('alpha', ctypes.c_float), ('vmax', ctypes.c_float), ('dtype', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
+class GConvDesc(ctypes.Structure):
+    """struct dlwpcs_gconv_desc (include/dlwpcs.h)"""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ('B', 'H', 'W', 'Cin', 'Cout', 'kh', 'kw', 'sh', 'sw', 'dh', 'dw', 'pad_t', 'pad_l', 'Ho', 'Wo',
+                 'flip_north_pole', 'dtype')]
+
+
+# name -> (restype, argtypes); must list EVERY symbol of include/dlwpcs.h (tests/test_abi.py checks this)
+PROTOTYPES = {
+    'dlwpcs_version': (c_int, []),
+    'dlwpcs_last_error': (ctypes.c_char_p, []),
+    'dlwpcs_halo_table': (c_int, [c_int, c_int, c_void_p]),
+    'dlwpcs_halo_inverse_table': (c_int, [c_int, c_int, c_void_p]),
+    'dlwpcs_pad_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dlwpcs_pad_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dlwpcs_conv_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    'dlwpcs_conv_fwd': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_void_p, c_void_p, c_void_p, c_size_t,
+                                                                                 c_void_p]),
+    'dlwpcs_conv_bwd_data': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 5 + [c_void_p, c_void_p, c_void_p,
+                                                                                      c_void_p, c_size_t, c_void_p]),
+    'dlwpcs_conv_bwd_weights': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_void_p] * 6 +
+                                [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'dlwpcs_gconv_fwd': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),
+    'dlwpcs_gconv_bwd_data': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 6),
+    'dlwpcs_gconv_bwd_weights': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),
+    'dlwpcs_act_fwd': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_int, c_void_p]),
+    'dlwpcs_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_int, c_void_p]),
+    'dlwpcs_avgpool2_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_avgpool2_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_upsample2_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_upsample2_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_concat2': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_split2': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_cf_to_cl': (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_int, c_void_p]),
+    'dlwpcs_cl_to_cf': (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_int, c_void_p]),
+    'dlwpcs_add': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'dlwpcs_mse_scratch_bytes': (c_size_t, []),
+    'dlwpcs_mse_fwd_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_void_p,
+                                   c_void_p]),
+    'dlwpcs_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float,
+                                 c_float, c_float, c_float, c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdlwpcs.so (once).  Raises loudly when it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise NativeError(
+                        'libdlwpcs.so not found at %s: build it with `python dlwp-cs_amd/build.py` '
+                        '(or __graft_entry__.build()).  The DLWP-CS MI355X engine has no CPU fallback.' % LIB_PATH)
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in PROTOTYPES.items():
+                    fn = getattr(handle, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().dlwpcs_last_error()
+        msg = msg.decode() if msg else ''
+        if rc == -1:
+            raise ValueError('%s: %s' % (what, msg))
+        if rc == -2:
+            raise NotImplementedError('%s: %s' % (what, msg))
+        raise NativeError('%s failed (code %d): %s' % (what, rc, msg))
+
+
+def require_device(t, what):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s: expected a torch.Tensor, got %r' % (what, type(t)))
+    if not t.is_cuda:
+        raise NativeError('%s: tensor is on %s; the DLWP-CS MI355X engine only runs on a HIP device '
+                          '(no CPU fallback).' % (what, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError('%s: dtype %s not supported (float32 this round)' % (what, t.dtype))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# Halo tables: host computation through the C ABI, cached per (N, p, device)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+_table_cache = {}
+
+
+def halo_table_host(N, p):
+    M = N + 2 * p
+    out = np.empty((6, M, M), dtype=np.int32)
+    check(lib().dlwpcs_halo_table(int(N), int(p), out.ctypes.data), 'dlwpcs_halo_table')
+    return out
+
+
+def halo_inverse_table_host(N, p):
+    out = np.empty((6 * N * N, 4), dtype=np.int32)
+    check(lib().dlwpcs_halo_inverse_table(int(N), int(p), out.ctypes.data), 'dlwpcs_halo_inverse_table')
+    return out
+
+
+def halo_tables(N, p, device):
+    """(table, inverse_table) int32 device tensors, immutable, cached."""
+    key = (int(N), int(p), str(device))
+    hit = _table_cache.get(key)
+    if hit is None:
+        t = torch.from_numpy(halo_table_host(N, p)).to(device)
+        inv = torch.from_numpy(halo_inverse_table_host(N, p)).to(device)
+        hit = (t, inv)
+        _table_cache[key] = hit
+    return hit

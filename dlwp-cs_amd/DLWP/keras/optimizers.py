@@ -1,0 +1,82 @@
+"""Optimizers of the shim.  Adam follows TF 2.1 keras defaults (reference Azure/train_cs.py:429: `Adam()`)."""
+import torch
+
+from .. import ops
+
+
+class Optimizer(object):
+    pass
+
+
+class Adam(Optimizer):
+    """
+    keras.optimizers.Adam(learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False).
+    State (m, v, step) lives in flat fp32 device buffers next to the model's flat parameter buffer; one HIP kernel
+    (`adam_kernel`) updates every parameter of the model per step.
+    """
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, lr=None, decay=0.,
+                 name='Adam', **kwargs):
+        if amsgrad:
+            raise NotImplementedError('Adam(amsgrad=True) is not built')
+        if lr is not None:
+            learning_rate = lr
+        self.learning_rate = float(learning_rate)
+        self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+        self.decay = float(decay)
+        if self.decay != 0.:
+            raise NotImplementedError('Adam(decay != 0) is not built')
+        self.name = name
+        self._m = self._v = self._step = None
+
+    @property
+    def lr(self):
+        return self.learning_rate
+
+    @lr.setter
+    def lr(self, value):
+        self.learning_rate = float(value)
+
+    @property
+    def iterations(self):
+        return 0 if self._step is None else int(self._step.item())
+
+    def _ensure_state(self, flat_params):
+        if self._m is None or self._m.numel() != flat_params.numel() or self._m.device != flat_params.device:
+            self._m = torch.zeros_like(flat_params)
+            self._v = torch.zeros_like(flat_params)
+            self._step = torch.zeros(1, dtype=torch.int32, device=flat_params.device)
+
+    def apply(self, flat_params, flat_grads, grad_scale=1.0):
+        self._ensure_state(flat_params)
+        ops.adam_step(flat_params, flat_grads, self._m, self._v, self._step, self.learning_rate, self.beta_1,
+                      self.beta_2, self.epsilon, grad_scale)
+
+    def get_config(self):
+        return {'name': self.name, 'learning_rate': self.learning_rate, 'beta_1': self.beta_1, 'beta_2': self.beta_2,
+                'epsilon': self.epsilon, 'amsgrad': False, 'decay': self.decay}
+
+    def state_dict(self):
+        if self._m is None:
+            return None
+        return {'m': self._m.cpu().numpy(), 'v': self._v.cpu().numpy(), 'step': int(self._step.item())}
+
+    def load_state_dict(self, state, flat_params):
+        if state is None:
+            return
+        self._ensure_state(flat_params)
+        self._m.copy_(torch.from_numpy(state['m']))
+        self._v.copy_(torch.from_numpy(state['v']))
+        self._step.fill_(int(state['step']))
+
+
+def get(identifier):
+    if isinstance(identifier, Optimizer):
+        return identifier
+    if isinstance(identifier, str) and identifier.lower() == 'adam':
+        return Adam()
+    if isinstance(identifier, dict) and identifier.get('name', '').lower() == 'adam':
+        cfg = dict(identifier)
+        cfg.pop('amsgrad', None)
+        return Adam(**cfg)
+    raise ValueError('Could not interpret optimizer identifier: %r (the DLWP-CS engine provides Adam)' % (identifier,))

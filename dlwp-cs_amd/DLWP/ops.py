@@ -1,0 +1,442 @@
+"""
+torch.autograd glue over the C ABI (include/dlwpcs.h).  Every function here launches hand-written HIP kernels from
+libdlwpcs.so on torch's current stream; torch only provides storage and the autograd tape.  All tensors on this level
+are channels_last `(B, 6, H, W, C)` float32 on a HIP device.
+"""
+import ctypes
+
+import torch
+
+from . import _native as nat
+from ._native import ConvDesc, GConvDesc, check, lib, ptr, require_device, stream_ptr
+
+# workspace: one growing byte buffer per device (caller-owned from the library's point of view)
+_workspaces = {}
+
+
+def _workspace(nbytes, device):
+    key = str(device)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise nat.NativeError('workspace would have to grow during graph capture; run one eager step first')
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# CubeSpherePadding2D  (reference DLWP/custom.py:1082-1308)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+class _CSPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        require_device(x, 'cs_pad')
+        x = _c(x)
+        B, F6, N, N2, C = x.shape
+        if F6 != 6 or N != N2:
+            raise ValueError('cs_pad: expected (B, 6, N, N, C), got %s' % (tuple(x.shape),))
+        table, inv = nat.halo_tables(N, p, x.device)
+        y = torch.empty((B, 6, N + 2 * p, N + 2 * p, C), dtype=x.dtype, device=x.device)
+        check(lib().dlwpcs_pad_fwd(ptr(x), ptr(y), B, N, C, p, nat.F32, ptr(table), stream_ptr()), 'dlwpcs_pad_fwd')
+        ctx.p, ctx.shape = p, (B, N, C)
+        ctx.inv = inv
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, C = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
+        check(lib().dlwpcs_pad_bwd(ptr(dy), ptr(dx), B, N, C, ctx.p, nat.F32, ptr(ctx.inv), stream_ptr()),
+              'dlwpcs_pad_bwd')
+        return dx, None
+
+
+def cs_pad(x, p):
+    """Halo-pad a cubed-sphere tensor (B,6,N,N,C) -> (B,6,N+2p,N+2p,C)."""
+    return _CSPad.apply(x, int(p))
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# Fused cubed-sphere convolution (reference DLWP/custom.py:921-1002 + :1082-1308 + Keras ReLU/UpSampling3D/concatenate)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax):
+    return ConvDesc(B=B, N=N, C0=C0, C1=C1, Cout=Cout, ksize=ksize, halo=int(halo), up0=int(up0),
+                    flip_north_pole=int(flip), act=int(act), alpha=float(alpha), vmax=float(vmax), dtype=nat.F32,
+                    reserved=0)
+
+
+class _CSConv(torch.autograd.Function):
+    """
+    y = act(conv(halo_pad(concat(up?(src0), src1))) + bias); see dlwpcs_conv_fwd in include/dlwpcs.h.
+    Inputs that may be None: src1, w_np, b_eq, b_pol, b_np.
+    """
+
+    @staticmethod
+    def forward(ctx, src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, ksize, halo, up0, flip, act, alpha, vmax):
+        require_device(src0, 'cs_conv')
+        src0 = _c(src0)
+        B = src0.shape[0]
+        if src0.dim() != 5 or src0.shape[1] != 6 or src0.shape[2] != src0.shape[3]:
+            raise ValueError('cs_conv: expected (B, 6, N, N, C), got %s' % (tuple(src0.shape),))
+        N = src0.shape[2] * (2 if up0 else 1)
+        C0 = src0.shape[4]
+        C1 = 0
+        if src1 is not None:
+            require_device(src1, 'cs_conv')
+            src1 = _c(src1)
+            if tuple(src1.shape[:4]) != (B, 6, N, N):
+                raise ValueError('cs_conv: src1 shape %s does not match (B,6,%d,%d,*)' % (tuple(src1.shape), N, N))
+            C1 = src1.shape[4]
+        kh, kw, cin, Cout = w_eq.shape
+        if kh != ksize or kw != ksize or cin != C0 + C1:
+            raise ValueError('cs_conv: kernel shape %s does not match ksize=%d, C_in=%d' % (tuple(w_eq.shape), ksize,
+                                                                                          C0 + C1))
+        w_eq, w_pol = _c(w_eq), _c(w_pol)
+        w_np = _c(w_np) if w_np is not None else None
+        d = _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax)
+        No = N if halo else N - ksize + 1
+        y = torch.empty((B, 6, No, No, Cout), dtype=src0.dtype, device=src0.device)
+        table = inv = None
+        if halo:
+            table, inv = nat.halo_tables(N, (ksize - 1) // 2, src0.device)
+        nbytes = lib().dlwpcs_conv_workspace_bytes(ctypes.byref(d))
+        ws = _workspace(nbytes, src0.device)
+        check(lib().dlwpcs_conv_fwd(ctypes.byref(d), ptr(src0), ptr(src1), ptr(w_eq), ptr(w_pol), ptr(w_np),
+                                    ptr(b_eq), ptr(b_pol), ptr(b_np), ptr(y), ptr(table), ptr(ws), ws.numel(),
+                                    stream_ptr()), 'dlwpcs_conv_fwd')
+        ctx.desc = d
+        ctx.tables = (table, inv)
+        ctx.has = (src1 is not None, w_np is not None, b_eq is not None, b_np is not None)
+        ctx.save_for_backward(src0, src1, w_eq, w_pol, w_np, y if act != nat.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        src0, src1, w_eq, w_pol, w_np, y = ctx.saved_tensors
+        d = ctx.desc
+        table, inv = ctx.tables
+        has_src1, has_np, has_bias, has_bnp = ctx.has
+        dy = _c(dy)
+        dev = dy.device
+        nbytes = lib().dlwpcs_conv_workspace_bytes(ctypes.byref(d))
+        ws = _workspace(nbytes, dev)
+        need = ctx.needs_input_grad
+        dsrc0 = torch.empty_like(src0) if need[0] else None
+        dsrc1 = torch.empty_like(src1) if (has_src1 and need[1]) else None
+        if dsrc0 is not None or dsrc1 is not None:
+            check(lib().dlwpcs_conv_bwd_data(ctypes.byref(d), ptr(dy), ptr(y), ptr(w_eq), ptr(w_pol), ptr(w_np),
+                                             ptr(dsrc0), ptr(dsrc1), ptr(inv), ptr(ws), ws.numel(), stream_ptr()),
+                  'dlwpcs_conv_bwd_data')
+        dw_eq = dw_pol = dw_np = db_eq = db_pol = db_np = None
+        if need[2] or need[3] or need[4] or need[5] or need[6] or need[7]:
+            dw_eq, dw_pol = torch.empty_like(w_eq), torch.empty_like(w_pol)
+            dw_np = torch.empty_like(w_np) if has_np else None
+            if has_bias:
+                db_eq = torch.empty(d.Cout, dtype=dy.dtype, device=dev)
+                db_pol = torch.empty(d.Cout, dtype=dy.dtype, device=dev)
+                db_np = torch.empty(d.Cout, dtype=dy.dtype, device=dev) if has_bnp else None
+            check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d), ptr(src0), ptr(src1), ptr(dy), ptr(y), ptr(dw_eq),
+                                                ptr(dw_pol), ptr(dw_np), ptr(db_eq), ptr(db_pol), ptr(db_np),
+                                                ptr(table), ptr(ws), ws.numel(), stream_ptr()),
+                  'dlwpcs_conv_bwd_weights')
+        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 7
+
+
+def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1=None, ksize=3, halo=True, up0=False,
+            flip_north_pole=True, act=nat.ACT_NONE, alpha=0.0, vmax=0.0):
+    if (w_np is None) != (b_np is None) and b_eq is not None:
+        raise ValueError('cs_conv: north-pole kernel and bias must be given together')
+    return _CSConv.apply(src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, int(ksize), bool(halo), bool(up0),
+                         bool(flip_north_pole), int(act), float(alpha), float(vmax))
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# Generic per-face convolution for the off-hot-path layer options (strides, dilation, 'same')
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def _same_pads(n, k, s, dil):
+    out = -(-n // s)
+    total = max((out - 1) * s + (k - 1) * dil + 1 - n, 0)
+    return total // 2, out
+
+
+class _GConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_eq, w_pol, w_np, b_eq, b_pol, b_np, strides, padding, dilation, flip):
+        require_device(x, 'cs_gconv')
+        x, w_eq, w_pol = _c(x), _c(w_eq), _c(w_pol)
+        w_np = _c(w_np) if w_np is not None else None
+        B, F6, H, W, Cin = x.shape
+        kh, kw, cin, Cout = w_eq.shape
+        if F6 != 6 or cin != Cin:
+            raise ValueError('cs_gconv: bad shapes x=%s kernel=%s' % (tuple(x.shape), tuple(w_eq.shape)))
+        sh, sw = strides
+        dh, dw = dilation
+        if padding == 'same':
+            pad_t, Ho = _same_pads(H, kh, sh, dh)
+            pad_l, Wo = _same_pads(W, kw, sw, dw)
+        elif padding == 'valid':
+            pad_t = pad_l = 0
+            Ho = (H - (kh - 1) * dh - 1) // sh + 1
+            Wo = (W - (kw - 1) * dw - 1) // sw + 1
+        else:
+            raise ValueError('padding must be "valid" or "same"')
+        if Ho < 1 or Wo < 1:
+            raise ValueError('cs_gconv: empty output')
+        d = GConvDesc(B=B, H=H, W=W, Cin=Cin, Cout=Cout, kh=kh, kw=kw, sh=sh, sw=sw, dh=dh, dw=dw, pad_t=pad_t,
+                      pad_l=pad_l, Ho=Ho, Wo=Wo, flip_north_pole=int(flip), dtype=nat.F32)
+        y = torch.empty((B, 6, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+        check(lib().dlwpcs_gconv_fwd(ctypes.byref(d), ptr(x), ptr(w_eq), ptr(w_pol), ptr(w_np), ptr(b_eq), ptr(b_pol),
+                                     ptr(b_np), ptr(y), stream_ptr()), 'dlwpcs_gconv_fwd')
+        ctx.desc = d
+        ctx.has = (w_np is not None, b_eq is not None, b_np is not None)
+        ctx.save_for_backward(x, w_eq, w_pol, w_np)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_eq, w_pol, w_np = ctx.saved_tensors
+        d = ctx.desc
+        has_np, has_bias, has_bnp = ctx.has
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib().dlwpcs_gconv_bwd_data(ctypes.byref(d), ptr(dy), ptr(w_eq), ptr(w_pol), ptr(w_np), ptr(dx),
+                                              stream_ptr()), 'dlwpcs_gconv_bwd_data')
+        dw_eq, dw_pol = torch.empty_like(w_eq), torch.empty_like(w_pol)
+        dw_np = torch.empty_like(w_np) if has_np else None
+        db_eq = db_pol = db_np = None
+        if has_bias:
+            db_eq = torch.empty(d.Cout, dtype=dy.dtype, device=dy.device)
+            db_pol = torch.empty_like(db_eq)
+            db_np = torch.empty_like(db_eq) if has_bnp else None
+        check(lib().dlwpcs_gconv_bwd_weights(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw_eq), ptr(dw_pol), ptr(dw_np),
+                                             ptr(db_eq), ptr(db_pol), ptr(db_np), stream_ptr()),
+              'dlwpcs_gconv_bwd_weights')
+        return dx, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, None, None, None, None
+
+
+def cs_gconv(x, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, strides=(1, 1), padding='valid',
+             dilation=(1, 1), flip_north_pole=True):
+    return _GConv.apply(x, w_eq, w_pol, w_np, b_eq, b_pol, b_np, tuple(strides), padding, tuple(dilation),
+                        bool(flip_north_pole))
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# Keras stock ops of the U-Net (Azure/train_cs.py:197-199)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, alpha, vmax):
+        require_device(x, 'leaky_clip_relu')
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(lib().dlwpcs_act_fwd(ptr(x), ptr(y), x.numel(), nat.ACT_LEAKY_CLIP, alpha, vmax, nat.F32, stream_ptr()),
+              'dlwpcs_act_fwd')
+        ctx.alpha, ctx.vmax = alpha, vmax
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib().dlwpcs_act_bwd(ptr(dy), ptr(y), ptr(dx), dy.numel(), nat.ACT_LEAKY_CLIP, ctx.alpha, ctx.vmax,
+                                   nat.F32, stream_ptr()), 'dlwpcs_act_bwd')
+        return dx, None, None
+
+
+def leaky_clip_relu(x, negative_slope=0.0, max_value=None):
+    vmax = float('inf') if max_value is None else float(max_value)
+    return _Act.apply(x, float(negative_slope), vmax)
+
+
+def _bnc(x, what):
+    require_device(x, what)
+    if x.dim() != 5 or x.shape[1] != 6 or x.shape[2] != x.shape[3]:
+        raise ValueError('%s: expected (B, 6, N, N, C), got %s' % (what, tuple(x.shape)))
+    return x.shape[0], x.shape[2], x.shape[4]
+
+
+class _AvgPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, N, C = _bnc(x, 'avgpool2')
+        if N % 2:
+            raise ValueError('avgpool2: odd face size %d' % N)
+        x = _c(x)
+        y = torch.empty((B, 6, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
+        check(lib().dlwpcs_avgpool2_fwd(ptr(x), ptr(y), B, N, C, nat.F32, stream_ptr()), 'dlwpcs_avgpool2_fwd')
+        ctx.shape = (B, N, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, C = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
+        check(lib().dlwpcs_avgpool2_bwd(ptr(dy), ptr(dx), B, N, C, nat.F32, stream_ptr()), 'dlwpcs_avgpool2_bwd')
+        return dx
+
+
+class _Upsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, N, C = _bnc(x, 'upsample2')
+        x = _c(x)
+        y = torch.empty((B, 6, 2 * N, 2 * N, C), dtype=x.dtype, device=x.device)
+        check(lib().dlwpcs_upsample2_fwd(ptr(x), ptr(y), B, N, C, nat.F32, stream_ptr()), 'dlwpcs_upsample2_fwd')
+        ctx.shape = (B, N, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, C = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
+        check(lib().dlwpcs_upsample2_bwd(ptr(dy), ptr(dx), B, N, C, nat.F32, stream_ptr()), 'dlwpcs_upsample2_bwd')
+        return dx
+
+
+def avgpool2(x):
+    return _AvgPool2.apply(x)
+
+
+def upsample2(x):
+    return _Upsample2.apply(x)
+
+
+class _Concat2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        require_device(a, 'concat2')
+        require_device(b, 'concat2')
+        if a.shape[:-1] != b.shape[:-1]:
+            raise ValueError('concat2: leading shapes differ: %s vs %s' % (tuple(a.shape), tuple(b.shape)))
+        a, b = _c(a), _c(b)
+        Ca, Cb = a.shape[-1], b.shape[-1]
+        rows = a.numel() // Ca
+        y = torch.empty(a.shape[:-1] + (Ca + Cb,), dtype=a.dtype, device=a.device)
+        check(lib().dlwpcs_concat2(ptr(a), ptr(b), ptr(y), rows, Ca, Cb, nat.F32, stream_ptr()), 'dlwpcs_concat2')
+        ctx.c = (Ca, Cb, rows, a.shape, b.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        Ca, Cb, rows, sa, sb = ctx.c
+        dy = _c(dy)
+        da = torch.empty(sa, dtype=dy.dtype, device=dy.device) if ctx.needs_input_grad[0] else None
+        db = torch.empty(sb, dtype=dy.dtype, device=dy.device) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            check(lib().dlwpcs_split2(ptr(dy), ptr(da), ptr(db), rows, Ca, Cb, nat.F32, stream_ptr()), 'dlwpcs_split2')
+        return da, db
+
+
+def concat_channels(tensors):
+    out = tensors[0]
+    for t in tensors[1:]:
+        out = _Concat2.apply(out, t)
+    return out
+
+
+class _Transpose(torch.autograd.Function):
+    """(B, C, S...) <-> (B, S..., C) layout conversion for data_format='channels_first' callers."""
+
+    @staticmethod
+    def forward(ctx, x, to_last):
+        require_device(x, 'layout')
+        x = _c(x)
+        B = x.shape[0]
+        if to_last:
+            C, spatial = x.shape[1], tuple(x.shape[2:])
+            S = x.numel() // (B * C) if B * C else 0
+            y = torch.empty((B,) + spatial + (C,), dtype=x.dtype, device=x.device)
+            check(lib().dlwpcs_cf_to_cl(ptr(x), ptr(y), B, C, S, nat.F32, stream_ptr()), 'dlwpcs_cf_to_cl')
+        else:
+            C, spatial = x.shape[-1], tuple(x.shape[1:-1])
+            S = x.numel() // (B * C) if B * C else 0
+            y = torch.empty((B, C) + spatial, dtype=x.dtype, device=x.device)
+            check(lib().dlwpcs_cl_to_cf(ptr(x), ptr(y), B, C, S, nat.F32, stream_ptr()), 'dlwpcs_cl_to_cf')
+        ctx.to_last = to_last
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _Transpose.apply(dy, not ctx.to_last), None
+
+
+def channels_first_to_last(x):
+    return _Transpose.apply(x, True)
+
+
+def channels_last_to_first(x):
+    return _Transpose.apply(x, False)
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# Loss and optimizer (Azure/train_cs.py:424-430)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+_mse_scratch = {}
+
+
+class _MSE(torch.autograd.Function):
+    """returns a (2,) tensor: [weight * mse, mae]; gradient flows through element 0 only."""
+
+    @staticmethod
+    def forward(ctx, y, t, weight):
+        require_device(y, 'mse')
+        require_device(t, 'mse')
+        if y.shape != t.shape:
+            raise ValueError('mse: shapes differ: %s vs %s' % (tuple(y.shape), tuple(t.shape)))
+        y, t = _c(y), _c(t)
+        key = str(y.device)
+        scratch = _mse_scratch.get(key)
+        if scratch is None:
+            scratch = torch.empty(lib().dlwpcs_mse_scratch_bytes(), dtype=torch.uint8, device=y.device)
+            _mse_scratch[key] = scratch
+        out = torch.zeros(2, dtype=torch.float32, device=y.device)
+        dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
+        check(lib().dlwpcs_mse_fwd_bwd(ptr(y), ptr(t), ptr(dy), ptr(out), y.numel(), weight, nat.F32, ptr(scratch),
+                                       stream_ptr()), 'dlwpcs_mse_fwd_bwd')
+        ctx.save_for_backward(dy)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (dy,) = ctx.saved_tensors
+        # Contract: the upstream gradient of out[0] is exactly 1 (DLWP.keras.Model sums the weighted losses and calls
+        # backward with ones); the forward kernel already wrote dy = weight * 2 (y - t) / n, so no extra pass here.
+        return dy, None, None
+
+
+def mse_mae(y, t, weight=1.0):
+    return _MSE.apply(y, t, float(weight))
+
+
+def adam_step(p, g, m, v, step_dev, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    """In-place TF2.1-keras Adam on flat fp32 device buffers; `step_dev` is an int32 device scalar (t-1)."""
+    for t in (p, g, m, v):
+        require_device(t, 'adam_step')
+    check(lib().dlwpcs_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(step_dev), lr, beta1, beta2, eps,
+                                 grad_scale, stream_ptr()), 'dlwpcs_adam_step')
+
+
+def add(a, b):
+    require_device(a, 'add')
+    require_device(b, 'add')
+    a, b = _c(a), _c(b)
+    y = torch.empty_like(a)
+    check(lib().dlwpcs_add(ptr(a), ptr(b), ptr(y), a.numel(), nat.F32, stream_ptr()), 'dlwpcs_add')
+    return y

@@ -1,0 +1,201 @@
+/*
+ * dlwpcs.h -- C ABI of the MI355X-native DLWP-CS cubed-sphere hot path (libdlwpcs.so, HIP, gfx950).
+ *
+ * This is the drop-in boundary described in SURVEY.md section 8(b): everything the Python layers
+ * `DLWP.custom.CubeSpherePadding2D` / `DLWP.custom.CubeSphereConv2D` (and the Keras stock ops wired between them in
+ * the DLWP-CS U-Net) need from the device.  Conventions:
+ *
+ *   - plain C types only; every tensor argument is a raw DEVICE pointer + explicit sizes.  No torch types.
+ *   - the CALLER owns every buffer (inputs, outputs, weights, gradients, tables, workspace); the library allocates
+ *     nothing and keeps no mutable global state, so it is re-entrant across streams and devices.
+ *   - every device entry point enqueues on the caller's `stream` (a hipStream_t) and returns without synchronising.
+ *   - return value: 0 = OK, <0 = error code (DLWPCS_E_*); a human-readable message for the calling thread is
+ *     available from dlwpcs_last_error().  Nothing throws across the boundary.
+ *   - tensors on the hot path are `channels_last`:  x[b][face][row][col][channel]  (face axis = 6,
+ *     faces 0-3 equatorial going east, 4 = south pole, 5 = north pole; reference DLWP/custom.py:1057-1070).
+ *     `channels_first` (B,C,6,H,W) callers convert with dlwpcs_cf_to_cl / dlwpcs_cl_to_cf.
+ *   - dtype: DLWPCS_F32 (this round).  Arithmetic is exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.
+ *
+ * Reference interfaces replaced (paths relative to the reference repository root):
+ *   CubeSpherePadding2D.call        DLWP/custom.py:1082-1308   -> dlwpcs_halo_table, dlwpcs_pad_fwd/_bwd
+ *   CubeSphereConv2D.call           DLWP/custom.py:921-1002    -> dlwpcs_conv_fwd / _bwd_data / _bwd_weights
+ *   ReLU(0.1,10), AveragePooling3D((1,2,2)), UpSampling3D((1,2,2)), concatenate
+ *                                   Azure/train_cs.py:197-199,277-305 -> epilogue/loader flags of dlwpcs_conv_*,
+ *                                                                 dlwpcs_act_*, dlwpcs_avgpool2_*, dlwpcs_upsample2_*
+ *   loss='mse', Adam()              Azure/train_cs.py:424-430  -> dlwpcs_mse_fwd_bwd, dlwpcs_adam_step
+ */
+#ifndef DLWPCS_H
+#define DLWPCS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLWPCS_VERSION 100            /* 0.1.0 */
+
+/* error codes */
+#define DLWPCS_OK             0
+#define DLWPCS_E_INVALID     -1       /* bad argument (shape, flag, null pointer) */
+#define DLWPCS_E_UNSUPPORTED -2       /* valid request this build has no kernel for */
+#define DLWPCS_E_WORKSPACE   -3       /* workspace too small */
+#define DLWPCS_E_LAUNCH      -4       /* HIP launch error */
+
+/* dtype tags */
+#define DLWPCS_F32 0
+
+/* activation tags (epilogue of conv_fwd, mask of the backward kernels) */
+#define DLWPCS_ACT_NONE        0
+#define DLWPCS_ACT_LEAKY_CLIP  1      /* keras ReLU(negative_slope=alpha, max_value=vmax): Azure/train_cs.py:199 */
+
+typedef void *dlwpcs_stream_t;        /* hipStream_t */
+
+int dlwpcs_version(void);
+const char *dlwpcs_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------- *
+ * Halo tables (HOST functions, no device work).  Replace the slice/reverse/transpose/concat graph of
+ * CubeSpherePadding2D.call (DLWP/custom.py:1082-1308) by one gather table.
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* out[6*M*M], M = N+2p: flat source index (face*N + row)*N + col of every padded cell. */
+int dlwpcs_halo_table(int N, int p, int32_t *out);
+
+/* inv[6*N*N*4]: for every source cell the up-to-4 EXTRA padded cells (flat index (face*M + i)*M + j) that read
+ * it besides its own identity copy at (face, row+p, col+p); unused slots are -1.  (Fan-out <= 5) */
+int dlwpcs_halo_inverse_table(int N, int p, int32_t *inv);
+
+/* ------------------------------------------------------------------------------------------------------------- *
+ * Stand-alone padding layer, channels_last.  x: (B,6,N,N,C)  y: (B,6,N+2p,N+2p,C)
+ * ------------------------------------------------------------------------------------------------------------- */
+int dlwpcs_pad_fwd(const void *x, void *y, int B, int N, int C, int p, int dtype,
+                   const int32_t *table_dev, dlwpcs_stream_t stream);
+/* dx[src] = sum of dy over every padded cell that gathered from src (deterministic inverse gather, no atomics). */
+int dlwpcs_pad_bwd(const void *dy, void *dx, int B, int N, int C, int p, int dtype,
+                   const int32_t *inv_table_dev, dlwpcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------- *
+ * Fused cubed-sphere convolution.
+ *
+ * Virtual input V (B,6,N,N,C0+C1) = concat_channels( up0 ? nearest_upsample_x2(src0) : src0 , src1 ).
+ *   halo == 1 : V is halo-padded on the fly through `table` (CubeSpherePadding2D(p=(k-1)/2) fused into the load)
+ *               and convolved 'valid' -> y (B,6,N,N,Cout).
+ *   halo == 0 : V is consumed as is ('valid'): y (B,6,N-k+1,N-k+1,Cout).  (CubeSphereConv2D on an already padded
+ *               tensor, or the 1x1 head.)
+ * Weight groups follow CubeSphereConv2D.call (DLWP/custom.py:921-1002): w_eq on faces 0-3, w_pol on face 4,
+ * face 5 uses w_np when given (independent_north_pole) else w_pol, with the kernel ROWS reversed when
+ * flip_north_pole (== flip -> conv -> flip of the reference for stride 1).  Kernels are HWIO (k,k,Cin,Cout) fp32,
+ * biases (Cout,) or NULL.  Epilogue: + bias, then `act`.
+ * k in {1,3}, stride 1, dilation 1 (the hot-path configuration, Azure/train_cs.py:200-207); anything else returns
+ * DLWPCS_E_UNSUPPORTED and is served by dlwpcs_conv_generic_*.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct dlwpcs_conv_desc {
+    int32_t B;              /* batch */
+    int32_t N;              /* face size of the virtual input V */
+    int32_t C0, C1;         /* channels of src0 / src1 (C1 = 0: no second source) */
+    int32_t Cout;
+    int32_t ksize;          /* 1 or 3 */
+    int32_t halo;           /* 1: fuse the cube-sphere halo gather, 0: plain 'valid' */
+    int32_t up0;            /* 1: src0 is (B,6,N/2,N/2,C0), nearest-upsampled x2 on load */
+    int32_t flip_north_pole;
+    int32_t act;            /* DLWPCS_ACT_* */
+    float   alpha, vmax;    /* parameters of DLWPCS_ACT_LEAKY_CLIP */
+    int32_t dtype;          /* DLWPCS_F32 */
+    int32_t reserved;
+} dlwpcs_conv_desc;
+
+size_t dlwpcs_conv_workspace_bytes(const dlwpcs_conv_desc *d);      /* max over fwd / bwd_data / bwd_weights */
+
+int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d,
+                    const void *src0, const void *src1,
+                    const void *w_eq, const void *w_pol, const void *w_np,
+                    const void *b_eq, const void *b_pol, const void *b_np,
+                    void *y, const int32_t *table_dev,
+                    void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
+
+/* Gradients w.r.t. the sources.  dy: gradient w.r.t. the (post-activation) output y; y: the saved forward output
+ * (needed when act != NONE: dz = dy * act'(.) is applied on load), NULL otherwise.
+ * dsrc0: same shape as src0 (the 2x2 block sum of the upsample adjoint is applied when up0), dsrc1 like src1.
+ * Either may be NULL to skip it (first layer).  inv_table_dev from dlwpcs_halo_inverse_table (halo==1 only). */
+int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d,
+                         const void *dy, const void *y,
+                         const void *w_eq, const void *w_pol, const void *w_np,
+                         void *dsrc0, void *dsrc1, const int32_t *inv_table_dev,
+                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
+
+/* Gradients w.r.t. kernels and biases (deterministic: fixed-order partial sums, no atomics).
+ * dw_*: HWIO like the kernels; db_*: (Cout,) or NULL.  dw_np/db_np NULL unless independent north pole. */
+int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d,
+                            const void *src0, const void *src1, const void *dy, const void *y,
+                            void *dw_eq, void *dw_pol, void *dw_np,
+                            void *db_eq, void *db_pol, void *db_np,
+                            const int32_t *table_dev,
+                            void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------- *
+ * Generic (any kernel size / stride / dilation / 'same') per-face convolution on an ALREADY PADDED channels_last
+ * tensor: the off-hot-path options of CubeSphereConv2D (DLWP/custom.py:824-842).  Direct VALU kernels.
+ * x: (B,6,H,W,Cin) -> y: (B,6,Ho,Wo,Cout);  pad_{t,l}: zero padding already resolved by the caller ('same').
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct dlwpcs_gconv_desc {
+    int32_t B, H, W, Cin, Cout;
+    int32_t kh, kw, sh, sw, dh, dw;
+    int32_t pad_t, pad_l;   /* zero padding before the first row / column ('same'), 0 for 'valid' */
+    int32_t Ho, Wo;
+    int32_t flip_north_pole;
+    int32_t dtype;
+} dlwpcs_gconv_desc;
+
+int dlwpcs_gconv_fwd(const dlwpcs_gconv_desc *d, const void *x,
+                     const void *w_eq, const void *w_pol, const void *w_np,
+                     const void *b_eq, const void *b_pol, const void *b_np, void *y, dlwpcs_stream_t stream);
+int dlwpcs_gconv_bwd_data(const dlwpcs_gconv_desc *d, const void *dy,
+                          const void *w_eq, const void *w_pol, const void *w_np, void *dx, dlwpcs_stream_t stream);
+int dlwpcs_gconv_bwd_weights(const dlwpcs_gconv_desc *d, const void *x, const void *dy,
+                             void *dw_eq, void *dw_pol, void *dw_np, void *db_eq, void *db_pol, void *db_np,
+                             dlwpcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------- *
+ * Keras stock ops between the custom layers (Azure/train_cs.py:197-199), channels_last, n = element count.
+ * ------------------------------------------------------------------------------------------------------------- */
+int dlwpcs_act_fwd(const void *x, void *y, size_t n, int act, float alpha, float vmax, int dtype,
+                   dlwpcs_stream_t stream);
+/* dx = dy * act'(.) evaluated from the saved OUTPUT y */
+int dlwpcs_act_bwd(const void *dy, const void *y, void *dx, size_t n, int act, float alpha, float vmax, int dtype,
+                   dlwpcs_stream_t stream);
+/* x: (B,6,N,N,C) -> y: (B,6,N/2,N/2,C), 2x2 mean;  backward spreads dy/4 */
+int dlwpcs_avgpool2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
+int dlwpcs_avgpool2_bwd(const void *dy, void *dx, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
+/* x: (B,6,N,N,C) -> y: (B,6,2N,2N,C), nearest;  backward sums 2x2 blocks */
+int dlwpcs_upsample2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
+int dlwpcs_upsample2_bwd(const void *dy, void *dx, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
+/* y[:, :Ca] = a, y[:, Ca:] = b over `rows` pixels;  split is the adjoint */
+int dlwpcs_concat2(const void *a, const void *b, void *y, size_t rows, int Ca, int Cb, int dtype,
+                   dlwpcs_stream_t stream);
+int dlwpcs_split2(const void *y, void *a, void *b, size_t rows, int Ca, int Cb, int dtype, dlwpcs_stream_t stream);
+/* layout converters for data_format='channels_first' callers: (B,C,S) <-> (B,S,C), S = 6*H*W */
+int dlwpcs_cf_to_cl(const void *x, void *y, int B, int C, size_t S, int dtype, dlwpcs_stream_t stream);
+int dlwpcs_cl_to_cf(const void *x, void *y, int B, int C, size_t S, int dtype, dlwpcs_stream_t stream);
+/* y = a + b (gradient accumulation at skip connections / shared weights) */
+int dlwpcs_add(const void *a, const void *b, void *y, size_t n, int dtype, dlwpcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------- *
+ * Training-step tail (Azure/train_cs.py:424-430): keras 'mse' with a loss weight, metric 'mae', and Adam.
+ * ------------------------------------------------------------------------------------------------------------- */
+/* loss_out[0] += weight*mean((y-t)^2), loss_out[1] += mean(|y-t|);  dy = weight*2*(y-t)/n  (dy may be NULL).
+ * scratch: >= dlwpcs_mse_scratch_bytes() bytes.  Deterministic two-stage reduction. */
+size_t dlwpcs_mse_scratch_bytes(void);
+int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float *loss_out, size_t n, float weight, int dtype,
+                       void *scratch, dlwpcs_stream_t stream);
+/* TF2.1-keras Adam on flat fp32 buffers: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps).
+ * `step_dev` points to a device int32 holding t-1 (incremented by the kernel), so the call is graph-capturable.
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int dlwpcs_adam_step(float *p, const float *g, float *m, float *v, size_t n, int32_t *step_dev,
+                     float lr, float beta1, float beta2, float eps, float grad_scale, dlwpcs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLWPCS_H */

@@ -1,0 +1,105 @@
+"""
+CPU tests of the C-ABI boundary: the shared library loads, exports every symbol include/dlwpcs.h declares, the ctypes
+prototype table covers the header, and the HOST entry points (halo tables, error reporting) behave.  No device work.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import cs_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'dlwpcs.h')
+
+
+def _header_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(dlwpcs_[a-z0-9_]+)\s*\(', text)))
+
+
+@pytest.fixture(scope='module')
+def native():
+    from DLWP import _native as nat
+    if not os.path.exists(nat.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('dlwpcs_build', os.path.join(ROOT, 'dlwp-cs_amd', 'build.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build(verbose=False)
+    return nat
+
+
+def test_header_declares_expected_surface():
+    syms = _header_symbols()
+    for must in ('dlwpcs_halo_table', 'dlwpcs_pad_fwd', 'dlwpcs_pad_bwd', 'dlwpcs_conv_fwd', 'dlwpcs_conv_bwd_data',
+                 'dlwpcs_conv_bwd_weights', 'dlwpcs_avgpool2_fwd', 'dlwpcs_upsample2_fwd', 'dlwpcs_adam_step'):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(native):
+    handle = ctypes.CDLL(native.LIB_PATH)
+    for sym in _header_symbols():
+        assert hasattr(handle, sym), 'libdlwpcs.so does not export %s' % sym
+
+
+def test_ctypes_prototypes_cover_header(native):
+    assert sorted(native.PROTOTYPES.keys()) == _header_symbols()
+
+
+def test_version_and_error_channel(native):
+    lib = native.lib()
+    assert lib.dlwpcs_version() == 100
+    out = np.zeros(4, dtype=np.int32)
+    rc = lib.dlwpcs_halo_table(0, 1, out.ctypes.data)
+    assert rc == -1
+    assert b'halo_table' in lib.dlwpcs_last_error()
+    with pytest.raises(ValueError):
+        native.check(rc, 'dlwpcs_halo_table')
+
+
+@pytest.mark.parametrize('N,p', [(4, 1), (8, 1), (8, 2), (8, 3), (12, 1), (24, 1), (48, 1), (96, 1)])
+def test_host_halo_table_matches_reference_golden(native, golden_dir, N, p):
+    g = np.load(os.path.join(golden_dir, 'g1_halo_tables.npz'))
+    assert np.array_equal(native.halo_table_host(N, p), g['table_N%d_p%d' % (N, p)])
+
+
+@pytest.mark.parametrize('N,p', [(4, 1), (8, 2), (12, 3), (48, 1)])
+def test_host_inverse_table_is_the_adjoint(native, N, p):
+    T = native.halo_table_host(N, p).reshape(-1)
+    inv = native.halo_inverse_table_host(N, p)
+    M = N + 2 * p
+    # rebuild the forward table from (identity + inverse lists)
+    rebuilt = np.full(6 * M * M, -1, dtype=np.int64)
+    for f in range(6):
+        for y in range(N):
+            for x in range(N):
+                rebuilt[(f * M + y + p) * M + x + p] = (f * N + y) * N + x
+    src, slot = np.nonzero(inv >= 0)
+    rebuilt[inv[src, slot]] = src
+    assert np.array_equal(rebuilt, T)
+    assert (inv >= 0).sum(axis=1).max() <= 4
+    assert np.array_equal(orc.halo_table(N, p).reshape(-1), T)
+
+
+def test_conv_descriptor_validation(native):
+    lib = native.lib()
+    d = native.ConvDesc(B=1, N=8, C0=4, C1=0, Cout=4, ksize=5, halo=0, up0=0, flip_north_pole=1, act=0, alpha=0.,
+                        vmax=0., dtype=0, reserved=0)
+    assert lib.dlwpcs_conv_workspace_bytes(ctypes.byref(d)) == 0        # k=5 is served by the generic path
+    assert b'kernel size' in lib.dlwpcs_last_error()
+    d.ksize = 3
+    assert lib.dlwpcs_conv_workspace_bytes(ctypes.byref(d)) > 0
+    # null pointers are rejected before any launch
+    rc = lib.dlwpcs_conv_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None, None, None, 0, None)
+    assert rc == -1
+
+
+def test_product_path_has_no_cpu_fallback(native):
+    import torch
+    from DLWP import ops
+    with pytest.raises(native.NativeError):
+        ops.cs_pad(torch.zeros(1, 6, 4, 4, 1), 1)

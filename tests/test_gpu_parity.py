@@ -1,0 +1,446 @@
+"""
+GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI (ctypes, DLWP.ops), against
+the CPU oracle (oracle/cs_oracle.py, fp64) and the golden vectors generated from the reference's own layer code.
+
+Bars: integer/byte-exact for pure data movement (halo gather, pooling layout, concat); fp32 kernels within 1e-5 relative
+(`max|d| / max|ref|`, the tolerance BASELINE.json's north_star states) of the fp64 oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    return torch.device('cuda', 0)
+
+
+def rel_err(a, ref):
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    denom = np.abs(ref).max()
+    return np.abs(a - ref).max() / (denom if denom > 0 else 1.0)
+
+
+def to_dev(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float32, device=_dev())
+
+
+def test_native_library_loaded():
+    from DLWP import _native as nat
+    assert nat.lib().dlwpcs_version() == 100
+    # the loaded shared object is the in-tree one
+    assert os.path.samefile(nat.LIB_PATH, os.path.join(os.path.dirname(nat.__file__), '..', 'lib', 'libdlwpcs.so'))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# halo gather
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('N,p,C', [(4, 1, 1), (8, 1, 3), (8, 2, 4), (8, 3, 5), (12, 1, 8), (48, 1, 4), (96, 1, 2)])
+def test_pad_forward_exact(N, p, C):
+    from DLWP import ops
+    rng = np.random.default_rng(N * 10 + p)
+    x = rng.standard_normal((2, 6, N, N, C)).astype(np.float32)
+    y = ops.cs_pad(to_dev(x), p).cpu().numpy()
+    assert np.array_equal(y, orc.cs_pad(x, p, 'channels_last'))
+
+
+def test_pad_golden(golden_dir):
+    from DLWP.custom import CubeSpherePadding2D
+    g = np.load(os.path.join(golden_dir, 'g2_padding.npz'))
+    x = g['x']
+    for p in (1, 2):
+        y = CubeSpherePadding2D(p, data_format='channels_last')(to_dev(x)).cpu().numpy()
+        assert np.array_equal(y, g['cl_p%d' % p])
+        xcf = np.ascontiguousarray(x.transpose(0, 4, 1, 2, 3))
+        y = CubeSpherePadding2D(p, data_format='channels_first')(to_dev(xcf)).cpu().numpy()
+        assert np.array_equal(y, g['cf_p%d' % p])
+
+
+@pytest.mark.parametrize('N,p,C', [(8, 1, 3), (8, 2, 4), (12, 1, 8), (24, 3, 2)])
+def test_pad_backward_is_adjoint(N, p, C):
+    from DLWP import ops
+    rng = np.random.default_rng(7)
+    x = to_dev(rng.standard_normal((2, 6, N, N, C))).requires_grad_(True)
+    gy = rng.standard_normal((2, 6, N + 2 * p, N + 2 * p, C)).astype(np.float32)
+    y = ops.cs_pad(x, p)
+    y.backward(to_dev(gy))
+    # oracle: scatter-add of gy through the table (fp64)
+    T = orc.halo_table(N, p).reshape(-1)
+    ref = np.zeros((2, 6 * N * N, C))
+    np.add.at(ref, (slice(None), T), gy.reshape(2, -1, C).astype(np.float64))
+    assert rel_err(x.grad.cpu().numpy().reshape(2, -1, C), ref) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fused convolution
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _rand_conv_params(rng, k, cin, cout, indep=False):
+    w = {n: rng.standard_normal((k, k, cin, cout)) * (1.0 / np.sqrt(k * k * cin)) for n in ('eq', 'pol', 'np')}
+    b = {n: rng.standard_normal((cout,)) * 0.1 for n in ('eq', 'pol', 'np')}
+    if not indep:
+        w['np'] = b['np'] = None
+    return w, b
+
+
+def _oracle_conv(x0, x1, up0, halo, w, b, k, flip, indep, act):
+    t = torch.tensor(x0, dtype=torch.float64)
+    if up0:
+        t = orc.upsample_122(t)
+    if x1 is not None:
+        t = torch.cat([t, torch.tensor(x1, dtype=torch.float64)], dim=-1)
+    t.requires_grad_(False)
+    if halo:
+        t = orc.cs_pad(t, (k - 1) // 2, 'channels_last')
+    tw = {n: (None if v is None else torch.tensor(v, dtype=torch.float64)) for n, v in w.items()}
+    tb = {n: (None if v is None else torch.tensor(v, dtype=torch.float64)) for n, v in b.items()}
+    y = orc.cs_conv2d(t, tw['eq'], tw['pol'], tw['np'], tb['eq'], tb['pol'], tb['np'], data_format='channels_last',
+                      flip_north_pole=flip, independent_north_pole=indep)
+    if act:
+        y = orc.relu_leaky_clip(y, 0.1, 10.0)
+    return y
+
+
+CONV_CASES = [
+    # B, N, C0, C1, Cout, k, halo, up0, flip, indep, act
+    (1, 48, 4, 0, 4, 3, True, False, True, False, False),      # BASELINE cfg 1 shape
+    (2, 8, 3, 0, 4, 3, True, False, True, False, True),        # scalar (C % 4 != 0) loader
+    (2, 12, 8, 0, 40, 3, True, False, True, False, True),      # 2 N tiles, partial
+    (2, 12, 64, 0, 128, 3, True, False, True, False, True),    # U-Net bottom: 4 N tiles, small face
+    (2, 24, 32, 0, 64, 3, True, False, True, False, True),
+    (2, 24, 16, 16, 32, 3, True, True, True, False, True),     # decoder: upsample + concat fused
+    (1, 48, 32, 32, 32, 3, True, True, True, False, True),
+    (2, 16, 12, 0, 20, 3, True, False, False, True, False),    # no flip, independent north pole
+    (2, 16, 12, 0, 20, 3, True, False, True, True, True),      # flip + independent north pole
+    (2, 10, 8, 0, 8, 3, False, False, True, False, False),     # plain 'valid' on an already padded tensor
+    (2, 48, 32, 0, 14, 1, False, False, True, False, False),   # 1x1 head
+    (1, 20, 5, 0, 7, 1, False, False, True, False, True),      # odd sizes everywhere
+    (3, 9, 6, 0, 33, 3, True, False, True, False, True),       # odd face size, partial N tile
+    (1, 96, 8, 0, 32, 3, True, False, True, False, True),      # C96
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward_and_backward(case):
+    from DLWP import ops
+    from DLWP._native import ACT_LEAKY_CLIP, ACT_NONE
+    B, N, C0, C1, Cout, k, halo, up0, flip, indep, act = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    n0 = N // 2 if up0 else N
+    x0 = rng.standard_normal((B, 6, n0, n0, C0))
+    x1 = rng.standard_normal((B, 6, N, N, C1)) if C1 else None
+    w, b = _rand_conv_params(rng, k, C0 + C1, Cout, indep)
+    # scale up so that the clip at 10 and the negative slope are both exercised
+    x0 *= 3.0
+    No = N if halo else N - k + 1
+    gy = rng.standard_normal((B, 6, No, No, Cout))
+
+    # oracle (fp64 autograd)
+    t0 = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
+    t1 = torch.tensor(x1, dtype=torch.float64, requires_grad=True) if C1 else None
+    tw = {n: (None if v is None else torch.tensor(v, dtype=torch.float64, requires_grad=True)) for n, v in w.items()}
+    tb = {n: (None if v is None else torch.tensor(v, dtype=torch.float64, requires_grad=True)) for n, v in b.items()}
+    t = orc.upsample_122(t0) if up0 else t0
+    if C1:
+        t = torch.cat([t, t1], dim=-1)
+    if halo:
+        t = orc.cs_pad(t, (k - 1) // 2, 'channels_last')
+    yref = orc.cs_conv2d(t, tw['eq'], tw['pol'], tw['np'], tb['eq'], tb['pol'], tb['np'], data_format='channels_last',
+                         flip_north_pole=flip, independent_north_pole=indep)
+    if act:
+        yref = orc.relu_leaky_clip(yref, 0.1, 10.0)
+    yref.backward(torch.tensor(gy, dtype=torch.float64))
+
+    # device
+    d0 = to_dev(x0).requires_grad_(True)
+    d1 = to_dev(x1).requires_grad_(True) if C1 else None
+    dw = {n: (None if v is None else to_dev(v).requires_grad_(True)) for n, v in w.items()}
+    db = {n: (None if v is None else to_dev(v).requires_grad_(True)) for n, v in b.items()}
+    y = ops.cs_conv(d0, dw['eq'], dw['pol'], dw['np'], db['eq'], db['pol'], db['np'], src1=d1, ksize=k, halo=halo,
+                    up0=up0, flip_north_pole=flip, act=ACT_LEAKY_CLIP if act else ACT_NONE, alpha=0.1, vmax=10.0)
+    assert rel_err(y.detach().cpu().numpy(), yref.detach().numpy()) < RTOL
+    y.backward(to_dev(gy))
+    assert rel_err(d0.grad.cpu().numpy(), t0.grad.numpy()) < RTOL
+    if C1:
+        assert rel_err(d1.grad.cpu().numpy(), t1.grad.numpy()) < RTOL
+    for n in ('eq', 'pol', 'np'):
+        if dw[n] is not None:
+            assert rel_err(dw[n].grad.cpu().numpy(), tw[n].grad.numpy()) < RTOL, 'dW ' + n
+            assert rel_err(db[n].grad.cpu().numpy(), tb[n].grad.numpy()) < RTOL, 'db ' + n
+
+
+def test_conv_cfg1_golden(golden_dir):
+    """BASELINE config 1 against the vector produced by the reference layers."""
+    from DLWP import ops
+    g = np.load(os.path.join(golden_dir, 'cfg1.npz'))
+    y = ops.cs_conv(to_dev(g['x']), to_dev(g['w_eq']), to_dev(g['w_pol']), None, to_dev(g['b_eq']), to_dev(g['b_pol']),
+                    None, ksize=3, halo=True)
+    assert rel_err(y.cpu().numpy(), g['y']) < RTOL
+
+
+def test_conv_wgrad_is_deterministic():
+    from DLWP import ops
+    rng = np.random.default_rng(11)
+    x = to_dev(rng.standard_normal((4, 6, 24, 24, 32)))
+    w, b = _rand_conv_params(rng, 3, 32, 64)
+    gy = to_dev(rng.standard_normal((4, 6, 24, 24, 64)))
+    grads = []
+    for _ in range(3):
+        dw = {n: to_dev(v).requires_grad_(True) for n, v in w.items() if v is not None}
+        db = {n: to_dev(v).requires_grad_(True) for n, v in b.items() if v is not None}
+        y = ops.cs_conv(x, dw['eq'], dw['pol'], None, db['eq'], db['pol'], None, ksize=3, halo=True)
+        y.backward(gy)
+        grads.append((dw['eq'].grad.clone(), dw['pol'].grad.clone(), db['eq'].grad.clone()))
+    for g in grads[1:]:
+        for a, bb in zip(g, grads[0]):
+            assert torch.equal(a, bb)       # bitwise: fixed-order reductions, no atomics
+
+
+def test_layers_golden_g3(golden_dir):
+    """Every CubeSphereConv2D option combination of the golden set, through the layer class."""
+    from DLWP.custom import CubeSphereConv2D
+    g = np.load(os.path.join(golden_dir, 'g3_conv.npz'))
+    x = g['x']
+    for name in g['case_names']:
+        name = str(name)
+        parts = name.split('_')
+        flip, indep = parts[1] == 'flip1', parts[2] == 'indep1'
+        df = 'channels_last' if parts[3] == 'cl' else 'channels_first'
+        use_bias, dil, stride, padding = parts[4] == 'bias1', int(parts[5][3:]), int(parts[6][1:]), parts[7]
+        lay = CubeSphereConv2D(4, 3, strides=stride, padding=padding, data_format=df, dilation_rate=dil,
+                               use_bias=use_bias, flip_north_pole=flip, independent_north_pole=indep)
+        xin = x if df == 'channels_last' else np.ascontiguousarray(x.transpose(0, 4, 1, 2, 3))
+        lay.build(xin.shape)
+        weights = [g['w_eq'], g['w_pol']] + ([g['w_np']] if indep else [])
+        if use_bias:
+            weights += [g['b_eq'], g['b_pol']] + ([g['b_np']] if indep else [])
+        lay.set_weights(weights)
+        y = lay(to_dev(xin)).cpu().numpy()
+        assert y.shape == tuple(lay.compute_output_shape(xin.shape))
+        assert rel_err(y, g[name]) < RTOL, name
+
+
+def test_gconv_backward():
+    from DLWP import ops
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((2, 6, 11, 11, 3))
+    w, b = _rand_conv_params(rng, 3, 3, 5, indep=True)
+    for (stride, padding, dil, flip) in [(2, 'same', 1, True), (1, 'valid', 2, True), (2, 'valid', 1, False)]:
+        t0 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        tw = {n: torch.tensor(v, dtype=torch.float64, requires_grad=True) for n, v in w.items()}
+        tb = {n: torch.tensor(v, dtype=torch.float64, requires_grad=True) for n, v in b.items()}
+        yref = orc.cs_conv2d(t0, tw['eq'], tw['pol'], tw['np'], tb['eq'], tb['pol'], tb['np'],
+                             strides=(stride, stride), padding=padding, dilation=(dil, dil),
+                             flip_north_pole=flip, independent_north_pole=True)
+        gy = rng.standard_normal(tuple(yref.shape))
+        yref.backward(torch.tensor(gy))
+        d0 = to_dev(x).requires_grad_(True)
+        dw = {n: to_dev(v).requires_grad_(True) for n, v in w.items()}
+        db = {n: to_dev(v).requires_grad_(True) for n, v in b.items()}
+        y = ops.cs_gconv(d0, dw['eq'], dw['pol'], dw['np'], db['eq'], db['pol'], db['np'], strides=(stride, stride),
+                         padding=padding, dilation=(dil, dil), flip_north_pole=flip)
+        assert rel_err(y.detach().cpu().numpy(), yref.detach().numpy()) < RTOL
+        y.backward(to_dev(gy))
+        assert rel_err(d0.grad.cpu().numpy(), t0.grad.numpy()) < RTOL
+        for n in ('eq', 'pol', 'np'):
+            assert rel_err(dw[n].grad.cpu().numpy(), tw[n].grad.numpy()) < RTOL
+            assert rel_err(db[n].grad.cpu().numpy(), tb[n].grad.numpy()) < RTOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stock ops
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('C', [3, 8])
+def test_pool_upsample_act_concat(C):
+    from DLWP import ops
+    rng = np.random.default_rng(31 + C)
+    x = rng.standard_normal((2, 6, 8, 8, C)).astype(np.float32) * 6
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    dx = to_dev(x).requires_grad_(True)
+    # avgpool
+    yr = orc.avgpool_122(tx)
+    y = ops.avgpool2(dx)
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().numpy()) < 1e-6
+    g = rng.standard_normal(tuple(yr.shape)).astype(np.float32)
+    yr.backward(torch.tensor(g, dtype=torch.float64))
+    y.backward(to_dev(g))
+    assert rel_err(dx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-6
+    # upsample
+    tx.grad = None
+    dx.grad = None
+    yr = orc.upsample_122(tx)
+    y = ops.upsample2(dx)
+    assert np.array_equal(y.detach().cpu().numpy(), yr.detach().numpy().astype(np.float32))
+    g = rng.standard_normal(tuple(yr.shape)).astype(np.float32)
+    yr.backward(torch.tensor(g, dtype=torch.float64))
+    y.backward(to_dev(g))
+    assert rel_err(dx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-6
+    # activation
+    tx.grad = None
+    dx.grad = None
+    yr = orc.relu_leaky_clip(tx, 0.1, 10.0)
+    y = ops.leaky_clip_relu(dx, 0.1, 10.0)
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().numpy()) < 1e-6
+    assert (y.detach().cpu().numpy() == 10.0).any() and (y.detach().cpu().numpy() < 0).any()
+    g = rng.standard_normal(tuple(yr.shape)).astype(np.float32)
+    yr.backward(torch.tensor(g, dtype=torch.float64))
+    y.backward(to_dev(g))
+    assert rel_err(dx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-6
+    # concat
+    x2 = rng.standard_normal((2, 6, 8, 8, C + 4)).astype(np.float32)
+    d2 = to_dev(x2).requires_grad_(True)
+    dx.grad = None
+    y = ops.concat_channels([dx, d2])
+    assert np.array_equal(y.detach().cpu().numpy(), np.concatenate([x, x2], axis=-1))
+    g = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(to_dev(g))
+    assert np.array_equal(dx.grad.cpu().numpy(), g[..., :C])
+    assert np.array_equal(d2.grad.cpu().numpy(), g[..., C:])
+
+
+def test_layout_converters_roundtrip():
+    from DLWP import ops
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal((2, 5, 6, 7, 7)).astype(np.float32)
+    y = ops.channels_first_to_last(to_dev(x))
+    assert np.array_equal(y.cpu().numpy(), x.transpose(0, 2, 3, 4, 1))
+    assert np.array_equal(ops.channels_last_to_first(y).cpu().numpy(), x)
+
+
+def test_mse_and_adam():
+    from DLWP import ops
+    rng = np.random.default_rng(51)
+    y = rng.standard_normal((3, 6, 8, 8, 5)).astype(np.float32)
+    t = rng.standard_normal((3, 6, 8, 8, 5)).astype(np.float32)
+    dy_ = to_dev(y).requires_grad_(True)
+    out = ops.mse_mae(dy_, to_dev(t), 0.5)
+    out.backward(torch.ones(2, device=out.device))
+    d = y.astype(np.float64) - t
+    assert abs(out[0].item() - 0.5 * (d ** 2).mean()) < 1e-6
+    assert abs(out[1].item() - np.abs(d).mean()) < 1e-6
+    assert rel_err(dy_.grad.cpu().numpy(), 0.5 * 2 * d / d.size) < 1e-6
+    # Adam, 3 steps against the oracle
+    n = 1000
+    p0 = rng.standard_normal(n).astype(np.float32)
+    p = to_dev(p0)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int32, device=p.device)
+    pr = torch.tensor(p0, dtype=torch.float64)
+    mr, vr = torch.zeros_like(pr), torch.zeros_like(pr)
+    for it in range(3):
+        g = rng.standard_normal(n).astype(np.float32)
+        ops.adam_step(p, to_dev(g), m, v, step)
+        orc.adam_step(pr, torch.tensor(g, dtype=torch.float64), mr, vr, it + 1)
+    assert step.item() == 3
+    assert rel_err(p.cpu().numpy(), pr.numpy()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# end to end: tiny U-Net through DLWP.keras.Model
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _build_unet2(N, c_in, c_out, base):
+    from DLWP.custom import CubeSphereConv2D, CubeSpherePadding2D
+    from DLWP.keras.layers import AveragePooling3D, Input, ReLU, UpSampling3D, concatenate
+    from DLWP.keras.models import Model
+    kw = dict(dilation_rate=1, padding='valid', activation='linear', data_format='channels_last',
+              independent_north_pole=False, flip_north_pole=True)
+    main_input = Input(shape=(6, N, N, c_in), name='main_input')
+    pad = CubeSpherePadding2D(1, data_format='channels_last')
+    pool = AveragePooling3D((1, 2, 2), data_format='channels_last')
+    up = UpSampling3D((1, 2, 2), data_format='channels_last')
+    relu = ReLU(negative_slope=0.1, max_value=10.)
+    plan = orc.unet2_channel_plan(c_in, c_out, base)
+    convs = [CubeSphereConv2D(co, k, **kw) for (_, co, k) in plan]
+    x0 = relu(convs[0](pad(main_input)))
+    x0 = relu(convs[1](pad(x0)))
+    x1 = pool(x0)
+    x1 = relu(convs[2](pad(x1)))
+    x1 = relu(convs[3](pad(x1)))
+    x2 = pool(x1)
+    x2 = relu(convs[4](pad(x2)))
+    x2 = relu(convs[5](pad(x2)))
+    x2 = up(x2)
+    x = concatenate([x2, x1], axis=-1)
+    x = relu(convs[6](pad(x)))
+    x = relu(convs[7](pad(x)))
+    x = up(x)
+    x = concatenate([x, x0], axis=-1)
+    x = relu(convs[8](pad(x)))
+    x = relu(convs[9](pad(x)))
+    y = convs[10](x)
+    return Model(inputs=main_input, outputs=y), convs
+
+
+def _set_params(convs, params):
+    for lay, prm in zip(convs, params):
+        lay.set_weights([prm['equatorial_kernel'].numpy(), prm['polar_kernel'].numpy(),
+                         prm['equatorial_bias'].numpy(), prm['polar_bias'].numpy()])
+
+
+def test_unet2_tiny_forward_golden_and_train_step(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g4_unet2_tiny.npz'))
+    model, convs = _build_unet2(8, 3, 3, 4)
+    assert model.n_fused == 10
+    params = orc.make_unet2_params(3, 3, base=4, seed=1)
+    _set_params(convs, params)
+    y = model.predict(g['x'].astype(np.float32))
+    assert rel_err(y, g['y']) < RTOL
+
+    # one Adam step on (x, target) against the oracle in fp64
+    rng = np.random.default_rng(61)
+    tgt = rng.standard_normal(g['y'].shape).astype(np.float32)
+    model.compile(optimizer='adam', loss='mse', metrics=['mae'])
+    _set_params(convs, params)
+    pr = [{k: v.clone().requires_grad_(True) for k, v in prm.items()} for prm in params]
+    yr = orc.unet2_forward(torch.tensor(g['x']), pr)
+    loss = orc.mse_loss(yr, torch.tensor(tgt, dtype=torch.float64))
+    loss.backward()
+    hist = model.fit(g['x'].astype(np.float32), tgt, batch_size=2, epochs=1, verbose=0, shuffle=False)
+    assert abs(hist.history['loss'][0] - loss.item()) < 1e-5 * max(1.0, abs(loss.item()))
+    # gradients left in the flat buffer by the step
+    k = 0
+    for lay, prm in zip(convs, pr):
+        for w, name in zip(lay.weights, ('equatorial_kernel', 'polar_kernel', 'equatorial_bias', 'polar_bias')):
+            assert rel_err(w.grad.cpu().numpy(), prm[name].grad.numpy()) < 5e-5, (lay.name, name)
+            k += 1
+    # parameters after the step
+    for lay, prm in zip(convs, pr):
+        for w, name in zip(lay.get_weights(), ('equatorial_kernel', 'polar_kernel', 'equatorial_bias', 'polar_bias')):
+            p = prm[name].detach().clone()
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            orc.adam_step(p, prm[name].grad, m, v, 1)
+            assert np.abs(w - p.numpy()).max() < 2e-5, (lay.name, name)
+
+
+def test_graph_replay_matches_eager():
+    """hipGraph-captured training steps give bitwise the same parameters as eager steps."""
+    rng = np.random.default_rng(71)
+    x = rng.standard_normal((4, 6, 8, 8, 3)).astype(np.float32)
+    t = rng.standard_normal((4, 6, 8, 8, 3)).astype(np.float32)
+    params = orc.make_unet2_params(3, 3, base=4, seed=2)
+    results = []
+    for use_graphs in (False, True):
+        model, convs = _build_unet2(8, 3, 3, 4)
+        model.use_graphs = use_graphs
+        model.compile(optimizer='adam', loss='mse')
+        _set_params(convs, params)
+        dx, dt = [to_dev(x)], [to_dev(t)]
+        for _ in range(4):
+            model.train_on_device_batch(dx, dt)
+        torch.cuda.synchronize()
+        results.append(np.concatenate([w.ravel() for w in model.get_weights()]))
+    assert np.array_equal(results[0], results[1])
