@@ -73,6 +73,11 @@ PROTOTYPES = {
                                    c_void_p]),
     'dlwpcs_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float,
                                  c_float, c_float, c_float, c_void_p]),
+    'dlwpcs_prof_enable': (c_int, [c_int]),
+    'dlwpcs_prof_reset': (c_int, []),
+    'dlwpcs_prof_count': (c_int, []),
+    'dlwpcs_prof_get': (c_int, [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(ctypes.c_double),
+                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None

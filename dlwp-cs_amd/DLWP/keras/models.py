@@ -39,9 +39,9 @@ class Model(object):
         if inputs is None or outputs is None:
             raise ValueError('Model needs `inputs` and `outputs`')
         self._single_input = not isinstance(inputs, (list, tuple))
-        self._single_output = not isinstance(outputs, (list, tuple))
         self.inputs = _as_list(inputs)
         self.outputs = _as_list(outputs)
+        self._single_output = len(self.outputs) == 1       # keras unpacks one-element output lists
         for t in self.inputs + self.outputs:
             if not isinstance(t, KTensor):
                 raise ValueError('Model inputs/outputs must be symbolic tensors created by Input() and layer calls')

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdlwpcs.so')
-SOURCES = ['halo_table.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_generic.hip']
+SOURCES = ['halo_table.cpp', 'prof.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_generic.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 CFLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-x', 'hip', '-Wall', '-Wno-unused-function']

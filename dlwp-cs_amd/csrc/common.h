@@ -19,6 +19,11 @@ inline int check_launch(const char *what) {
     return DLWPCS_OK;
 }
 
+// opt-in launch profiler (prof.cpp)
+bool prof_enabled();
+int prof_begin(const char *tag, double flops, double bytes, hipStream_t s);
+void prof_end(int idx, hipStream_t s);
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -501,6 +501,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
 int launch_src_grad(const float *dxv, float *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int up,
                     int halo, hipStream_t s);
 
+struct Work { double flops, bytes; };   // algorithmic work of one launch (for the opt-in profiler)
+
 // rows of the face touched by `pix` consecutive flat pixels whose first pixel is a multiple of `pix`
 static int tile_rows_for(int pix, int No) {
     if (pix % No == 0) return pix / No;
@@ -509,7 +511,7 @@ static int tile_rows_for(int pix, int No) {
 }
 
 template <int KS, int KC, int MT, int NT, int WM, int WN, bool VEC>
-static int launch_conv_cfg(ConvKParams P, hipStream_t s) {
+static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
     const int face_pix = P.No * P.No;
     // band = whole rows when that does not cost extra workgroups, else a flat range of BM pixels (partial rows)
@@ -533,25 +535,45 @@ static int launch_conv_cfg(ConvKParams P, hipStream_t s) {
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     dim3 grid((unsigned)(P.B * 6 * P.nblk_face), (unsigned)ceil_div(P.NTtot, NTB));
+    int pidx = -1;
+    if (prof_enabled()) {
+        char tag[128];
+        snprintf(tag, sizeof(tag), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", KS, KC, MT, NT, WM, WN, VEC ? "true" : "false");
+        pidx = prof_begin(tag, W.flops, W.bytes, s);
+    }
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, P);
+    if (pidx >= 0) prof_end(pidx, s);
     return check_launch("conv_mfma");
 }
 
 template <int KS, bool VEC>
-static int launch_conv(const ConvKParams &P, hipStream_t s) {
+static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
     const int face_pix = P.No * P.No;
-    if constexpr (KS == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VEC>(P, s);
+    if constexpr (KS == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VEC>(P, W, s);
     else {
-    if (P.NTtot == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VEC>(P, s);
-    if (P.NTtot == 2) return launch_conv_cfg<KS, 16, 3, 1, 2, 2, VEC>(P, s);
-    if (face_pix <= 320) return launch_conv_cfg<KS, 16, 5, 1, 1, 4, VEC>(P, s);
-    return launch_conv_cfg<KS, 16, 3, 1, 1, 4, VEC>(P, s);
+    if (P.NTtot == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VEC>(P, W, s);
+    if (P.NTtot == 2) return launch_conv_cfg<KS, 16, 3, 1, 2, 2, VEC>(P, W, s);
+    if (face_pix <= 320) return launch_conv_cfg<KS, 16, 5, 1, 1, 4, VEC>(P, W, s);
+    return launch_conv_cfg<KS, 16, 3, 1, 1, 4, VEC>(P, W, s);
     }
 }
 
-static int dispatch_conv(int KS, bool vec, const ConvKParams &P, hipStream_t s) {
-    if (KS == 3) return vec ? launch_conv<3, true>(P, s) : launch_conv<3, false>(P, s);
-    return vec ? launch_conv<1, true>(P, s) : launch_conv<1, false>(P, s);
+static int dispatch_conv(int KS, bool vec, const ConvKParams &P, const Work &W, hipStream_t s) {
+    if (KS == 3) return vec ? launch_conv<3, true>(P, W, s) : launch_conv<3, false>(P, W, s);
+    return vec ? launch_conv<1, true>(P, W, s) : launch_conv<1, false>(P, W, s);
+}
+
+// algorithmic work of one convolution pass: flops = 2*B*6*N^2*k^2*Cin*Cout; bytes = unpadded input and
+// output touched once + the weights.
+static Work conv_work(const dlwpcs_conv_desc *d) {
+    const double No = d->halo ? d->N : d->N - d->ksize + 1;
+    const double Cin = d->C0 + d->C1, taps = (double)d->ksize * d->ksize;
+    const double n0 = d->up0 ? d->N / 2 : d->N;
+    Work w;
+    w.flops = 2.0 * d->B * 6 * No * No * taps * Cin * d->Cout;
+    w.bytes = 4.0 * (d->B * 6.0 * (n0 * n0 * d->C0 + (double)d->N * d->N * d->C1 + No * No * d->Cout) +
+                     2.0 * taps * Cin * d->Cout);
+    return w;
 }
 
 struct Geometry {
@@ -674,7 +696,7 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
     P.mode = d->halo ? MODE_HALO : MODE_DIRECT;
     P.act = d->act; P.alpha = d->alpha; P.vmax = d->vmax;
     const bool vec = (d->C0 % 4 == 0) && (d->C1 % 4 == 0);
-    return dispatch_conv(d->ksize, vec, P, s);
+    return dispatch_conv(d->ksize, vec, P, conv_work(d), s);
 }
 
 extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, const void *y,
@@ -704,7 +726,7 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     P.CG = ceil_div(d->Cout, 8); P.NTtot = ceil_div(Cin, 32); P.up0 = 0;
     P.mode = MODE_ZERO;
     P.act = DLWPCS_ACT_NONE; P.alpha = d->alpha; P.vmax = d->vmax;
-    rc = dispatch_conv(d->ksize, d->Cout % 4 == 0, P, s);
+    rc = dispatch_conv(d->ksize, d->Cout % 4 == 0, P, conv_work(d), s);
     if (rc) return rc;
     // dxv is the gradient of the (halo-padded, if halo) virtual input: (B,6,Nv,Nv,Cin), Nv = No + k - 1
     // halo: Nv = N + 2; plain: Nv = N.  Route to the sources (inverse halo gather, upsample adjoint, channel split).
@@ -774,7 +796,13 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));    \
         }                                                                                                                 \
+        int pidx = -1;                                                                                                    \
+        if (prof_enabled()) {                                                                                             \
+            const Work wk = conv_work(d);                                                                                 \
+            pidx = prof_begin("wgrad_mfma_kernel<" #KSV ", " #VECV ">", wk.flops, wk.bytes, s);                           \
+        }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, W);                                                             \
+        if (pidx >= 0) prof_end(pidx, s);                                                                                 \
     } while (0)
     if (KS == 3) { if (vec) WG_LAUNCH(3, true); else WG_LAUNCH(3, false); }
     else { if (vec) WG_LAUNCH(1, true); else WG_LAUNCH(1, false); }

@@ -195,6 +195,17 @@ int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float *loss_out, 
 int dlwpcs_adam_step(float *p, const float *g, float *m, float *v, size_t n, int32_t *step_dev,
                      float lr, float beta1, float beta2, float eps, float grad_scale, dlwpcs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------- *
+ * Opt-in launch profiler (bench.py `roofline`): when enabled, every MFMA convolution kernel launch is bracketed by two
+ * HIP events recorded on the launch stream.  Off by default; do not enable while a stream is being graph-captured.
+ * dlwpcs_prof_get: tag = kernel name as rocprofv3 prints it (template arguments included), ms = event-elapsed time,
+ * flops / bytes = ALGORITHMIC work of that launch (2*B*6*N^2*k^2*Cin*Cout; unpadded tensors touched once + weights).
+ * ------------------------------------------------------------------------------------------------------------- */
+int dlwpcs_prof_enable(int on);
+int dlwpcs_prof_reset(void);
+int dlwpcs_prof_count(void);
+int dlwpcs_prof_get(int i, char *tag, int tag_len, double *ms, double *flops, double *bytes);
+
 #ifdef __cplusplus
 }
 #endif

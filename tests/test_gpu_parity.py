@@ -226,7 +226,7 @@ def test_layers_golden_g3(golden_dir):
         if use_bias:
             weights += [g['b_eq'], g['b_pol']] + ([g['b_np']] if indep else [])
         lay.set_weights(weights)
-        y = lay(to_dev(xin)).cpu().numpy()
+        y = lay(to_dev(xin)).detach().cpu().numpy()
         assert y.shape == tuple(lay.compute_output_shape(xin.shape))
         assert rel_err(y, g[name]) < RTOL, name
 
