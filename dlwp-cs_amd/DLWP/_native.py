@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libdlwpcs.so')
 F32 = 0
 ACT_NONE = 0
 ACT_LEAKY_CLIP = 1
+CONV_ACCUMULATE_WGRAD = 1
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -29,7 +30,7 @@ class ConvDesc(ctypes.Structure):
                 ('Cout', ctypes.c_int32), ('ksize', ctypes.c_int32), ('halo', ctypes.c_int32),
                 ('up0', ctypes.c_int32), ('flip_north_pole', ctypes.c_int32), ('act', ctypes.c_int32),
                 ('alpha', ctypes.c_float), ('vmax', ctypes.c_float), ('dtype', ctypes.c_int32),
-                ('reserved', ctypes.c_int32)]
+                ('flags', ctypes.c_int32)]
 
 
 class GConvDesc(ctypes.Structure):

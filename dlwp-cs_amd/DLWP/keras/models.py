@@ -298,7 +298,11 @@ class Model(object):
         stats = [ops.mse_mae(o, t, w) for o, t, w in zip(outs, targets, self.loss_weights)]
         if train:
             ones = [torch.ones(2, dtype=torch.float32, device=stats[0].device) for _ in stats]
-            torch.autograd.backward(stats, ones)
+            ops.DIRECT_PARAM_GRADS = True       # weight gradients accumulate straight into the flat gradient buffer
+            try:
+                torch.autograd.backward(stats, ones)
+            finally:
+                ops.DIRECT_PARAM_GRADS = False
         return torch.stack([s.detach() for s in stats])
 
     def _apply_gradients(self):

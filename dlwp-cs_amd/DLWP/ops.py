@@ -10,6 +10,10 @@ import torch
 from . import _native as nat
 from ._native import ConvDesc, GConvDesc, check, lib, ptr, require_device, stream_ptr
 
+# When True, convolution backward accumulates weight gradients directly into the parameters' preset `.grad` buffers
+# (DLWP.keras.Model turns this on around its training step; plain autograd use keeps the standard semantics).
+DIRECT_PARAM_GRADS = False
+
 # workspace: one growing byte buffer per device (caller-owned from the library's point of view)
 _workspaces = {}
 
@@ -70,7 +74,7 @@ def cs_pad(x, p):
 def _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax):
     return ConvDesc(B=B, N=N, C0=C0, C1=C1, Cout=Cout, ksize=ksize, halo=int(halo), up0=int(up0),
                     flip_north_pole=int(flip), act=int(act), alpha=float(alpha), vmax=float(vmax), dtype=nat.F32,
-                    reserved=0)
+                    flags=0)
 
 
 class _CSConv(torch.autograd.Function):
@@ -115,6 +119,8 @@ class _CSConv(torch.autograd.Function):
         ctx.desc = d
         ctx.tables = (table, inv)
         ctx.has = (src1 is not None, w_np is not None, b_eq is not None, b_np is not None)
+        # parameter objects (leaves whose .grad may be a view into the model's flat gradient buffer, see backward)
+        ctx.params = (w_eq, w_pol, w_np, b_eq, b_pol, b_np)
         ctx.save_for_backward(src0, src1, w_eq, w_pol, w_np, y if act != nat.ACT_NONE else None)
         return y
 
@@ -136,7 +142,21 @@ class _CSConv(torch.autograd.Function):
                                              ptr(dsrc0), ptr(dsrc1), ptr(inv), ptr(ws), ws.numel(), stream_ptr()),
                   'dlwpcs_conv_bwd_data')
         dw_eq = dw_pol = dw_np = db_eq = db_pol = db_np = None
-        if need[2] or need[3] or need[4] or need[5] or need[6] or need[7]:
+        if DIRECT_PARAM_GRADS and (need[2] or need[3]) and all(
+                p is None or (p.is_leaf and p.grad is not None and p.grad.is_contiguous()) for p in ctx.params):
+            # Accumulate straight into the preset .grad buffers (views of the model's flat gradient buffer, zeroed once
+            # per step): no temporaries, no AccumulateGrad add kernels; shared layers simply accumulate twice.
+            pe, pp, pn, be, bp, bn = ctx.params
+            d2 = ConvDesc.from_buffer_copy(d)
+            d2.flags = d.flags | nat.CONV_ACCUMULATE_WGRAD
+            check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d2), ptr(src0), ptr(src1), ptr(dy), ptr(y), ptr(pe.grad),
+                                                ptr(pp.grad), ptr(None if pn is None else pn.grad),
+                                                ptr(None if be is None else be.grad),
+                                                ptr(None if bp is None else bp.grad),
+                                                ptr(None if bn is None else bn.grad),
+                                                ptr(table), ptr(ws), ws.numel(), stream_ptr()),
+                  'dlwpcs_conv_bwd_weights')
+        elif need[2] or need[3] or need[4] or need[5] or need[6] or need[7]:
             dw_eq, dw_pol = torch.empty_like(w_eq), torch.empty_like(w_pol)
             dw_np = torch.empty_like(w_np) if has_np else None
             if has_bias:

@@ -72,77 +72,69 @@ __device__ __forceinline__ bool resolve_cell(const ConvKParams &P, int f, int iy
     return (vy >= 0) & (vy < P.Nin) & (vx >= 0) & (vx < P.Nin);
 }
 
-// Stage channels [c_begin, c_begin+NCH) of tile rows [y0, y0+rows) (padded coords) into lds[pix][STRIDE].
-template <int KS, int NCH, int STRIDE, bool VEC, int NTHREADS>
-__device__ __forceinline__ void stage_input(const ConvKParams &P, float *lds, int b, int f, int y0, int rows, int c_begin) {
-    const int tile_pix = rows * P.W2;
-    const int tid = threadIdx.x;
-    if (VEC) {
-        constexpr int Q = NCH / 4;
-        for (int item = tid; item < tile_pix * Q; item += NTHREADS) {
-            const int pix = item / Q, q = item % Q;
-            const int ty = __umulhi((uint32_t)pix, P.magicW2);
-            const int tx = pix - ty * P.W2;
-            const int c = c_begin + q * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int vf, vy, vx;
-            if (c < P.Cin && resolve_cell<KS>(P, f, y0 + ty, tx, vf, vy, vx)) {
-                if (c < P.C0) {
-                    const int g = P.up0 ? (P.Nin >> 1) : P.Nin;
-                    const int sy = P.up0 ? (vy >> 1) : vy, sx = P.up0 ? (vx >> 1) : vx;
-                    const size_t off = ((((size_t)b * 6 + vf) * g + sy) * g + sx) * P.C0 + c;
-                    v = *reinterpret_cast<const float4 *>(P.src0 + off);
-                    if (P.ymask) {
-                        const float4 yv = *reinterpret_cast<const float4 *>(P.ymask + off);
-                        v.x *= act_leaky_clip_grad_from_y(yv.x, P.alpha, P.vmax);
-                        v.y *= act_leaky_clip_grad_from_y(yv.y, P.alpha, P.vmax);
-                        v.z *= act_leaky_clip_grad_from_y(yv.z, P.alpha, P.vmax);
-                        v.w *= act_leaky_clip_grad_from_y(yv.w, P.alpha, P.vmax);
-                    }
-                } else {
-                    const size_t off = ((((size_t)b * 6 + vf) * P.Nin + vy) * P.Nin + vx) * P.C1 + (c - P.C0);
-                    v = *reinterpret_cast<const float4 *>(P.src1 + off);
-                }
-            }
-            *reinterpret_cast<float4 *>(lds + pix * STRIDE + q * 4) = v;
-        }
-    } else {
-        for (int item = tid; item < tile_pix * NCH; item += NTHREADS) {
-            const int pix = item / NCH, q = item % NCH;
-            const int ty = __umulhi((uint32_t)pix, P.magicW2);
-            const int tx = pix - ty * P.W2;
-            const int c = c_begin + q;
-            float v = 0.f;
-            int vf, vy, vx;
-            if (c < P.Cin && resolve_cell<KS>(P, f, y0 + ty, tx, vf, vy, vx)) {
-                if (c < P.C0) {
-                    const int g = P.up0 ? (P.Nin >> 1) : P.Nin;
-                    const int sy = P.up0 ? (vy >> 1) : vy, sx = P.up0 ? (vx >> 1) : vx;
-                    const size_t off = ((((size_t)b * 6 + vf) * g + sy) * g + sx) * P.C0 + c;
-                    v = P.src0[off];
-                    if (P.ymask) v *= act_leaky_clip_grad_from_y(P.ymask[off], P.alpha, P.vmax);
-                } else {
-                    v = P.src1[((((size_t)b * 6 + vf) * P.Nin + vy) * P.Nin + vx) * P.C1 + (c - P.C0)];
-                }
-            }
-            lds[pix * STRIDE + q] = v;
-        }
-    }
+// VW consecutive channels as one register vector
+template <int VW> struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<2> { typedef float2 type; };
+template <> struct VecT<4> { typedef float4 type; };
+
+__device__ __forceinline__ void vzero(float &v) { v = 0.f; }
+__device__ __forceinline__ void vzero(float2 &v) { v = make_float2(0.f, 0.f); }
+__device__ __forceinline__ void vzero(float4 &v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vmask(float &v, const float &y, float a, float m) { v *= act_leaky_clip_grad_from_y(y, a, m); }
+__device__ __forceinline__ void vmask(float2 &v, const float2 &y, float a, float m) {
+    v.x *= act_leaky_clip_grad_from_y(y.x, a, m); v.y *= act_leaky_clip_grad_from_y(y.y, a, m);
+}
+__device__ __forceinline__ void vmask(float4 &v, const float4 &y, float a, float m) {
+    v.x *= act_leaky_clip_grad_from_y(y.x, a, m); v.y *= act_leaky_clip_grad_from_y(y.y, a, m);
+    v.z *= act_leaky_clip_grad_from_y(y.z, a, m); v.w *= act_leaky_clip_grad_from_y(y.w, a, m);
+}
+__device__ __forceinline__ float vsel(bool c, float v) { return c ? v : 0.f; }
+__device__ __forceinline__ float2 vsel(bool c, float2 v) { return c ? v : make_float2(0.f, 0.f); }
+__device__ __forceinline__ float4 vsel(bool c, float4 v) { return c ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// Per-sample-relative element offsets of tile pixel `pix` in src0 (off0) and src1 (off1); -1 = zero cell.
+// This is where the cube-sphere halo (table gather), the nearest-upsampling of src0 and the zero border of the data
+// gradient are resolved.  It runs ONCE per tile and item (the result is channel-chunk invariant) so that the per-chunk
+// fetch below is straight-line code: every load of a chunk is issued back to back and stays in flight.
+template <int KS>
+__device__ __forceinline__ void source_offsets(const ConvKParams &P, int f, int y0, int pix, bool in_tile, int &off0, int &off1) {
+    const int ty = __umulhi((uint32_t)pix, P.magicW2);
+    const int tx = pix - ty * P.W2;
+    int vf, vy, vx;
+    const bool ok = in_tile && resolve_cell<KS>(P, f, y0 + ty, tx, vf, vy, vx);
+    if (!ok) { off0 = -1; off1 = -1; return; }
+    const int g = P.up0 ? (P.Nin >> 1) : P.Nin;
+    const int sy = P.up0 ? (vy >> 1) : vy, sx = P.up0 ? (vx >> 1) : vx;
+    off0 = ((vf * g + sy) * g + sx) * P.C0;
+    off1 = ((vf * P.Nin + vy) * P.Nin + vx) * P.C1;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Forward / data-gradient kernel
+// Forward / data-gradient kernel: software-pipelined over KC-channel chunks.
+//   chunk c+1 is fetched from HBM/L2 into registers (input tile with halo + packed weights) while the matrix cores work
+//   on chunk c out of LDS; the registers are written to the other LDS buffer afterwards; ONE barrier per chunk.
+//   LDS per buffer: input tile rows*W2 pixels x (KC+4) floats + weights NTB*KCG*TAPS*256 floats; two buffers; sized so
+//   that two workgroups fit a CU (KC = 8: 2*(24+9) KB at N = 48), i.e. two waves per SIMD feed each matrix core.
+//   MASK: data-gradient mode with an activation: dz = dy * act'(y) applied while fetching.
 // ------------------------------------------------------------------------------------------------------------------
-template <int KS, int KC, int MT, int NT, int WM, int WN, bool VEC>
-__global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvKParams P) {
+template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, bool MASK>
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvKParams P) {
     constexpr int TAPS = KS * KS;
     constexpr int KCP = KC + 4;
     constexpr int KCG = KC / 8;
+    constexpr int Q = KC / VW;                      // vectors per pixel per chunk
     constexpr int NTB = NT * WN;
     constexpr int NTHREADS = 64 * WM * WN;
+    constexpr int IT_IN = 3 * KC / VW;              // input vectors per thread per chunk: capacity 3*NTHREADS pixels
+    constexpr int WF4 = NTB * KCG * TAPS * 64;      // float4 per weight chunk
+    constexpr int IT_W = (WF4 + NTHREADS - 1) / NTHREADS;
+    constexpr int GF4 = TAPS * 64;                  // float4 per (n tile, channel group)
+    static_assert(NTHREADS % Q == 0, "thread -> channel-vector mapping must not depend on the item");
+    typedef typename VecT<VW>::type V;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *lds_in = smem;
-    float *lds_w = smem + P.tile_rows_max * P.W2 * KCP;
+    const int in_floats = P.tile_rows_max * P.W2 * KCP;
+    const int buf_floats = in_floats + WF4 * 4;
 
     const uint32_t nblk = gridDim.x;
     const uint32_t L = xcd_remap(blockIdx.x, nblk);
@@ -157,14 +149,23 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvKPara
     const int y0 = __umulhi((uint32_t)m0, P.magicNo);
     const int ylast = __umulhi((uint32_t)(m0 + npix - 1), P.magicNo);
     const int rows = ylast - y0 + KS;
+    const int nitems = rows * P.W2 * Q;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
     const int v = f < 4 ? 0 : (f == 4 ? 1 : 2);
+    const float4 *wsrc = reinterpret_cast<const float4 *>(P.wpk);
 
-    // per-lane LDS base (in floats) of the A operand for each of this wave's M tiles
+    // sample bases of the sources (src1 aliases src0 when absent so that the straight-line fetch never dereferences null)
+    const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
+    const float *s0b = P.src0 + (size_t)b * 6 * g0 * g0 * P.C0;
+    const float *s1b = P.C1 > 0 ? P.src1 + (size_t)b * 6 * P.Nin * P.Nin * P.C1 : s0b;
+    const float *ymb = MASK ? P.ymask + (size_t)b * 6 * g0 * g0 * P.C0 : nullptr;
+    const int qv = (tid % Q) * VW;                  // channel offset of this thread's vectors inside a chunk
+
+    // per-lane LDS offset (floats) of the A operand for each of this wave's M tiles
     int abase[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -187,28 +188,65 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvKPara
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    const int nchunks = (P.CG + KCG - 1) / KCG;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int ncg = min(KCG, P.CG - ch * KCG);
-        stage_input<KS, KC, KCP, VEC, NTHREADS>(P, lds_in, b, f, y0, rows, ch * KC);
-        // weights of this chunk: for each of the block's N tiles, ncg contiguous groups of TAPS*256 floats
-        {
-            constexpr int GF4 = TAPS * 64;   // float4 per (ntile, cg)
-            const int total = NTB * ncg * GF4;
-            for (int it = tid; it < total; it += NTHREADS) {
-                const int g = it / GF4, w = it % GF4;
-                const int ntl = g / ncg, cgl = g % ncg;
-                const int ntile = nt0 + ntl;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ntile < P.NTtot) {
-                    const size_t src = ((((size_t)v * P.NTtot + ntile) * P.CG + (ch * KCG + cgl)) * GF4 + w);
-                    val = reinterpret_cast<const float4 *>(P.wpk)[src];
-                }
-                reinterpret_cast<float4 *>(lds_w)[(ntl * KCG + cgl) * GF4 + w] = val;
+    V pre_in[IT_IN];
+    float4 pre_w[IT_W];
+    int off0[IT_IN], off1[IT_IN];
+
+    auto prepare = [&](int batch) {
+#pragma unroll
+        for (int i = 0; i < IT_IN; ++i) {
+            const int e = tid + (batch * IT_IN + i) * NTHREADS;
+            source_offsets<KS>(P, f, y0, e / Q, e < nitems, off0[i], off1[i]);
+        }
+    };
+    // straight-line: every load of the chunk is issued back to back, nothing waits until commit()
+    auto fetch = [&](int ch, bool with_weights) {
+        const int c = ch * KC + qv;
+        const bool c_ok = c < P.Cin;
+        const bool from0 = c < P.C0;
+#pragma unroll
+        for (int i = 0; i < IT_IN; ++i) {
+            const int o = from0 ? off0[i] : off1[i];
+            const bool ok = c_ok && o >= 0;
+            const float *ptr = ok ? (from0 ? s0b + (size_t)o + c : s1b + (size_t)o + (c - P.C0)) : s0b;
+            V val = *reinterpret_cast<const V *>(ptr);
+            if (MASK) {
+                const float *yp = ok ? ymb + (size_t)o + c : ymb;
+                vmask(val, *reinterpret_cast<const V *>(yp), P.alpha, P.vmax);
+            }
+            pre_in[i] = vsel(ok, val);
+        }
+        if (with_weights) {
+#pragma unroll
+            for (int i = 0; i < IT_W; ++i) {
+                const int idx = min(tid + i * NTHREADS, WF4 - 1);
+                const int g = idx / GF4, w = idx % GF4;
+                const int ntl = g / KCG, cgl = g % KCG;
+                const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
+                const bool ok = ntile < P.NTtot && cg < P.CG;
+                const float4 val = wsrc[ok ? (((size_t)v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0];
+                pre_w[i] = vsel(ok, val);
             }
         }
-        __syncthreads();
-        for (int cgl = 0; cgl < ncg; ++cgl) {
+    };
+    auto commit = [&](float *buf, int batch, bool with_weights) {
+#pragma unroll
+        for (int i = 0; i < IT_IN; ++i) {
+            const int e = tid + (batch * IT_IN + i) * NTHREADS;
+            if (e < nitems) *reinterpret_cast<V *>(buf + (e / Q) * KCP + qv) = pre_in[i];
+        }
+        if (with_weights) {
+#pragma unroll
+            for (int i = 0; i < IT_W; ++i) {
+                const int idx = tid + i * NTHREADS;
+                if (idx < WF4) reinterpret_cast<float4 *>(buf + in_floats)[idx] = pre_w[i];
+            }
+        }
+    };
+    auto compute = [&](const float *buf) {
+        const float *lds_in = buf, *lds_w = buf + in_floats;
+#pragma unroll
+        for (int cgl = 0; cgl < KCG; ++cgl) {
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int dy = tap / KS, dx = tap % KS;
@@ -231,7 +269,32 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvKPara
                     }
             }
         }
+    };
+
+    const int nchunks = (P.CG + KCG - 1) / KCG;
+    const int nbatch = (nitems + IT_IN * NTHREADS - 1) / (IT_IN * NTHREADS);
+    if (nbatch == 1) {
+        prepare(0);
+        fetch(0, true);
+        commit(smem, 0, true);
         __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            float *cur = smem + (ch & 1) * buf_floats;
+            float *nxt = smem + ((ch + 1) & 1) * buf_floats;
+            const bool more = ch + 1 < nchunks;
+            if (more) fetch(ch + 1, true);       // global loads stay in flight while the matrix cores run
+            compute(cur);
+            if (more) commit(nxt, 0, true);
+            __syncthreads();
+        }
+    } else {
+        // tile wider than the register prefetch capacity (N >~ 256): stage synchronously, single buffer
+        for (int ch = 0; ch < nchunks; ++ch) {
+            for (int bt = 0; bt < nbatch; ++bt) { prepare(bt); fetch(ch, bt == 0); commit(smem, bt, bt == 0); }
+            __syncthreads();
+            compute(smem);
+            __syncthreads();
+        }
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31 (output channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
@@ -311,53 +374,80 @@ __global__ void __launch_bounds__(256) pack_bias_kernel(const float *__restrict_
 // pole, tap rows reversed when flip_north_pole).
 // ------------------------------------------------------------------------------------------------------------------
 struct WgradKParams {
-    ConvKParams c;          // loader description of the virtual input (src0/src1/table/mode/...), ymask unused here
+    ConvKParams c;          // description of the virtual input (src0/src1/table/mode/...), ymask unused here
     const float *dy, *y;    // (B,6,No,No,Cout); y nullable
-    float *partial;         // [nslots][TAPS][CinP][CoutP]
-    float *bpartial;        // [nslots][CoutP] or nullptr
+    float *partial;         // [nworkers][TAPS][CinP][CoutP]
+    float *bpartial;        // [nworkers][CoutP] or nullptr
     int CinP, CoutP;        // multiples of 32
-    int NB;                 // samples per workgroup
-    int ngroups;            // ceil(B / NB)
-    int mask_act;
+    int n_eq, n_4, n_5;     // workers per face class (equatorial faces 0-3 / face 4 / face 5); grid.x = their sum
+    int pipelined;          // two LDS buffers + register prefetch (else synchronous staging, one buffer)
+    uint32_t magicN, magicN2;
 };
 
-template <int KS, bool VEC>
-__global__ void __launch_bounds__(256, 2) wgrad_mfma_kernel(const WgradKParams W) {
+// Weight-gradient kernel, persistent form.  GEMM view per tap: D[ci][co] += sum_pixels Xpad[pixel+tap][ci] * dZ[pixel][co],
+// dZ = dy * act'(y).  The accumulators D (k*k taps x 32 x 32, 9 x 16 VGPRs per lane) do not depend on WHICH pixels are
+// summed, so a worker (workgroup of 8 waves, one per CU) owns one (ci tile, co tile) pair and streams through a STATIC,
+// strided list of work items (sample, face, band of <= 192 pixels) of its face class; per item the 8 waves split the
+// pixel pairs (MFMA K = 2 pixels).  Two-deep software pipeline across items: while item t is on the matrix cores, the
+// X / dZ tiles of item t+1 are in flight to registers and the halo-table entries of item t+2 are being read.
+// At the end the 8 waves are summed through LDS in a fixed order and ONE partial per worker is written; a second kernel
+// adds the workers' partials in a fixed order per face class (no atomics -> bitwise reproducible) and applies the
+// weight-group map (class 0 -> equatorial kernel, 1 -> polar, 2 -> polar or north pole, tap rows reversed when flipping).
+template <int KS, int VW, bool MASK>
+__global__ void __launch_bounds__(512, 2) wgrad_mfma_kernel(const WgradKParams W) {
     constexpr int TAPS = KS * KS;
-    constexpr int XS = 32;      // X tile row stride (floats)
+    constexpr int XS = 32;                  // X tile row stride (floats) = the 32 input channels of this ci tile
+    constexpr int QX = 32 / VW;             // vectors per X pixel
+    constexpr int IT_X = 28 / VW;           // X vectors per thread per item: capacity 448 tile pixels
+    constexpr int IT_DY = 3;                // dZ float4 per thread per item: capacity 192 pixels (x 8 float4)
+    constexpr int NT_ = 512;
+    typedef typename VecT<VW>::type V;
     const ConvKParams &P = W.c;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *lds_x = smem;                                              // [tile_rows_max*W2][32]
-    float *lds_dy = lds_x + P.tile_rows_max * P.W2 * XS;              // [pix_cap][32]
     const int pix_cap = (P.pix_per_block + 1) & ~1;
-    int *lds_pb = reinterpret_cast<int *>(lds_dy + pix_cap * 32);     // [pix_cap] tile offsets of each output pixel
-    // reduction scratch aliases the X tile after the main loop (needs 4*1024 floats = 16 KB)
+    const int x_floats = P.tile_rows_max * P.W2 * XS;
+    const int buf_floats = x_floats + pix_cap * 32 + pix_cap;      // X tile, dZ tile, per-pixel X offsets
+    // the 32 KB cross-wave reduction scratch aliases the buffers after the main loop
 
-    const uint32_t L = xcd_remap(blockIdx.x, gridDim.x);
-    const int grp = L % W.ngroups;
-    const int blk = (L / W.ngroups) % P.nblk_face;
-    const int f = L / (W.ngroups * P.nblk_face);
+    const int worker = blockIdx.x;
     const int cit = blockIdx.y, cot = blockIdx.z;
+    int j, nj, nfaces, fbase;
+    if (worker < W.n_eq) { j = worker; nj = W.n_eq; nfaces = 4; fbase = 0; }
+    else if (worker < W.n_eq + W.n_4) { j = worker - W.n_eq; nj = W.n_4; nfaces = 1; fbase = 4; }
+    else { j = worker - W.n_eq - W.n_4; nj = W.n_5; nfaces = 1; fbase = 5; }
+    const int nbands = P.nblk_face;
+    const int total_items = P.B * nfaces * nbands;
+    const int n_my = j < total_items ? (total_items - j + nj - 1) / nj : 0;
 
     const int face_pix = P.No * P.No;
-    const int m0 = blk * P.pix_per_block;
-    const int npix = min(P.pix_per_block, face_pix - m0);
-    const int y0 = __umulhi((uint32_t)m0, P.magicNo);
-    const int ylast = __umulhi((uint32_t)(m0 + npix - 1), P.magicNo);
-    const int rows = ylast - y0 + KS;
+    const bool vec_dy = (P.Cout % 4 == 0);
+    const int nitems_dy = vec_dy ? pix_cap * 8 : pix_cap * 32;
+    const int M = P.Nin + KS - 1;           // padded face size (MODE_HALO)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
+    const int cx = cit * 32 + (tid % QX) * VW;          // this thread's input channel(s): fixed for the whole kernel
+    const bool cx_ok = cx < P.Cin;
+    const bool from0 = cx < P.C0;
+    const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
+    const int csub = from0 ? cx : cx - P.C0;
+    const int cstride = from0 ? P.C0 : P.C1;
 
-    for (int k = tid; k < pix_cap; k += 256) {
-        int base = 0;
-        if (k < npix) {
-            const int gm = m0 + k;
-            const int oy = __umulhi((uint32_t)gm, P.magicNo);
-            base = ((oy - y0) * P.W2 + (gm - oy * P.No)) * XS;
-        }
-        lds_pb[k] = base;
-    }
+    struct Item { int b, f, m0, npix, y0, rows; };
+    auto item_of = [&](int k) {
+        Item it;
+        const int t = j + k * nj;
+        const int band = t % nbands;
+        const int r = t / nbands;
+        it.f = fbase + r % nfaces;
+        it.b = r / nfaces;
+        it.m0 = band * P.pix_per_block;
+        it.npix = min(P.pix_per_block, face_pix - it.m0);
+        it.y0 = __umulhi((uint32_t)it.m0, P.magicNo);
+        const int ylast = __umulhi((uint32_t)(it.m0 + it.npix - 1), P.magicNo);
+        it.rows = ylast - it.y0 + KS;
+        return it;
+    };
 
     f32x16 acc[TAPS];
 #pragma unroll
@@ -366,52 +456,121 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_kernel(const WgradKParams W
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;   // bias partial: thread (co = tid&31, part = tid>>5)
 
-    const int nsteps = pix_cap / 2;
-    const int b_begin = grp * W.NB, b_end = min(P.B, b_begin + W.NB);
-    for (int b = b_begin; b < b_end; ++b) {
-        __syncthreads();   // previous sample's tiles fully consumed (also orders lds_pb on the first pass)
-        stage_input<KS, 32, XS, VEC, 256>(P, lds_x, b, f, y0, rows, cit * 32);
-        // dZ tile: [pix][32 output channels of tile cot], masked by act'(y), zero beyond npix / Cout
-        {
-            const float *dyb = W.dy + (((size_t)b * 6 + f) * face_pix + m0) * P.Cout;
-            const float *yb = W.y ? W.y + (((size_t)b * 6 + f) * face_pix + m0) * P.Cout : nullptr;
-            const bool vec_dy = (P.Cout % 4 == 0);
-            if (vec_dy) {
-                for (int it = tid; it < pix_cap * 8; it += 256) {
-                    const int k = it >> 3, q = it & 7;
-                    const int co = cot * 32 + q * 4;
-                    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k < npix && co < P.Cout) {
-                        g = *reinterpret_cast<const float4 *>(dyb + (size_t)k * P.Cout + co);
-                        if (W.mask_act) {
-                            const float4 yv = *reinterpret_cast<const float4 *>(yb + (size_t)k * P.Cout + co);
-                            g.x *= act_leaky_clip_grad_from_y(yv.x, P.alpha, P.vmax);
-                            g.y *= act_leaky_clip_grad_from_y(yv.y, P.alpha, P.vmax);
-                            g.z *= act_leaky_clip_grad_from_y(yv.z, P.alpha, P.vmax);
-                            g.w *= act_leaky_clip_grad_from_y(yv.w, P.alpha, P.vmax);
-                        }
-                    }
-                    *reinterpret_cast<float4 *>(lds_dy + k * 32 + q * 4) = g;
-                }
+    V pre_x[IT_X];
+    float4 pre_dy[IT_DY];
+    int tbl[IT_X];      // stage A: raw halo-table entries of item k+2 (or tile coordinates when there is no halo)
+    int off[IT_X];      // stage B: element offsets (per sample) of item k+1, -1 = nothing to load
+
+    // stage A: read the halo table for the tile pixels of an item (flat source index on the Nin grid)
+    auto issue_table = [&](const Item &it, int batch) {
+        const int nitems_x = it.rows * P.W2 * QX;
+#pragma unroll
+        for (int i = 0; i < IT_X; ++i) {
+            const int e = min(tid + (batch * IT_X + i) * NT_, nitems_x - 1);
+            const int pix = e / QX;
+            const int ty = __umulhi((uint32_t)pix, P.magicW2);
+            const int tx = pix - ty * P.W2;
+            if (P.mode == MODE_HALO) tbl[i] = P.table[(it.f * M + it.y0 + ty) * M + tx];
+            else tbl[i] = (it.f * P.Nin + it.y0 + ty) * P.Nin + tx;          // MODE_DIRECT: identity
+        }
+    };
+    // stage B: table entry -> element offset into the source this thread reads (upsampling folded in)
+    auto make_offsets = [&](const Item &it, int batch) {
+        const int nitems_x = it.rows * P.W2 * QX;
+#pragma unroll
+        for (int i = 0; i < IT_X; ++i) {
+            const int e = tid + (batch * IT_X + i) * NT_;
+            const int idx = tbl[i];
+            const int vf = __umulhi((uint32_t)idx, W.magicN2);
+            const int rem = idx - vf * P.Nin * P.Nin;
+            const int vy = __umulhi((uint32_t)rem, W.magicN);
+            const int vx = rem - vy * P.Nin;
+            int o;
+            if (from0) {
+                const int sy = P.up0 ? (vy >> 1) : vy, sx = P.up0 ? (vx >> 1) : vx;
+                o = ((vf * g0 + sy) * g0 + sx) * P.C0;
             } else {
-                for (int it = tid; it < pix_cap * 32; it += 256) {
-                    const int k = it >> 5, q = it & 31;
-                    const int co = cot * 32 + q;
-                    float g = 0.f;
-                    if (k < npix && co < P.Cout) {
-                        g = dyb[(size_t)k * P.Cout + co];
-                        if (W.mask_act) g *= act_leaky_clip_grad_from_y(yb[(size_t)k * P.Cout + co], P.alpha, P.vmax);
-                    }
-                    lds_dy[k * 32 + q] = g;
+                o = idx * P.C1;
+            }
+            off[i] = (e < nitems_x && cx_ok) ? o + csub : -1;
+        }
+        (void)cstride;
+    };
+    // stage C: straight-line loads of the X tile (through the offsets) and of the dZ tile
+    auto issue_data = [&](const Item &it, int batch) {
+        const float *sb = from0 ? P.src0 + (size_t)it.b * 6 * g0 * g0 * P.C0
+                                : P.src1 + (size_t)it.b * 6 * P.Nin * P.Nin * P.C1;
+#pragma unroll
+        for (int i = 0; i < IT_X; ++i) {
+            const bool ok = off[i] >= 0;
+            const V val = *reinterpret_cast<const V *>(ok ? sb + (size_t)off[i] : P.src0);
+            pre_x[i] = vsel(ok, val);
+        }
+        const size_t rowbase = (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * P.Cout;
+        const float *dyb = W.dy + rowbase;
+        const float *yb = MASK ? W.y + rowbase : nullptr;
+#pragma unroll
+        for (int i = 0; i < IT_DY; ++i) {
+            const int e = tid + (batch * IT_DY + i) * NT_;
+            if (vec_dy) {
+                const int k = e >> 3, co = cot * 32 + (e & 7) * 4;
+                const bool ok = e < nitems_dy && k < it.npix && co < P.Cout;
+                const size_t o = ok ? (size_t)k * P.Cout + co : 0;
+                float4 g = *reinterpret_cast<const float4 *>(dyb + o);
+                if (MASK) vmask(g, *reinterpret_cast<const float4 *>(yb + o), P.alpha, P.vmax);
+                pre_dy[i] = vsel(ok, g);
+            } else {
+                // scalar dZ path (Cout % 4 != 0): 4 consecutive scalars per slot
+                float gs[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e4 = e * 4 + u;
+                    const int k = e4 >> 5, co = cot * 32 + (e4 & 31);
+                    const bool ok = e4 < nitems_dy && k < it.npix && co < P.Cout;
+                    const size_t o = ok ? (size_t)k * P.Cout + co : 0;
+                    float g = dyb[o];
+                    if (MASK) vmask(g, yb[o], P.alpha, P.vmax);
+                    gs[u] = ok ? g : 0.f;
                 }
+                pre_dy[i] = make_float4(gs[0], gs[1], gs[2], gs[3]);
             }
         }
-        __syncthreads();
+    };
+    auto commit = [&](float *buf, const Item &it, int batch) {
+        const int nitems_x = it.rows * P.W2 * QX;
+#pragma unroll
+        for (int i = 0; i < IT_X; ++i) {
+            const int e = tid + (batch * IT_X + i) * NT_;
+            if (e < nitems_x) *reinterpret_cast<V *>(buf + (e / QX) * XS + (tid % QX) * VW) = pre_x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < IT_DY; ++i) {
+            const int e = tid + (batch * IT_DY + i) * NT_;
+            // both dZ paths hold 4 consecutive floats of the [pix][32] tile per slot
+            if (e * 4 < pix_cap * 32) *reinterpret_cast<float4 *>(buf + x_floats + e * 4) = pre_dy[i];
+        }
+        if (batch == 0) {
+            int *pb = reinterpret_cast<int *>(buf + x_floats + pix_cap * 32);
+            for (int k = tid; k < pix_cap; k += NT_) {
+                int base = 0;
+                if (k < it.npix) {
+                    const int gm = it.m0 + k;
+                    const int oy = __umulhi((uint32_t)gm, P.magicNo);
+                    base = ((oy - it.y0) * P.W2 + (gm - oy * P.No)) * XS;
+                }
+                pb[k] = base;
+            }
+        }
+    };
+    const int nsteps = pix_cap / 2;
+    auto compute = [&](const float *buf, const Item &it) {
+        const float *lds_x = buf, *lds_dy = buf + x_floats;
+        const int *lds_pb = reinterpret_cast<const int *>(buf + x_floats + pix_cap * 32);
         if (W.bpartial && cit == 0) {
             const int co = tid & 31, part = tid >> 5;
-            for (int k = part; k < npix; k += 8) bsum += lds_dy[k * 32 + co];
+            for (int k = part; k < it.npix; k += 16) bsum += lds_dy[k * 32 + co];
         }
-        for (int s = wave; s < nsteps; s += 4) {
+        for (int s = wave; s < nsteps; s += 8) {
             const int k = 2 * s + half;
             const int pb = lds_pb[k];
             const float bval = lds_dy[k * 32 + l31];
@@ -422,13 +581,47 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_kernel(const WgradKParams W
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bval, acc[tap], 0, 0, 0);
             }
         }
-    }
-    __syncthreads();
+    };
 
-    // cross-wave reduction through LDS (fixed order w = 0..3), one tap at a time
-    const int slot = (f * P.nblk_face + blk) * W.ngroups + grp;
-    float *red = lds_x;
-    float *pout = W.partial + (size_t)slot * TAPS * W.CinP * W.CoutP;
+    if (W.pipelined) {
+        if (n_my > 0) {
+            const Item i0 = item_of(0);
+            issue_table(i0, 0);
+            make_offsets(i0, 0);
+            issue_data(i0, 0);
+            if (n_my > 1) issue_table(item_of(1), 0);
+            commit(smem, i0, 0);
+            if (n_my > 1) make_offsets(item_of(1), 0);
+        }
+        __syncthreads();
+        for (int k = 0; k < n_my; ++k) {
+            float *cur = smem + (k & 1) * buf_floats;
+            float *nxt = smem + ((k + 1) & 1) * buf_floats;
+            const Item it = item_of(k);
+            if (k + 1 < n_my) issue_data(item_of(k + 1), 0);       // uses off[] of item k+1
+            if (k + 2 < n_my) issue_table(item_of(k + 2), 0);      // table entries of item k+2 in flight
+            compute(cur, it);
+            if (k + 1 < n_my) commit(nxt, item_of(k + 1), 0);
+            if (k + 2 < n_my) make_offsets(item_of(k + 2), 0);
+            __syncthreads();
+        }
+    } else {
+        for (int k = 0; k < n_my; ++k) {
+            const Item it = item_of(k);
+            const int nbx = (it.rows * P.W2 * QX + IT_X * NT_ - 1) / (IT_X * NT_);
+            const int nbd = (nitems_dy + IT_DY * NT_ * (vec_dy ? 1 : 4) - 1) / (IT_DY * NT_ * (vec_dy ? 1 : 4));
+            const int nb = max(nbx, nbd);
+            __syncthreads();
+            for (int bt = 0; bt < nb; ++bt) { issue_table(it, bt); make_offsets(it, bt); issue_data(it, bt); commit(smem, it, bt); }
+            __syncthreads();
+            compute(smem, it);
+        }
+        __syncthreads();
+    }
+
+    // cross-wave reduction through LDS (fixed order w = 0..7), one tap at a time
+    float *red = smem;
+    float *pout = W.partial + (size_t)worker * TAPS * W.CinP * W.CoutP;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
@@ -438,9 +631,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_kernel(const WgradKParams W
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * 256;
-            const float sum = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * NT_;
+            const float sum = ((red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e])) +
+                              ((red[4096 + e] + red[5120 + e]) + (red[6144 + e] + red[7168 + e]));
             const int ci = e >> 5, co = e & 31;
             pout[((size_t)tap * W.CinP + cit * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
         }
@@ -452,46 +646,75 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_kernel(const WgradKParams W
         if (tid < 32) {
             float s = 0.f;
 #pragma unroll
-            for (int part = 0; part < 8; ++part) s += red[part * 32 + tid];
-            W.bpartial[(size_t)slot * W.CoutP + cot * 32 + tid] = s;
+            for (int part = 0; part < 16; ++part) s += red[part * 32 + tid];
+            W.bpartial[(size_t)worker * W.CoutP + cot * 32 + tid] = s;
         }
     }
 }
 
-// Sum the per-slot partials in fixed order and route them to the weight groups.
+// Sum the per-slot partials in a fixed order and route them to the weight groups.  Workgroup = 16 outputs x 16 slot
+// phases: thread (o, ph) adds slots ph, ph+16, ... (fixed order), the 16 phases are then combined through LDS in a fixed
+// tree -> bitwise reproducible, and enough workgroups (outputs/16) to fill the chip.  accumulate != 0: add to the
+// destination instead of overwriting it (shared layers / direct accumulation into the flat gradient buffer).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bpartial,
                                                            float *__restrict__ dw_eq, float *__restrict__ dw_pol,
                                                            float *__restrict__ dw_np, float *__restrict__ db_eq,
                                                            float *__restrict__ db_pol, float *__restrict__ db_np,
                                                            int KS, int Cin, int Cout, int CinP, int CoutP,
-                                                           int slots_per_face, int flip) {
+                                                           int n_eq, int n_4, int n_5, int flip, int accumulate) {
     const int TAPS = KS * KS;
     const int nW = TAPS * Cin * Cout;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + o;
     const size_t slot_stride = (size_t)TAPS * CinP * CoutP;
-    if (e < nW) {
+    float s_eq = 0.f, s_4 = 0.f, s_5 = 0.f;
+    const bool is_w = e < nW, is_b = (!is_w) && bpartial && e < nW + Cout;
+    const int e4 = n_eq, e5 = n_eq + n_4, e6 = n_eq + n_4 + n_5;
+    if (is_w) {
         const int co = e % Cout, ci = (e / Cout) % Cin, tap = e / (Cout * Cin);
         const size_t off = ((size_t)tap * CinP + ci) * CoutP + co;
         const int ty = tap / KS, tx = tap % KS;
-        const size_t off_flip = ((size_t)((KS - 1 - ty) * KS + tx) * CinP + ci) * CoutP + co;
-        float s_eq = 0.f, s_4 = 0.f, s_5 = 0.f;
-        for (int s = 0; s < 4 * slots_per_face; ++s) s_eq += partial[(size_t)s * slot_stride + off];
-        for (int s = 4 * slots_per_face; s < 5 * slots_per_face; ++s) s_4 += partial[(size_t)s * slot_stride + off];
         // face 5 ran with the row-reversed kernel: its partial for tap row r belongs to kernel row KS-1-r
-        const size_t o5 = flip ? off_flip : off;
-        for (int s = 5 * slots_per_face; s < 6 * slots_per_face; ++s) s_5 += partial[(size_t)s * slot_stride + o5];
-        dw_eq[e] = s_eq;
-        if (dw_np) { dw_pol[e] = s_4; dw_np[e] = s_5; }
-        else dw_pol[e] = s_4 + s_5;
-    } else if (bpartial && e < nW + Cout) {
+        const size_t o5 = flip ? ((size_t)((KS - 1 - ty) * KS + tx) * CinP + ci) * CoutP + co : off;
+        for (int s = ph; s < e4; s += 16) s_eq += partial[(size_t)s * slot_stride + off];
+        for (int s = e4 + ph; s < e5; s += 16) s_4 += partial[(size_t)s * slot_stride + off];
+        for (int s = e5 + ph; s < e6; s += 16) s_5 += partial[(size_t)s * slot_stride + o5];
+    } else if (is_b) {
         const int co = e - nW;
-        float s_eq = 0.f, s_4 = 0.f, s_5 = 0.f;
-        for (int s = 0; s < 4 * slots_per_face; ++s) s_eq += bpartial[(size_t)s * CoutP + co];
-        for (int s = 4 * slots_per_face; s < 5 * slots_per_face; ++s) s_4 += bpartial[(size_t)s * CoutP + co];
-        for (int s = 5 * slots_per_face; s < 6 * slots_per_face; ++s) s_5 += bpartial[(size_t)s * CoutP + co];
-        if (db_eq) db_eq[co] = s_eq;
-        if (db_np) { if (db_pol) db_pol[co] = s_4; db_np[co] = s_5; }
-        else if (db_pol) db_pol[co] = s_4 + s_5;
+        for (int s = ph; s < e4; s += 16) s_eq += bpartial[(size_t)s * CoutP + co];
+        for (int s = e4 + ph; s < e5; s += 16) s_4 += bpartial[(size_t)s * CoutP + co];
+        for (int s = e5 + ph; s < e6; s += 16) s_5 += bpartial[(size_t)s * CoutP + co];
+    }
+    __shared__ float red[3][256];
+    red[0][threadIdx.x] = s_eq; red[1][threadIdx.x] = s_4; red[2][threadIdx.x] = s_5;
+    __syncthreads();
+    for (int st = 8; st > 0; st >>= 1) {
+        if (ph < st) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + st * 16];
+            red[1][threadIdx.x] += red[1][threadIdx.x + st * 16];
+            red[2][threadIdx.x] += red[2][threadIdx.x + st * 16];
+        }
+        __syncthreads();
+    }
+    if (ph != 0) return;
+    s_eq = red[0][o]; s_4 = red[1][o]; s_5 = red[2][o];
+    if (is_w) {
+        if (accumulate) {
+            dw_eq[e] += s_eq;
+            if (dw_np) { dw_pol[e] += s_4; dw_np[e] += s_5; } else dw_pol[e] += s_4 + s_5;
+        } else {
+            dw_eq[e] = s_eq;
+            if (dw_np) { dw_pol[e] = s_4; dw_np[e] = s_5; } else dw_pol[e] = s_4 + s_5;
+        }
+    } else if (is_b) {
+        const int co = e - nW;
+        if (accumulate) {
+            if (db_eq) db_eq[co] += s_eq;
+            if (db_np) { if (db_pol) db_pol[co] += s_4; db_np[co] += s_5; } else if (db_pol) db_pol[co] += s_4 + s_5;
+        } else {
+            if (db_eq) db_eq[co] = s_eq;
+            if (db_np) { if (db_pol) db_pol[co] = s_4; db_np[co] = s_5; } else if (db_pol) db_pol[co] = s_4 + s_5;
+        }
     }
 }
 
@@ -510,7 +733,7 @@ static int tile_rows_for(int pix, int No) {
     return r > No ? No : r;
 }
 
-template <int KS, int KC, int MT, int NT, int WM, int WN, bool VEC>
+template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, bool MASK>
 static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
     const int face_pix = P.No * P.No;
@@ -527,9 +750,12 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     P.magicW2 = div_magic(P.W2);
     P.magicNo = div_magic(P.No);
     P.tile_rows_max = tile_rows_for(pix, P.No) + (KS - 1);
-    const size_t lds = ((size_t)P.tile_rows_max * P.W2 * (KC + 4) + (size_t)NTB * (KC / 8) * KS * KS * 256) * sizeof(float);
+    const size_t buf = ((size_t)P.tile_rows_max * P.W2 * (KC + 4) + (size_t)NTB * (KC / 8) * KS * KS * 256) * sizeof(float);
+    const size_t cap_items = (size_t)(3 * KC / VW) * NTHREADS;
+    const bool pipelined = (size_t)P.tile_rows_max * P.W2 * (KC / VW) <= cap_items;
+    const size_t lds = pipelined ? 2 * buf : buf;
     if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv: LDS tile of %zu bytes exceeds 160 KiB (N=%d)", lds, P.No);
-    auto kern = conv_mfma_kernel<KS, KC, MT, NT, WM, WN, VEC>;
+    auto kern = conv_mfma_kernel<KS, KC, MT, NT, WM, WN, VW, MASK>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -538,7 +764,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     int pidx = -1;
     if (prof_enabled()) {
         char tag[128];
-        snprintf(tag, sizeof(tag), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", KS, KC, MT, NT, WM, WN, VEC ? "true" : "false");
+        snprintf(tag, sizeof(tag), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", KS, KC, MT, NT, WM, WN, VW, MASK ? "true" : "false");
         pidx = prof_begin(tag, W.flops, W.bytes, s);
     }
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, P);
@@ -546,21 +772,36 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     return check_launch("conv_mfma");
 }
 
-template <int KS, bool VEC>
+template <int KS, int VW, bool MASK>
 static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
     const int face_pix = P.No * P.No;
-    if constexpr (KS == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VEC>(P, W, s);
+    if constexpr (KS == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VW, MASK>(P, W, s);
+    else if constexpr (VW != 4) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MASK>(P, W, s);   // odd channel counts: one generic tiling
     else {
-    if (P.NTtot == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VEC>(P, W, s);
-    if (P.NTtot == 2) return launch_conv_cfg<KS, 16, 3, 1, 2, 2, VEC>(P, W, s);
-    if (face_pix <= 320) return launch_conv_cfg<KS, 16, 5, 1, 1, 4, VEC>(P, W, s);
-    return launch_conv_cfg<KS, 16, 3, 1, 1, 4, VEC>(P, W, s);
+        if (P.NTtot == 1) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MASK>(P, W, s);
+        if (P.NTtot == 2) return launch_conv_cfg<KS, 8, 3, 1, 2, 2, VW, MASK>(P, W, s);
+        if (face_pix <= 320) return launch_conv_cfg<KS, 8, 5, 1, 1, 4, VW, MASK>(P, W, s);
+        return launch_conv_cfg<KS, 8, 3, 1, 1, 4, VW, MASK>(P, W, s);
     }
 }
 
-static int dispatch_conv(int KS, bool vec, const ConvKParams &P, const Work &W, hipStream_t s) {
-    if (KS == 3) return vec ? launch_conv<3, true>(P, W, s) : launch_conv<3, false>(P, W, s);
-    return vec ? launch_conv<1, true>(P, W, s) : launch_conv<1, false>(P, W, s);
+template <int KS, bool MASK>
+static int dispatch_vw(int vw, const ConvKParams &P, const Work &W, hipStream_t s) {
+    if (vw == 4) return launch_conv<KS, 4, MASK>(P, W, s);
+    if (vw == 2) return launch_conv<KS, 2, MASK>(P, W, s);
+    return launch_conv<KS, 1, MASK>(P, W, s);
+}
+
+static int dispatch_conv(int KS, int vw, const ConvKParams &P, const Work &W, hipStream_t s) {
+    const bool mask = P.ymask != nullptr;
+    if (KS == 3) return mask ? dispatch_vw<3, true>(vw, P, W, s) : dispatch_vw<3, false>(vw, P, W, s);
+    return mask ? dispatch_vw<1, true>(vw, P, W, s) : dispatch_vw<1, false>(vw, P, W, s);
+}
+
+static inline int vec_width(int c0, int c1) {
+    if (c0 % 4 == 0 && c1 % 4 == 0) return 4;
+    if (c0 % 2 == 0 && c1 % 2 == 0) return 2;
+    return 1;
 }
 
 // algorithmic work of one convolution pass: flops = 2*B*6*N^2*k^2*Cin*Cout; bytes = unpadded input and
@@ -598,23 +839,28 @@ static inline int out_size(const dlwpcs_conv_desc *d) { return d->halo ? d->N : 
 // workspace layout (bytes, 256-aligned regions)
 struct WsLayout {
     size_t wpk_f, bias, wpk_b, dxv, partial, bpartial, total;
-    int slots_per_face, NB, ngroups, wg_pix, wg_nblk;
+    int n_eq, n_4, n_5, wg_pix, wg_nblk;
 };
 
-static void wgrad_tiling(const dlwpcs_conv_desc *d, int &pix, int &nblk, int &NB, int &ngroups) {
+// persistent weight-gradient launch geometry: pixels per work item, items (bands) per face, workers per face class
+static void wgrad_tiling(const dlwpcs_conv_desc *d, int &pix, int &nblk, int &n_eq, int &n_4, int &n_5) {
     const int No = out_size(d);
     const int face_pix = No * No;
-    const int CAP = 192;
+    const int CAP = 192;     // pixels per work item: 2 LDS buffers of (X tile + dZ tile) in one CU's 160 KB
     pix = CAP;
     if (No <= CAP) pix = (CAP / No) * No;
     if (pix > face_pix) pix = face_pix;
     nblk = ceil_div(face_pix, pix);
     const int CinP = ceil_div(d->C0 + d->C1, 32) * 32, CoutP = ceil_div(d->Cout, 32) * 32;
-    const int tiles = (CinP / 32) * (CoutP / 32);
-    // aim for >= ~512 workgroups (2 per CU) while keeping the number of partial slots small
-    NB = 1;
-    while (NB < d->B && (long)6 * nblk * tiles * ceil_div(d->B, NB * 2) >= 512) NB *= 2;
-    ngroups = ceil_div(d->B > 0 ? d->B : 1, NB);
+    const int pairs = (CinP / 32) * (CoutP / 32);
+    int wpp = 256 / pairs;               // one worker per CU (256 CUs) spread over the (ci, co) tile pairs
+    if (wpp < 3) wpp = 3;
+    const long items_per_face = (long)(d->B > 0 ? d->B : 1) * nblk;
+    if (wpp > 6 * items_per_face) wpp = (int)(6 * items_per_face);
+    if (wpp < 3) wpp = 3;
+    n_4 = (wpp + 3) / 6; if (n_4 < 1) n_4 = 1;
+    n_5 = n_4;
+    n_eq = wpp - n_4 - n_5; if (n_eq < 1) n_eq = 1;
 }
 
 static WsLayout ws_layout(const dlwpcs_conv_desc *d) {
@@ -629,14 +875,14 @@ static WsLayout ws_layout(const dlwpcs_conv_desc *d) {
     L.wpk_b = off; off += align_up((size_t)3 * NTb * CGb * TAPS * 256 * 4, 256);
     const int Nv = d->halo ? d->N + d->ksize - 1 : d->N;      // face size of the virtual-input gradient
     L.dxv = off;   off += align_up((size_t)d->B * 6 * Nv * Nv * Cin * 4, 256);
-    int pix, nblk, NB, ngroups;
-    wgrad_tiling(d, pix, nblk, NB, ngroups);
-    L.wg_pix = pix; L.wg_nblk = nblk; L.NB = NB; L.ngroups = ngroups;
-    L.slots_per_face = nblk * ngroups;
+    int pix, nblk;
+    wgrad_tiling(d, pix, nblk, L.n_eq, L.n_4, L.n_5);
+    L.wg_pix = pix; L.wg_nblk = nblk;
+    const int nworkers = L.n_eq + L.n_4 + L.n_5;
     const int CinP = ceil_div(Cin, 32) * 32, CoutP = ceil_div(d->Cout, 32) * 32;
     // dxv and the wgrad partials are never live at the same time but are kept disjoint for simplicity of reasoning
-    L.partial = off;  off += align_up((size_t)6 * L.slots_per_face * TAPS * CinP * CoutP * 4, 256);
-    L.bpartial = off; off += align_up((size_t)6 * L.slots_per_face * CoutP * 4, 256);
+    L.partial = off;  off += align_up((size_t)nworkers * TAPS * CinP * CoutP * 4, 256);
+    L.bpartial = off; off += align_up((size_t)nworkers * CoutP * 4, 256);
     (void)No;
     L.total = off;
     return L;
@@ -695,8 +941,7 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
     P.CG = ceil_div(Cin, 8); P.NTtot = NTtot; P.up0 = d->up0;
     P.mode = d->halo ? MODE_HALO : MODE_DIRECT;
     P.act = d->act; P.alpha = d->alpha; P.vmax = d->vmax;
-    const bool vec = (d->C0 % 4 == 0) && (d->C1 % 4 == 0);
-    return dispatch_conv(d->ksize, vec, P, conv_work(d), s);
+    return dispatch_conv(d->ksize, vec_width(d->C0, d->C1), P, conv_work(d), s);
 }
 
 extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, const void *y,
@@ -726,7 +971,7 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     P.CG = ceil_div(d->Cout, 8); P.NTtot = ceil_div(Cin, 32); P.up0 = 0;
     P.mode = MODE_ZERO;
     P.act = DLWPCS_ACT_NONE; P.alpha = d->alpha; P.vmax = d->vmax;
-    rc = dispatch_conv(d->ksize, d->Cout % 4 == 0, P, conv_work(d), s);
+    rc = dispatch_conv(d->ksize, vec_width(d->Cout, 0), P, conv_work(d), s);
     if (rc) return rc;
     // dxv is the gradient of the (halo-padded, if halo) virtual input: (B,6,Nv,Nv,Cin), Nv = No + k - 1
     // halo: Nv = N + 2; plain: Nv = N.  Route to the sources (inverse halo gather, upsample adjoint, channel split).
@@ -758,6 +1003,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     char *ws = (char *)workspace;
     const int Cin = d->C0 + d->C1, KS = d->ksize, TAPS = KS * KS;
     const int CinP = ceil_div(Cin, 32) * 32, CoutP = ceil_div(d->Cout, 32) * 32;
+    if (d->B == 0 && (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD)) return DLWPCS_OK;
     if (d->B == 0) {
         (void)hipMemsetAsync(dw_eq, 0, (size_t)TAPS * Cin * d->Cout * 4, s);
         (void)hipMemsetAsync(dw_pol, 0, (size_t)TAPS * Cin * d->Cout * 4, s);
@@ -781,17 +1027,24 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     W.partial = (float *)(ws + L.partial);
     const bool want_bias = db_eq || db_pol || db_np;
     W.bpartial = want_bias ? (float *)(ws + L.bpartial) : nullptr;
-    W.CinP = CinP; W.CoutP = CoutP; W.NB = L.NB; W.ngroups = L.ngroups;
-    W.mask_act = d->act != DLWPCS_ACT_NONE;
+    W.CinP = CinP; W.CoutP = CoutP;
+    W.n_eq = L.n_eq; W.n_4 = L.n_4; W.n_5 = L.n_5;
+    W.magicN = div_magic(P.Nin); W.magicN2 = div_magic(P.Nin * P.Nin);
+    if (P.C1 == 0) P.src1 = P.src0;
+    const bool mask = d->act != DLWPCS_ACT_NONE;
     const int pix_cap = (L.wg_pix + 1) & ~1;
-    size_t lds = ((size_t)P.tile_rows_max * P.W2 * 32 + (size_t)pix_cap * 32) * 4 + (size_t)pix_cap * 4;
-    if (lds < 4 * 1024 * 4) lds = 4 * 1024 * 4;      // the 16 KB cross-wave reduction scratch aliases the tiles
+    const int vw = vec_width(d->C0, d->C1);
+    const size_t bufb = ((size_t)P.tile_rows_max * P.W2 * 32 + (size_t)pix_cap * 32 + pix_cap) * 4;
+    const bool fits_regs = (size_t)P.tile_rows_max * P.W2 * (32 / vw) <= (size_t)(28 / vw) * 512 &&
+                           (size_t)pix_cap * 8 <= (size_t)3 * 512;
+    W.pipelined = (fits_regs && 2 * bufb <= 160 * 1024) ? 1 : 0;
+    size_t lds = W.pipelined ? 2 * bufb : bufb;
+    if (lds < 8 * 1024 * 4) lds = 8 * 1024 * 4;       // the 32 KB cross-wave reduction scratch aliases the buffers
     if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
-    const bool vec = (d->C0 % 4 == 0) && (d->C1 % 4 == 0);
-    dim3 grid((unsigned)(6 * L.wg_nblk * L.ngroups), (unsigned)(CinP / 32), (unsigned)(CoutP / 32));
-#define WG_LAUNCH(KSV, VECV)                                                                                              \
+    dim3 grid((unsigned)(L.n_eq + L.n_4 + L.n_5), (unsigned)(CinP / 32), (unsigned)(CoutP / 32));
+#define WG_LAUNCH(KSV, VWV, MASKV)                                                                                        \
     do {                                                                                                                  \
-        auto kern = wgrad_mfma_kernel<KSV, VECV>;                                                                         \
+        auto kern = wgrad_mfma_kernel<KSV, VWV, MASKV>;                                                                   \
         if (lds > 64 * 1024) {                                                                                            \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));    \
@@ -799,19 +1052,23 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
         int pidx = -1;                                                                                                    \
         if (prof_enabled()) {                                                                                             \
             const Work wk = conv_work(d);                                                                                 \
-            pidx = prof_begin("wgrad_mfma_kernel<" #KSV ", " #VECV ">", wk.flops, wk.bytes, s);                           \
+            pidx = prof_begin("wgrad_mfma_kernel<" #KSV ", " #VWV ", " #MASKV ">", wk.flops, wk.bytes, s);                \
         }                                                                                                                 \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, W);                                                             \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, W);                                                             \
         if (pidx >= 0) prof_end(pidx, s);                                                                                 \
     } while (0)
-    if (KS == 3) { if (vec) WG_LAUNCH(3, true); else WG_LAUNCH(3, false); }
-    else { if (vec) WG_LAUNCH(1, true); else WG_LAUNCH(1, false); }
+#define WG_VW(KSV, MASKV)                                                                                                 \
+    do { if (vw == 4) WG_LAUNCH(KSV, 4, MASKV); else if (vw == 2) WG_LAUNCH(KSV, 2, MASKV); else WG_LAUNCH(KSV, 1, MASKV); } while (0)
+    if (KS == 3) { if (mask) WG_VW(3, true); else WG_VW(3, false); }
+    else { if (mask) WG_VW(1, true); else WG_VW(1, false); }
+#undef WG_VW
 #undef WG_LAUNCH
     rc = check_launch("wgrad_mfma");
     if (rc) return rc;
     const int nout = TAPS * Cin * d->Cout + (want_bias ? d->Cout : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(nout, 256)), dim3(256), 0, s, W.partial, W.bpartial,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(nout, 16)), dim3(256), 0, s, W.partial, W.bpartial,
                        (float *)dw_eq, (float *)dw_pol, (float *)dw_np, (float *)db_eq, (float *)db_pol, (float *)db_np,
-                       KS, Cin, d->Cout, CinP, CoutP, L.slots_per_face, d->flip_north_pole);
+                       KS, Cin, d->Cout, CinP, CoutP, L.n_eq, L.n_4, L.n_5, d->flip_north_pole,
+                       (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0);
     return check_launch("wgrad_reduce");
 }

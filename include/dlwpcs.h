@@ -7,7 +7,8 @@
  *
  *   - plain C types only; every tensor argument is a raw DEVICE pointer + explicit sizes.  No torch types.
  *   - the CALLER owns every buffer (inputs, outputs, weights, gradients, tables, workspace); the library allocates
- *     nothing and keeps no mutable global state, so it is re-entrant across streams and devices.
+ *     nothing and keeps no mutable global state (the opt-in launch profiler at the end of this header excepted), so it
+ *     is re-entrant across streams and devices.
  *   - every device entry point enqueues on the caller's `stream` (a hipStream_t) and returns without synchronising.
  *   - return value: 0 = OK, <0 = error code (DLWPCS_E_*); a human-readable message for the calling thread is
  *     available from dlwpcs_last_error().  Nothing throws across the boundary.
@@ -89,8 +90,11 @@ int dlwpcs_pad_bwd(const void *dy, void *dx, int B, int N, int C, int p, int dty
  * flip_north_pole (== flip -> conv -> flip of the reference for stride 1).  Kernels are HWIO (k,k,Cin,Cout) fp32,
  * biases (Cout,) or NULL.  Epilogue: + bias, then `act`.
  * k in {1,3}, stride 1, dilation 1 (the hot-path configuration, Azure/train_cs.py:200-207); anything else returns
- * DLWPCS_E_UNSUPPORTED and is served by dlwpcs_conv_generic_*.
+ * DLWPCS_E_UNSUPPORTED and is served by dlwpcs_gconv_*.
  * ------------------------------------------------------------------------------------------------------------- */
+/* dlwpcs_conv_desc.flags */
+#define DLWPCS_CONV_ACCUMULATE_WGRAD 1   /* bwd_weights ADDS to dw_* / db_* (shared layers, flat gradient buffer) */
+
 typedef struct dlwpcs_conv_desc {
     int32_t B;              /* batch */
     int32_t N;              /* face size of the virtual input V */
@@ -103,7 +107,7 @@ typedef struct dlwpcs_conv_desc {
     int32_t act;            /* DLWPCS_ACT_* */
     float   alpha, vmax;    /* parameters of DLWPCS_ACT_LEAKY_CLIP */
     int32_t dtype;          /* DLWPCS_F32 */
-    int32_t reserved;
+    int32_t flags;          /* DLWPCS_CONV_* bits */
 } dlwpcs_conv_desc;
 
 size_t dlwpcs_conv_workspace_bytes(const dlwpcs_conv_desc *d);      /* max over fwd / bwd_data / bwd_weights */

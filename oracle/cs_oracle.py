@@ -48,7 +48,17 @@ def _rows_source(f, a, b, N, p, top):
     raise ValueError(f)
 
 
+_TABLE_CACHE = {}
+
+
 def halo_table(N, p):
+    key = (int(N), int(p))
+    if key not in _TABLE_CACHE:
+        _TABLE_CACHE[key] = _halo_table_uncached(N, p)
+    return _TABLE_CACHE[key].copy()
+
+
+def _halo_table_uncached(N, p):
     """
     int32 array T of shape (6, M, M), M = N + 2p, such that for the reference layer
     `out[b, f, i, j, c] == in[b].reshape(6*N*N, C)[T[f, i, j], c]` (channels_last), identically for channels_first.
@@ -93,11 +103,11 @@ def cs_pad(x, p, data_format='channels_last'):
     if data_format == 'channels_first':   # (B, C, 6, N, N)
         B, C, Fc, N, _ = xt.shape
         T = torch.as_tensor(halo_table(N, p).astype(np.int64)).reshape(-1)
-        out = xt.reshape(B, C, 6 * N * N)[:, :, T].reshape(B, C, 6, N + 2 * p, N + 2 * p)
+        out = torch.index_select(xt.reshape(B, C, 6 * N * N), 2, T).reshape(B, C, 6, N + 2 * p, N + 2 * p)
     else:                                 # (B, 6, N, N, C)
         B, Fc, N, _, C = xt.shape
         T = torch.as_tensor(halo_table(N, p).astype(np.int64)).reshape(-1)
-        out = xt.reshape(B, 6 * N * N, C)[:, T, :].reshape(B, 6, N + 2 * p, N + 2 * p, C)
+        out = torch.index_select(xt.reshape(B, 6 * N * N, C), 1, T).reshape(B, 6, N + 2 * p, N + 2 * p, C)
     assert Fc == 6
     return out.numpy() if is_np else out
 

@@ -88,7 +88,7 @@ def test_host_inverse_table_is_the_adjoint(native, N, p):
 def test_conv_descriptor_validation(native):
     lib = native.lib()
     d = native.ConvDesc(B=1, N=8, C0=4, C1=0, Cout=4, ksize=5, halo=0, up0=0, flip_north_pole=1, act=0, alpha=0.,
-                        vmax=0., dtype=0, reserved=0)
+                        vmax=0., dtype=0, flags=0)
     assert lib.dlwpcs_conv_workspace_bytes(ctypes.byref(d)) == 0        # k=5 is served by the generic path
     assert b'kernel size' in lib.dlwpcs_last_error()
     d.ksize = 3
