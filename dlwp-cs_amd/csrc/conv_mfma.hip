@@ -19,6 +19,7 @@
 //     the 4 consecutive K values it feeds to 4 successive MFMAs; face 5's row-reversed kernel is a packing variant.
 //   - A operand: one ds_read_b128 per (tap, 8-channel group, M tile) = 4 MFMAs' worth; K order inside a group is
 //     {lanes 0-31: c0..c3, lanes 32-63: c4..c7} x step j, identical on the A and B side.
+#include <stdlib.h>
 #include "common.h"
 
 namespace dlwpcs {
@@ -44,8 +45,10 @@ struct ConvKParams {
     int pix_per_block;          // valid pixels per workgroup (<= 32*MT*WM)
     int nblk_face;              // workgroups per (sample, face)
     int W2;                     // tile width = No + KS - 1
-    uint32_t magicW2, magicNo;
+    uint32_t magicW2, magicNo, magicN, magicN2;
     int tile_rows_max;          // rows reserved in LDS
+    int ntiles;                 // B * 6 * nblk_face (persistent kernel)
+    long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -283,10 +286,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvKP
             float *nxt = smem + ((ch + 1) & 1) * buf_floats;
             const bool more = ch + 1 < nchunks;
             if (more) fetch(ch + 1, true);       // global loads stay in flight while the matrix cores run
-            compute(cur);
-            if (more) commit(nxt, 0, true);
-            __syncthreads();
-        }
+                compute(cur);
+                if (more) commit(nxt, 0, true);
+                __syncthreads();
+            }
     } else {
         // tile wider than the register prefetch capacity (N >~ 256): stage synchronously, single buffer
         for (int ch = 0; ch < nchunks; ++ch) {
@@ -317,6 +320,344 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvKP
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined form of the forward / data-gradient kernel (the one the hot path runs).
+//
+// Why: a per-tile workgroup spends ~30% of its life in a prologue (halo-table reads -> offsets -> first chunk) and an
+// epilogue (bias, activation, 48 stores per lane) during which its waves issue no MFMA, and because all workgroups of a
+// launch do the same work they hit those phases -- and the memory system -- in lock step across the chip.
+// Here a workgroup loops over a static, strided list of tiles and treats the (tile, channel-chunk) pairs as ONE stream:
+//     iteration g:  issue the global loads of chunk g+1 (possibly the first chunk of the NEXT tile)
+//                   read the halo table of the next tile (at the first chunk of a tile)
+//                   MFMAs of chunk g out of LDS buffer g&1
+//                   write chunk g+1 from registers to LDS buffer (g+1)&1; table entries -> offsets of the next tile
+//                   (last chunk of a tile) bias + activation + stores of the finished tile, accumulators reset
+//                   one barrier
+// so after the first tile nothing the matrix cores need is ever waited for: loads have a whole chunk of MFMAs (~7k
+// cycles) to land, stores drain behind the next tile's MFMAs.  Needs >= 2 chunks per tile (C_in > KC).
+// ------------------------------------------------------------------------------------------------------------------
+#ifdef DLWPCS_TIMELINE
+#define TL_MARK() do { if (tlp && tli < 64) tlp[tli++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TL_MARK() do { } while (0)
+#endif
+
+template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, bool MASK>
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_pp_kernel(const ConvKParams P) {
+    constexpr int TAPS = KS * KS;
+    constexpr int KCP = KC + 4;
+    constexpr int KCG = KC / 8;
+    constexpr int Q = KC / VW;
+    constexpr int NTB = NT * WN;
+    constexpr int NTHREADS = 64 * WM * WN;
+    constexpr int IT_IN = 3 * KC / VW;
+    constexpr int WF4 = NTB * KCG * TAPS * 64;
+    constexpr int IT_W = (WF4 + NTHREADS - 1) / NTHREADS;
+    constexpr int GF4 = TAPS * 64;
+    static_assert(NTHREADS % Q == 0, "thread -> channel-vector mapping must not depend on the item");
+    typedef typename VecT<VW>::type V;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int in_floats = P.tile_rows_max * P.W2 * KCP;
+    const int buf_floats = in_floats + WF4 * 4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nt0 = blockIdx.y * NTB;
+    const int face_pix = P.No * P.No;
+    const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
+    const int qv = (tid % Q) * VW;
+    const float4 *wsrc = reinterpret_cast<const float4 *>(P.wpk);
+    const int G = gridDim.x;
+#ifdef DLWPCS_TIMELINE
+    int tli = 0;
+    long long *tlp = (P.dbg && tid == 0 && blockIdx.y == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
+#endif
+
+    struct Geo { int b, f, v, m0, npix, y0, nitems; };
+    auto geo_of = [&](int t) {
+        Geo gq;
+        const uint32_t L = xcd_remap((uint32_t)t, (uint32_t)P.ntiles);
+        const int blk = L % P.nblk_face;
+        gq.f = (L / P.nblk_face) % 6;
+        gq.b = L / (P.nblk_face * 6);
+        gq.v = gq.f < 4 ? 0 : (gq.f == 4 ? 1 : 2);
+        gq.m0 = blk * P.pix_per_block;
+        gq.npix = min(P.pix_per_block, face_pix - gq.m0);
+        gq.y0 = __umulhi((uint32_t)gq.m0, P.magicNo);
+        const int ylast = __umulhi((uint32_t)(gq.m0 + gq.npix - 1), P.magicNo);
+        gq.nitems = (ylast - gq.y0 + KS) * P.W2 * Q;
+        return gq;
+    };
+
+    // bias of the three face variants, read once
+    float bias_v[3][NT];
+#pragma unroll
+    for (int vv = 0; vv < 3; ++vv)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = (nt0 + wn * NT + nt) * 32 + l31;
+            bias_v[vv][nt] = (P.bias && co < P.Cout) ? P.bias[(size_t)vv * P.NTtot * 32 + co] : 0.f;
+        }
+
+    f32x16 acc[MT][NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    };
+    zero_acc();
+
+    int abase[MT];
+    auto set_abase = [&](const Geo &gq) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = (wm * MT + mt) * 32 + l31;
+            int base = 0;
+            if (m < gq.npix) {
+                const int gm = gq.m0 + m;
+                const int oy = __umulhi((uint32_t)gm, P.magicNo);
+                const int ox = gm - oy * P.No;
+                base = ((oy - gq.y0) * P.W2 + ox) * KCP;
+            }
+            abase[mt] = base + half * 4;
+        }
+    };
+
+    V pre_in[IT_IN];
+    float4 pre_w[IT_W];
+    int sidx_c[IT_IN];      // flat source index (face*Nin + row)*Nin + col of each tile pixel, current tile; -1 = zero
+    int sidx_n[IT_IN];      // same for the next tile (filled by the halo-table loads in flight)
+
+    // read the halo table (or form the identity / zero-border index) for every tile pixel of a tile
+    auto issue_tables = [&](const Geo &gq, int (&sidx)[IT_IN]) {
+#pragma unroll
+        for (int i = 0; i < IT_IN; ++i) {
+            const int e = tid + i * NTHREADS;
+            const int ec = min(e, gq.nitems - 1);
+            const int pix = ec / Q;
+            const int ty = __umulhi((uint32_t)pix, P.magicW2);
+            const int tx = pix - ty * P.W2;
+            const int iy = gq.y0 + ty;
+            int val;
+            if (P.mode == MODE_HALO) {
+                const int M = P.Nin + KS - 1;
+                val = P.table[(gq.f * M + iy) * M + tx];
+            } else if (P.mode == MODE_DIRECT) {
+                val = (gq.f * P.Nin + iy) * P.Nin + tx;
+            } else {    // MODE_ZERO: zero border of width KS-1
+                const int vy = iy - (KS - 1), vx = tx - (KS - 1);
+                const bool ok = (vy >= 0) & (vy < P.Nin) & (vx >= 0) & (vx < P.Nin);
+                val = ok ? (gq.f * P.Nin + vy) * P.Nin + vx : -1;
+            }
+            sidx[i] = e < gq.nitems ? val : -1;
+        }
+    };
+    // straight-line: all loads of the chunk are issued back to back; offsets derived from the flat source index
+    auto fetch = [&](const Geo &gq, int ch, const int (&sidx)[IT_IN]) {
+        const float *s0b = P.src0 + (size_t)gq.b * 6 * g0 * g0 * P.C0;
+        const float *s1b = P.C1 > 0 ? P.src1 + (size_t)gq.b * 6 * P.Nin * P.Nin * P.C1 : s0b;
+        const float *ymb = MASK ? P.ymask + (size_t)gq.b * 6 * g0 * g0 * P.C0 : nullptr;
+        const int c = ch * KC + qv;
+        const bool c_ok = c < P.Cin;
+        const bool from0 = c < P.C0;
+#pragma unroll
+        for (int i = 0; i < IT_IN; ++i) {
+            const int idx = sidx[i];
+            const bool ok = c_ok && idx >= 0;
+            const int ii = ok ? idx : 0;
+            int o;
+            if (from0) {
+                if (P.up0) {
+                    const int vf = __umulhi((uint32_t)ii, P.magicN2);
+                    const int rem = ii - vf * P.Nin * P.Nin;
+                    const int vy = __umulhi((uint32_t)rem, P.magicN);
+                    const int vx = rem - vy * P.Nin;
+                    o = ((vf * g0 + (vy >> 1)) * g0 + (vx >> 1)) * P.C0 + c;
+                } else {
+                    o = ii * P.C0 + c;
+                }
+            } else {
+                o = ii * P.C1 + (c - P.C0);
+            }
+            const float *ptr = (from0 ? s0b : s1b) + (ok ? (size_t)o : 0);
+            V val = *reinterpret_cast<const V *>(ptr);
+            if (MASK) vmask(val, *reinterpret_cast<const V *>(ymb + (ok ? (size_t)o : 0)), P.alpha, P.vmax);
+            pre_in[i] = vsel(ok, val);
+        }
+#pragma unroll
+        for (int i = 0; i < IT_W; ++i) {
+            const int idx = min(tid + i * NTHREADS, WF4 - 1);
+            const int g = idx / GF4, w = idx % GF4;
+            const int ntl = g / KCG, cgl = g % KCG;
+            const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
+            const bool ok = ntile < P.NTtot && cg < P.CG;
+            const float4 val = wsrc[ok ? (((size_t)gq.v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0];
+            pre_w[i] = vsel(ok, val);
+        }
+    };
+    auto commit = [&](float *buf, const Geo &gq) {
+#pragma unroll
+        for (int i = 0; i < IT_IN; ++i) {
+            const int e = tid + i * NTHREADS;
+            if (e < gq.nitems) *reinterpret_cast<V *>(buf + (e / Q) * KCP + qv) = pre_in[i];
+        }
+#pragma unroll
+        for (int i = 0; i < IT_W; ++i) {
+            const int idx = tid + i * NTHREADS;
+            if (idx < WF4) reinterpret_cast<float4 *>(buf + in_floats)[idx] = pre_w[i];
+        }
+    };
+    auto compute = [&](const float *buf) {
+        const float *lds_in = buf, *lds_w = buf + in_floats;
+#pragma unroll
+        for (int cgl = 0; cgl < KCG; ++cgl) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int dy = tap / KS, dx = tap % KS;
+                const int tapoff = (dy * P.W2 + dx) * KCP + cgl * 8;
+                float4 a[MT], bw[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4 *>(lds_in + abase[mt] + tapoff);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bw[nt] = *reinterpret_cast<const float4 *>(
+                        lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 128 + l31 * 4);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bw[nt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bw[nt].y, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bw[nt].z, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bw[nt].w, acc[mt][nt], 0, 0, 0);
+                    }
+            }
+        }
+    };
+    // bias + activation + stores of a finished tile (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+    // Wide path (C_out % 4 == 0): each half M tile (16 pixels x 32 channels) is transposed through a wave-private
+    // 16 x 36-float LDS patch so that every lane stores 16 B and 8 lanes cover one 128-B line: 4 dwordx4 stores per
+    // M tile instead of 16 dword stores (the store ISSUE rate, not bandwidth, is what the epilogue costs).
+    float *stage = smem + 2 * buf_floats + wave * (16 * 36);
+    auto epilogue = [&](const Geo &gq) {
+        float *outp = P.out + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
+        const bool wide = (P.Cout & 3) == 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cot = (nt0 + wn * NT + nt) * 32;
+            const int co = cot + l31;
+            const float bv = gq.v == 0 ? bias_v[0][nt] : (gq.v == 1 ? bias_v[1][nt] : bias_v[2][nt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (wide) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) {
+                            const int r = h * 8 + rr;
+                            float val = acc[mt][nt][r] + bv;
+                            if (P.act == DLWPCS_ACT_LEAKY_CLIP) val = act_leaky_clip(val, P.alpha, P.vmax);
+                            stage[((rr & 3) + 8 * (rr >> 2) + 4 * half) * 36 + l31] = val;
+                        }
+                        // wave-private patch: a wave executes in lock step, LDS ops complete in order -> no barrier
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int row = (lane >> 3) + 8 * j;
+                            const int quad = lane & 7;
+                            const float4 v4 = *reinterpret_cast<const float4 *>(stage + row * 36 + quad * 4);
+                            const int m = (wm * MT + mt) * 32 + h * 16 + row;
+                            const int c4 = cot + quad * 4;
+                            if (m < gq.npix && c4 < P.Cout)
+                                *reinterpret_cast<float4 *>(outp + (size_t)(gq.m0 + m) * P.Cout + c4) = v4;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                } else if (co < P.Cout) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (m < gq.npix) {
+                            float val = acc[mt][nt][r] + bv;
+                            if (P.act == DLWPCS_ACT_LEAKY_CLIP) val = act_leaky_clip(val, P.alpha, P.vmax);
+                            outp[(size_t)(gq.m0 + m) * P.Cout + co] = val;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    const int nchunks = (P.CG + KCG - 1) / KCG;          // >= 2 (launcher guarantees)
+    int t = blockIdx.x;
+    if (t >= P.ntiles) return;
+    TL_MARK();
+    Geo cur = geo_of(t);
+    issue_tables(cur, sidx_c);
+    set_abase(cur);
+    fetch(cur, 0, sidx_c);
+    commit(smem, cur);
+    __syncthreads();
+    TL_MARK();
+    int gpar = 0;
+    // One tile per trip; the chunk loop is peeled into first / middle / last so that every register array (prefetch
+    // registers, source indices, accumulators) is defined unconditionally on every path (no phi copies -> no spills).
+    // On the final tile the "next tile" is the tile itself: its table reads and first chunk are fetched again and
+    // never used, which keeps the code straight-line.
+    while (true) {
+        const bool have_next = t + G < P.ntiles;
+        const Geo nxt = geo_of(have_next ? t + G : t);
+        // ---- first chunk: also start reading the next tile's halo-table entries
+        {
+            float *bcur = smem + gpar * buf_floats, *bnxt = smem + (gpar ^ 1) * buf_floats;
+            fetch(cur, 1, sidx_c);
+            issue_tables(nxt, sidx_n);
+            TL_MARK();
+            compute(bcur);
+            TL_MARK();
+            commit(bnxt, cur);
+            TL_MARK();
+            __syncthreads();
+            gpar ^= 1;
+        }
+        // ---- middle chunks
+        for (int c = 1; c < nchunks - 1; ++c) {
+            float *bcur = smem + gpar * buf_floats, *bnxt = smem + (gpar ^ 1) * buf_floats;
+            fetch(cur, c + 1, sidx_c);
+            compute(bcur);
+            commit(bnxt, cur);
+            __syncthreads();
+            gpar ^= 1;
+        }
+        // ---- last chunk: the stream moves on to the next tile; finish this one
+        {
+            float *bcur = smem + gpar * buf_floats, *bnxt = smem + (gpar ^ 1) * buf_floats;
+            fetch(nxt, 0, sidx_n);
+            TL_MARK();
+            compute(bcur);
+            TL_MARK();
+            commit(bnxt, nxt);
+            epilogue(cur);
+            zero_acc();
+            TL_MARK();
+            __syncthreads();
+            gpar ^= 1;
+        }
+        if (!have_next) break;
+        t += G;
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < IT_IN; ++i) sidx_c[i] = sidx_n[i];
+        set_abase(cur);
+    }
+    TL_MARK();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -753,21 +1094,52 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     const size_t buf = ((size_t)P.tile_rows_max * P.W2 * (KC + 4) + (size_t)NTB * (KC / 8) * KS * KS * 256) * sizeof(float);
     const size_t cap_items = (size_t)(3 * KC / VW) * NTHREADS;
     const bool pipelined = (size_t)P.tile_rows_max * P.W2 * (KC / VW) <= cap_items;
-    const size_t lds = pipelined ? 2 * buf : buf;
+    size_t lds = pipelined ? 2 * buf : buf;
     if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv: LDS tile of %zu bytes exceeds 160 KiB (N=%d)", lds, P.No);
     auto kern = conv_mfma_kernel<KS, KC, MT, NT, WM, WN, VW, MASK>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    dim3 grid((unsigned)(P.B * 6 * P.nblk_face), (unsigned)ceil_div(P.NTtot, NTB));
+    P.ntiles = P.B * 6 * P.nblk_face;
+    P.magicN = div_magic(P.Nin);
+    P.magicN2 = div_magic(P.Nin * P.Nin);
+    P.dbg = nullptr;
+#ifdef DLWPCS_TIMELINE
+    { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
+#endif
+    const int nchunks = ceil_div(P.CG, KC / 8);
+    const bool persistent = pipelined && nchunks >= 2 && (long)P.Nin * P.Nin * 6 < (1l << 24);
     int pidx = -1;
-    if (prof_enabled()) {
-        char tag[128];
-        snprintf(tag, sizeof(tag), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", KS, KC, MT, NT, WM, WN, VW, MASK ? "true" : "false");
-        pidx = prof_begin(tag, W.flops, W.bytes, s);
+    if (persistent) {
+        auto kpp = conv_mfma_pp_kernel<KS, KC, MT, NT, WM, WN, VW, MASK>;
+        lds += (size_t)(WM * WN) * 16 * 36 * sizeof(float);      // wave-private epilogue transpose patches
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)kpp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        // one resident set of workgroups: 256 CUs x as many workgroups as the LDS footprint admits (<= 2)
+        int per_cu = (int)((160 * 1024) / lds);
+        if (per_cu > 2) per_cu = 2;
+        if (per_cu < 1) per_cu = 1;
+        int gx = 256 * per_cu;
+        if (gx > P.ntiles) gx = P.ntiles;
+        dim3 grid((unsigned)gx, (unsigned)ceil_div(P.NTtot, NTB));
+        if (prof_enabled()) {
+            char tag[128];
+            snprintf(tag, sizeof(tag), "conv_mfma_pp_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", KS, KC, MT, NT, WM, WN, VW, MASK ? "true" : "false");
+            pidx = prof_begin(tag, W.flops, W.bytes, s);
+        }
+        hipLaunchKernelGGL(kpp, grid, dim3(NTHREADS), lds, s, P);
+    } else {
+        dim3 grid((unsigned)P.ntiles, (unsigned)ceil_div(P.NTtot, NTB));
+        if (prof_enabled()) {
+            char tag[128];
+            snprintf(tag, sizeof(tag), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", KS, KC, MT, NT, WM, WN, VW, MASK ? "true" : "false");
+            pidx = prof_begin(tag, W.flops, W.bytes, s);
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, P);
     }
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, P);
     if (pidx >= 0) prof_end(pidx, s);
     return check_launch("conv_mfma");
 }
@@ -775,7 +1147,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
 template <int KS, int VW, bool MASK>
 static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
     const int face_pix = P.No * P.No;
-    if constexpr (KS == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VW, MASK>(P, W, s);
+    if constexpr (KS == 1) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MASK>(P, W, s);
     else if constexpr (VW != 4) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MASK>(P, W, s);   // odd channel counts: one generic tiling
     else {
         if (P.NTtot == 1) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MASK>(P, W, s);
