@@ -21,7 +21,7 @@ import time
 import numpy as np
 import torch
 
-from .. import ops
+from .. import ops, parallel
 from .._native import ACT_LEAKY_CLIP, ACT_NONE
 from . import backend, callbacks as cbks, optimizers
 from .engine import KTensor, Layer
@@ -252,11 +252,8 @@ class Model(object):
         self._flatten_parameters()
         self._graphs.clear()
         self._seen_batch.clear()
-        self._world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self._world = torch.distributed.get_world_size()
-            if self._world > 1:      # identical replicas: rank 0's initial weights everywhere
-                torch.distributed.broadcast(self._flat_params, src=0)
+        self._world = parallel.world()[1]
+        parallel.broadcast_parameters(self._flat_params)     # identical replicas: rank 0's initial weights everywhere
         self._compiled = True
 
     def _metric_names(self):
@@ -306,9 +303,8 @@ class Model(object):
         return torch.stack([s.detach() for s in stats])
 
     def _apply_gradients(self):
-        if self._world > 1:
-            torch.distributed.all_reduce(self._flat_grads)      # RCCL over xGMI: one flat buffer per step
-        self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0 / self._world)
+        scale = parallel.allreduce_gradients(self._flat_grads)  # RCCL over xGMI: one flat 2.7 MB buffer per step
+        self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=scale)
 
     def _train_step_eager(self, inputs, targets):
         self._flat_grads.zero_()
@@ -337,8 +333,7 @@ class Model(object):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         g['fwd_bwd'].replay()
-        if self._world > 1:
-            torch.distributed.all_reduce(self._flat_grads)
+        parallel.allreduce_gradients(self._flat_grads)          # between the two graphs (scale is baked into 'update')
         g['update'].replay()
         return g['stats']
 

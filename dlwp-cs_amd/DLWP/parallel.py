@@ -1,0 +1,41 @@
+"""
+Data-parallel plumbing of the engine: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on
+MI355X; "gloo" in the CPU tests).  The path shards over the batch axis only: every rank holds a full
+replica of the 2.7 MB parameter buffer and exchanges exactly one flat fp32 gradient buffer per step.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    """(rank, world_size) of this process; (0, 1) outside a process group."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def broadcast_parameters(flat_params, src=0):
+    """Make every replica start from rank `src`'s parameters (called once by Model.compile)."""
+    if world()[1] > 1:
+        dist.broadcast(flat_params, src=src)
+    return flat_params
+
+
+def allreduce_gradients(flat_grads):
+    """
+    Sum the flat gradient buffer over all ranks (in place) and return the scale (1/world) the optimizer applies, so that
+    the update equals the gradient of the mean loss over the global batch (equal per-rank batch sizes).
+    """
+    w = world()[1]
+    if w > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+    return 1.0 / w
+
+
+def shard_bounds(n, rank=None, world_size=None):
+    """[start, stop) of this rank's contiguous shard of `n` samples (weak scaling: global batch = per-GPU batch x world)."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    base, extra = divmod(n, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
