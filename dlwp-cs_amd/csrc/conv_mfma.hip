@@ -51,39 +51,12 @@ struct ConvKParams {
     long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
 };
 
-// ------------------------------------------------------------------------------------------------------------------
-// Resolve one cell of the padded virtual input to (valid, face, vy, vx) on the Nin grid.
-// ------------------------------------------------------------------------------------------------------------------
-template <int KS>
-__device__ __forceinline__ bool resolve_cell(const ConvKParams &P, int f, int iy, int ix, int &vf, int &vy, int &vx) {
-    vf = f;
-    if (P.mode == MODE_DIRECT) { vy = iy; vx = ix; return true; }
-    if (P.mode == MODE_HALO) {
-        constexpr int p = (KS - 1) / 2;
-        const int N = P.Nin;
-        if (iy >= p && iy < N + p && ix >= p && ix < N + p) { vy = iy - p; vx = ix - p; return true; }
-        const int M = N + 2 * p;
-        const int idx = P.table[(f * M + iy) * M + ix];
-        vf = idx / (N * N);
-        const int rem = idx - vf * N * N;
-        vy = rem / N;
-        vx = rem - vy * N;
-        return true;
-    }
-    // MODE_ZERO: zero border of width KS-1 (full correlation of the data gradient)
-    vy = iy - (KS - 1); vx = ix - (KS - 1);
-    return (vy >= 0) & (vy < P.Nin) & (vx >= 0) & (vx < P.Nin);
-}
-
 // VW consecutive channels as one register vector
 template <int VW> struct VecT;
 template <> struct VecT<1> { typedef float type; };
 template <> struct VecT<2> { typedef float2 type; };
 template <> struct VecT<4> { typedef float4 type; };
 
-__device__ __forceinline__ void vzero(float &v) { v = 0.f; }
-__device__ __forceinline__ void vzero(float2 &v) { v = make_float2(0.f, 0.f); }
-__device__ __forceinline__ void vzero(float4 &v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void vmask(float &v, const float &y, float a, float m) { v *= act_leaky_clip_grad_from_y(y, a, m); }
 __device__ __forceinline__ void vmask(float2 &v, const float2 &y, float a, float m) {
     v.x *= act_leaky_clip_grad_from_y(y.x, a, m); v.y *= act_leaky_clip_grad_from_y(y.y, a, m);
@@ -96,286 +69,59 @@ __device__ __forceinline__ float vsel(bool c, float v) { return c ? v : 0.f; }
 __device__ __forceinline__ float2 vsel(bool c, float2 v) { return c ? v : make_float2(0.f, 0.f); }
 __device__ __forceinline__ float4 vsel(bool c, float4 v) { return c ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// Per-sample-relative element offsets of tile pixel `pix` in src0 (off0) and src1 (off1); -1 = zero cell.
-// This is where the cube-sphere halo (table gather), the nearest-upsampling of src0 and the zero border of the data
-// gradient are resolved.  It runs ONCE per tile and item (the result is channel-chunk invariant) so that the per-chunk
-// fetch below is straight-line code: every load of a chunk is issued back to back and stays in flight.
-template <int KS>
-__device__ __forceinline__ void source_offsets(const ConvKParams &P, int f, int y0, int pix, bool in_tile, int &off0, int &off1) {
-    const int ty = __umulhi((uint32_t)pix, P.magicW2);
-    const int tx = pix - ty * P.W2;
-    int vf, vy, vx;
-    const bool ok = in_tile && resolve_cell<KS>(P, f, y0 + ty, tx, vf, vy, vx);
-    if (!ok) { off0 = -1; off1 = -1; return; }
-    const int g = P.up0 ? (P.Nin >> 1) : P.Nin;
-    const int sy = P.up0 ? (vy >> 1) : vy, sx = P.up0 ? (vx >> 1) : vx;
-    off0 = ((vf * g + sy) * g + sx) * P.C0;
-    off1 = ((vf * P.Nin + vy) * P.Nin + vx) * P.C1;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Forward / data-gradient kernel: software-pipelined over KC-channel chunks.
-//   chunk c+1 is fetched from HBM/L2 into registers (input tile with halo + packed weights) while the matrix cores work
-//   on chunk c out of LDS; the registers are written to the other LDS buffer afterwards; ONE barrier per chunk.
-//   LDS per buffer: input tile rows*W2 pixels x (KC+4) floats + weights NTB*KCG*TAPS*256 floats; two buffers; sized so
-//   that two workgroups fit a CU (KC = 8: 2*(24+9) KB at N = 48), i.e. two waves per SIMD feed each matrix core.
-//   MASK: data-gradient mode with an activation: dz = dy * act'(y) applied while fetching.
-// ------------------------------------------------------------------------------------------------------------------
-template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, bool MASK>
-__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvKParams P) {
-    constexpr int TAPS = KS * KS;
-    constexpr int KCP = KC + 4;
-    constexpr int KCG = KC / 8;
-    constexpr int Q = KC / VW;                      // vectors per pixel per chunk
-    constexpr int NTB = NT * WN;
-    constexpr int NTHREADS = 64 * WM * WN;
-    constexpr int IT_IN = 3 * KC / VW;              // input vectors per thread per chunk: capacity 3*NTHREADS pixels
-    constexpr int WF4 = NTB * KCG * TAPS * 64;      // float4 per weight chunk
-    constexpr int IT_W = (WF4 + NTHREADS - 1) / NTHREADS;
-    constexpr int GF4 = TAPS * 64;                  // float4 per (n tile, channel group)
-    static_assert(NTHREADS % Q == 0, "thread -> channel-vector mapping must not depend on the item");
-    typedef typename VecT<VW>::type V;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int in_floats = P.tile_rows_max * P.W2 * KCP;
-    const int buf_floats = in_floats + WF4 * 4;
-
-    const uint32_t nblk = gridDim.x;
-    const uint32_t L = xcd_remap(blockIdx.x, nblk);
-    const int blk = L % P.nblk_face;
-    const int f = (L / P.nblk_face) % 6;
-    const int b = L / (P.nblk_face * 6);
-    const int nt0 = blockIdx.y * NTB;
-
-    const int face_pix = P.No * P.No;
-    const int m0 = blk * P.pix_per_block;
-    const int npix = min(P.pix_per_block, face_pix - m0);
-    const int y0 = __umulhi((uint32_t)m0, P.magicNo);
-    const int ylast = __umulhi((uint32_t)(m0 + npix - 1), P.magicNo);
-    const int rows = ylast - y0 + KS;
-    const int nitems = rows * P.W2 * Q;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int v = f < 4 ? 0 : (f == 4 ? 1 : 2);
-    const float4 *wsrc = reinterpret_cast<const float4 *>(P.wpk);
-
-    // sample bases of the sources (src1 aliases src0 when absent so that the straight-line fetch never dereferences null)
-    const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
-    const float *s0b = P.src0 + (size_t)b * 6 * g0 * g0 * P.C0;
-    const float *s1b = P.C1 > 0 ? P.src1 + (size_t)b * 6 * P.Nin * P.Nin * P.C1 : s0b;
-    const float *ymb = MASK ? P.ymask + (size_t)b * 6 * g0 * g0 * P.C0 : nullptr;
-    const int qv = (tid % Q) * VW;                  // channel offset of this thread's vectors inside a chunk
-
-    // per-lane LDS offset (floats) of the A operand for each of this wave's M tiles
-    int abase[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = (wm * MT + mt) * 32 + l31;
-        int base = 0;
-        if (m < npix) {
-            const int gm = m0 + m;
-            const int oy = __umulhi((uint32_t)gm, P.magicNo);
-            const int ox = gm - oy * P.No;
-            base = ((oy - y0) * P.W2 + ox) * KCP;
-        }
-        abase[mt] = base + half * 4;
-    }
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-    V pre_in[IT_IN];
-    float4 pre_w[IT_W];
-    int off0[IT_IN], off1[IT_IN];
-
-    auto prepare = [&](int batch) {
-#pragma unroll
-        for (int i = 0; i < IT_IN; ++i) {
-            const int e = tid + (batch * IT_IN + i) * NTHREADS;
-            source_offsets<KS>(P, f, y0, e / Q, e < nitems, off0[i], off1[i]);
-        }
-    };
-    // straight-line: every load of the chunk is issued back to back, nothing waits until commit()
-    auto fetch = [&](int ch, bool with_weights) {
-        const int c = ch * KC + qv;
-        const bool c_ok = c < P.Cin;
-        const bool from0 = c < P.C0;
-#pragma unroll
-        for (int i = 0; i < IT_IN; ++i) {
-            const int o = from0 ? off0[i] : off1[i];
-            const bool ok = c_ok && o >= 0;
-            const float *ptr = ok ? (from0 ? s0b + (size_t)o + c : s1b + (size_t)o + (c - P.C0)) : s0b;
-            V val = *reinterpret_cast<const V *>(ptr);
-            if (MASK) {
-                const float *yp = ok ? ymb + (size_t)o + c : ymb;
-                vmask(val, *reinterpret_cast<const V *>(yp), P.alpha, P.vmax);
-            }
-            pre_in[i] = vsel(ok, val);
-        }
-        if (with_weights) {
-#pragma unroll
-            for (int i = 0; i < IT_W; ++i) {
-                const int idx = min(tid + i * NTHREADS, WF4 - 1);
-                const int g = idx / GF4, w = idx % GF4;
-                const int ntl = g / KCG, cgl = g % KCG;
-                const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
-                const bool ok = ntile < P.NTtot && cg < P.CG;
-                const float4 val = wsrc[ok ? (((size_t)v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0];
-                pre_w[i] = vsel(ok, val);
-            }
-        }
-    };
-    auto commit = [&](float *buf, int batch, bool with_weights) {
-#pragma unroll
-        for (int i = 0; i < IT_IN; ++i) {
-            const int e = tid + (batch * IT_IN + i) * NTHREADS;
-            if (e < nitems) *reinterpret_cast<V *>(buf + (e / Q) * KCP + qv) = pre_in[i];
-        }
-        if (with_weights) {
-#pragma unroll
-            for (int i = 0; i < IT_W; ++i) {
-                const int idx = tid + i * NTHREADS;
-                if (idx < WF4) reinterpret_cast<float4 *>(buf + in_floats)[idx] = pre_w[i];
-            }
-        }
-    };
-    auto compute = [&](const float *buf) {
-        const float *lds_in = buf, *lds_w = buf + in_floats;
-#pragma unroll
-        for (int cgl = 0; cgl < KCG; ++cgl) {
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int dy = tap / KS, dx = tap % KS;
-                const int tapoff = (dy * P.W2 + dx) * KCP + cgl * 8;
-                float4 a[MT], bw[NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4 *>(lds_in + abase[mt] + tapoff);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bw[nt] = *reinterpret_cast<const float4 *>(
-                        lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 128 + l31 * 4);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bw[nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bw[nt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bw[nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bw[nt].w, acc[mt][nt], 0, 0, 0);
-                    }
-            }
-        }
-    };
-
-    const int nchunks = (P.CG + KCG - 1) / KCG;
-    const int nbatch = (nitems + IT_IN * NTHREADS - 1) / (IT_IN * NTHREADS);
-    if (nbatch == 1) {
-        prepare(0);
-        fetch(0, true);
-        commit(smem, 0, true);
-        __syncthreads();
-        for (int ch = 0; ch < nchunks; ++ch) {
-            float *cur = smem + (ch & 1) * buf_floats;
-            float *nxt = smem + ((ch + 1) & 1) * buf_floats;
-            const bool more = ch + 1 < nchunks;
-            if (more) fetch(ch + 1, true);       // global loads stay in flight while the matrix cores run
-                compute(cur);
-                if (more) commit(nxt, 0, true);
-                __syncthreads();
-            }
-    } else {
-        // tile wider than the register prefetch capacity (N >~ 256): stage synchronously, single buffer
-        for (int ch = 0; ch < nchunks; ++ch) {
-            for (int bt = 0; bt < nbatch; ++bt) { prepare(bt); fetch(ch, bt == 0); commit(smem, bt, bt == 0); }
-            __syncthreads();
-            compute(smem);
-            __syncthreads();
-        }
-    }
-
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31 (output channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
-    float *outp = P.out + ((size_t)b * 6 + f) * face_pix * P.Cout;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int co = (nt0 + wn * NT + nt) * 32 + l31;
-        if (co >= P.Cout) continue;
-        const float bv = P.bias ? P.bias[(size_t)v * P.NTtot * 32 + co] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < npix) {
-                    float val = acc[mt][nt][r] + bv;
-                    if (P.act == DLWPCS_ACT_LEAKY_CLIP) val = act_leaky_clip(val, P.alpha, P.vmax);
-                    outp[(size_t)(m0 + m) * P.Cout + co] = val;
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Persistent, software-pipelined form of the forward / data-gradient kernel (the one the hot path runs).
-//
-// Why: a per-tile workgroup spends ~30% of its life in a prologue (halo-table reads -> offsets -> first chunk) and an
-// epilogue (bias, activation, 48 stores per lane) during which its waves issue no MFMA, and because all workgroups of a
-// launch do the same work they hit those phases -- and the memory system -- in lock step across the chip.
-// Here a workgroup loops over a static, strided list of tiles and treats the (tile, channel-chunk) pairs as ONE stream:
-//     iteration g:  issue the global loads of chunk g+1 (possibly the first chunk of the NEXT tile)
-//                   read the halo table of the next tile (at the first chunk of a tile)
-//                   MFMAs of chunk g out of LDS buffer g&1
-//                   write chunk g+1 from registers to LDS buffer (g+1)&1; table entries -> offsets of the next tile
-//                   (last chunk of a tile) bias + activation + stores of the finished tile, accumulators reset
-//                   one barrier
-// so after the first tile nothing the matrix cores need is ever waited for: loads have a whole chunk of MFMAs (~7k
-// cycles) to land, stores drain behind the next tile's MFMAs.  Needs >= 2 chunks per tile (C_in > KC).
-// ------------------------------------------------------------------------------------------------------------------
 #ifdef DLWPCS_TIMELINE
-#define TL_MARK() do { if (tlp && tli < 64) tlp[tli++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TL_MARK() do { if (tlp && tli < 32) tlp[tli++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PL_MARK() do { if (plp && pli < 32) plp[pli++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TL_MARK() do { } while (0)
+#define PL_MARK() do { } while (0)
 #endif
 
-template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, bool MASK>
-__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_pp_kernel(const ConvKParams P) {
+// ------------------------------------------------------------------------------------------------------------------
+// Forward / data-gradient kernel: persistent, wave-specialised.
+//
+// A workgroup = NCW consumer waves (one per SIMD: ds_read + MFMA only) + NCW producer waves (global -> LDS copies); one
+// workgroup per CU.  The (tile, channel chunk) pairs of the workgroup's static tile list form one stream; LDS holds
+// two chunk buffers:
+//     producers:  fill(0); B; fill(1); B; fill(2); B; ...          (B = workgroup barrier, one per chunk)
+//     consumers:           B; mma(0);  B; mma(1);  B; mma(2); ...
+// so chunk g+1 is being fetched while the matrix cores run chunk g, and a consumer's instruction stream between two
+// barriers is nothing but LDS fragment reads (double-buffered in registers) and MFMAs.
+//
+// Producer code is STRAIGHT-LINE per chunk: every address is computed with selects, every load of the chunk (weights,
+// input tile, and -- at a tile's first chunk -- the next tile's halo-table entries) is issued back to back and waited
+// for once.  This matters: with any branch between two loads hipcc waits vmcnt(0) per load (measured: 12 serialised L2
+// round trips, ~17k cycles per chunk, the consumers idle at every barrier).  MODE is a template parameter for that reason.
+//   MODE_HALO  : cube-sphere halo resolved through the (6,N+2,N+2) table          (forward, fused padding)
+//   MODE_DIRECT: input consumed as is ('valid' on an already padded tensor, 1x1)   (forward)
+//   MODE_ZERO  : zero border of width k-1 = full correlation                        (data gradient)
+//   MASK       : dz = dy * act'(y) applied while fetching                           (data gradient through an activation)
+// ------------------------------------------------------------------------------------------------------------------
+template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK>
+__global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P) {
     constexpr int TAPS = KS * KS;
     constexpr int KCP = KC + 4;
     constexpr int KCG = KC / 8;
     constexpr int Q = KC / VW;
     constexpr int NTB = NT * WN;
-    constexpr int NTHREADS = 64 * WM * WN;
-    constexpr int IT_IN = 3 * KC / VW;
-    constexpr int WF4 = NTB * KCG * TAPS * 64;
-    constexpr int IT_W = (WF4 + NTHREADS - 1) / NTHREADS;
+    constexpr int NCT = 64 * WM * WN;               // consumer threads == producer threads
+    constexpr int WF4 = NTB * KCG * TAPS * 64;      // float4 per weight chunk
     constexpr int GF4 = TAPS * 64;
-    static_assert(NTHREADS % Q == 0, "thread -> channel-vector mapping must not depend on the item");
+    constexpr int ITS = 3 * KC / VW;                // input vectors per producer thread per chunk (3*NCT pixels)
+    constexpr int ITW = (WF4 + NCT - 1) / NCT;
+    static_assert(NCT % Q == 0, "thread -> channel-vector mapping must not depend on the item");
     typedef typename VecT<VW>::type V;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int in_floats = P.tile_rows_max * P.W2 * KCP;
     const int buf_floats = in_floats + WF4 * 4;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int half = lane >> 5, l31 = lane & 31;
+    const bool is_producer = tid >= NCT;
     const int nt0 = blockIdx.y * NTB;
     const int face_pix = P.No * P.No;
     const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
-    const int qv = (tid % Q) * VW;
-    const float4 *wsrc = reinterpret_cast<const float4 *>(P.wpk);
     const int G = gridDim.x;
-#ifdef DLWPCS_TIMELINE
-    int tli = 0;
-    long long *tlp = (P.dbg && tid == 0 && blockIdx.y == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
-#endif
+    const int nchunks = (P.CG + KCG - 1) / KCG;
 
     struct Geo { int b, f, v, m0, npix, y0, nitems; };
     auto geo_of = [&](int t) {
@@ -393,7 +139,136 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_pp_kernel(const Con
         return gq;
     };
 
-    // bias of the three face variants, read once
+    if (is_producer) {
+        // =========================================== producers ===========================================
+        const int ptid = tid - NCT;
+        const int qv = (ptid % Q) * VW;
+        const float4 *wsrc = reinterpret_cast<const float4 *>(P.wpk);
+        int t = blockIdx.x;
+        if (t >= P.ntiles) return;
+#ifdef DLWPCS_TIMELINE
+        int pli = 0;
+        long long *plp = (P.dbg && ptid == 0 && blockIdx.y == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
+#endif
+        // (address of the table entry | direct flat source index) of tile item slot i; select-only arithmetic
+        auto table_addr = [&](const Geo &gq, int i) -> int {
+            const int e = min(ptid + i * NCT, gq.nitems - 1);
+            const int pix = e / Q;
+            const int ty = __umulhi((uint32_t)pix, P.magicW2);
+            const int tx = pix - ty * P.W2;
+            const int iy = gq.y0 + ty;
+            if (MODE == MODE_HALO) {
+                const int M = P.Nin + KS - 1;
+                return (gq.f * M + iy) * M + tx;
+            } else if (MODE == MODE_DIRECT) {
+                return (gq.f * P.Nin + iy) * P.Nin + tx;
+            } else {
+                const int vy = iy - (KS - 1), vx = tx - (KS - 1);
+                const bool ok = (vy >= 0) & (vy < P.Nin) & (vx >= 0) & (vx < P.Nin);
+                return ok ? (gq.f * P.Nin + vy) * P.Nin + vx : -1;
+            }
+        };
+        // flat source index on the Nin grid (-1 = zero cell) of every item slot of a tile, all loads in flight at once
+        auto lookup = [&](const Geo &gq, int (&sidx)[ITS]) {
+#pragma unroll
+            for (int i = 0; i < ITS; ++i) {
+                const int a = table_addr(gq, i);
+                const int v0 = (MODE == MODE_HALO) ? P.table[a] : a;
+                sidx[i] = (ptid + i * NCT < gq.nitems) ? v0 : -1;
+            }
+        };
+        int sidx[ITS], sidx_n[ITS];
+        Geo gq = geo_of(t);
+        lookup(gq, sidx);
+        int g = 0;
+
+        // one chunk: weights + input tile (+ optionally the next tile's table entries) -> LDS, straight-line
+        auto fill = [&](const Geo &gc, const Geo &gn, int ch, bool prefetch_next) {
+            float *buf = smem + (g & 1) * buf_floats;
+            const float *s0b = P.src0 + (size_t)gc.b * 6 * g0 * g0 * P.C0;
+            const float *s1b = P.C1 > 0 ? P.src1 + (size_t)gc.b * 6 * P.Nin * P.Nin * P.C1 : s0b;
+            const float *ymb = MASK ? P.ymask + (size_t)gc.b * 6 * g0 * g0 * P.C0 : nullptr;
+            const int c = ch * KC + qv;
+            const bool c_ok = c < P.Cin;
+            const bool from0 = c < P.C0;
+            const float *sb = from0 ? s0b : s1b;
+            const int cs = from0 ? c : c - P.C0;              // channel inside the chosen source
+            const int cstride = from0 ? P.C0 : P.C1;
+            const bool up = from0 && P.up0;
+            PL_MARK();
+            float4 wv[ITW];
+#pragma unroll
+            for (int u = 0; u < ITW; ++u) {
+                const int idx = min(ptid + u * NCT, WF4 - 1);
+                const int gg = idx / GF4, w = idx % GF4;
+                const int ntl = gg / KCG, cgl = gg % KCG;
+                const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
+                const bool ok = ntile < P.NTtot && cg < P.CG;
+                wv[u] = vsel(ok, wsrc[ok ? (((size_t)gc.v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0]);
+            }
+            V val[ITS];
+            V ymv[MASK ? ITS : 1];
+            bool okv[ITS];
+#pragma unroll
+            for (int i = 0; i < ITS; ++i) {
+                const int idx = sidx[i];
+                const bool ok = c_ok && idx >= 0;
+                const int ii = ok ? idx : 0;
+                // nearest-upsampled source: (face, y, x) on the Nin grid -> (face, y/2, x/2) on the Nin/2 grid
+                const int vf = __umulhi((uint32_t)ii, P.magicN2);
+                const int rem = ii - vf * P.Nin * P.Nin;
+                const int vy = __umulhi((uint32_t)rem, P.magicN);
+                const int vx = rem - vy * P.Nin;
+                const int pix_up = (vf * g0 + (vy >> 1)) * g0 + (vx >> 1);
+                const int pix = up ? pix_up : ii;
+                const size_t oo = ok ? (size_t)pix * cstride + cs : 0;
+                val[i] = *reinterpret_cast<const V *>(sb + oo);
+                if (MASK) ymv[i] = *reinterpret_cast<const V *>(ymb + oo);
+                okv[i] = ok;
+            }
+            if (prefetch_next) lookup(gn, sidx_n);
+            PL_MARK();
+            // act' mask only after EVERY load has been issued (a use right behind its load makes hipcc wait per load)
+            if (MASK) {
+#pragma unroll
+                for (int i = 0; i < ITS; ++i) vmask(val[i], ymv[i], P.alpha, P.vmax);
+            }
+#pragma unroll
+            for (int i = 0; i < ITS; ++i) {
+                const int e = ptid + i * NCT;
+                if (e < gc.nitems) *reinterpret_cast<V *>(buf + (e / Q) * KCP + qv) = vsel(okv[i], val[i]);
+            }
+#pragma unroll
+            for (int u = 0; u < ITW; ++u) {
+                const int idx = ptid + u * NCT;
+                if (idx < WF4) reinterpret_cast<float4 *>(buf + in_floats)[idx] = wv[u];
+            }
+            PL_MARK();
+            __syncthreads();            // B_g: chunk g is in LDS
+            ++g;
+        };
+
+        while (true) {
+            const bool have_next = t + G < P.ntiles;
+            const Geo gn = geo_of(have_next ? t + G : t);
+            fill(gq, gn, 0, true);                              // first chunk + next tile's table entries
+            for (int ch = 1; ch < nchunks; ++ch) fill(gq, gn, ch, false);
+            if (!have_next) break;
+            t += G;
+            gq = gn;
+#pragma unroll
+            for (int i = 0; i < ITS; ++i) sidx[i] = sidx_n[i];
+        }
+        return;
+    }
+
+    // ============================================= consumers =============================================
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    // NOTE: no s_setprio(1) here: a prioritised wave waiting for the busy matrix pipe still wins its SIMD's issue
+    // arbitration and starves the co-resident producer wave's address arithmetic.
+
     float bias_v[3][NT];
 #pragma unroll
     for (int vv = 0; vv < 3; ++vv)
@@ -404,18 +279,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_pp_kernel(const Con
         }
 
     f32x16 acc[MT][NT];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    };
-    zero_acc();
-
-    int abase[MT];
-    auto set_abase = [&](const Geo &gq) {
+    float *stage = smem + 2 * buf_floats + wave * (16 * 36);
+    int g = 0;
+#ifdef DLWPCS_TIMELINE
+    int tli = 0;
+    long long *tlp = (P.dbg && tid == 0 && blockIdx.y == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
+#endif
+    TL_MARK();
+    for (int t = blockIdx.x; t < P.ntiles; t += G) {
+        const Geo gq = geo_of(t);
+        int abase[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = (wm * MT + mt) * 32 + l31;
@@ -428,125 +301,58 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_pp_kernel(const Con
             }
             abase[mt] = base + half * 4;
         }
-    };
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    V pre_in[IT_IN];
-    float4 pre_w[IT_W];
-    int sidx_c[IT_IN];      // flat source index (face*Nin + row)*Nin + col of each tile pixel, current tile; -1 = zero
-    int sidx_n[IT_IN];      // same for the next tile (filled by the halo-table loads in flight)
-
-    // read the halo table (or form the identity / zero-border index) for every tile pixel of a tile
-    auto issue_tables = [&](const Geo &gq, int (&sidx)[IT_IN]) {
-#pragma unroll
-        for (int i = 0; i < IT_IN; ++i) {
-            const int e = tid + i * NTHREADS;
-            const int ec = min(e, gq.nitems - 1);
-            const int pix = ec / Q;
-            const int ty = __umulhi((uint32_t)pix, P.magicW2);
-            const int tx = pix - ty * P.W2;
-            const int iy = gq.y0 + ty;
-            int val;
-            if (P.mode == MODE_HALO) {
-                const int M = P.Nin + KS - 1;
-                val = P.table[(gq.f * M + iy) * M + tx];
-            } else if (P.mode == MODE_DIRECT) {
-                val = (gq.f * P.Nin + iy) * P.Nin + tx;
-            } else {    // MODE_ZERO: zero border of width KS-1
-                const int vy = iy - (KS - 1), vx = tx - (KS - 1);
-                const bool ok = (vy >= 0) & (vy < P.Nin) & (vx >= 0) & (vx < P.Nin);
-                val = ok ? (gq.f * P.Nin + vy) * P.Nin + vx : -1;
-            }
-            sidx[i] = e < gq.nitems ? val : -1;
-        }
-    };
-    // straight-line: all loads of the chunk are issued back to back; offsets derived from the flat source index
-    auto fetch = [&](const Geo &gq, int ch, const int (&sidx)[IT_IN]) {
-        const float *s0b = P.src0 + (size_t)gq.b * 6 * g0 * g0 * P.C0;
-        const float *s1b = P.C1 > 0 ? P.src1 + (size_t)gq.b * 6 * P.Nin * P.Nin * P.C1 : s0b;
-        const float *ymb = MASK ? P.ymask + (size_t)gq.b * 6 * g0 * g0 * P.C0 : nullptr;
-        const int c = ch * KC + qv;
-        const bool c_ok = c < P.Cin;
-        const bool from0 = c < P.C0;
-#pragma unroll
-        for (int i = 0; i < IT_IN; ++i) {
-            const int idx = sidx[i];
-            const bool ok = c_ok && idx >= 0;
-            const int ii = ok ? idx : 0;
-            int o;
-            if (from0) {
-                if (P.up0) {
-                    const int vf = __umulhi((uint32_t)ii, P.magicN2);
-                    const int rem = ii - vf * P.Nin * P.Nin;
-                    const int vy = __umulhi((uint32_t)rem, P.magicN);
-                    const int vx = rem - vy * P.Nin;
-                    o = ((vf * g0 + (vy >> 1)) * g0 + (vx >> 1)) * P.C0 + c;
-                } else {
-                    o = ii * P.C0 + c;
-                }
-            } else {
-                o = ii * P.C1 + (c - P.C0);
-            }
-            const float *ptr = (from0 ? s0b : s1b) + (ok ? (size_t)o : 0);
-            V val = *reinterpret_cast<const V *>(ptr);
-            if (MASK) vmask(val, *reinterpret_cast<const V *>(ymb + (ok ? (size_t)o : 0)), P.alpha, P.vmax);
-            pre_in[i] = vsel(ok, val);
-        }
-#pragma unroll
-        for (int i = 0; i < IT_W; ++i) {
-            const int idx = min(tid + i * NTHREADS, WF4 - 1);
-            const int g = idx / GF4, w = idx % GF4;
-            const int ntl = g / KCG, cgl = g % KCG;
-            const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
-            const bool ok = ntile < P.NTtot && cg < P.CG;
-            const float4 val = wsrc[ok ? (((size_t)gq.v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0];
-            pre_w[i] = vsel(ok, val);
-        }
-    };
-    auto commit = [&](float *buf, const Geo &gq) {
-#pragma unroll
-        for (int i = 0; i < IT_IN; ++i) {
-            const int e = tid + i * NTHREADS;
-            if (e < gq.nitems) *reinterpret_cast<V *>(buf + (e / Q) * KCP + qv) = pre_in[i];
-        }
-#pragma unroll
-        for (int i = 0; i < IT_W; ++i) {
-            const int idx = tid + i * NTHREADS;
-            if (idx < WF4) reinterpret_cast<float4 *>(buf + in_floats)[idx] = pre_w[i];
-        }
-    };
-    auto compute = [&](const float *buf) {
-        const float *lds_in = buf, *lds_w = buf + in_floats;
-#pragma unroll
-        for (int cgl = 0; cgl < KCG; ++cgl) {
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
+        for (int ch = 0; ch < nchunks; ++ch, ++g) {
+            TL_MARK();
+            __syncthreads();                // B_g: chunk g has been written by the producers
+            TL_MARK();
+            const float *lds_in = smem + (g & 1) * buf_floats, *lds_w = lds_in + in_floats;
+            // Explicit two-register-set pipeline over the (channel group, tap) steps: the fragments of step s+1 are
+            // read from LDS BEFORE the MFMAs of step s are issued (left alone, the compiler reuses one register set
+            // and stalls on lgkmcnt after every step).
+            constexpr int NSTEP = KCG * TAPS;
+            float4 fa[2][MT], fb[2][NT];
+            auto load_frag = [&](int step, float4 (&a)[MT], float4 (&bq)[NT]) {
+                const int cgl = step / TAPS, tap = step % TAPS;
                 const int dy = tap / KS, dx = tap % KS;
                 const int tapoff = (dy * P.W2 + dx) * KCP + cgl * 8;
-                float4 a[MT], bw[NT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4 *>(lds_in + abase[mt] + tapoff);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    bw[nt] = *reinterpret_cast<const float4 *>(
+                    bq[nt] = *reinterpret_cast<const float4 *>(
                         lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 128 + l31 * 4);
+            };
+            load_frag(0, fa[0], fb[0]);
+#pragma unroll
+            for (int step = 0; step < NSTEP; ++step) {
+                const int cur = step & 1;
+                if (step + 1 < NSTEP) load_frag(step + 1, fa[cur ^ 1], fb[cur ^ 1]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bw[nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bw[nt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bw[nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bw[nt].w, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt].x, fb[cur][nt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt].y, fb[cur][nt].y, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt].z, fb[cur][nt].z, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt].w, fb[cur][nt].w, acc[mt][nt], 0, 0, 0);
                     }
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);     // DS reads of step s+1 first
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0); // then the MFMAs of step s
             }
         }
-    };
-    // bias + activation + stores of a finished tile (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
-    // Wide path (C_out % 4 == 0): each half M tile (16 pixels x 32 channels) is transposed through a wave-private
-    // 16 x 36-float LDS patch so that every lane stores 16 B and 8 lanes cover one 128-B line: 4 dwordx4 stores per
-    // M tile instead of 16 dword stores (the store ISSUE rate, not bandwidth, is what the epilogue costs).
-    float *stage = smem + 2 * buf_floats + wave * (16 * 36);
-    auto epilogue = [&](const Geo &gq) {
+
+        // ---- tile epilogue: bias + activation + stores (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+        // Wide path (C_out % 4 == 0): each half M tile (16 pixels x 32 channels) is transposed through a wave-private
+        // 16 x 36-float LDS patch so that every lane stores 16 B and 8 lanes cover one 128-B line: 4 dwordx4 stores per
+        // M tile instead of 16 dword stores (the epilogue is store-issue bound, not bandwidth bound).
+        TL_MARK();
         float *outp = P.out + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
         const bool wide = (P.Cout & 3) == 0;
 #pragma unroll
@@ -566,7 +372,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_pp_kernel(const Con
                             if (P.act == DLWPCS_ACT_LEAKY_CLIP) val = act_leaky_clip(val, P.alpha, P.vmax);
                             stage[((rr & 3) + 8 * (rr >> 2) + 4 * half) * 36 + l31] = val;
                         }
-                        // wave-private patch: a wave executes in lock step, LDS ops complete in order -> no barrier
+                        // wave-private patch: the wave runs in lock step and its LDS ops complete in order -> no barrier
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
@@ -593,71 +399,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_pp_kernel(const Con
                 }
             }
         }
-    };
-
-    const int nchunks = (P.CG + KCG - 1) / KCG;          // >= 2 (launcher guarantees)
-    int t = blockIdx.x;
-    if (t >= P.ntiles) return;
-    TL_MARK();
-    Geo cur = geo_of(t);
-    issue_tables(cur, sidx_c);
-    set_abase(cur);
-    fetch(cur, 0, sidx_c);
-    commit(smem, cur);
-    __syncthreads();
-    TL_MARK();
-    int gpar = 0;
-    // One tile per trip; the chunk loop is peeled into first / middle / last so that every register array (prefetch
-    // registers, source indices, accumulators) is defined unconditionally on every path (no phi copies -> no spills).
-    // On the final tile the "next tile" is the tile itself: its table reads and first chunk are fetched again and
-    // never used, which keeps the code straight-line.
-    while (true) {
-        const bool have_next = t + G < P.ntiles;
-        const Geo nxt = geo_of(have_next ? t + G : t);
-        // ---- first chunk: also start reading the next tile's halo-table entries
-        {
-            float *bcur = smem + gpar * buf_floats, *bnxt = smem + (gpar ^ 1) * buf_floats;
-            fetch(cur, 1, sidx_c);
-            issue_tables(nxt, sidx_n);
-            TL_MARK();
-            compute(bcur);
-            TL_MARK();
-            commit(bnxt, cur);
-            TL_MARK();
-            __syncthreads();
-            gpar ^= 1;
-        }
-        // ---- middle chunks
-        for (int c = 1; c < nchunks - 1; ++c) {
-            float *bcur = smem + gpar * buf_floats, *bnxt = smem + (gpar ^ 1) * buf_floats;
-            fetch(cur, c + 1, sidx_c);
-            compute(bcur);
-            commit(bnxt, cur);
-            __syncthreads();
-            gpar ^= 1;
-        }
-        // ---- last chunk: the stream moves on to the next tile; finish this one
-        {
-            float *bcur = smem + gpar * buf_floats, *bnxt = smem + (gpar ^ 1) * buf_floats;
-            fetch(nxt, 0, sidx_n);
-            TL_MARK();
-            compute(bcur);
-            TL_MARK();
-            commit(bnxt, nxt);
-            epilogue(cur);
-            zero_acc();
-            TL_MARK();
-            __syncthreads();
-            gpar ^= 1;
-        }
-        if (!have_next) break;
-        t += G;
-        cur = nxt;
-#pragma unroll
-        for (int i = 0; i < IT_IN; ++i) sidx_c[i] = sidx_n[i];
-        set_abase(cur);
+        TL_MARK();
     }
-    TL_MARK();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -721,34 +464,37 @@ struct WgradKParams {
     float *bpartial;        // [nworkers][CoutP] or nullptr
     int CinP, CoutP;        // multiples of 32
     int n_eq, n_4, n_5;     // workers per face class (equatorial faces 0-3 / face 4 / face 5); grid.x = their sum
-    int pipelined;          // two LDS buffers + register prefetch (else synchronous staging, one buffer)
-    uint32_t magicN, magicN2;
 };
 
-// Weight-gradient kernel, persistent form.  GEMM view per tap: D[ci][co] += sum_pixels Xpad[pixel+tap][ci] * dZ[pixel][co],
-// dZ = dy * act'(y).  The accumulators D (k*k taps x 32 x 32, 9 x 16 VGPRs per lane) do not depend on WHICH pixels are
-// summed, so a worker (workgroup of 8 waves, one per CU) owns one (ci tile, co tile) pair and streams through a STATIC,
-// strided list of work items (sample, face, band of <= 192 pixels) of its face class; per item the 8 waves split the
-// pixel pairs (MFMA K = 2 pixels).  Two-deep software pipeline across items: while item t is on the matrix cores, the
-// X / dZ tiles of item t+1 are in flight to registers and the halo-table entries of item t+2 are being read.
-// At the end the 8 waves are summed through LDS in a fixed order and ONE partial per worker is written; a second kernel
-// adds the workers' partials in a fixed order per face class (no atomics -> bitwise reproducible) and applies the
-// weight-group map (class 0 -> equatorial kernel, 1 -> polar, 2 -> polar or north pole, tap rows reversed when flipping).
+// Weight-gradient kernel: persistent + wave-specialised.  GEMM view per tap:
+//     D[ci][co] += sum_pixels Xpad[pixel + tap][ci] * dZ[pixel][co],      dZ = dy * act'(y).
+// The accumulators D (k*k taps x 32 x 32, 9 x 16 VGPRs per lane) do not depend on WHICH pixels are summed, so a worker
+// (one workgroup per CU: 4 consumer + 4 producer waves) owns one (ci tile, co tile) pair and streams through a STATIC,
+// strided list of work items (sample, face, band of <= 192 pixels) of its face class:
+//     producers:  fill(0); B; fill(1); B; ...     X tile (band + halo rows, 32 channels) and dZ tile (band, 32 channels)
+//     consumers:           B; mma(0);  B; ...     the 4 consumer waves split the pixel pairs (MFMA K = 2 pixels)
+// Producer code is straight-line per item (see conv_mfma_ws_kernel for why); the halo-table entries of item t+1 are read
+// together with the data of item t.  Consumers double-buffer their operand registers (10 LDS reads of step s+1 are issued
+// before the 9 MFMAs of step s).  At the end the 4 consumer waves are summed through LDS in a fixed order and ONE partial
+// per worker is written; wgrad_reduce_kernel adds the workers' partials in a fixed order per face class (no atomics ->
+// bitwise reproducible) and applies the weight-group map (class 0 -> equatorial kernel, 1 -> polar, 2 -> polar or north
+// pole, tap rows reversed when flipping).  Bias gradients: the producers of ci tile 0 sum dZ as it passes through their
+// registers.
 template <int KS, int VW, bool MASK>
-__global__ void __launch_bounds__(512, 2) wgrad_mfma_kernel(const WgradKParams W) {
+__global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
     constexpr int TAPS = KS * KS;
     constexpr int XS = 32;                  // X tile row stride (floats) = the 32 input channels of this ci tile
     constexpr int QX = 32 / VW;             // vectors per X pixel
-    constexpr int IT_X = 28 / VW;           // X vectors per thread per item: capacity 448 tile pixels
-    constexpr int IT_DY = 3;                // dZ float4 per thread per item: capacity 192 pixels (x 8 float4)
-    constexpr int NT_ = 512;
+    constexpr int NCT = 256;                // consumer threads == producer threads
+    constexpr int IT_X = 56 / VW;           // X vectors per producer thread per item: capacity 448 tile pixels
+    constexpr int IT_DY = 6;                // dZ float4 per producer thread per item: capacity 192 pixels (x 8 float4)
     typedef typename VecT<VW>::type V;
     const ConvKParams &P = W.c;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int pix_cap = (P.pix_per_block + 1) & ~1;
     const int x_floats = P.tile_rows_max * P.W2 * XS;
-    const int buf_floats = x_floats + pix_cap * 32 + pix_cap;      // X tile, dZ tile, per-pixel X offsets
-    // the 32 KB cross-wave reduction scratch aliases the buffers after the main loop
+    const int buf_floats = x_floats + pix_cap * 32;                // X tile, dZ tile
+    // the 16 KB cross-wave reduction scratch aliases buffer 0 after the main loop
 
     const int worker = blockIdx.x;
     const int cit = blockIdx.y, cot = blockIdx.z;
@@ -759,25 +505,13 @@ __global__ void __launch_bounds__(512, 2) wgrad_mfma_kernel(const WgradKParams W
     const int nbands = P.nblk_face;
     const int total_items = P.B * nfaces * nbands;
     const int n_my = j < total_items ? (total_items - j + nj - 1) / nj : 0;
-
     const int face_pix = P.No * P.No;
-    const bool vec_dy = (P.Cout % 4 == 0);
-    const int nitems_dy = vec_dy ? pix_cap * 8 : pix_cap * 32;
-    const int M = P.Nin + KS - 1;           // padded face size (MODE_HALO)
+    const int tid = threadIdx.x;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int cx = cit * 32 + (tid % QX) * VW;          // this thread's input channel(s): fixed for the whole kernel
-    const bool cx_ok = cx < P.Cin;
-    const bool from0 = cx < P.C0;
-    const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
-    const int csub = from0 ? cx : cx - P.C0;
-    const int cstride = from0 ? P.C0 : P.C1;
-
-    struct Item { int b, f, m0, npix, y0, rows; };
+    struct Item { int b, f, m0, npix, y0, nitems; };
     auto item_of = [&](int k) {
         Item it;
-        const int t = j + k * nj;
+        const int t = j + max(min(k, n_my - 1), 0) * nj;
         const int band = t % nbands;
         const int r = t / nbands;
         it.f = fbase + r % nfaces;
@@ -786,183 +520,209 @@ __global__ void __launch_bounds__(512, 2) wgrad_mfma_kernel(const WgradKParams W
         it.npix = min(P.pix_per_block, face_pix - it.m0);
         it.y0 = __umulhi((uint32_t)it.m0, P.magicNo);
         const int ylast = __umulhi((uint32_t)(it.m0 + it.npix - 1), P.magicNo);
-        it.rows = ylast - it.y0 + KS;
+        it.nitems = (ylast - it.y0 + KS) * P.W2 * QX;
         return it;
     };
 
+    if (tid >= NCT) {
+        // =========================================== producers ===========================================
+        const int ptid = tid - NCT;
+        const int cx = cit * 32 + (ptid % QX) * VW;         // this thread's input channel(s): fixed for the whole kernel
+        const bool cx_ok = cx < P.Cin;
+        const bool from0 = cx < P.C0;
+        const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
+        const int cs = from0 ? cx : cx - P.C0;
+        const int cstride = from0 ? P.C0 : P.C1;
+        const bool up = from0 && P.up0;
+        const int M = P.Nin + KS - 1;
+        const bool vec_dy = (P.Cout % 4 == 0);
+        const bool want_bias = W.bpartial != nullptr && cit == 0;
+        float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);     // dZ column sums of this thread's (pixel subset, 4 channels)
+        int sidx[IT_X], sidx_n[IT_X];
+        auto lookup = [&](const Item &it, int (&sx)[IT_X]) {
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int e = min(ptid + i * NCT, it.nitems - 1);
+                const int pix = e / QX;
+                const int ty = __umulhi((uint32_t)pix, P.magicW2);
+                const int tx = pix - ty * P.W2;
+                const int iy = it.y0 + ty;
+                int v0;
+                if (P.mode == MODE_HALO) v0 = P.table[(it.f * M + iy) * M + tx];
+                else v0 = (it.f * P.Nin + iy) * P.Nin + tx;
+                sx[i] = (ptid + i * NCT < it.nitems) ? v0 : -1;
+            }
+        };
+        Item cur = item_of(0);
+        if (n_my > 0) lookup(cur, sidx);
+#ifdef DLWPCS_TIMELINE
+        int pli = 0;
+        long long *plp = (P.dbg && ptid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
+#endif
+        for (int k = 0; k < n_my; ++k) {
+            PL_MARK();
+            float *buf = smem + (k & 1) * buf_floats;
+            const Item nxt = item_of(k + 1);
+            const float *sb = from0 ? P.src0 + (size_t)cur.b * 6 * g0 * g0 * P.C0
+                                    : P.src1 + (size_t)cur.b * 6 * P.Nin * P.Nin * P.C1;
+            // ---- X tile: every load in flight at once
+            V xv[IT_X];
+            bool xok[IT_X];
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int idx = sidx[i];
+                const bool ok = cx_ok && idx >= 0;
+                const int ii = ok ? idx : 0;
+                const int vf = __umulhi((uint32_t)ii, P.magicN2);
+                const int rem = ii - vf * P.Nin * P.Nin;
+                const int vy = __umulhi((uint32_t)rem, P.magicN);
+                const int vx = rem - vy * P.Nin;
+                const int pix_up = (vf * g0 + (vy >> 1)) * g0 + (vx >> 1);
+                const int pix = up ? pix_up : ii;
+                xv[i] = *reinterpret_cast<const V *>(sb + (ok ? (size_t)pix * cstride + cs : 0));
+                xok[i] = ok;
+            }
+            // ---- dZ tile [pix][32 output channels of tile cot] = dy * act'(y), zero beyond npix / Cout
+            const size_t rowbase = (((size_t)cur.b * 6 + cur.f) * face_pix + cur.m0) * P.Cout;
+            const float *dyb = W.dy + rowbase;
+            const float *yb = MASK ? W.y + rowbase : nullptr;
+            float4 dv[IT_DY], yv[MASK ? IT_DY : 1];
+            bool dok[IT_DY];
+            if (vec_dy) {
+#pragma unroll
+                for (int i = 0; i < IT_DY; ++i) {
+                    const int e = ptid + i * NCT;
+                    const int kk = e >> 3, co = cot * 32 + (e & 7) * 4;
+                    const bool ok = kk < cur.npix && co < P.Cout;
+                    const size_t o = ok ? (size_t)kk * P.Cout + co : 0;
+                    dv[i] = *reinterpret_cast<const float4 *>(dyb + o);
+                    if (MASK) yv[i] = *reinterpret_cast<const float4 *>(yb + o);
+                    dok[i] = ok;
+                }
+            } else {
+                // C_out % 4 != 0 (e.g. the 14-channel head): scalar gather, 4 consecutive tile floats per slot
+#pragma unroll
+                for (int i = 0; i < IT_DY; ++i) {
+                    float gs[4], ys[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e4 = (ptid + i * NCT) * 4 + u;
+                        const int kk = e4 >> 5, co = cot * 32 + (e4 & 31);
+                        const bool ok = kk < cur.npix && co < P.Cout;
+                        const size_t o = ok ? (size_t)kk * P.Cout + co : 0;
+                        gs[u] = ok ? dyb[o] : 0.f;
+                        ys[u] = MASK ? yb[o] : 0.f;
+                    }
+                    dv[i] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+                    if (MASK) yv[i] = make_float4(ys[0], ys[1], ys[2], ys[3]);
+                    dok[i] = true;
+                }
+            }
+            lookup(nxt, sidx_n);                                   // next item's halo-table entries ride along
+            PL_MARK();
+            // dZ = dy * act'(y), applied only after EVERY load of the item has been issued
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) {
+                if (MASK) vmask(dv[i], yv[i], P.alpha, P.vmax);
+                dv[i] = vsel(dok[i], dv[i]);
+            }
+            // ---- registers -> LDS
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int e = ptid + i * NCT;
+                if (e < cur.nitems) *reinterpret_cast<V *>(buf + (e / QX) * XS + (ptid % QX) * VW) = vsel(xok[i], xv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) {
+                const int e = ptid + i * NCT;
+                if (e * 4 < pix_cap * 32) *reinterpret_cast<float4 *>(buf + x_floats + e * 4) = dv[i];
+                if (want_bias) { bsum.x += dv[i].x; bsum.y += dv[i].y; bsum.z += dv[i].z; bsum.w += dv[i].w; }
+            }
+            PL_MARK();
+            __syncthreads();            // B_k: item k is in LDS
+            cur = nxt;
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) sidx[i] = sidx_n[i];
+        }
+        // ---- bias partial: thread (q = ptid & 7, 32 pixel phases) holds sums of channels 4q..4q+3 -> fixed-order tree
+        __syncthreads();                // consumers are done with the buffers (matches the consumers' final barrier)
+        if (want_bias) {
+            float *red = smem + 4096;   // behind the consumers' 4 x 1024-float reduction scratch
+            red[ptid * 4 + 0] = bsum.x; red[ptid * 4 + 1] = bsum.y; red[ptid * 4 + 2] = bsum.z; red[ptid * 4 + 3] = bsum.w;
+        }
+        __syncthreads();
+        if (want_bias && ptid < 32) {
+            // channel c = ptid: quad q = c >> 2, component c & 3; sum over the 32 threads with (t & 7) == q
+            float sum = 0.f;
+            const float *red = smem + 4096;
+#pragma unroll
+            for (int ph = 0; ph < 32; ++ph) sum += red[((ph * 8 + (ptid >> 2)) * 4) + (ptid & 3)];
+            W.bpartial[(size_t)worker * W.CoutP + cot * 32 + ptid] = sum;
+        }
+        // the consumers' tap loop below executes 2 barriers per tap: keep the barrier counts of both halves equal
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) { __syncthreads(); __syncthreads(); }
+        return;
+    }
+
+    // ============================================= consumers =============================================
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
     f32x16 acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float bsum = 0.f;   // bias partial: thread (co = tid&31, part = tid>>5)
 
-    V pre_x[IT_X];
-    float4 pre_dy[IT_DY];
-    int tbl[IT_X];      // stage A: raw halo-table entries of item k+2 (or tile coordinates when there is no halo)
-    int off[IT_X];      // stage B: element offsets (per sample) of item k+1, -1 = nothing to load
-
-    // stage A: read the halo table for the tile pixels of an item (flat source index on the Nin grid)
-    auto issue_table = [&](const Item &it, int batch) {
-        const int nitems_x = it.rows * P.W2 * QX;
+    const int nsteps = pix_cap / 2;             // pixel pairs per item
+    const int S = (((nsteps + 3) / 4) + 1) & ~1; // steps per consumer wave, rounded up to even (extra steps add zero)
+#ifdef DLWPCS_TIMELINE
+    int tli = 0;
+    long long *tlp = (P.dbg && tid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
+#endif
+    for (int k = 0; k < n_my; ++k) {
+        TL_MARK();
+        __syncthreads();                        // B_k
+        TL_MARK();
+        const float *lds_x = smem + (k & 1) * buf_floats, *lds_dy = lds_x + x_floats;
+        const Item it = item_of(k);
+        // operands of step si: pixel kk = 2*s + half, s = wave + 4*si.  Branch-free: out-of-range steps read a clamped
+        // (valid) address and multiply by a zero dZ, so the loop body is straight-line and the two register sets can be
+        // software-pipelined (10 LDS reads of step si+1 before the 9 MFMAs of step si).
+        auto frag = [&](int si, float (&a)[TAPS], float &bq) {
+            const int s = wave + 4 * si;
+            const int k2 = 2 * s + half;
+            const int kk = min(k2, pix_cap - 1);
+            const int gm = it.m0 + min(kk, it.npix - 1);
+            const int oy = __umulhi((uint32_t)gm, P.magicNo);
+            const int pb = ((oy - it.y0) * P.W2 + (gm - oy * P.No)) * XS + l31;
+            const float bv = lds_dy[kk * 32 + l31];
+            bq = (s < nsteps) ? bv : 0.f;
 #pragma unroll
-        for (int i = 0; i < IT_X; ++i) {
-            const int e = min(tid + (batch * IT_X + i) * NT_, nitems_x - 1);
-            const int pix = e / QX;
-            const int ty = __umulhi((uint32_t)pix, P.magicW2);
-            const int tx = pix - ty * P.W2;
-            if (P.mode == MODE_HALO) tbl[i] = P.table[(it.f * M + it.y0 + ty) * M + tx];
-            else tbl[i] = (it.f * P.Nin + it.y0 + ty) * P.Nin + tx;          // MODE_DIRECT: identity
-        }
-    };
-    // stage B: table entry -> element offset into the source this thread reads (upsampling folded in)
-    auto make_offsets = [&](const Item &it, int batch) {
-        const int nitems_x = it.rows * P.W2 * QX;
+            for (int tap = 0; tap < TAPS; ++tap) a[tap] = lds_x[pb + ((tap / KS) * P.W2 + (tap % KS)) * XS];
+        };
+        float fa[2][TAPS], fb[2];
+        frag(0, fa[0], fb[0]);
+        for (int si = 0; si < S; si += 2) {
+            frag(si + 1, fa[1], fb[1]);
 #pragma unroll
-        for (int i = 0; i < IT_X; ++i) {
-            const int e = tid + (batch * IT_X + i) * NT_;
-            const int idx = tbl[i];
-            const int vf = __umulhi((uint32_t)idx, W.magicN2);
-            const int rem = idx - vf * P.Nin * P.Nin;
-            const int vy = __umulhi((uint32_t)rem, W.magicN);
-            const int vx = rem - vy * P.Nin;
-            int o;
-            if (from0) {
-                const int sy = P.up0 ? (vy >> 1) : vy, sx = P.up0 ? (vx >> 1) : vx;
-                o = ((vf * g0 + sy) * g0 + sx) * P.C0;
-            } else {
-                o = idx * P.C1;
-            }
-            off[i] = (e < nitems_x && cx_ok) ? o + csub : -1;
-        }
-        (void)cstride;
-    };
-    // stage C: straight-line loads of the X tile (through the offsets) and of the dZ tile
-    auto issue_data = [&](const Item &it, int batch) {
-        const float *sb = from0 ? P.src0 + (size_t)it.b * 6 * g0 * g0 * P.C0
-                                : P.src1 + (size_t)it.b * 6 * P.Nin * P.Nin * P.C1;
+            for (int tap = 0; tap < TAPS; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][tap], fb[0], acc[tap], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TAPS + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);
+            frag(si + 2, fa[0], fb[0]);
 #pragma unroll
-        for (int i = 0; i < IT_X; ++i) {
-            const bool ok = off[i] >= 0;
-            const V val = *reinterpret_cast<const V *>(ok ? sb + (size_t)off[i] : P.src0);
-            pre_x[i] = vsel(ok, val);
+            for (int tap = 0; tap < TAPS; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][tap], fb[1], acc[tap], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TAPS + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);
         }
-        const size_t rowbase = (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * P.Cout;
-        const float *dyb = W.dy + rowbase;
-        const float *yb = MASK ? W.y + rowbase : nullptr;
-#pragma unroll
-        for (int i = 0; i < IT_DY; ++i) {
-            const int e = tid + (batch * IT_DY + i) * NT_;
-            if (vec_dy) {
-                const int k = e >> 3, co = cot * 32 + (e & 7) * 4;
-                const bool ok = e < nitems_dy && k < it.npix && co < P.Cout;
-                const size_t o = ok ? (size_t)k * P.Cout + co : 0;
-                float4 g = *reinterpret_cast<const float4 *>(dyb + o);
-                if (MASK) vmask(g, *reinterpret_cast<const float4 *>(yb + o), P.alpha, P.vmax);
-                pre_dy[i] = vsel(ok, g);
-            } else {
-                // scalar dZ path (Cout % 4 != 0): 4 consecutive scalars per slot
-                float gs[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e4 = e * 4 + u;
-                    const int k = e4 >> 5, co = cot * 32 + (e4 & 31);
-                    const bool ok = e4 < nitems_dy && k < it.npix && co < P.Cout;
-                    const size_t o = ok ? (size_t)k * P.Cout + co : 0;
-                    float g = dyb[o];
-                    if (MASK) vmask(g, yb[o], P.alpha, P.vmax);
-                    gs[u] = ok ? g : 0.f;
-                }
-                pre_dy[i] = make_float4(gs[0], gs[1], gs[2], gs[3]);
-            }
-        }
-    };
-    auto commit = [&](float *buf, const Item &it, int batch) {
-        const int nitems_x = it.rows * P.W2 * QX;
-#pragma unroll
-        for (int i = 0; i < IT_X; ++i) {
-            const int e = tid + (batch * IT_X + i) * NT_;
-            if (e < nitems_x) *reinterpret_cast<V *>(buf + (e / QX) * XS + (tid % QX) * VW) = pre_x[i];
-        }
-#pragma unroll
-        for (int i = 0; i < IT_DY; ++i) {
-            const int e = tid + (batch * IT_DY + i) * NT_;
-            // both dZ paths hold 4 consecutive floats of the [pix][32] tile per slot
-            if (e * 4 < pix_cap * 32) *reinterpret_cast<float4 *>(buf + x_floats + e * 4) = pre_dy[i];
-        }
-        if (batch == 0) {
-            int *pb = reinterpret_cast<int *>(buf + x_floats + pix_cap * 32);
-            for (int k = tid; k < pix_cap; k += NT_) {
-                int base = 0;
-                if (k < it.npix) {
-                    const int gm = it.m0 + k;
-                    const int oy = __umulhi((uint32_t)gm, P.magicNo);
-                    base = ((oy - it.y0) * P.W2 + (gm - oy * P.No)) * XS;
-                }
-                pb[k] = base;
-            }
-        }
-    };
-    const int nsteps = pix_cap / 2;
-    auto compute = [&](const float *buf, const Item &it) {
-        const float *lds_x = buf, *lds_dy = buf + x_floats;
-        const int *lds_pb = reinterpret_cast<const int *>(buf + x_floats + pix_cap * 32);
-        if (W.bpartial && cit == 0) {
-            const int co = tid & 31, part = tid >> 5;
-            for (int k = part; k < it.npix; k += 16) bsum += lds_dy[k * 32 + co];
-        }
-        for (int s = wave; s < nsteps; s += 8) {
-            const int k = 2 * s + half;
-            const int pb = lds_pb[k];
-            const float bval = lds_dy[k * 32 + l31];
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int dy = tap / KS, dx = tap % KS;
-                const float aval = lds_x[pb + (dy * P.W2 + dx) * XS + l31];
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bval, acc[tap], 0, 0, 0);
-            }
-        }
-    };
-
-    if (W.pipelined) {
-        if (n_my > 0) {
-            const Item i0 = item_of(0);
-            issue_table(i0, 0);
-            make_offsets(i0, 0);
-            issue_data(i0, 0);
-            if (n_my > 1) issue_table(item_of(1), 0);
-            commit(smem, i0, 0);
-            if (n_my > 1) make_offsets(item_of(1), 0);
-        }
-        __syncthreads();
-        for (int k = 0; k < n_my; ++k) {
-            float *cur = smem + (k & 1) * buf_floats;
-            float *nxt = smem + ((k + 1) & 1) * buf_floats;
-            const Item it = item_of(k);
-            if (k + 1 < n_my) issue_data(item_of(k + 1), 0);       // uses off[] of item k+1
-            if (k + 2 < n_my) issue_table(item_of(k + 2), 0);      // table entries of item k+2 in flight
-            compute(cur, it);
-            if (k + 1 < n_my) commit(nxt, item_of(k + 1), 0);
-            if (k + 2 < n_my) make_offsets(item_of(k + 2), 0);
-            __syncthreads();
-        }
-    } else {
-        for (int k = 0; k < n_my; ++k) {
-            const Item it = item_of(k);
-            const int nbx = (it.rows * P.W2 * QX + IT_X * NT_ - 1) / (IT_X * NT_);
-            const int nbd = (nitems_dy + IT_DY * NT_ * (vec_dy ? 1 : 4) - 1) / (IT_DY * NT_ * (vec_dy ? 1 : 4));
-            const int nb = max(nbx, nbd);
-            __syncthreads();
-            for (int bt = 0; bt < nb; ++bt) { issue_table(it, bt); make_offsets(it, bt); issue_data(it, bt); commit(smem, it, bt); }
-            __syncthreads();
-            compute(smem, it);
-        }
-        __syncthreads();
     }
+    __syncthreads();                            // all consumers finished reading the last buffer
+    __syncthreads();                            // (producers stage their bias sums between these two)
 
-    // cross-wave reduction through LDS (fixed order w = 0..7), one tap at a time
+    // cross-wave reduction through LDS (fixed order w = 0..3), one tap at a time
     float *red = smem;
     float *pout = W.partial + (size_t)worker * TAPS * W.CinP * W.CoutP;
+    const int ctid = tid;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
@@ -972,24 +732,13 @@ __global__ void __launch_bounds__(512, 2) wgrad_mfma_kernel(const WgradKParams W
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = tid + i * NT_;
-            const float sum = ((red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e])) +
-                              ((red[4096 + e] + red[5120 + e]) + (red[6144 + e] + red[7168 + e]));
+        for (int i = 0; i < 4; ++i) {
+            const int e = ctid + i * NCT;
+            const float sum = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
             const int ci = e >> 5, co = e & 31;
             pout[((size_t)tap * W.CinP + cit * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
         }
         __syncthreads();
-    }
-    if (W.bpartial && cit == 0) {
-        red[tid] = bsum;
-        __syncthreads();
-        if (tid < 32) {
-            float s = 0.f;
-#pragma unroll
-            for (int part = 0; part < 16; ++part) s += red[part * 32 + tid];
-            W.bpartial[(size_t)worker * W.CoutP + cot * 32 + tid] = s;
-        }
     }
 }
 
@@ -1074,11 +823,11 @@ static int tile_rows_for(int pix, int No) {
     return r > No ? No : r;
 }
 
-template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, bool MASK>
+template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK>
 static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
     const int face_pix = P.No * P.No;
-    // band = whole rows when that does not cost extra workgroups, else a flat range of BM pixels (partial rows)
+    // band = whole rows when that does not cost extra tiles, else a flat range of BM pixels (partial rows)
     int pix = BM < face_pix ? BM : face_pix;
     if (P.No <= BM) {
         int whole = (BM / P.No) * P.No;
@@ -1090,84 +839,71 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     P.W2 = P.No + KS - 1;
     P.magicW2 = div_magic(P.W2);
     P.magicNo = div_magic(P.No);
-    P.tile_rows_max = tile_rows_for(pix, P.No) + (KS - 1);
-    const size_t buf = ((size_t)P.tile_rows_max * P.W2 * (KC + 4) + (size_t)NTB * (KC / 8) * KS * KS * 256) * sizeof(float);
-    const size_t cap_items = (size_t)(3 * KC / VW) * NTHREADS;
-    const bool pipelined = (size_t)P.tile_rows_max * P.W2 * (KC / VW) <= cap_items;
-    size_t lds = pipelined ? 2 * buf : buf;
-    if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv: LDS tile of %zu bytes exceeds 160 KiB (N=%d)", lds, P.No);
-    auto kern = conv_mfma_kernel<KS, KC, MT, NT, WM, WN, VW, MASK>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
-    P.ntiles = P.B * 6 * P.nblk_face;
     P.magicN = div_magic(P.Nin);
     P.magicN2 = div_magic(P.Nin * P.Nin);
+    P.tile_rows_max = tile_rows_for(pix, P.No) + (KS - 1);
+    P.ntiles = P.B * 6 * P.nblk_face;
     P.dbg = nullptr;
 #ifdef DLWPCS_TIMELINE
     { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-    const int nchunks = ceil_div(P.CG, KC / 8);
-    const bool persistent = pipelined && nchunks >= 2 && (long)P.Nin * P.Nin * 6 < (1l << 24);
-    int pidx = -1;
-    if (persistent) {
-        auto kpp = conv_mfma_pp_kernel<KS, KC, MT, NT, WM, WN, VW, MASK>;
-        lds += (size_t)(WM * WN) * 16 * 36 * sizeof(float);      // wave-private epilogue transpose patches
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *)kpp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
-        // one resident set of workgroups: 256 CUs x as many workgroups as the LDS footprint admits (<= 2)
-        int per_cu = (int)((160 * 1024) / lds);
-        if (per_cu > 2) per_cu = 2;
-        if (per_cu < 1) per_cu = 1;
-        int gx = 256 * per_cu;
-        if (gx > P.ntiles) gx = P.ntiles;
-        dim3 grid((unsigned)gx, (unsigned)ceil_div(P.NTtot, NTB));
-        if (prof_enabled()) {
-            char tag[128];
-            snprintf(tag, sizeof(tag), "conv_mfma_pp_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", KS, KC, MT, NT, WM, WN, VW, MASK ? "true" : "false");
-            pidx = prof_begin(tag, W.flops, W.bytes, s);
-        }
-        hipLaunchKernelGGL(kpp, grid, dim3(NTHREADS), lds, s, P);
-    } else {
-        dim3 grid((unsigned)P.ntiles, (unsigned)ceil_div(P.NTtot, NTB));
-        if (prof_enabled()) {
-            char tag[128];
-            snprintf(tag, sizeof(tag), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", KS, KC, MT, NT, WM, WN, VW, MASK ? "true" : "false");
-            pidx = prof_begin(tag, W.flops, W.bytes, s);
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, P);
+    const size_t buf = ((size_t)P.tile_rows_max * P.W2 * (KC + 4) + (size_t)NTB * (KC / 8) * KS * KS * 256) * sizeof(float);
+    const size_t lds = 2 * buf + (size_t)(WM * WN) * 16 * 36 * sizeof(float);     // + wave-private epilogue patches
+    if (lds > 160 * 1024)
+        return fail(DLWPCS_E_UNSUPPORTED, "conv: LDS tile of %zu bytes exceeds 160 KiB (face size %d)", lds, P.No);
+    if ((size_t)P.tile_rows_max * P.W2 > (size_t)3 * NTHREADS)
+        return fail(DLWPCS_E_UNSUPPORTED, "conv: tile of %d x %d pixels exceeds the producers' register capacity", P.tile_rows_max, P.W2);
+    if ((long)P.Nin * P.Nin * 6 >= (1l << 16) * 6 && (long)P.Nin * P.Nin >= (1l << 16))
+        return fail(DLWPCS_E_UNSUPPORTED, "conv: face size %d too large for the 16-bit index arithmetic", P.Nin);
+    auto kern = conv_mfma_ws_kernel<KS, KC, MT, NT, WM, WN, VW, MODE, MASK>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
+    int gx = 256;                                   // one workgroup (consumers + producers) per CU
+    if (gx > P.ntiles) gx = P.ntiles;
+    dim3 grid((unsigned)gx, (unsigned)ceil_div(P.NTtot, NTB));
+    int pidx = -1;
+    if (prof_enabled()) {
+        char tag[160];
+        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s>", KS, KC, MT, NT, WM, WN, VW, MODE,
+                 MASK ? "true" : "false");
+        pidx = prof_begin(tag, W.flops, W.bytes, s);
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(2 * NTHREADS), lds, s, P);
     if (pidx >= 0) prof_end(pidx, s);
     return check_launch("conv_mfma");
 }
 
-template <int KS, int VW, bool MASK>
+template <int KS, int VW, int MODE, bool MASK>
 static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
     const int face_pix = P.No * P.No;
-    if constexpr (KS == 1) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MASK>(P, W, s);
-    else if constexpr (VW != 4) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MASK>(P, W, s);   // odd channel counts: one generic tiling
+    if constexpr (KS == 1) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
+    else if constexpr (VW != 4) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);   // odd channel counts
     else {
-        if (P.NTtot == 1) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MASK>(P, W, s);
-        if (P.NTtot == 2) return launch_conv_cfg<KS, 8, 3, 1, 2, 2, VW, MASK>(P, W, s);
-        if (face_pix <= 320) return launch_conv_cfg<KS, 8, 5, 1, 1, 4, VW, MASK>(P, W, s);
-        return launch_conv_cfg<KS, 8, 3, 1, 1, 4, VW, MASK>(P, W, s);
+        if (P.NTtot == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
+        if (P.NTtot == 2) return launch_conv_cfg<KS, 16, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
+        if (face_pix <= 320) return launch_conv_cfg<KS, 8, 5, 1, 1, 4, VW, MODE, MASK>(P, W, s);
+        return launch_conv_cfg<KS, 8, 3, 1, 1, 4, VW, MODE, MASK>(P, W, s);
     }
 }
 
-template <int KS, bool MASK>
+template <int KS, int MODE, bool MASK>
 static int dispatch_vw(int vw, const ConvKParams &P, const Work &W, hipStream_t s) {
-    if (vw == 4) return launch_conv<KS, 4, MASK>(P, W, s);
-    if (vw == 2) return launch_conv<KS, 2, MASK>(P, W, s);
-    return launch_conv<KS, 1, MASK>(P, W, s);
+    if (vw == 4) return launch_conv<KS, 4, MODE, MASK>(P, W, s);
+    if (vw == 2) return launch_conv<KS, 2, MODE, MASK>(P, W, s);
+    return launch_conv<KS, 1, MODE, MASK>(P, W, s);
 }
 
+// forward: MODE_HALO / MODE_DIRECT without mask; data gradient: MODE_ZERO (k=3) or MODE_DIRECT (k=1) with/without mask
 static int dispatch_conv(int KS, int vw, const ConvKParams &P, const Work &W, hipStream_t s) {
     const bool mask = P.ymask != nullptr;
-    if (KS == 3) return mask ? dispatch_vw<3, true>(vw, P, W, s) : dispatch_vw<3, false>(vw, P, W, s);
-    return mask ? dispatch_vw<1, true>(vw, P, W, s) : dispatch_vw<1, false>(vw, P, W, s);
+    if (KS == 3) {
+        if (P.mode == MODE_HALO) return dispatch_vw<3, MODE_HALO, false>(vw, P, W, s);
+        if (P.mode == MODE_DIRECT) return dispatch_vw<3, MODE_DIRECT, false>(vw, P, W, s);
+        return mask ? dispatch_vw<3, MODE_ZERO, true>(vw, P, W, s) : dispatch_vw<3, MODE_ZERO, false>(vw, P, W, s);
+    }
+    return mask ? dispatch_vw<1, MODE_DIRECT, true>(vw, P, W, s) : dispatch_vw<1, MODE_DIRECT, false>(vw, P, W, s);
 }
 
 static inline int vec_width(int c0, int c1) {
@@ -1401,17 +1137,22 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     W.bpartial = want_bias ? (float *)(ws + L.bpartial) : nullptr;
     W.CinP = CinP; W.CoutP = CoutP;
     W.n_eq = L.n_eq; W.n_4 = L.n_4; W.n_5 = L.n_5;
-    W.magicN = div_magic(P.Nin); W.magicN2 = div_magic(P.Nin * P.Nin);
+    P.magicN = div_magic(P.Nin); P.magicN2 = div_magic(P.Nin * P.Nin);
+    P.dbg = nullptr;
+#ifdef DLWPCS_TIMELINE
+    { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
+#endif
     if (P.C1 == 0) P.src1 = P.src0;
     const bool mask = d->act != DLWPCS_ACT_NONE;
     const int pix_cap = (L.wg_pix + 1) & ~1;
     const int vw = vec_width(d->C0, d->C1);
-    const size_t bufb = ((size_t)P.tile_rows_max * P.W2 * 32 + (size_t)pix_cap * 32 + pix_cap) * 4;
-    const bool fits_regs = (size_t)P.tile_rows_max * P.W2 * (32 / vw) <= (size_t)(28 / vw) * 512 &&
-                           (size_t)pix_cap * 8 <= (size_t)3 * 512;
-    W.pipelined = (fits_regs && 2 * bufb <= 160 * 1024) ? 1 : 0;
-    size_t lds = W.pipelined ? 2 * bufb : bufb;
-    if (lds < 8 * 1024 * 4) lds = 8 * 1024 * 4;       // the 32 KB cross-wave reduction scratch aliases the buffers
+    const size_t bufb = ((size_t)P.tile_rows_max * P.W2 * 32 + (size_t)pix_cap * 32) * 4;
+    if ((size_t)P.tile_rows_max * P.W2 > 448 || pix_cap > 192)
+        return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: tile of %d x %d pixels exceeds the producers' register capacity", P.tile_rows_max, P.W2);
+    if ((long)P.Nin * P.Nin >= (1l << 16))
+        return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: face size %d too large for the 16-bit index arithmetic", P.Nin);
+    size_t lds = 2 * bufb;
+    if (lds < (4096 + 1024) * 4) lds = (4096 + 1024) * 4;     // cross-wave reduction scratch + bias staging alias the buffers
     if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
     dim3 grid((unsigned)(L.n_eq + L.n_4 + L.n_5), (unsigned)(CinP / 32), (unsigned)(CoutP / 32));
 #define WG_LAUNCH(KSV, VWV, MASKV)                                                                                        \
