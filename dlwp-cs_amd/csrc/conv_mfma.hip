@@ -823,17 +823,24 @@ static int tile_rows_for(int pix, int No) {
     return r > No ? No : r;
 }
 
+// pixels per tile for a workgroup that can hold BM pixels: whole rows when that does not cost extra tiles, else a flat
+// range of BM pixels (partial rows)
+static int tile_pixels(int BM, int No) {
+    const int face_pix = No * No;
+    int pix = BM < face_pix ? BM : face_pix;
+    if (No <= BM) {
+        int whole = (BM / No) * No;
+        if (whole > face_pix) whole = face_pix;
+        if (ceil_div(face_pix, whole) <= ceil_div(face_pix, pix)) pix = whole;
+    }
+    return pix;
+}
+
 template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK>
 static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
     const int face_pix = P.No * P.No;
-    // band = whole rows when that does not cost extra tiles, else a flat range of BM pixels (partial rows)
-    int pix = BM < face_pix ? BM : face_pix;
-    if (P.No <= BM) {
-        int whole = (BM / P.No) * P.No;
-        if (whole > face_pix) whole = face_pix;
-        if (ceil_div(face_pix, whole) <= ceil_div(face_pix, pix)) pix = whole;
-    }
+    const int pix = tile_pixels(BM, P.No);
     P.pix_per_block = pix;
     P.nblk_face = ceil_div(face_pix, pix);
     P.W2 = P.No + KS - 1;
@@ -881,6 +888,8 @@ static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
     if constexpr (KS == 1) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
     else if constexpr (VW != 4) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);   // odd channel counts
     else {
+        // Measured (MI355X, batch 32): the smaller tiles (MT = 2 / MT = 1) that would even out the tile count per CU
+        // lose more to halo re-staging (the producers become the bottleneck) than they gain -> fixed MT = 3 tilings.
         if (P.NTtot == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
         if (P.NTtot == 2) return launch_conv_cfg<KS, 16, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
         if (face_pix <= 320) return launch_conv_cfg<KS, 8, 5, 1, 1, 4, VW, MODE, MASK>(P, W, s);
