@@ -26,6 +26,9 @@ sys.path.insert(0, ROOT)
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense (measured 2495)
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+BF16_MFMA_KERNELS = ('conv_mfma_ws_kernel<unsigned short', 'wgrad_bf16_kernel')
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
 FLOP_PER_SAMPLE_FWD = {            # BASELINE.md section 2 (2*6*N^2*k^2*Cin*Cout summed over the conv layers)
     'unet2': None, 'encoder6': None}
@@ -142,6 +145,9 @@ def main():
     ap.add_argument('--face', type=int, default=48)
     ap.add_argument('--channels', type=int, default=14, help='input (= output) channels: 7 variables x 2 time steps')
     ap.add_argument('--base', type=int, default=32)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='activation dtype: f32 = exact-fp32 MFMA everywhere; bf16 = bf16 activations + bf16 MFMA, '
+                         'fp32 master weights / gradients / Adam (BASELINE config 3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graphs', action='store_true')
@@ -150,6 +156,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('DLWPCS_BENCH_SHARE_GPU') == '1':
+        local_rank = 0
     if world != args.gpus:
         if rank == 0 and world == 1 and args.gpus > 1:
             sys.stderr.write('bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`\n'
@@ -161,18 +169,26 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # RCCL over xGMI.  DLWPCS_BENCH_BACKEND=gloo + DLWPCS_BENCH_SHARE_GPU=1 exist only to exercise this exact code path
+        # on a single-GPU box (all ranks on cuda:0, host-staged all-reduce); never used for a reported number.
+        be = os.environ.get('DLWPCS_BENCH_BACKEND', 'nccl')
+        if be == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            torch.distributed.init_process_group(be)
 
     from DLWP.keras import backend
     backend.set_device('cuda:%d' % local_rank)
     N, C, base, B = args.face, args.channels, args.base, args.batch
     np.random.seed(1)
+    backend.set_compute_dtype('bfloat16' if args.dtype == 'bf16' else 'float32')
     model = build_model(args.workload, N, C, C, base)
     model.use_graphs = not args.no_graphs
+    adt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     model.compile(optimizer='adam', loss='mse')
     rng = np.random.default_rng(1000 + rank)
     dev = backend.device()
-    dx = [torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)]
+    dx = [torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(adt)]
     with torch.no_grad():
         oshape = model.predict_on_device(dx[0][:1]).shape[1:]
     dt = [torch.tensor(rng.standard_normal((B,) + tuple(oshape)), dtype=torch.float32, device=dev)]
@@ -203,7 +219,7 @@ def main():
         result = {
             'metric': 'cubed-sphere samples/sec (fwd+bwd)', 'value': round(value, 2), 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': '%s C%d: x (%d,6,%d,%d,%d) per GPU, %d out channels, base %d, MSE + Adam, '
                                    'fwd+bwd+update' % (args.workload, N, B, N, N, C, C, base),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
@@ -213,20 +229,32 @@ def main():
     if rank == 0 and not args.no_roofline:
         agg = roofline_pass(model, dx, dt)
         if agg:
+            # per kernel: the roofline that bounds it = the larger of (algorithmic flops / matrix peak of the instruction
+            # it issues) and (algorithmic bytes / HBM peak); frac = that bound time / measured time
+            def bound_of(name, cnt, ms, fl, by):
+                peak_f = PEAK_BF16_MFMA_TFLOPS if name.startswith(BF16_MFMA_KERNELS) else PEAK_FP32_MFMA_TFLOPS
+                t_f, t_b = fl / (peak_f * 1e12), by / (PEAK_HBM_GBS * 1e9)
+                t = ms * 1e-3
+                if t_f >= t_b:
+                    return {'bound': 'mfma', 'achieved': round(fl / t / 1e12, 3), 'peak': peak_f, 'unit': 'TFLOP/s',
+                            'frac': round(t_f / t, 4)}
+                return {'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round(t_b / t, 4)}
             name, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
-            achieved = fl / (ms * 1e-3) / 1e12
-            result['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                                  'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                                  'traffic': None, 'kernel': name, 'launches': cnt,
-                                  'avg_launch_us': round(1e3 * ms / cnt, 2),
-                                  'algorithmic_gflop_per_launch': round(fl / cnt / 1e9, 3),
-                                  'algorithmic_mbytes_per_launch': round(by / cnt / 1e6, 3)}
+            rf = bound_of(name, cnt, ms, fl, by)
+            rf.update({'traffic': None, 'kernel': name, 'launches': cnt, 'avg_launch_us': round(1e3 * ms / cnt, 2),
+                       'algorithmic_gflop_per_launch': round(fl / cnt / 1e9, 3),
+                       'algorithmic_mbytes_per_launch': round(by / cnt / 1e6, 3)})
             tot_ms = sum(v[1] for v in agg.values())
             tot_fl = sum(v[2] for v in agg.values())
-            result['roofline']['all_mfma_kernels_tflops'] = round(tot_fl / (tot_ms * 1e-3) / 1e12, 3)
-            result['roofline']['per_kernel'] = {k: {'launches': v[0], 'avg_us': round(1e3 * v[1] / v[0], 2),
-                                                    'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
-                                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+            rf['all_mfma_kernels_tflops'] = round(tot_fl / (tot_ms * 1e-3) / 1e12, 3)
+            rf['per_kernel'] = {}
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                bk = bound_of(k, *v)
+                rf['per_kernel'][k] = {'launches': v[0], 'avg_us': round(1e3 * v[1] / v[0], 2),
+                                       'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2), 'bound': bk['bound'],
+                                       'frac': bk['frac']}
+            result['roofline'] = rf
     elif world > 1 and not args.no_roofline:
         pass
     if world > 1:

@@ -16,6 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libdlwpcs.so')
 
 F32 = 0
+BF16 = 1
+MSE_TARGET_F32 = 0x100
 ACT_NONE = 0
 ACT_LEAKY_CLIP = 1
 CONV_ACCUMULATE_WGRAD = 1
@@ -125,8 +127,13 @@ def require_device(t, what):
     if not t.is_cuda:
         raise NativeError('%s: tensor is on %s; the DLWP-CS MI355X engine only runs on a HIP device '
                           '(no CPU fallback).' % (what, t.device))
-    if t.dtype != torch.float32:
-        raise TypeError('%s: dtype %s not supported (float32 this round)' % (what, t.dtype))
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('%s: dtype %s not supported (float32 or bfloat16)' % (what, t.dtype))
+
+
+def dtype_tag(t):
+    """DLWPCS_* dtype tag of an activation tensor."""
+    return BF16 if t.dtype == torch.bfloat16 else F32
 
 
 def stream_ptr():

@@ -4,6 +4,6 @@ Minimal, TensorFlow-free functional-API shim: exactly the subset of `tensorflow.
 concatenate, Reshape, Permute, Adam, callbacks.  Symbolic graph building is pure host Python; execution dispatches to the
 HIP kernels of libdlwpcs.so through DLWP.ops.
 """
-from . import backend, callbacks, layers, models, optimizers   # noqa: F401
+from . import backend, callbacks, layers, mixed_precision, models, optimizers   # noqa: F401
 from .layers import Input   # noqa: F401
 from .models import Model   # noqa: F401

@@ -30,6 +30,27 @@ def floatx():
     return 'float32'
 
 
+# Compute dtype of the ACTIVATIONS ('float32' | 'bfloat16'); parameters, gradients and optimizer state are always fp32.
+# 'bfloat16' is the engine's counterpart of the reference's mixed-precision graph rewrite (Azure/train_cs.py:429).
+_compute_dtype = 'float32'
+
+
+def set_compute_dtype(name):
+    global _compute_dtype
+    name = {'bf16': 'bfloat16', 'f32': 'float32', 'mixed_bfloat16': 'bfloat16'}.get(name, name)
+    if name not in ('float32', 'bfloat16'):
+        raise ValueError('compute dtype must be "float32" or "bfloat16", got %r' % (name,))
+    _compute_dtype = name
+
+
+def compute_dtype():
+    return _compute_dtype
+
+
+def torch_dtype(name=None):
+    return torch.bfloat16 if (name or _compute_dtype) == 'bfloat16' else torch.float32
+
+
 def image_data_format():
     return 'channels_last'
 

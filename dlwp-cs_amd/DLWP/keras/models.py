@@ -53,6 +53,8 @@ class Model(object):
         self.metrics = []
         self.history = None
         self.use_graphs = os.environ.get('DLWPCS_GRAPHS', '1') != '0'
+        # activation dtype on the device ('float32' | 'bfloat16'); parameters / gradients / Adam state are always fp32
+        self.compute_dtype = backend.compute_dtype()
         self._compiled = False
         self._flat_params = self._flat_grads = None
         self._graphs = {}
@@ -148,6 +150,8 @@ class Model(object):
         self.n_fused = len(fused)
 
     def _forward(self, inputs):
+        want = backend.torch_dtype(self.compute_dtype)
+        inputs = [v if v.dtype == want else v.to(want) for v in inputs]
         values = {t.uid: v for t, v in zip(self.inputs, inputs)}
         for st in self._plan:
             if st[0] == 'fused_conv':
@@ -355,11 +359,14 @@ class Model(object):
     # -------------------------------------------------------------------------------------------------------------- #
     # data plumbing
     # -------------------------------------------------------------------------------------------------------------- #
-    def _to_device(self, arr):
+    def _to_device(self, arr, target=False):
+        """host array / tensor -> device tensor in the model's compute dtype (targets stay fp32: the loss is fp32)."""
+        dt = torch.float32 if target else backend.torch_dtype(self.compute_dtype)
         if isinstance(arr, torch.Tensor):
-            return arr.to(backend.device(), dtype=torch.float32)
+            return arr.to(backend.device(), dtype=dt)
         a = np.ascontiguousarray(arr, dtype=np.float32)
-        return torch.from_numpy(a).to(backend.device(), non_blocking=False)
+        t = torch.from_numpy(a).to(backend.device(), non_blocking=False)
+        return t if dt == torch.float32 else t.to(dt)
 
     def _standardize_inputs(self, x):
         if isinstance(x, dict):
@@ -447,7 +454,7 @@ class Model(object):
                 if cbl.wants_batch_logs:
                     cbl.call('on_train_batch_begin', bi, None)
                 dx = [self._to_device(a) for a in bx]
-                dt = [self._to_device(a) for a in by]
+                dt = [self._to_device(a, target=True) for a in by]
                 if count == 0 and epoch == initial_epoch:
                     self._check_shapes(dx, self.inputs, 'input')
                     self._check_shapes(dt, self.outputs, 'target')
@@ -482,7 +489,7 @@ class Model(object):
                 if steps is not None and bi >= steps:
                     break
                 dx = [self._to_device(a) for a in bx]
-                dt = [self._to_device(a) for a in by]
+                dt = [self._to_device(a, target=True) for a in by]
                 n = dx[0].shape[0]
                 stats = self._loss_and_backward(dx, dt, train=False)
                 sums += stats.double() * n            # keras weights batches by their size
@@ -509,7 +516,7 @@ class Model(object):
                 if outs is None:
                     outs = [np.empty((n,) + tuple(r.shape[1:]), dtype=np.float32) for r in res]
                 for o, r in zip(outs, res):
-                    o[s:s + bs] = r.cpu().numpy()
+                    o[s:s + bs] = r.float().cpu().numpy()
         if outs is None:
             outs = [np.empty((0,) + tuple(o.shape[1:]), dtype=np.float32) for o in self.outputs]
         return outs[0] if self._single_output else outs
@@ -542,7 +549,7 @@ class Model(object):
                                          % (tuple(res[-1].shape), tuple(state.shape)))
                     state = res[-1]
                     for k in range(n_steps):
-                        out_series[t * n_steps + k, s:s + bs] = res[k].cpu().numpy()
+                        out_series[t * n_steps + k, s:s + bs] = res[k].float().cpu().numpy()
 
     def reset_states(self):
         pass

@@ -1,7 +1,8 @@
 """
 torch.autograd glue over the C ABI (include/dlwpcs.h).  Every function here launches hand-written HIP kernels from
 libdlwpcs.so on torch's current stream; torch only provides storage and the autograd tape.  All tensors on this level
-are channels_last `(B, 6, H, W, C)` float32 on a HIP device.
+are channels_last `(B, 6, H, W, C)` on a HIP device, float32 or bfloat16 (activations only; parameters, their gradients
+and the optimizer state are always float32 -- see the dtype note in include/dlwpcs.h).
 """
 import ctypes
 
@@ -47,7 +48,8 @@ class _CSPad(torch.autograd.Function):
             raise ValueError('cs_pad: expected (B, 6, N, N, C), got %s' % (tuple(x.shape),))
         table, inv = nat.halo_tables(N, p, x.device)
         y = torch.empty((B, 6, N + 2 * p, N + 2 * p, C), dtype=x.dtype, device=x.device)
-        check(lib().dlwpcs_pad_fwd(ptr(x), ptr(y), B, N, C, p, nat.F32, ptr(table), stream_ptr()), 'dlwpcs_pad_fwd')
+        check(lib().dlwpcs_pad_fwd(ptr(x), ptr(y), B, N, C, p, nat.dtype_tag(x), ptr(table), stream_ptr()),
+              'dlwpcs_pad_fwd')
         ctx.p, ctx.shape = p, (B, N, C)
         ctx.inv = inv
         return y
@@ -57,7 +59,7 @@ class _CSPad(torch.autograd.Function):
         B, N, C = ctx.shape
         dy = _c(dy)
         dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
-        check(lib().dlwpcs_pad_bwd(ptr(dy), ptr(dx), B, N, C, ctx.p, nat.F32, ptr(ctx.inv), stream_ptr()),
+        check(lib().dlwpcs_pad_bwd(ptr(dy), ptr(dx), B, N, C, ctx.p, nat.dtype_tag(dy), ptr(ctx.inv), stream_ptr()),
               'dlwpcs_pad_bwd')
         return dx, None
 
@@ -71,10 +73,15 @@ def cs_pad(x, p):
 # Fused cubed-sphere convolution (reference DLWP/custom.py:921-1002 + :1082-1308 + Keras ReLU/UpSampling3D/concatenate)
 # ------------------------------------------------------------------------------------------------------------------ #
 
-def _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax):
+def _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax, dtype=nat.F32):
     return ConvDesc(B=B, N=N, C0=C0, C1=C1, Cout=Cout, ksize=ksize, halo=int(halo), up0=int(up0),
-                    flip_north_pole=int(flip), act=int(act), alpha=float(alpha), vmax=float(vmax), dtype=nat.F32,
+                    flip_north_pole=int(flip), act=int(act), alpha=float(alpha), vmax=float(vmax), dtype=int(dtype),
                     flags=0)
+
+
+def _f32_param(t, what):
+    if t is not None and t.dtype != torch.float32:
+        raise TypeError('%s: parameters must be float32 master copies, got %s' % (what, t.dtype))
 
 
 class _CSConv(torch.autograd.Function):
@@ -99,13 +106,17 @@ class _CSConv(torch.autograd.Function):
             if tuple(src1.shape[:4]) != (B, 6, N, N):
                 raise ValueError('cs_conv: src1 shape %s does not match (B,6,%d,%d,*)' % (tuple(src1.shape), N, N))
             C1 = src1.shape[4]
+            if src1.dtype != src0.dtype:
+                raise TypeError('cs_conv: src0 is %s but src1 is %s' % (src0.dtype, src1.dtype))
+        for prm in (w_eq, w_pol, w_np, b_eq, b_pol, b_np):
+            _f32_param(prm, 'cs_conv')
         kh, kw, cin, Cout = w_eq.shape
         if kh != ksize or kw != ksize or cin != C0 + C1:
             raise ValueError('cs_conv: kernel shape %s does not match ksize=%d, C_in=%d' % (tuple(w_eq.shape), ksize,
                                                                                           C0 + C1))
         w_eq, w_pol = _c(w_eq), _c(w_pol)
         w_np = _c(w_np) if w_np is not None else None
-        d = _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax)
+        d = _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax, nat.dtype_tag(src0))
         No = N if halo else N - ksize + 1
         y = torch.empty((B, 6, No, No, Cout), dtype=src0.dtype, device=src0.device)
         table = inv = None
@@ -160,9 +171,9 @@ class _CSConv(torch.autograd.Function):
             dw_eq, dw_pol = torch.empty_like(w_eq), torch.empty_like(w_pol)
             dw_np = torch.empty_like(w_np) if has_np else None
             if has_bias:
-                db_eq = torch.empty(d.Cout, dtype=dy.dtype, device=dev)
-                db_pol = torch.empty(d.Cout, dtype=dy.dtype, device=dev)
-                db_np = torch.empty(d.Cout, dtype=dy.dtype, device=dev) if has_bnp else None
+                db_eq = torch.empty(d.Cout, dtype=torch.float32, device=dev)
+                db_pol = torch.empty(d.Cout, dtype=torch.float32, device=dev)
+                db_np = torch.empty(d.Cout, dtype=torch.float32, device=dev) if has_bnp else None
             check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d), ptr(src0), ptr(src1), ptr(dy), ptr(y), ptr(dw_eq),
                                                 ptr(dw_pol), ptr(dw_np), ptr(db_eq), ptr(db_pol), ptr(db_np),
                                                 ptr(table), ptr(ws), ws.numel(), stream_ptr()),
@@ -192,6 +203,9 @@ class _GConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_eq, w_pol, w_np, b_eq, b_pol, b_np, strides, padding, dilation, flip):
         require_device(x, 'cs_gconv')
+        if x.dtype != torch.float32:
+            raise NotImplementedError('cs_gconv (strides / dilation / "same"): float32 only; the bfloat16 path serves the '
+                                      'hot configuration (k in {1,3}, stride 1)')
         x, w_eq, w_pol = _c(x), _c(w_eq), _c(w_pol)
         w_np = _c(w_np) if w_np is not None else None
         B, F6, H, W, Cin = x.shape
@@ -261,7 +275,8 @@ class _Act(torch.autograd.Function):
         require_device(x, 'leaky_clip_relu')
         x = _c(x)
         y = torch.empty_like(x)
-        check(lib().dlwpcs_act_fwd(ptr(x), ptr(y), x.numel(), nat.ACT_LEAKY_CLIP, alpha, vmax, nat.F32, stream_ptr()),
+        check(lib().dlwpcs_act_fwd(ptr(x), ptr(y), x.numel(), nat.ACT_LEAKY_CLIP, alpha, vmax, nat.dtype_tag(x),
+                                   stream_ptr()),
               'dlwpcs_act_fwd')
         ctx.alpha, ctx.vmax = alpha, vmax
         ctx.save_for_backward(y)
@@ -273,7 +288,7 @@ class _Act(torch.autograd.Function):
         dy = _c(dy)
         dx = torch.empty_like(dy)
         check(lib().dlwpcs_act_bwd(ptr(dy), ptr(y), ptr(dx), dy.numel(), nat.ACT_LEAKY_CLIP, ctx.alpha, ctx.vmax,
-                                   nat.F32, stream_ptr()), 'dlwpcs_act_bwd')
+                                   nat.dtype_tag(dy), stream_ptr()), 'dlwpcs_act_bwd')
         return dx, None, None
 
 
@@ -297,7 +312,7 @@ class _AvgPool2(torch.autograd.Function):
             raise ValueError('avgpool2: odd face size %d' % N)
         x = _c(x)
         y = torch.empty((B, 6, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
-        check(lib().dlwpcs_avgpool2_fwd(ptr(x), ptr(y), B, N, C, nat.F32, stream_ptr()), 'dlwpcs_avgpool2_fwd')
+        check(lib().dlwpcs_avgpool2_fwd(ptr(x), ptr(y), B, N, C, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_avgpool2_fwd')
         ctx.shape = (B, N, C)
         return y
 
@@ -306,7 +321,8 @@ class _AvgPool2(torch.autograd.Function):
         B, N, C = ctx.shape
         dy = _c(dy)
         dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
-        check(lib().dlwpcs_avgpool2_bwd(ptr(dy), ptr(dx), B, N, C, nat.F32, stream_ptr()), 'dlwpcs_avgpool2_bwd')
+        check(lib().dlwpcs_avgpool2_bwd(ptr(dy), ptr(dx), B, N, C, nat.dtype_tag(dy), stream_ptr()),
+              'dlwpcs_avgpool2_bwd')
         return dx
 
 
@@ -316,7 +332,8 @@ class _Upsample2(torch.autograd.Function):
         B, N, C = _bnc(x, 'upsample2')
         x = _c(x)
         y = torch.empty((B, 6, 2 * N, 2 * N, C), dtype=x.dtype, device=x.device)
-        check(lib().dlwpcs_upsample2_fwd(ptr(x), ptr(y), B, N, C, nat.F32, stream_ptr()), 'dlwpcs_upsample2_fwd')
+        check(lib().dlwpcs_upsample2_fwd(ptr(x), ptr(y), B, N, C, nat.dtype_tag(x), stream_ptr()),
+              'dlwpcs_upsample2_fwd')
         ctx.shape = (B, N, C)
         return y
 
@@ -325,7 +342,8 @@ class _Upsample2(torch.autograd.Function):
         B, N, C = ctx.shape
         dy = _c(dy)
         dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
-        check(lib().dlwpcs_upsample2_bwd(ptr(dy), ptr(dx), B, N, C, nat.F32, stream_ptr()), 'dlwpcs_upsample2_bwd')
+        check(lib().dlwpcs_upsample2_bwd(ptr(dy), ptr(dx), B, N, C, nat.dtype_tag(dy), stream_ptr()),
+              'dlwpcs_upsample2_bwd')
         return dx
 
 
@@ -344,11 +362,14 @@ class _Concat2(torch.autograd.Function):
         require_device(b, 'concat2')
         if a.shape[:-1] != b.shape[:-1]:
             raise ValueError('concat2: leading shapes differ: %s vs %s' % (tuple(a.shape), tuple(b.shape)))
+        if a.dtype != b.dtype:
+            raise TypeError('concat2: dtypes differ: %s vs %s' % (a.dtype, b.dtype))
         a, b = _c(a), _c(b)
         Ca, Cb = a.shape[-1], b.shape[-1]
         rows = a.numel() // Ca
         y = torch.empty(a.shape[:-1] + (Ca + Cb,), dtype=a.dtype, device=a.device)
-        check(lib().dlwpcs_concat2(ptr(a), ptr(b), ptr(y), rows, Ca, Cb, nat.F32, stream_ptr()), 'dlwpcs_concat2')
+        check(lib().dlwpcs_concat2(ptr(a), ptr(b), ptr(y), rows, Ca, Cb, nat.dtype_tag(a), stream_ptr()),
+              'dlwpcs_concat2')
         ctx.c = (Ca, Cb, rows, a.shape, b.shape)
         return y
 
@@ -359,7 +380,8 @@ class _Concat2(torch.autograd.Function):
         da = torch.empty(sa, dtype=dy.dtype, device=dy.device) if ctx.needs_input_grad[0] else None
         db = torch.empty(sb, dtype=dy.dtype, device=dy.device) if ctx.needs_input_grad[1] else None
         if da is not None or db is not None:
-            check(lib().dlwpcs_split2(ptr(dy), ptr(da), ptr(db), rows, Ca, Cb, nat.F32, stream_ptr()), 'dlwpcs_split2')
+            check(lib().dlwpcs_split2(ptr(dy), ptr(da), ptr(db), rows, Ca, Cb, nat.dtype_tag(dy), stream_ptr()),
+                  'dlwpcs_split2')
         return da, db
 
 
@@ -382,12 +404,12 @@ class _Transpose(torch.autograd.Function):
             C, spatial = x.shape[1], tuple(x.shape[2:])
             S = x.numel() // (B * C) if B * C else 0
             y = torch.empty((B,) + spatial + (C,), dtype=x.dtype, device=x.device)
-            check(lib().dlwpcs_cf_to_cl(ptr(x), ptr(y), B, C, S, nat.F32, stream_ptr()), 'dlwpcs_cf_to_cl')
+            check(lib().dlwpcs_cf_to_cl(ptr(x), ptr(y), B, C, S, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_cf_to_cl')
         else:
             C, spatial = x.shape[-1], tuple(x.shape[1:-1])
             S = x.numel() // (B * C) if B * C else 0
             y = torch.empty((B, C) + spatial, dtype=x.dtype, device=x.device)
-            check(lib().dlwpcs_cl_to_cf(ptr(x), ptr(y), B, C, S, nat.F32, stream_ptr()), 'dlwpcs_cl_to_cf')
+            check(lib().dlwpcs_cl_to_cf(ptr(x), ptr(y), B, C, S, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_cl_to_cf')
         ctx.to_last = to_last
         return y
 
@@ -420,6 +442,11 @@ class _MSE(torch.autograd.Function):
         require_device(t, 'mse')
         if y.shape != t.shape:
             raise ValueError('mse: shapes differ: %s vs %s' % (tuple(y.shape), tuple(t.shape)))
+        tag = nat.dtype_tag(y)
+        if y.dtype != t.dtype:
+            if t.dtype != torch.float32:
+                raise TypeError('mse: prediction is %s but target is %s' % (y.dtype, t.dtype))
+            tag |= nat.MSE_TARGET_F32           # bf16 prediction scored against the fp32 target
         y, t = _c(y), _c(t)
         key = str(y.device)
         scratch = _mse_scratch.get(key)
@@ -428,7 +455,7 @@ class _MSE(torch.autograd.Function):
             _mse_scratch[key] = scratch
         out = torch.zeros(2, dtype=torch.float32, device=y.device)
         dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
-        check(lib().dlwpcs_mse_fwd_bwd(ptr(y), ptr(t), ptr(dy), ptr(out), y.numel(), weight, nat.F32, ptr(scratch),
+        check(lib().dlwpcs_mse_fwd_bwd(ptr(y), ptr(t), ptr(dy), ptr(out), y.numel(), weight, tag, ptr(scratch),
                                        stream_ptr()), 'dlwpcs_mse_fwd_bwd')
         ctx.save_for_backward(dy)
         return out
@@ -449,6 +476,7 @@ def adam_step(p, g, m, v, step_dev, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, g
     """In-place TF2.1-keras Adam on flat fp32 device buffers; `step_dev` is an int32 device scalar (t-1)."""
     for t in (p, g, m, v):
         require_device(t, 'adam_step')
+        _f32_param(t, 'adam_step')
     check(lib().dlwpcs_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(step_dev), lr, beta1, beta2, eps,
                                  grad_scale, stream_ptr()), 'dlwpcs_adam_step')
 
@@ -458,5 +486,5 @@ def add(a, b):
     require_device(b, 'add')
     a, b = _c(a), _c(b)
     y = torch.empty_like(a)
-    check(lib().dlwpcs_add(ptr(a), ptr(b), ptr(y), a.numel(), nat.F32, stream_ptr()), 'dlwpcs_add')
+    check(lib().dlwpcs_add(ptr(a), ptr(b), ptr(y), a.numel(), nat.dtype_tag(a), stream_ptr()), 'dlwpcs_add')
     return y

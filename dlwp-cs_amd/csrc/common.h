@@ -50,4 +50,20 @@ __device__ __forceinline__ float act_leaky_clip_grad_from_y(float y, float alpha
     return y < 0.f ? alpha : ((y > 0.f && y < vmax) ? 1.f : 0.f);
 }
 
+// ---- bf16 storage (DLWPCS_BF16): raw 16-bit patterns in memory, fp32 in registers ------------------------------
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+// round-to-nearest-even, one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
+}
+static inline size_t dtype_size(int dtype) { return dtype == DLWPCS_BF16 ? 2 : 4; }
+static inline bool dtype_ok(int dtype) { return dtype == DLWPCS_F32 || dtype == DLWPCS_BF16; }
+
 }  // namespace dlwpcs

@@ -29,15 +29,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { MODE_DIRECT = 0, MODE_HALO = 1, MODE_ZERO = 2 };
 
 struct ConvKParams {
-    const float *src0, *src1;   // virtual-input sources, channels_last
-    const float *ymask;         // data-gradient mode: saved forward output, act' applied on load (or nullptr)
-    const float *wpk;           // packed weights [3][NTtot][CG][TAPS][2][32][4]
-    const float *bias;          // packed bias [3][NTtot*32] or nullptr
-    float *out;                 // (B,6,No,No,Cout)
+    const void *src0, *src1;    // virtual-input sources, channels_last, element type T
+    const void *ymask;          // data-gradient mode: saved forward output (T), act' applied on load (or nullptr)
+    const void *wpk;            // packed weights [3][NTtot][CG][TAPS][2][32][16 B]: 4 fp32 / 8 bf16 per lane
+    const float *bias;          // packed bias [3][NTtot*32] fp32 or nullptr
+    void *out;                  // (B,6,No,No,Cout), element type T
     const int32_t *table;       // (6, Nin+2, Nin+2) halo table (MODE_HALO, k=3)
     int B, Nin, No;             // face size of V, face size of the output
     int C0, C1, Cin, Cout;      // Cin = C0 + C1
-    int CG, NTtot;              // ceil(Cin/8), ceil(Cout/32)
+    int CG, NTtot;              // ceil(Cin/CGW) (CGW = 8 fp32 / 16 bf16 channels per MFMA operand group), ceil(Cout/32)
     int up0;                    // src0 lives on the Nin/2 grid
     int mode;
     int act;                    // epilogue activation
@@ -51,12 +51,17 @@ struct ConvKParams {
     long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
 };
 
-// VW consecutive channels as one register vector
-template <int VW> struct VecT;
-template <> struct VecT<1> { typedef float type; };
-template <> struct VecT<2> { typedef float2 type; };
-template <> struct VecT<4> { typedef float4 type; };
+// VW consecutive channels of element type T as one register vector
+template <typename T, int VW> struct VecT;
+template <> struct VecT<float, 1> { typedef float type; };
+template <> struct VecT<float, 2> { typedef float2 type; };
+template <> struct VecT<float, 4> { typedef float4 type; };
+template <> struct VecT<bf16_t, 1> { typedef uint16_t type; };
+template <> struct VecT<bf16_t, 2> { typedef uint32_t type; };
+template <> struct VecT<bf16_t, 4> { typedef uint2 type; };
+template <> struct VecT<bf16_t, 8> { typedef uint4 type; };
 
+// v *= act'(y): fp32 vectors
 __device__ __forceinline__ void vmask(float &v, const float &y, float a, float m) { v *= act_leaky_clip_grad_from_y(y, a, m); }
 __device__ __forceinline__ void vmask(float2 &v, const float2 &y, float a, float m) {
     v.x *= act_leaky_clip_grad_from_y(y.x, a, m); v.y *= act_leaky_clip_grad_from_y(y.y, a, m);
@@ -65,9 +70,42 @@ __device__ __forceinline__ void vmask(float4 &v, const float4 &y, float a, float
     v.x *= act_leaky_clip_grad_from_y(y.x, a, m); v.y *= act_leaky_clip_grad_from_y(y.y, a, m);
     v.z *= act_leaky_clip_grad_from_y(y.z, a, m); v.w *= act_leaky_clip_grad_from_y(y.w, a, m);
 }
+// bf16 vectors (raw bit patterns): the product is rounded back to bf16 (dz is a bf16 tensor in this mode)
+__device__ __forceinline__ uint32_t bmask2(uint32_t v, uint32_t y, float a, float m) {
+    return f2bf2(bf_lo(v) * act_leaky_clip_grad_from_y(bf_lo(y), a, m), bf_hi(v) * act_leaky_clip_grad_from_y(bf_hi(y), a, m));
+}
+__device__ __forceinline__ void vmask(uint16_t &v, const uint16_t &y, float a, float m) { v = f2bf(bf2f(v) * act_leaky_clip_grad_from_y(bf2f(y), a, m)); }
+__device__ __forceinline__ void vmask(uint32_t &v, const uint32_t &y, float a, float m) { v = bmask2(v, y, a, m); }
+__device__ __forceinline__ void vmask(uint2 &v, const uint2 &y, float a, float m) { v.x = bmask2(v.x, y.x, a, m); v.y = bmask2(v.y, y.y, a, m); }
+__device__ __forceinline__ void vmask(uint4 &v, const uint4 &y, float a, float m) {
+    v.x = bmask2(v.x, y.x, a, m); v.y = bmask2(v.y, y.y, a, m); v.z = bmask2(v.z, y.z, a, m); v.w = bmask2(v.w, y.w, a, m);
+}
 __device__ __forceinline__ float vsel(bool c, float v) { return c ? v : 0.f; }
 __device__ __forceinline__ float2 vsel(bool c, float2 v) { return c ? v : make_float2(0.f, 0.f); }
 __device__ __forceinline__ float4 vsel(bool c, float4 v) { return c ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ uint16_t vsel(bool c, uint16_t v) { return c ? v : (uint16_t)0; }
+__device__ __forceinline__ uint32_t vsel(bool c, uint32_t v) { return c ? v : 0u; }
+__device__ __forceinline__ uint2 vsel(bool c, uint2 v) { return c ? v : make_uint2(0u, 0u); }
+__device__ __forceinline__ uint4 vsel(bool c, uint4 v) { return c ? v : make_uint4(0u, 0u, 0u, 0u); }
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// one (M tile, N tile) update from a 16-B A and a 16-B B fragment:
+//   fp32: 4 x v_mfma_f32_32x32x2_f32  (K = 8 channels per fragment pair)
+//   bf16: 1 x v_mfma_f32_32x32x16_bf16 (K = 16 channels per fragment pair)
+template <typename T> __device__ __forceinline__ void frag_mma(f32x16 &acc, const uint4 &a, const uint4 &b);
+template <> __device__ __forceinline__ void frag_mma<float>(f32x16 &acc, const uint4 &a, const uint4 &b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void frag_mma<bf16_t>(f32x16 &acc, const uint4 &a, const uint4 &b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <typename T> struct MmaPerFrag;
+template <> struct MmaPerFrag<float> { static constexpr int N = 4; };
+template <> struct MmaPerFrag<bf16_t> { static constexpr int N = 1; };
 
 #ifdef DLWPCS_TIMELINE
 #define TL_MARK() do { if (tlp && tli < 32) tlp[tli++] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -97,23 +135,28 @@ __device__ __forceinline__ float4 vsel(bool c, float4 v) { return c ? v : make_f
 //   MODE_ZERO  : zero border of width k-1 = full correlation                        (data gradient)
 //   MASK       : dz = dy * act'(y) applied while fetching                           (data gradient through an activation)
 // ------------------------------------------------------------------------------------------------------------------
-template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK>
+// T = element type of the activations in HBM / LDS (float, or bf16_t with bf16 MFMA); all LDS geometry is in BYTES and
+// identical for both: a pixel row holds KC channels (64 B at KC = 16 fp32 / 32 bf16) + 16 B pad.
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK>
 __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P) {
+    constexpr int ES = sizeof(T);
+    constexpr int CGW = 32 / ES;                    // channels per MFMA operand group (two 16-B half fragments)
     constexpr int TAPS = KS * KS;
-    constexpr int KCP = KC + 4;
-    constexpr int KCG = KC / 8;
+    constexpr int RB = KC * ES + 16;                // LDS bytes per tile pixel
+    constexpr int KCG = KC / CGW;
     constexpr int Q = KC / VW;
     constexpr int NTB = NT * WN;
     constexpr int NCT = 64 * WM * WN;               // consumer threads == producer threads
-    constexpr int WF4 = NTB * KCG * TAPS * 64;      // float4 per weight chunk
+    constexpr int WF4 = NTB * KCG * TAPS * 64;      // 16-B entries per weight chunk
     constexpr int GF4 = TAPS * 64;
     constexpr int ITS = 3 * KC / VW;                // input vectors per producer thread per chunk (3*NCT pixels)
     constexpr int ITW = (WF4 + NCT - 1) / NCT;
     static_assert(NCT % Q == 0, "thread -> channel-vector mapping must not depend on the item");
-    typedef typename VecT<VW>::type V;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int in_floats = P.tile_rows_max * P.W2 * KCP;
-    const int buf_floats = in_floats + WF4 * 4;
+    static_assert(KC % CGW == 0 && KC % VW == 0, "chunk must hold whole operand groups and whole vectors");
+    typedef typename VecT<T, VW>::type V;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int in_bytes = P.tile_rows_max * P.W2 * RB;
+    const int buf_bytes = in_bytes + WF4 * 16;
 
     const int tid = threadIdx.x;
     const bool is_producer = tid >= NCT;
@@ -143,7 +186,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         // =========================================== producers ===========================================
         const int ptid = tid - NCT;
         const int qv = (ptid % Q) * VW;
-        const float4 *wsrc = reinterpret_cast<const float4 *>(P.wpk);
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.wpk);
         int t = blockIdx.x;
         if (t >= P.ntiles) return;
 #ifdef DLWPCS_TIMELINE
@@ -184,19 +227,19 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 
         // one chunk: weights + input tile (+ optionally the next tile's table entries) -> LDS, straight-line
         auto fill = [&](const Geo &gc, const Geo &gn, int ch, bool prefetch_next) {
-            float *buf = smem + (g & 1) * buf_floats;
-            const float *s0b = P.src0 + (size_t)gc.b * 6 * g0 * g0 * P.C0;
-            const float *s1b = P.C1 > 0 ? P.src1 + (size_t)gc.b * 6 * P.Nin * P.Nin * P.C1 : s0b;
-            const float *ymb = MASK ? P.ymask + (size_t)gc.b * 6 * g0 * g0 * P.C0 : nullptr;
+            char *buf = smem + (g & 1) * buf_bytes;
+            const T *s0b = reinterpret_cast<const T *>(P.src0) + (size_t)gc.b * 6 * g0 * g0 * P.C0;
+            const T *s1b = P.C1 > 0 ? reinterpret_cast<const T *>(P.src1) + (size_t)gc.b * 6 * P.Nin * P.Nin * P.C1 : s0b;
+            const T *ymb = MASK ? reinterpret_cast<const T *>(P.ymask) + (size_t)gc.b * 6 * g0 * g0 * P.C0 : nullptr;
             const int c = ch * KC + qv;
             const bool c_ok = c < P.Cin;
             const bool from0 = c < P.C0;
-            const float *sb = from0 ? s0b : s1b;
+            const T *sb = from0 ? s0b : s1b;
             const int cs = from0 ? c : c - P.C0;              // channel inside the chosen source
             const int cstride = from0 ? P.C0 : P.C1;
             const bool up = from0 && P.up0;
             PL_MARK();
-            float4 wv[ITW];
+            uint4 wv[ITW];
 #pragma unroll
             for (int u = 0; u < ITW; ++u) {
                 const int idx = min(ptid + u * NCT, WF4 - 1);
@@ -236,12 +279,12 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 #pragma unroll
             for (int i = 0; i < ITS; ++i) {
                 const int e = ptid + i * NCT;
-                if (e < gc.nitems) *reinterpret_cast<V *>(buf + (e / Q) * KCP + qv) = vsel(okv[i], val[i]);
+                if (e < gc.nitems) *reinterpret_cast<V *>(buf + (e / Q) * RB + qv * ES) = vsel(okv[i], val[i]);
             }
 #pragma unroll
             for (int u = 0; u < ITW; ++u) {
                 const int idx = ptid + u * NCT;
-                if (idx < WF4) reinterpret_cast<float4 *>(buf + in_floats)[idx] = wv[u];
+                if (idx < WF4) reinterpret_cast<uint4 *>(buf + in_bytes)[idx] = wv[u];
             }
             PL_MARK();
             __syncthreads();            // B_g: chunk g is in LDS
@@ -279,7 +322,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         }
 
     f32x16 acc[MT][NT];
-    float *stage = smem + 2 * buf_floats + wave * (16 * 36);
+    float *stage = reinterpret_cast<float *>(smem + 2 * buf_bytes) + wave * (16 * 36);
     int g = 0;
 #ifdef DLWPCS_TIMELINE
     int tli = 0;
@@ -297,9 +340,9 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 const int gm = gq.m0 + m;
                 const int oy = __umulhi((uint32_t)gm, P.magicNo);
                 const int ox = gm - oy * P.No;
-                base = ((oy - gq.y0) * P.W2 + ox) * KCP;
+                base = ((oy - gq.y0) * P.W2 + ox) * RB;
             }
-            abase[mt] = base + half * 4;
+            abase[mt] = base + half * 16;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -312,22 +355,22 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             TL_MARK();
             __syncthreads();                // B_g: chunk g has been written by the producers
             TL_MARK();
-            const float *lds_in = smem + (g & 1) * buf_floats, *lds_w = lds_in + in_floats;
+            const char *lds_in = smem + (g & 1) * buf_bytes, *lds_w = lds_in + in_bytes;
             // Explicit two-register-set pipeline over the (channel group, tap) steps: the fragments of step s+1 are
             // read from LDS BEFORE the MFMAs of step s are issued (left alone, the compiler reuses one register set
             // and stalls on lgkmcnt after every step).
             constexpr int NSTEP = KCG * TAPS;
-            float4 fa[2][MT], fb[2][NT];
-            auto load_frag = [&](int step, float4 (&a)[MT], float4 (&bq)[NT]) {
+            uint4 fa[2][MT], fb[2][NT];
+            auto load_frag = [&](int step, uint4 (&a)[MT], uint4 (&bq)[NT]) {
                 const int cgl = step / TAPS, tap = step % TAPS;
                 const int dy = tap / KS, dx = tap % KS;
-                const int tapoff = (dy * P.W2 + dx) * KCP + cgl * 8;
+                const int tapoff = (dy * P.W2 + dx) * RB + cgl * 32;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4 *>(lds_in + abase[mt] + tapoff);
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const uint4 *>(lds_in + abase[mt] + tapoff);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    bq[nt] = *reinterpret_cast<const float4 *>(
-                        lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 128 + l31 * 4);
+                    bq[nt] = *reinterpret_cast<const uint4 *>(
+                        lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 512 + l31 * 16);
             };
             load_frag(0, fa[0], fb[0]);
 #pragma unroll
@@ -337,23 +380,18 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt].x, fb[cur][nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt].y, fb[cur][nt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt].z, fb[cur][nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt].w, fb[cur][nt].w, acc[mt][nt], 0, 0, 0);
-                    }
-                __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);     // DS reads of step s+1 first
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0); // then the MFMAs of step s
+                    for (int nt = 0; nt < NT; ++nt) frag_mma<T>(acc[mt][nt], fa[cur][mt], fb[cur][nt]);
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);                          // DS reads of step s+1 first
+                __builtin_amdgcn_sched_group_barrier(0x008, MmaPerFrag<T>::N * MT * NT, 0);       // then the MFMAs of step s
             }
         }
 
         // ---- tile epilogue: bias + activation + stores (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
         // Wide path (C_out % 4 == 0): each half M tile (16 pixels x 32 channels) is transposed through a wave-private
-        // 16 x 36-float LDS patch so that every lane stores 16 B and 8 lanes cover one 128-B line: 4 dwordx4 stores per
-        // M tile instead of 16 dword stores (the epilogue is store-issue bound, not bandwidth bound).
+        // 16 x 36-float LDS patch so that every lane stores 4 channels (16 B fp32 / 8 B bf16) and 8 lanes cover one
+        // pixel's 32 channels: 4 wide stores per M tile instead of 16 scalar stores (the epilogue is store-issue bound).
         TL_MARK();
-        float *outp = P.out + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
+        T *outp = reinterpret_cast<T *>(P.out) + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
         const bool wide = (P.Cout & 3) == 0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -381,8 +419,11 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                             const float4 v4 = *reinterpret_cast<const float4 *>(stage + row * 36 + quad * 4);
                             const int m = (wm * MT + mt) * 32 + h * 16 + row;
                             const int c4 = cot + quad * 4;
-                            if (m < gq.npix && c4 < P.Cout)
-                                *reinterpret_cast<float4 *>(outp + (size_t)(gq.m0 + m) * P.Cout + c4) = v4;
+                            if (m < gq.npix && c4 < P.Cout) {
+                                T *dst = outp + (size_t)(gq.m0 + m) * P.Cout + c4;
+                                if constexpr (ES == 4) *reinterpret_cast<float4 *>(dst) = v4;
+                                else *reinterpret_cast<uint2 *>(dst) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
+                            }
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
@@ -393,7 +434,8 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                         if (m < gq.npix) {
                             float val = acc[mt][nt][r] + bv;
                             if (P.act == DLWPCS_ACT_LEAKY_CLIP) val = act_leaky_clip(val, P.alpha, P.vmax);
-                            outp[(size_t)(gq.m0 + m) * P.Cout + co] = val;
+                            if constexpr (ES == 4) outp[(size_t)(gq.m0 + m) * P.Cout + co] = val;
+                            else outp[(size_t)(gq.m0 + m) * P.Cout + co] = f2bf(val);
                         }
                     }
                 }
@@ -410,21 +452,25 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 // row(r) = KS-1-r on variant 2 when flip_north_pole (flip -> conv -> flip == row-reversed kernel), else r.
 // Also packs the biases to [3][NTtot*32].
 // ------------------------------------------------------------------------------------------------------------------
+// T = MFMA operand type: float -> 4 values per 16-B lane entry (K group of 8), bf16_t -> 8 values (K group of 16; the
+// fp32 master weights are rounded to bf16 here, once per call).
+template <typename T>
 __global__ void __launch_bounds__(256) pack_weights_kernel(const float *__restrict__ w_eq, const float *__restrict__ w_pol,
-                                                           const float *__restrict__ w_np, float *__restrict__ out,
+                                                           const float *__restrict__ w_np, T *__restrict__ out,
                                                            int KS, int Cin, int Cout, int K, int Ncol, int CG, int NTtot,
                                                            int flip, int transposed, size_t total) {
+    constexpr int J = 16 / (int)sizeof(T);
     const int TAPS = KS * KS;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         size_t r = e;
-        const int j = r % 4; r /= 4;
+        const int j = r % J; r /= J;
         const int n = r % 32; r /= 32;
         const int hf = r % 2; r /= 2;
         const int tap = r % TAPS; r /= TAPS;
         const int cg = r % CG; r /= CG;
         const int nt = r % NTtot; r /= NTtot;
         const int v = (int)r;
-        const int k = cg * 8 + hf * 4 + j, col = nt * 32 + n;
+        const int k = (cg * 2 + hf) * J + j, col = nt * 32 + n;
         float val = 0.f;
         if (k < K && col < Ncol) {
             const float *w = v == 0 ? w_eq : (v == 1 ? w_pol : (w_np ? w_np : w_pol));
@@ -434,7 +480,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float *__restri
             if (v == 2 && flip) ty = KS - 1 - ty;
             val = w[((size_t)(ty * KS + tx) * Cin + ci) * Cout + co];
         }
-        out[e] = val;
+        if constexpr (sizeof(T) == 4) out[e] = val; else out[e] = f2bf(val);
     }
 }
 
@@ -459,7 +505,7 @@ __global__ void __launch_bounds__(256) pack_bias_kernel(const float *__restrict_
 // ------------------------------------------------------------------------------------------------------------------
 struct WgradKParams {
     ConvKParams c;          // description of the virtual input (src0/src1/table/mode/...), ymask unused here
-    const float *dy, *y;    // (B,6,No,No,Cout); y nullable
+    const void *dy, *y;     // (B,6,No,No,Cout), element type T; y nullable
     float *partial;         // [nworkers][TAPS][CinP][CoutP]
     float *bpartial;        // [nworkers][CoutP] or nullptr
     int CinP, CoutP;        // multiples of 32
@@ -480,17 +526,41 @@ struct WgradKParams {
 // bitwise reproducible) and applies the weight-group map (class 0 -> equatorial kernel, 1 -> polar, 2 -> polar or north
 // pole, tap rows reversed when flipping).  Bias gradients: the producers of ci tile 0 sum dZ as it passes through their
 // registers.
-template <int KS, int VW, bool MASK>
+//
+// T = element type of X and dZ in HBM.  bf16 inputs are widened to fp32 by the producers on their way into LDS, the
+// consumers are the same exact-fp32 MFMA loop for both (wgrad_bf16_kernel below is the bf16-MFMA version for the
+// hot-path shapes; this kernel is its general fallback).
+// fp32 <- raw register vectors
+__device__ __forceinline__ void st_f32(float *d, float v) { *d = v; }
+__device__ __forceinline__ void st_f32(float *d, float2 v) { *reinterpret_cast<float2 *>(d) = v; }
+__device__ __forceinline__ void st_f32(float *d, float4 v) { *reinterpret_cast<float4 *>(d) = v; }
+__device__ __forceinline__ void st_f32(float *d, uint16_t v) { *d = bf2f(v); }
+__device__ __forceinline__ void st_f32(float *d, uint32_t v) { *reinterpret_cast<float2 *>(d) = make_float2(bf_lo(v), bf_hi(v)); }
+__device__ __forceinline__ void st_f32(float *d, uint2 v) { *reinterpret_cast<float4 *>(d) = make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y)); }
+__device__ __forceinline__ void st_f32(float *d, uint4 v) {
+    reinterpret_cast<float4 *>(d)[0] = make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
+    reinterpret_cast<float4 *>(d)[1] = make_float4(bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
+}
+__device__ __forceinline__ float4 to_f4(float4 v) { return v; }
+__device__ __forceinline__ float4 to_f4(uint2 v) { return make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y)); }
+__device__ __forceinline__ float4 pack4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+__device__ __forceinline__ uint2 pack4(bf16_t a, bf16_t b, bf16_t c, bf16_t d) {
+    return make_uint2((uint32_t)a | ((uint32_t)b << 16), (uint32_t)c | ((uint32_t)d << 16));
+}
+
+template <typename T, int KS, int VW, bool MASK>
 __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
     constexpr int TAPS = KS * KS;
     constexpr int XS = 32;                  // X tile row stride (floats) = the 32 input channels of this ci tile
     constexpr int QX = 32 / VW;             // vectors per X pixel
     constexpr int NCT = 256;                // consumer threads == producer threads
     constexpr int IT_X = 56 / VW;           // X vectors per producer thread per item: capacity 448 tile pixels
-    constexpr int IT_DY = 6;                // dZ float4 per producer thread per item: capacity 192 pixels (x 8 float4)
-    typedef typename VecT<VW>::type V;
+    constexpr int IT_DY = 6;                // dZ quads per producer thread per item: capacity 192 pixels (x 8 quads)
+    typedef typename VecT<T, VW>::type V;
+    typedef typename VecT<T, 4>::type DV;   // 4 consecutive output channels as loaded from HBM
     const ConvKParams &P = W.c;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *smem = reinterpret_cast<float *>(smem_raw);
     const int pix_cap = (P.pix_per_block + 1) & ~1;
     const int x_floats = P.tile_rows_max * P.W2 * XS;
     const int buf_floats = x_floats + pix_cap * 32;                // X tile, dZ tile
@@ -535,7 +605,7 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
         const int cstride = from0 ? P.C0 : P.C1;
         const bool up = from0 && P.up0;
         const int M = P.Nin + KS - 1;
-        const bool vec_dy = (P.Cout % 4 == 0);
+        const bool vec_dy = (P.Cout % 4 == 0);      // block-uniform
         const bool want_bias = W.bpartial != nullptr && cit == 0;
         float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);     // dZ column sums of this thread's (pixel subset, 4 channels)
         int sidx[IT_X], sidx_n[IT_X];
@@ -563,8 +633,8 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
             PL_MARK();
             float *buf = smem + (k & 1) * buf_floats;
             const Item nxt = item_of(k + 1);
-            const float *sb = from0 ? P.src0 + (size_t)cur.b * 6 * g0 * g0 * P.C0
-                                    : P.src1 + (size_t)cur.b * 6 * P.Nin * P.Nin * P.C1;
+            const T *sb = from0 ? reinterpret_cast<const T *>(P.src0) + (size_t)cur.b * 6 * g0 * g0 * P.C0
+                                : reinterpret_cast<const T *>(P.src1) + (size_t)cur.b * 6 * P.Nin * P.Nin * P.C1;
             // ---- X tile: every load in flight at once
             V xv[IT_X];
             bool xok[IT_X];
@@ -584,9 +654,10 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
             }
             // ---- dZ tile [pix][32 output channels of tile cot] = dy * act'(y), zero beyond npix / Cout
             const size_t rowbase = (((size_t)cur.b * 6 + cur.f) * face_pix + cur.m0) * P.Cout;
-            const float *dyb = W.dy + rowbase;
-            const float *yb = MASK ? W.y + rowbase : nullptr;
+            const T *dyb = reinterpret_cast<const T *>(W.dy) + rowbase;
+            const T *yb = MASK ? reinterpret_cast<const T *>(W.y) + rowbase : nullptr;
             float4 dv[IT_DY], yv[MASK ? IT_DY : 1];
+            DV dvr[IT_DY], yvr[MASK ? IT_DY : 1];
             bool dok[IT_DY];
             if (vec_dy) {
 #pragma unroll
@@ -595,26 +666,26 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
                     const int kk = e >> 3, co = cot * 32 + (e & 7) * 4;
                     const bool ok = kk < cur.npix && co < P.Cout;
                     const size_t o = ok ? (size_t)kk * P.Cout + co : 0;
-                    dv[i] = *reinterpret_cast<const float4 *>(dyb + o);
-                    if (MASK) yv[i] = *reinterpret_cast<const float4 *>(yb + o);
+                    dvr[i] = *reinterpret_cast<const DV *>(dyb + o);
+                    if (MASK) yvr[i] = *reinterpret_cast<const DV *>(yb + o);
                     dok[i] = ok;
                 }
             } else {
                 // C_out % 4 != 0 (e.g. the 14-channel head): scalar gather, 4 consecutive tile floats per slot
 #pragma unroll
                 for (int i = 0; i < IT_DY; ++i) {
-                    float gs[4], ys[4];
+                    T gs[4], ys[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int e4 = (ptid + i * NCT) * 4 + u;
                         const int kk = e4 >> 5, co = cot * 32 + (e4 & 31);
                         const bool ok = kk < cur.npix && co < P.Cout;
                         const size_t o = ok ? (size_t)kk * P.Cout + co : 0;
-                        gs[u] = ok ? dyb[o] : 0.f;
-                        ys[u] = MASK ? yb[o] : 0.f;
+                        gs[u] = ok ? dyb[o] : (T)0;
+                        ys[u] = MASK ? yb[o] : (T)0;
                     }
-                    dv[i] = make_float4(gs[0], gs[1], gs[2], gs[3]);
-                    if (MASK) yv[i] = make_float4(ys[0], ys[1], ys[2], ys[3]);
+                    dvr[i] = pack4(gs[0], gs[1], gs[2], gs[3]);
+                    if (MASK) yvr[i] = pack4(ys[0], ys[1], ys[2], ys[3]);
                     dok[i] = true;
                 }
             }
@@ -623,14 +694,15 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
             // dZ = dy * act'(y), applied only after EVERY load of the item has been issued
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
-                if (MASK) vmask(dv[i], yv[i], P.alpha, P.vmax);
+                dv[i] = to_f4(dvr[i]);
+                if (MASK) { yv[i] = to_f4(yvr[i]); vmask(dv[i], yv[i], P.alpha, P.vmax); }
                 dv[i] = vsel(dok[i], dv[i]);
             }
             // ---- registers -> LDS
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int e = ptid + i * NCT;
-                if (e < cur.nitems) *reinterpret_cast<V *>(buf + (e / QX) * XS + (ptid % QX) * VW) = vsel(xok[i], xv[i]);
+                if (e < cur.nitems) st_f32(buf + (e / QX) * XS + (ptid % QX) * VW, vsel(xok[i], xv[i]));
             }
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
@@ -811,8 +883,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
 // ------------------------------------------------------------------------------------------------------------------
 // Host side: configuration choice and launches
 // ------------------------------------------------------------------------------------------------------------------
-int launch_src_grad(const float *dxv, float *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int up,
-                    int halo, hipStream_t s);
+int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int up,
+                    int halo, int dtype, hipStream_t s);
 
 struct Work { double flops, bytes; };   // algorithmic work of one launch (for the opt-in profiler)
 
@@ -836,8 +908,13 @@ static int tile_pixels(int BM, int No) {
     return pix;
 }
 
-template <int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK>
+template <typename T> struct TName;
+template <> struct TName<float> { static const char *str() { return "float"; } };
+template <> struct TName<bf16_t> { static const char *str() { return "unsigned short"; } };
+
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK>
 static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
+    constexpr int ES = sizeof(T), CGW = 32 / ES;
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
     const int face_pix = P.No * P.No;
     const int pix = tile_pixels(BM, P.No);
@@ -854,7 +931,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
 #ifdef DLWPCS_TIMELINE
     { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-    const size_t buf = ((size_t)P.tile_rows_max * P.W2 * (KC + 4) + (size_t)NTB * (KC / 8) * KS * KS * 256) * sizeof(float);
+    const size_t buf = (size_t)P.tile_rows_max * P.W2 * (KC * ES + 16) + (size_t)NTB * (KC / CGW) * KS * KS * 1024;
     const size_t lds = 2 * buf + (size_t)(WM * WN) * 16 * 36 * sizeof(float);     // + wave-private epilogue patches
     if (lds > 160 * 1024)
         return fail(DLWPCS_E_UNSUPPORTED, "conv: LDS tile of %zu bytes exceeds 160 KiB (face size %d)", lds, P.No);
@@ -862,7 +939,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
         return fail(DLWPCS_E_UNSUPPORTED, "conv: tile of %d x %d pixels exceeds the producers' register capacity", P.tile_rows_max, P.W2);
     if ((long)P.Nin * P.Nin * 6 >= (1l << 16) * 6 && (long)P.Nin * P.Nin >= (1l << 16))
         return fail(DLWPCS_E_UNSUPPORTED, "conv: face size %d too large for the 16-bit index arithmetic", P.Nin);
-    auto kern = conv_mfma_ws_kernel<KS, KC, MT, NT, WM, WN, VW, MODE, MASK>;
+    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -873,8 +950,8 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     int pidx = -1;
     if (prof_enabled()) {
         char tag[160];
-        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s>", KS, KC, MT, NT, WM, WN, VW, MODE,
-                 MASK ? "true" : "false");
+        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s>", TName<T>::str(), KS, KC, MT,
+                 NT, WM, WN, VW, MODE, MASK ? "true" : "false");
         pidx = prof_begin(tag, W.flops, W.bytes, s);
     }
     hipLaunchKernelGGL(kern, grid, dim3(2 * NTHREADS), lds, s, P);
@@ -882,44 +959,58 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     return check_launch("conv_mfma");
 }
 
-template <int KS, int VW, int MODE, bool MASK>
+template <typename T, int KS, int VW, int MODE, bool MASK>
 static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
     const int face_pix = P.No * P.No;
-    if constexpr (KS == 1) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
-    else if constexpr (VW != 4) return launch_conv_cfg<KS, 8, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);   // odd channel counts
+    constexpr int VWF = 16 / (int)sizeof(T);        // full 16-B vectors
+    constexpr int K2 = 64 / (int)sizeof(T);         // channels in a 64-B chunk row (16 fp32 / 32 bf16)
+    constexpr int K1 = K2 / 2;
+    if constexpr (KS == 1) return launch_conv_cfg<T, KS, K1, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
+    else if constexpr (VW != VWF) return launch_conv_cfg<T, KS, K1, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);   // odd channel counts
     else {
         // Measured (MI355X, batch 32): the smaller tiles (MT = 2 / MT = 1) that would even out the tile count per CU
         // lose more to halo re-staging (the producers become the bottleneck) than they gain -> fixed MT = 3 tilings.
-        if (P.NTtot == 1) return launch_conv_cfg<KS, 16, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
-        if (P.NTtot == 2) return launch_conv_cfg<KS, 16, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
-        if (face_pix <= 320) return launch_conv_cfg<KS, 8, 5, 1, 1, 4, VW, MODE, MASK>(P, W, s);
-        return launch_conv_cfg<KS, 8, 3, 1, 1, 4, VW, MODE, MASK>(P, W, s);
+        if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
+        if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
+        if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK>(P, W, s);
+        return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK>(P, W, s);
     }
 }
 
-template <int KS, int MODE, bool MASK>
+template <typename T, int KS, int MODE, bool MASK>
 static int dispatch_vw(int vw, const ConvKParams &P, const Work &W, hipStream_t s) {
-    if (vw == 4) return launch_conv<KS, 4, MODE, MASK>(P, W, s);
-    if (vw == 2) return launch_conv<KS, 2, MODE, MASK>(P, W, s);
-    return launch_conv<KS, 1, MODE, MASK>(P, W, s);
+    if constexpr (sizeof(T) == 4) {
+        if (vw == 4) return launch_conv<T, KS, 4, MODE, MASK>(P, W, s);
+    } else {
+        if (vw == 8) return launch_conv<T, KS, 8, MODE, MASK>(P, W, s);
+    }
+    if (vw >= 2) return launch_conv<T, KS, 2, MODE, MASK>(P, W, s);
+    return launch_conv<T, KS, 1, MODE, MASK>(P, W, s);
 }
 
 // forward: MODE_HALO / MODE_DIRECT without mask; data gradient: MODE_ZERO (k=3) or MODE_DIRECT (k=1) with/without mask
-static int dispatch_conv(int KS, int vw, const ConvKParams &P, const Work &W, hipStream_t s) {
+template <typename T>
+static int dispatch_conv_t(int KS, int vw, const ConvKParams &P, const Work &W, hipStream_t s) {
     const bool mask = P.ymask != nullptr;
     if (KS == 3) {
-        if (P.mode == MODE_HALO) return dispatch_vw<3, MODE_HALO, false>(vw, P, W, s);
-        if (P.mode == MODE_DIRECT) return dispatch_vw<3, MODE_DIRECT, false>(vw, P, W, s);
-        return mask ? dispatch_vw<3, MODE_ZERO, true>(vw, P, W, s) : dispatch_vw<3, MODE_ZERO, false>(vw, P, W, s);
+        if (P.mode == MODE_HALO) return dispatch_vw<T, 3, MODE_HALO, false>(vw, P, W, s);
+        if (P.mode == MODE_DIRECT) return dispatch_vw<T, 3, MODE_DIRECT, false>(vw, P, W, s);
+        return mask ? dispatch_vw<T, 3, MODE_ZERO, true>(vw, P, W, s) : dispatch_vw<T, 3, MODE_ZERO, false>(vw, P, W, s);
     }
-    return mask ? dispatch_vw<1, MODE_DIRECT, true>(vw, P, W, s) : dispatch_vw<1, MODE_DIRECT, false>(vw, P, W, s);
+    return mask ? dispatch_vw<T, 1, MODE_DIRECT, true>(vw, P, W, s) : dispatch_vw<T, 1, MODE_DIRECT, false>(vw, P, W, s);
+}
+static int dispatch_conv(int dtype, int KS, int vw, const ConvKParams &P, const Work &W, hipStream_t s) {
+    return dtype == DLWPCS_BF16 ? dispatch_conv_t<bf16_t>(KS, vw, P, W, s) : dispatch_conv_t<float>(KS, vw, P, W, s);
 }
 
-static inline int vec_width(int c0, int c1) {
+// widest channel vector (elements) both sources allow: 16 B at most
+static inline int vec_width(int c0, int c1, int dtype) {
+    if (dtype == DLWPCS_BF16 && c0 % 8 == 0 && c1 % 8 == 0) return 8;
     if (c0 % 4 == 0 && c1 % 4 == 0) return 4;
     if (c0 % 2 == 0 && c1 % 2 == 0) return 2;
     return 1;
 }
+static inline int cgw_of(int dtype) { return dtype == DLWPCS_BF16 ? 16 : 8; }
 
 // algorithmic work of one convolution pass: flops = 2*B*6*N^2*k^2*Cin*Cout; bytes = unpadded input and
 // output touched once + the weights.
@@ -929,8 +1020,8 @@ static Work conv_work(const dlwpcs_conv_desc *d) {
     const double n0 = d->up0 ? d->N / 2 : d->N;
     Work w;
     w.flops = 2.0 * d->B * 6 * No * No * taps * Cin * d->Cout;
-    w.bytes = 4.0 * (d->B * 6.0 * (n0 * n0 * d->C0 + (double)d->N * d->N * d->C1 + No * No * d->Cout) +
-                     2.0 * taps * Cin * d->Cout);
+    w.bytes = (double)dtype_size(d->dtype) * d->B * 6.0 * (n0 * n0 * d->C0 + (double)d->N * d->N * d->C1 + No * No * d->Cout) +
+              4.0 * 2.0 * taps * Cin * d->Cout;
     return w;
 }
 
@@ -940,7 +1031,7 @@ struct Geometry {
 
 static int validate(const dlwpcs_conv_desc *d, const char *who) {
     if (!d) return fail(DLWPCS_E_INVALID, "%s: null descriptor", who);
-    if (d->dtype != DLWPCS_F32) return fail(DLWPCS_E_UNSUPPORTED, "%s: dtype %d not built", who, d->dtype);
+    if (!dtype_ok(d->dtype)) return fail(DLWPCS_E_UNSUPPORTED, "%s: dtype %d not built", who, d->dtype);
     if (d->ksize != 1 && d->ksize != 3) return fail(DLWPCS_E_UNSUPPORTED, "%s: kernel size %d (MFMA path serves 1 and 3)", who, d->ksize);
     if (d->B < 0 || d->N < 1 || d->C0 < 1 || d->C1 < 0 || d->Cout < 1) return fail(DLWPCS_E_INVALID, "%s: bad shape B=%d N=%d C0=%d C1=%d Cout=%d", who, d->B, d->N, d->C0, d->C1, d->Cout);
     if (d->up0 && (d->N % 2)) return fail(DLWPCS_E_INVALID, "%s: up0 needs even N", who);
@@ -983,15 +1074,16 @@ static void wgrad_tiling(const dlwpcs_conv_desc *d, int &pix, int &nblk, int &n_
 static WsLayout ws_layout(const dlwpcs_conv_desc *d) {
     WsLayout L{};
     const int Cin = d->C0 + d->C1, TAPS = d->ksize * d->ksize;
-    const int CGf = ceil_div(Cin, 8), NTf = ceil_div(d->Cout, 32);
-    const int CGb = ceil_div(d->Cout, 8), NTb = ceil_div(Cin, 32);
+    const int cgw = cgw_of(d->dtype);
+    const int CGf = ceil_div(Cin, cgw), NTf = ceil_div(d->Cout, 32);
+    const int CGb = ceil_div(d->Cout, cgw), NTb = ceil_div(Cin, 32);
     const int No = out_size(d);
     size_t off = 0;
     L.wpk_f = off; off += align_up((size_t)3 * NTf * CGf * TAPS * 256 * 4, 256);
     L.bias = off;  off += align_up((size_t)3 * NTf * 32 * 4, 256);
     L.wpk_b = off; off += align_up((size_t)3 * NTb * CGb * TAPS * 256 * 4, 256);
     const int Nv = d->halo ? d->N + d->ksize - 1 : d->N;      // face size of the virtual-input gradient
-    L.dxv = off;   off += align_up((size_t)d->B * 6 * Nv * Nv * Cin * 4, 256);
+    L.dxv = off;   off += align_up((size_t)d->B * 6 * Nv * Nv * Cin * dtype_size(d->dtype), 256);
     int pix, nblk;
     wgrad_tiling(d, pix, nblk, L.n_eq, L.n_4, L.n_5);
     L.wg_pix = pix; L.wg_nblk = nblk;
@@ -1005,15 +1097,21 @@ static WsLayout ws_layout(const dlwpcs_conv_desc *d) {
     return L;
 }
 
-static void launch_pack(const void *w_eq, const void *w_pol, const void *w_np, float *out, int KS, int Cin, int Cout,
-                        int transposed, int flip, hipStream_t s) {
+static void launch_pack(const void *w_eq, const void *w_pol, const void *w_np, void *out, int KS, int Cin, int Cout,
+                        int transposed, int flip, int dtype, hipStream_t s) {
     const int K = transposed ? Cout : Cin, Ncol = transposed ? Cin : Cout;
-    const int CG = ceil_div(K, 8), NTtot = ceil_div(Ncol, 32);
-    const size_t total = (size_t)3 * NTtot * CG * KS * KS * 256;
+    const int CG = ceil_div(K, cgw_of(dtype)), NTtot = ceil_div(Ncol, 32);
+    const size_t total = (size_t)3 * NTtot * CG * KS * KS * 64 * (16 / dtype_size(dtype));
     size_t g = (total + 255) / 256;
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float *)w_eq, (const float *)w_pol,
-                       (const float *)w_np, out, KS, Cin, Cout, K, Ncol, CG, NTtot, flip, transposed, total);
+    if (dtype == DLWPCS_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, s, (const float *)w_eq,
+                           (const float *)w_pol, (const float *)w_np, (bf16_t *)out, KS, Cin, Cout, K, Ncol, CG, NTtot, flip,
+                           transposed, total);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float *)w_eq,
+                           (const float *)w_pol, (const float *)w_np, (float *)out, KS, Cin, Cout, K, Ncol, CG, NTtot, flip,
+                           transposed, total);
 }
 
 }  // namespace dlwpcs
@@ -1042,8 +1140,9 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)workspace;
     const int Cin = d->C0 + d->C1;
-    float *wpk = (float *)(ws + L.wpk_f), *bpk = (float *)(ws + L.bias);
-    launch_pack(w_eq, w_pol, w_np, wpk, d->ksize, Cin, d->Cout, 0, d->flip_north_pole, s);
+    void *wpk = ws + L.wpk_f;
+    float *bpk = (float *)(ws + L.bias);
+    launch_pack(w_eq, w_pol, w_np, wpk, d->ksize, Cin, d->Cout, 0, d->flip_north_pole, d->dtype, s);
     const int NTtot = ceil_div(d->Cout, 32);
     if (b_eq) {
         const int n = 3 * NTtot * 32;
@@ -1051,14 +1150,14 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
                            (const float *)b_pol, (const float *)b_np, bpk, d->Cout, NTtot * 32);
     }
     ConvKParams P{};
-    P.src0 = (const float *)src0; P.src1 = (const float *)src1; P.ymask = nullptr;
-    P.wpk = wpk; P.bias = b_eq ? bpk : nullptr; P.out = (float *)y; P.table = table_dev;
+    P.src0 = src0; P.src1 = src1; P.ymask = nullptr;
+    P.wpk = wpk; P.bias = b_eq ? bpk : nullptr; P.out = y; P.table = table_dev;
     P.B = d->B; P.Nin = d->N; P.No = out_size(d);
     P.C0 = d->C0; P.C1 = d->C1; P.Cin = Cin; P.Cout = d->Cout;
-    P.CG = ceil_div(Cin, 8); P.NTtot = NTtot; P.up0 = d->up0;
+    P.CG = ceil_div(Cin, cgw_of(d->dtype)); P.NTtot = NTtot; P.up0 = d->up0;
     P.mode = d->halo ? MODE_HALO : MODE_DIRECT;
     P.act = d->act; P.alpha = d->alpha; P.vmax = d->vmax;
-    return dispatch_conv(d->ksize, vec_width(d->C0, d->C1), P, conv_work(d), s);
+    return dispatch_conv(d->dtype, d->ksize, vec_width(d->C0, d->C1, d->dtype), P, conv_work(d), s);
 }
 
 extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, const void *y,
@@ -1077,27 +1176,27 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)workspace;
     const int Cin = d->C0 + d->C1;
-    float *wpk = (float *)(ws + L.wpk_b), *dxv = (float *)(ws + L.dxv);
-    launch_pack(w_eq, w_pol, w_np, wpk, d->ksize, Cin, d->Cout, 1, d->flip_north_pole, s);
+    void *wpk = ws + L.wpk_b, *dxv = ws + L.dxv;
+    launch_pack(w_eq, w_pol, w_np, wpk, d->ksize, Cin, d->Cout, 1, d->flip_north_pole, d->dtype, s);
     const int No = out_size(d);
     ConvKParams P{};
-    P.src0 = (const float *)dy; P.src1 = nullptr; P.ymask = d->act != DLWPCS_ACT_NONE ? (const float *)y : nullptr;
+    P.src0 = dy; P.src1 = nullptr; P.ymask = d->act != DLWPCS_ACT_NONE ? y : nullptr;
     P.wpk = wpk; P.bias = nullptr; P.out = dxv; P.table = nullptr;
     P.B = d->B; P.Nin = No; P.No = No + d->ksize - 1;     // full correlation: output = input + k - 1
     P.C0 = d->Cout; P.C1 = 0; P.Cin = d->Cout; P.Cout = Cin;
-    P.CG = ceil_div(d->Cout, 8); P.NTtot = ceil_div(Cin, 32); P.up0 = 0;
+    P.CG = ceil_div(d->Cout, cgw_of(d->dtype)); P.NTtot = ceil_div(Cin, 32); P.up0 = 0;
     P.mode = MODE_ZERO;
     P.act = DLWPCS_ACT_NONE; P.alpha = d->alpha; P.vmax = d->vmax;
-    rc = dispatch_conv(d->ksize, vec_width(d->Cout, 0), P, conv_work(d), s);
+    rc = dispatch_conv(d->dtype, d->ksize, vec_width(d->Cout, 0, d->dtype), P, conv_work(d), s);
     if (rc) return rc;
     // dxv is the gradient of the (halo-padded, if halo) virtual input: (B,6,Nv,Nv,Cin), Nv = No + k - 1
     // halo: Nv = N + 2; plain: Nv = N.  Route to the sources (inverse halo gather, upsample adjoint, channel split).
     if (dsrc0) {
-        rc = launch_src_grad(dxv, (float *)dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->up0, d->halo, s);
+        rc = launch_src_grad(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->up0, d->halo, d->dtype, s);
         if (rc) return rc;
     }
     if (dsrc1 && d->C1 > 0) {
-        rc = launch_src_grad(dxv, (float *)dsrc1, inv_table_dev, d->B, d->N, Cin, d->C0, d->C1, 0, d->halo, s);
+        rc = launch_src_grad(dxv, dsrc1, inv_table_dev, d->B, d->N, Cin, d->C0, d->C1, 0, d->halo, d->dtype, s);
         if (rc) return rc;
     }
     return DLWPCS_OK;
@@ -1132,7 +1231,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     }
     WgradKParams W{};
     ConvKParams &P = W.c;
-    P.src0 = (const float *)src0; P.src1 = (const float *)src1; P.ymask = nullptr; P.table = table_dev;
+    P.src0 = src0; P.src1 = src1; P.ymask = nullptr; P.table = table_dev;
     P.B = d->B; P.Nin = d->N; P.No = out_size(d);
     P.C0 = d->C0; P.C1 = d->C1; P.Cin = Cin; P.Cout = d->Cout; P.up0 = d->up0;
     P.mode = d->halo ? MODE_HALO : MODE_DIRECT;
@@ -1140,7 +1239,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     P.pix_per_block = L.wg_pix; P.nblk_face = L.wg_nblk;
     P.W2 = P.No + KS - 1; P.magicW2 = div_magic(P.W2); P.magicNo = div_magic(P.No);
     P.tile_rows_max = tile_rows_for(L.wg_pix, P.No) + (KS - 1);
-    W.dy = (const float *)dy; W.y = (const float *)y;
+    W.dy = dy; W.y = y;
     W.partial = (float *)(ws + L.partial);
     const bool want_bias = db_eq || db_pol || db_np;
     W.bpartial = want_bias ? (float *)(ws + L.bpartial) : nullptr;
@@ -1154,7 +1253,8 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     if (P.C1 == 0) P.src1 = P.src0;
     const bool mask = d->act != DLWPCS_ACT_NONE;
     const int pix_cap = (L.wg_pix + 1) & ~1;
-    const int vw = vec_width(d->C0, d->C1);
+    const int vw = vec_width(d->C0, d->C1, d->dtype);
+    const bool bf = d->dtype == DLWPCS_BF16;
     const size_t bufb = ((size_t)P.tile_rows_max * P.W2 * 32 + (size_t)pix_cap * 32) * 4;
     if ((size_t)P.tile_rows_max * P.W2 > 448 || pix_cap > 192)
         return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: tile of %d x %d pixels exceeds the producers' register capacity", P.tile_rows_max, P.W2);
@@ -1164,9 +1264,9 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     if (lds < (4096 + 1024) * 4) lds = (4096 + 1024) * 4;     // cross-wave reduction scratch + bias staging alias the buffers
     if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
     dim3 grid((unsigned)(L.n_eq + L.n_4 + L.n_5), (unsigned)(CinP / 32), (unsigned)(CoutP / 32));
-#define WG_LAUNCH(KSV, VWV, MASKV)                                                                                        \
+#define WG_LAUNCH(TV, TS, KSV, VWV, MASKV)                                                                                \
     do {                                                                                                                  \
-        auto kern = wgrad_mfma_kernel<KSV, VWV, MASKV>;                                                                   \
+        auto kern = wgrad_mfma_kernel<TV, KSV, VWV, MASKV>;                                                               \
         if (lds > 64 * 1024) {                                                                                            \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));    \
@@ -1174,13 +1274,23 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
         int pidx = -1;                                                                                                    \
         if (prof_enabled()) {                                                                                             \
             const Work wk = conv_work(d);                                                                                 \
-            pidx = prof_begin("wgrad_mfma_kernel<" #KSV ", " #VWV ", " #MASKV ">", wk.flops, wk.bytes, s);                \
+            pidx = prof_begin("wgrad_mfma_kernel<" TS ", " #KSV ", " #VWV ", " #MASKV ">", wk.flops, wk.bytes, s);        \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, W);                                                             \
         if (pidx >= 0) prof_end(pidx, s);                                                                                 \
     } while (0)
 #define WG_VW(KSV, MASKV)                                                                                                 \
-    do { if (vw == 4) WG_LAUNCH(KSV, 4, MASKV); else if (vw == 2) WG_LAUNCH(KSV, 2, MASKV); else WG_LAUNCH(KSV, 1, MASKV); } while (0)
+    do {                                                                                                                  \
+        if (bf) {                                                                                                         \
+            if (vw == 8) WG_LAUNCH(bf16_t, "unsigned short", KSV, 8, MASKV);                                              \
+            else if (vw >= 2) WG_LAUNCH(bf16_t, "unsigned short", KSV, 2, MASKV);                                         \
+            else WG_LAUNCH(bf16_t, "unsigned short", KSV, 1, MASKV);                                                      \
+        } else {                                                                                                          \
+            if (vw == 4) WG_LAUNCH(float, "float", KSV, 4, MASKV);                                                        \
+            else if (vw == 2) WG_LAUNCH(float, "float", KSV, 2, MASKV);                                                   \
+            else WG_LAUNCH(float, "float", KSV, 1, MASKV);                                                                \
+        }                                                                                                                 \
+    } while (0)
     if (KS == 3) { if (mask) WG_VW(3, true); else WG_VW(3, false); }
     else { if (mask) WG_VW(1, true); else WG_VW(1, false); }
 #undef WG_VW

@@ -13,16 +13,75 @@ static inline dim3 stream_grid(size_t work_items, int block = 256) {
     return dim3((unsigned)g);
 }
 
-template <typename V> struct VecW;
-template <> struct VecW<float> { static constexpr int W = 1; };
-template <> struct VecW<float4> { static constexpr int W = 4; };
+// ---- storage vectors and their fp32 register image ------------------------------------------------------------
+// A kernel instantiated on a storage type V moves VT<V>::N consecutive channels per lane; arithmetic happens on the
+// fp32 image Acc<N> and is rounded once on store (bf16: round-to-nearest-even), so the fp32 instantiations are
+// bit-identical to plain float code.
+struct H2 { uint32_t u; };                  // 2 x bf16
+struct alignas(16) H8 { uint4 u; };         // 8 x bf16
+template <int N> struct Acc { float v[N]; };
+template <int N> __device__ __forceinline__ Acc<N> vadd(Acc<N> a, const Acc<N> &b) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) a.v[i] += b.v[i];
+    return a;
+}
+template <int N> __device__ __forceinline__ Acc<N> vscale(Acc<N> a, float s) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) a.v[i] *= s;
+    return a;
+}
+template <int N> __device__ __forceinline__ Acc<N> vzero() {
+    Acc<N> a;
+#pragma unroll
+    for (int i = 0; i < N; ++i) a.v[i] = 0.f;
+    return a;
+}
+template <typename V> struct VT;
+template <> struct VT<float> {
+    static constexpr int N = 1;
+    static __device__ __forceinline__ Acc<1> ld(const float *p) { Acc<1> a; a.v[0] = *p; return a; }
+    static __device__ __forceinline__ void st(float *p, const Acc<1> &a) { *p = a.v[0]; }
+};
+template <> struct VT<float4> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ Acc<4> ld(const float4 *p) { const float4 q = *p; Acc<4> a; a.v[0] = q.x; a.v[1] = q.y; a.v[2] = q.z; a.v[3] = q.w; return a; }
+    static __device__ __forceinline__ void st(float4 *p, const Acc<4> &a) { *p = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]); }
+};
+template <> struct VT<bf16_t> {
+    static constexpr int N = 1;
+    static __device__ __forceinline__ Acc<1> ld(const bf16_t *p) { Acc<1> a; a.v[0] = bf2f(*p); return a; }
+    static __device__ __forceinline__ void st(bf16_t *p, const Acc<1> &a) { *p = f2bf(a.v[0]); }
+};
+template <> struct VT<H2> {
+    static constexpr int N = 2;
+    static __device__ __forceinline__ Acc<2> ld(const H2 *p) { const uint32_t u = p->u; Acc<2> a; a.v[0] = bf_lo(u); a.v[1] = bf_hi(u); return a; }
+    static __device__ __forceinline__ void st(H2 *p, const Acc<2> &a) { p->u = f2bf2(a.v[0], a.v[1]); }
+};
+template <> struct VT<H8> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ Acc<8> ld(const H8 *p) {
+        const uint4 q = p->u; Acc<8> a;
+        a.v[0] = bf_lo(q.x); a.v[1] = bf_hi(q.x); a.v[2] = bf_lo(q.y); a.v[3] = bf_hi(q.y);
+        a.v[4] = bf_lo(q.z); a.v[5] = bf_hi(q.z); a.v[6] = bf_lo(q.w); a.v[7] = bf_hi(q.w);
+        return a;
+    }
+    static __device__ __forceinline__ void st(H8 *p, const Acc<8> &a) {
+        p->u = make_uint4(f2bf2(a.v[0], a.v[1]), f2bf2(a.v[2], a.v[3]), f2bf2(a.v[4], a.v[5]), f2bf2(a.v[6], a.v[7]));
+    }
+};
 
-__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
-__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float vscale(float a, float s) { return a * s; }
-__device__ __forceinline__ float4 vscale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
-__device__ __forceinline__ float vzero(float) { return 0.f; }
-__device__ __forceinline__ float4 vzero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// f(tag, width): widest storage vector that divides every channel count in play (g = their gcd-like common divisor)
+template <typename F> static inline void dispatch_vec(int dtype, int g, F &&f) {
+    if (dtype == DLWPCS_BF16) {
+        if (g % 8 == 0) f(H8{}, 8); else if (g % 2 == 0) f(H2{}, 2); else f(bf16_t{}, 1);
+    } else {
+        if (g % 4 == 0) f(float4{}, 4); else f(float{}, 1);
+    }
+}
+// pure data movement: widest power-of-two byte vector dividing `row_bytes`
+template <typename F> static inline void dispatch_mover(size_t row_bytes, F &&f) {
+    if (row_bytes % 16 == 0) f(uint4{}, 16); else if (row_bytes % 4 == 0) f(uint32_t{}, 4); else f(uint16_t{}, 2);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // CubeSpherePadding2D forward: y[b][dst][c] = x[b][T[dst]][c]           (DLWP/custom.py:1082-1308 as one gather)
@@ -55,16 +114,16 @@ __global__ void __launch_bounds__(256) pad_bwd_kernel(const V *__restrict__ dy, 
         const size_t b = pix / src_cells;
         const int xx = src % N, yy = (src / N) % N, f = src / (N * N);
         const V *base = dy + b * dst_cells * (size_t)CV + cv;
-        V acc = base[(size_t)((f * M + yy + p) * M + xx + p) * CV];
+        auto acc = VT<V>::ld(base + (size_t)((f * M + yy + p) * M + xx + p) * CV);
         const bool border = (yy < p) | (yy >= N - p) | (xx < p) | (xx >= N - p);
         if (border) {
             const int4 t = *reinterpret_cast<const int4 *>(inv + (size_t)src * 4);
-            if (t.x >= 0) acc = vadd(acc, base[(size_t)t.x * CV]);
-            if (t.y >= 0) acc = vadd(acc, base[(size_t)t.y * CV]);
-            if (t.z >= 0) acc = vadd(acc, base[(size_t)t.z * CV]);
-            if (t.w >= 0) acc = vadd(acc, base[(size_t)t.w * CV]);
+            if (t.x >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.x * CV));
+            if (t.y >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.y * CV));
+            if (t.z >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.z * CV));
+            if (t.w >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.w * CV));
         }
-        dx[e] = acc;
+        VT<V>::st(dx + e, acc);
     }
 }
 
@@ -85,23 +144,23 @@ __global__ void __launch_bounds__(256) pad_bwd_src_kernel(const V *__restrict__ 
         const size_t b = pix / out_cells;
         const int xo = cell % No, yo = (cell / No) % No, f = cell / (No * No);
         const V *base = dxpad + b * dst_cells * (size_t)CTV + choffV + cv;
-        V acc = vzero(V());
+        auto acc = vzero<VT<V>::N>();
         const int reps = up ? 2 : 1;
         for (int uy = 0; uy < reps; ++uy)
             for (int ux = 0; ux < reps; ++ux) {
                 const int yy = up ? 2 * yo + uy : yo, xx = up ? 2 * xo + ux : xo;
-                acc = vadd(acc, base[(size_t)((f * M + yy + p) * M + xx + p) * CTV]);
+                acc = vadd(acc, VT<V>::ld(base + (size_t)((f * M + yy + p) * M + xx + p) * CTV));
                 const bool border = (yy < p) | (yy >= N - p) | (xx < p) | (xx >= N - p);
                 if (border) {
                     const int src = (f * N + yy) * N + xx;
                     const int4 t = *reinterpret_cast<const int4 *>(inv + (size_t)src * 4);
-                    if (t.x >= 0) acc = vadd(acc, base[(size_t)t.x * CTV]);
-                    if (t.y >= 0) acc = vadd(acc, base[(size_t)t.y * CTV]);
-                    if (t.z >= 0) acc = vadd(acc, base[(size_t)t.z * CTV]);
-                    if (t.w >= 0) acc = vadd(acc, base[(size_t)t.w * CTV]);
+                    if (t.x >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.x * CTV));
+                    if (t.y >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.y * CTV));
+                    if (t.z >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.z * CTV));
+                    if (t.w >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.w * CTV));
                 }
             }
-        dsrc[e] = acc;
+        VT<V>::st(dsrc + e, acc);
     }
 }
 
@@ -118,50 +177,60 @@ __global__ void __launch_bounds__(256) window_src_kernel(const V *__restrict__ d
         const size_t b = pix / out_cells;
         const int xo = cell % No, yo = (cell / No) % No, f = cell / (No * No);
         const V *base = dxv + b * (size_t)6 * N * N * CTV + choffV + cv;
-        V acc = vzero(V());
+        auto acc = vzero<VT<V>::N>();
         const int reps = up ? 2 : 1;
         for (int uy = 0; uy < reps; ++uy)
             for (int ux = 0; ux < reps; ++ux) {
                 const int yy = up ? 2 * yo + uy : yo, xx = up ? 2 * xo + ux : xo;
-                acc = vadd(acc, base[(size_t)((f * N + yy) * N + xx) * CTV]);
+                acc = vadd(acc, VT<V>::ld(base + (size_t)((f * N + yy) * N + xx) * CTV));
             }
-        dsrc[e] = acc;
+        VT<V>::st(dsrc + e, acc);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // activation: keras ReLU(negative_slope, max_value)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) act_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n,
+template <typename V, typename S>
+__global__ void __launch_bounds__(256) act_fwd_kernel(const S *__restrict__ x, S *__restrict__ y, size_t n,
                                                       float alpha, float vmax) {
-    const size_t n4 = n / 4;
-    const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    float4 *y4 = reinterpret_cast<float4 *>(y);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 v = x4[i];
-        v.x = act_leaky_clip(v.x, alpha, vmax); v.y = act_leaky_clip(v.y, alpha, vmax);
-        v.z = act_leaky_clip(v.z, alpha, vmax); v.w = act_leaky_clip(v.w, alpha, vmax);
-        y4[i] = v;
+    constexpr int W = VT<V>::N;
+    const size_t nv = n / W;
+    const V *xv = reinterpret_cast<const V *>(x);
+    V *yv = reinterpret_cast<V *>(y);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        auto v = VT<V>::ld(xv + i);
+#pragma unroll
+        for (int k = 0; k < W; ++k) v.v[k] = act_leaky_clip(v.v[k], alpha, vmax);
+        VT<V>::st(yv + i, v);
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        y[i] = act_leaky_clip(x[i], alpha, vmax);
+    for (size_t i = nv * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        auto v = VT<S>::ld(x + i);
+        v.v[0] = act_leaky_clip(v.v[0], alpha, vmax);
+        VT<S>::st(y + i, v);
+    }
 }
 
-__global__ void __launch_bounds__(256) act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
-                                                      float *__restrict__ dx, size_t n, float alpha, float vmax) {
-    const size_t n4 = n / 4;
-    const float4 *g4 = reinterpret_cast<const float4 *>(dy);
-    const float4 *y4 = reinterpret_cast<const float4 *>(y);
-    float4 *o4 = reinterpret_cast<float4 *>(dx);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 g = g4[i];
-        const float4 v = y4[i];
-        g.x *= act_leaky_clip_grad_from_y(v.x, alpha, vmax); g.y *= act_leaky_clip_grad_from_y(v.y, alpha, vmax);
-        g.z *= act_leaky_clip_grad_from_y(v.z, alpha, vmax); g.w *= act_leaky_clip_grad_from_y(v.w, alpha, vmax);
-        o4[i] = g;
+template <typename V, typename S>
+__global__ void __launch_bounds__(256) act_bwd_kernel(const S *__restrict__ dy, const S *__restrict__ y,
+                                                      S *__restrict__ dx, size_t n, float alpha, float vmax) {
+    constexpr int W = VT<V>::N;
+    const size_t nv = n / W;
+    const V *gv = reinterpret_cast<const V *>(dy);
+    const V *yv = reinterpret_cast<const V *>(y);
+    V *ov = reinterpret_cast<V *>(dx);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        auto g = VT<V>::ld(gv + i);
+        const auto v = VT<V>::ld(yv + i);
+#pragma unroll
+        for (int k = 0; k < W; ++k) g.v[k] *= act_leaky_clip_grad_from_y(v.v[k], alpha, vmax);
+        VT<V>::st(ov + i, g);
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dx[i] = dy[i] * act_leaky_clip_grad_from_y(y[i], alpha, vmax);
+    for (size_t i = nv * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        auto g = VT<S>::ld(dy + i);
+        g.v[0] *= act_leaky_clip_grad_from_y(VT<S>::ld(y + i).v[0], alpha, vmax);
+        VT<S>::st(dx + i, g);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -180,7 +249,7 @@ __global__ void __launch_bounds__(256) avgpool2_fwd_kernel(const V *__restrict__
         const size_t plane = pix / No;
         const V *r0 = x + ((plane * N + 2 * yo) * N + 2 * xo) * CV + cv;
         const V *r1 = r0 + (size_t)N * CV;
-        y[e] = vscale(vadd(vadd(r0[0], r0[CV]), vadd(r1[0], r1[CV])), 0.25f);
+        VT<V>::st(y + e, vscale(vadd(vadd(VT<V>::ld(r0), VT<V>::ld(r0 + CV)), vadd(VT<V>::ld(r1), VT<V>::ld(r1 + CV))), 0.25f));
     }
 }
 
@@ -195,7 +264,7 @@ __global__ void __launch_bounds__(256) avgpool2_bwd_kernel(const V *__restrict__
         const int xx = (int)(pix % N); pix /= N;
         const int yy = (int)(pix % N);
         const size_t plane = pix / N;
-        dx[e] = vscale(dy[((plane * No + yy / 2) * No + xx / 2) * CV + cv], 0.25f);
+        VT<V>::st(dx + e, vscale(VT<V>::ld(dy + ((plane * No + yy / 2) * No + xx / 2) * CV + cv), 0.25f));
     }
 }
 
@@ -227,7 +296,7 @@ __global__ void __launch_bounds__(256) upsample2_bwd_kernel(const V *__restrict_
         const size_t plane = pix / N;
         const V *r0 = dy + ((plane * Ni + 2 * yo) * Ni + 2 * xo) * CV + cv;
         const V *r1 = r0 + (size_t)Ni * CV;
-        dx[e] = vadd(vadd(r0[0], r0[CV]), vadd(r1[0], r1[CV]));
+        VT<V>::st(dx + e, vadd(vadd(VT<V>::ld(r0), VT<V>::ld(r0 + CV)), vadd(VT<V>::ld(r1), VT<V>::ld(r1 + CV))));
     }
 }
 
@@ -258,35 +327,38 @@ __global__ void __launch_bounds__(256) split2_kernel(const V *__restrict__ y, V 
     }
 }
 
-__global__ void __launch_bounds__(256) add_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                                                  float *__restrict__ y, size_t n) {
-    const size_t n4 = n / 4;
-    const float4 *a4 = reinterpret_cast<const float4 *>(a);
-    const float4 *b4 = reinterpret_cast<const float4 *>(b);
-    float4 *y4 = reinterpret_cast<float4 *>(y);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
-        y4[i] = vadd(a4[i], b4[i]);
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        y[i] = a[i] + b[i];
+template <typename V, typename S>
+__global__ void __launch_bounds__(256) add_kernel(const S *__restrict__ a, const S *__restrict__ b,
+                                                  S *__restrict__ y, size_t n) {
+    constexpr int W = VT<V>::N;
+    const size_t nv = n / W;
+    const V *av = reinterpret_cast<const V *>(a);
+    const V *bv = reinterpret_cast<const V *>(b);
+    V *yv = reinterpret_cast<V *>(y);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x)
+        VT<V>::st(yv + i, vadd(VT<V>::ld(av + i), VT<V>::ld(bv + i)));
+    for (size_t i = nv * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        VT<S>::st(y + i, vadd(VT<S>::ld(a + i), VT<S>::ld(b + i)));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // (B, C, S) <-> (B, S, C) through a padded 32x32 LDS tile (coalesced on both sides)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict__ x, float *__restrict__ y,
+template <typename S>
+__global__ void __launch_bounds__(256) transpose_kernel(const S *__restrict__ x, S *__restrict__ y,
                                                         int R, size_t Ccols) {
-    // x: (batch, R, Ccols) -> y: (batch, Ccols, R)
-    __shared__ float tile[32][33];
+    // x: (batch, R, Ccols) -> y: (batch, Ccols, R); pure data movement on the raw element bits
+    __shared__ S tile[32][33];
     const size_t b = blockIdx.z;
     const size_t c0 = (size_t)blockIdx.x * 32;
     const int r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const float *xb = x + b * (size_t)R * Ccols;
-    float *yb = y + b * (size_t)R * Ccols;
+    const S *xb = x + b * (size_t)R * Ccols;
+    S *yb = y + b * (size_t)R * Ccols;
     for (int k = ty; k < 32; k += 8) {
         const int r = r0 + k;
         const size_t c = c0 + tx;
-        tile[k][tx] = (r < R && c < Ccols) ? xb[(size_t)r * Ccols + c] : 0.f;
+        tile[k][tx] = (r < R && c < Ccols) ? xb[(size_t)r * Ccols + c] : (S)0;
     }
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
@@ -301,15 +373,16 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int MSE_BLOCKS = 1024;
 
-__global__ void __launch_bounds__(256) mse_stage1_kernel(const float *__restrict__ y, const float *__restrict__ t,
-                                                         float *__restrict__ dy, float *__restrict__ partial, size_t n,
+template <typename S, typename TT>
+__global__ void __launch_bounds__(256) mse_stage1_kernel(const S *__restrict__ y, const TT *__restrict__ t,
+                                                         S *__restrict__ dy, float *__restrict__ partial, size_t n,
                                                          float gscale) {
     float sq = 0.f, ab = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float d = y[i] - t[i];
+        const float d = VT<S>::ld(y + i).v[0] - VT<TT>::ld(t + i).v[0];
         sq += d * d;
         ab += fabsf(d);
-        if (dy) dy[i] = gscale * d;
+        if (dy) { Acc<1> g; g.v[0] = gscale * d; VT<S>::st(dy + i, g); }
     }
     __shared__ float s_sq[256], s_ab[256];
     s_sq[threadIdx.x] = sq; s_ab[threadIdx.x] = ab;
@@ -362,113 +435,105 @@ __global__ void step_inc_kernel(int32_t *step) { *step += 1; }
 using namespace dlwpcs;
 
 #define REQUIRE(cond, ...) do { if (!(cond)) return fail(DLWPCS_E_INVALID, __VA_ARGS__); } while (0)
-#define REQUIRE_F32(dt, who) do { if ((dt) != DLWPCS_F32) return fail(DLWPCS_E_UNSUPPORTED, who ": dtype %d not built", (int)(dt)); } while (0)
+#define REQUIRE_DTYPE(dt, who) do { if (!dtype_ok(dt)) return fail(DLWPCS_E_UNSUPPORTED, who ": dtype %d not built", (int)(dt)); } while (0)
 
 extern "C" int dlwpcs_pad_fwd(const void *x, void *y, int B, int N, int C, int p, int dtype,
                               const int32_t *table_dev, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "pad_fwd");
+    REQUIRE_DTYPE(dtype, "pad_fwd");
     REQUIRE(x && y && table_dev, "pad_fwd: null pointer");
     REQUIRE(B >= 0 && N >= 1 && C >= 1 && p >= 0 && p <= N, "pad_fwd: bad shape B=%d N=%d C=%d p=%d", B, N, C, p);
     if (B == 0) return DLWPCS_OK;
     const int M = N + 2 * p;
     hipStream_t s = (hipStream_t)stream;
-    if (C % 4 == 0) {
-        const size_t total = (size_t)B * 6 * M * M * (C / 4);
-        hipLaunchKernelGGL(pad_fwd_kernel<float4>, stream_grid(total), dim3(256), 0, s, (const float4 *)x, (float4 *)y,
-                           table_dev, total, C / 4, 6 * N * N, 6 * M * M);
-    } else {
-        const size_t total = (size_t)B * 6 * M * M * C;
-        hipLaunchKernelGGL(pad_fwd_kernel<float>, stream_grid(total), dim3(256), 0, s, (const float *)x, (float *)y,
-                           table_dev, total, C, 6 * N * N, 6 * M * M);
-    }
+    const size_t row_bytes = (size_t)C * dtype_size(dtype);
+    dispatch_mover(row_bytes, [&](auto tag, int w) {
+        using V = decltype(tag);
+        const int CV = (int)(row_bytes / w);
+        const size_t total = (size_t)B * 6 * M * M * CV;
+        hipLaunchKernelGGL(pad_fwd_kernel<V>, stream_grid(total), dim3(256), 0, s, (const V *)x, (V *)y, table_dev, total,
+                           CV, 6 * N * N, 6 * M * M);
+    });
     return check_launch("pad_fwd");
 }
 
 extern "C" int dlwpcs_pad_bwd(const void *dy, void *dx, int B, int N, int C, int p, int dtype,
                               const int32_t *inv_table_dev, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "pad_bwd");
+    REQUIRE_DTYPE(dtype, "pad_bwd");
     REQUIRE(dy && dx && inv_table_dev, "pad_bwd: null pointer");
     REQUIRE(B >= 0 && N >= 1 && C >= 1 && p >= 0 && p <= N, "pad_bwd: bad shape B=%d N=%d C=%d p=%d", B, N, C, p);
     if (B == 0) return DLWPCS_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (C % 4 == 0) {
-        const size_t total = (size_t)B * 6 * N * N * (C / 4);
-        hipLaunchKernelGGL(pad_bwd_kernel<float4>, stream_grid(total), dim3(256), 0, s, (const float4 *)dy, (float4 *)dx,
-                           inv_table_dev, total, C / 4, N, p);
-    } else {
-        const size_t total = (size_t)B * 6 * N * N * C;
-        hipLaunchKernelGGL(pad_bwd_kernel<float>, stream_grid(total), dim3(256), 0, s, (const float *)dy, (float *)dx,
-                           inv_table_dev, total, C, N, p);
-    }
+    dispatch_vec(dtype, C, [&](auto tag, int w) {
+        using V = decltype(tag);
+        const size_t total = (size_t)B * 6 * N * N * (C / w);
+        hipLaunchKernelGGL(pad_bwd_kernel<V>, stream_grid(total), dim3(256), 0, s, (const V *)dy, (V *)dx, inv_table_dev,
+                           total, C / w, N, p);
+    });
     return check_launch("pad_bwd");
 }
 
 namespace dlwpcs {
 // used by conv_bwd_data: gradient of one virtual-input source out of the (padded or plain) virtual-input gradient
-int launch_src_grad(const float *dxv, float *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int up,
-                    int halo, hipStream_t s) {
+int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int up,
+                    int halo, int dtype, hipStream_t s) {
     const int No = up ? N / 2 : N;
-    const bool vec = (CT % 4 == 0) && (choff % 4 == 0) && (CS % 4 == 0);
-    if (halo) {
-        if (vec) {
-            const size_t total = (size_t)B * 6 * No * No * (CS / 4);
-            hipLaunchKernelGGL(pad_bwd_src_kernel<float4>, stream_grid(total), dim3(256), 0, s, (const float4 *)dxv,
-                               (float4 *)dsrc, inv, total, CS / 4, CT / 4, choff / 4, N, up);
-        } else {
-            const size_t total = (size_t)B * 6 * No * No * CS;
-            hipLaunchKernelGGL(pad_bwd_src_kernel<float>, stream_grid(total), dim3(256), 0, s, dxv, dsrc, inv, total, CS,
-                               CT, choff, N, up);
-        }
-    } else {
-        if (vec) {
-            const size_t total = (size_t)B * 6 * No * No * (CS / 4);
-            hipLaunchKernelGGL(window_src_kernel<float4>, stream_grid(total), dim3(256), 0, s, (const float4 *)dxv,
-                               (float4 *)dsrc, total, CS / 4, CT / 4, choff / 4, N, up);
-        } else {
-            const size_t total = (size_t)B * 6 * No * No * CS;
-            hipLaunchKernelGGL(window_src_kernel<float>, stream_grid(total), dim3(256), 0, s, dxv, dsrc, total, CS, CT,
-                               choff, N, up);
-        }
-    }
+    // common divisor of the three channel counts decides the vector width
+    int g = 8;
+    while (g > 1 && (CT % g || choff % g || CS % g)) g >>= 1;
+    dispatch_vec(dtype, g, [&](auto tag, int w) {
+        using V = decltype(tag);
+        const size_t total = (size_t)B * 6 * No * No * (CS / w);
+        if (halo)
+            hipLaunchKernelGGL(pad_bwd_src_kernel<V>, stream_grid(total), dim3(256), 0, s, (const V *)dxv, (V *)dsrc, inv,
+                               total, CS / w, CT / w, choff / w, N, up);
+        else
+            hipLaunchKernelGGL(window_src_kernel<V>, stream_grid(total), dim3(256), 0, s, (const V *)dxv, (V *)dsrc, total,
+                               CS / w, CT / w, choff / w, N, up);
+    });
     return check_launch("src_grad");
 }
 }  // namespace dlwpcs
 
 extern "C" int dlwpcs_act_fwd(const void *x, void *y, size_t n, int act, float alpha, float vmax, int dtype,
                               dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "act_fwd");
+    REQUIRE_DTYPE(dtype, "act_fwd");
     REQUIRE(x && y, "act_fwd: null pointer");
     REQUIRE(act == DLWPCS_ACT_LEAKY_CLIP, "act_fwd: unknown activation %d", act);
     if (n == 0) return DLWPCS_OK;
-    hipLaunchKernelGGL(act_fwd_kernel, stream_grid(n / 4 + 1), dim3(256), 0, (hipStream_t)stream, (const float *)x,
-                       (float *)y, n, alpha, vmax);
+    if (dtype == DLWPCS_BF16)
+        hipLaunchKernelGGL((act_fwd_kernel<H8, bf16_t>), stream_grid(n / 8 + 1), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t *)x, (bf16_t *)y, n, alpha, vmax);
+    else
+        hipLaunchKernelGGL((act_fwd_kernel<float4, float>), stream_grid(n / 4 + 1), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)x, (float *)y, n, alpha, vmax);
     return check_launch("act_fwd");
 }
 
 extern "C" int dlwpcs_act_bwd(const void *dy, const void *y, void *dx, size_t n, int act, float alpha, float vmax,
                               int dtype, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "act_bwd");
+    REQUIRE_DTYPE(dtype, "act_bwd");
     REQUIRE(dy && y && dx, "act_bwd: null pointer");
     REQUIRE(act == DLWPCS_ACT_LEAKY_CLIP, "act_bwd: unknown activation %d", act);
     if (n == 0) return DLWPCS_OK;
-    hipLaunchKernelGGL(act_bwd_kernel, stream_grid(n / 4 + 1), dim3(256), 0, (hipStream_t)stream, (const float *)dy,
-                       (const float *)y, (float *)dx, n, alpha, vmax);
+    if (dtype == DLWPCS_BF16)
+        hipLaunchKernelGGL((act_bwd_kernel<H8, bf16_t>), stream_grid(n / 8 + 1), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t *)dy, (const bf16_t *)y, (bf16_t *)dx, n, alpha, vmax);
+    else
+        hipLaunchKernelGGL((act_bwd_kernel<float4, float>), stream_grid(n / 4 + 1), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)dy, (const float *)y, (float *)dx, n, alpha, vmax);
     return check_launch("act_bwd");
 }
 
 #define POOL_LAUNCH(KERNEL, IN, OUT, TOTAL_PIX, NARG)                                                                  \
-    if (C % 4 == 0) {                                                                                                  \
-        const size_t total = (size_t)(TOTAL_PIX) * (C / 4);                                                            \
-        hipLaunchKernelGGL(KERNEL<float4>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, (const float4 *)(IN), \
-                           (float4 *)(OUT), total, C / 4, NARG);                                                       \
-    } else {                                                                                                           \
-        const size_t total = (size_t)(TOTAL_PIX) * C;                                                                  \
-        hipLaunchKernelGGL(KERNEL<float>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, (const float *)(IN),   \
-                           (float *)(OUT), total, C, NARG);                                                            \
-    }
+    dispatch_vec(dtype, C, [&](auto tag, int w) {                                                                      \
+        using V = decltype(tag);                                                                                       \
+        const size_t total = (size_t)(TOTAL_PIX) * (C / w);                                                            \
+        hipLaunchKernelGGL(KERNEL<V>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, (const V *)(IN),          \
+                           (V *)(OUT), total, C / w, NARG);                                                            \
+    });
 
 extern "C" int dlwpcs_avgpool2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "avgpool2_fwd");
+    REQUIRE_DTYPE(dtype, "avgpool2_fwd");
     REQUIRE(x && y, "avgpool2_fwd: null pointer");
     REQUIRE(B >= 0 && N >= 2 && N % 2 == 0 && C >= 1, "avgpool2_fwd: bad shape B=%d N=%d C=%d", B, N, C);
     if (B == 0) return DLWPCS_OK;
@@ -476,7 +541,7 @@ extern "C" int dlwpcs_avgpool2_fwd(const void *x, void *y, int B, int N, int C, 
     return check_launch("avgpool2_fwd");
 }
 extern "C" int dlwpcs_avgpool2_bwd(const void *dy, void *dx, int B, int N, int C, int dtype, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "avgpool2_bwd");
+    REQUIRE_DTYPE(dtype, "avgpool2_bwd");
     REQUIRE(dy && dx, "avgpool2_bwd: null pointer");
     REQUIRE(B >= 0 && N >= 2 && N % 2 == 0 && C >= 1, "avgpool2_bwd: bad shape B=%d N=%d C=%d", B, N, C);
     if (B == 0) return DLWPCS_OK;
@@ -484,15 +549,22 @@ extern "C" int dlwpcs_avgpool2_bwd(const void *dy, void *dx, int B, int N, int C
     return check_launch("avgpool2_bwd");
 }
 extern "C" int dlwpcs_upsample2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "upsample2_fwd");
+    REQUIRE_DTYPE(dtype, "upsample2_fwd");
     REQUIRE(x && y, "upsample2_fwd: null pointer");
     REQUIRE(B >= 0 && N >= 1 && C >= 1, "upsample2_fwd: bad shape B=%d N=%d C=%d", B, N, C);
     if (B == 0) return DLWPCS_OK;
-    POOL_LAUNCH(upsample2_fwd_kernel, x, y, (size_t)B * 6 * (2 * N) * (2 * N), N)
+    const size_t row_bytes = (size_t)C * dtype_size(dtype);
+    dispatch_mover(row_bytes, [&](auto tag, int w) {
+        using V = decltype(tag);
+        const int CV = (int)(row_bytes / w);
+        const size_t total = (size_t)B * 6 * (2 * N) * (2 * N) * CV;
+        hipLaunchKernelGGL(upsample2_fwd_kernel<V>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, (const V *)x,
+                           (V *)y, total, CV, N);
+    });
     return check_launch("upsample2_fwd");
 }
 extern "C" int dlwpcs_upsample2_bwd(const void *dy, void *dx, int B, int N, int C, int dtype, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "upsample2_bwd");
+    REQUIRE_DTYPE(dtype, "upsample2_bwd");
     REQUIRE(dy && dx, "upsample2_bwd: null pointer");
     REQUIRE(B >= 0 && N >= 1 && C >= 1, "upsample2_bwd: bad shape B=%d N=%d C=%d", B, N, C);
     if (B == 0) return DLWPCS_OK;
@@ -502,73 +574,71 @@ extern "C" int dlwpcs_upsample2_bwd(const void *dy, void *dx, int B, int N, int 
 
 extern "C" int dlwpcs_concat2(const void *a, const void *b, void *y, size_t rows, int Ca, int Cb, int dtype,
                               dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "concat2");
+    REQUIRE_DTYPE(dtype, "concat2");
     REQUIRE(a && b && y && Ca >= 1 && Cb >= 1, "concat2: bad arguments");
     if (rows == 0) return DLWPCS_OK;
-    if (Ca % 4 == 0 && Cb % 4 == 0) {
-        const size_t total = rows * ((Ca + Cb) / 4);
-        hipLaunchKernelGGL(concat2_kernel<float4>, stream_grid(total), dim3(256), 0, (hipStream_t)stream,
-                           (const float4 *)a, (const float4 *)b, (float4 *)y, total, Ca / 4, Cb / 4);
-    } else {
-        const size_t total = rows * (Ca + Cb);
-        hipLaunchKernelGGL(concat2_kernel<float>, stream_grid(total), dim3(256), 0, (hipStream_t)stream,
-                           (const float *)a, (const float *)b, (float *)y, total, Ca, Cb);
-    }
+    const size_t ba = (size_t)Ca * dtype_size(dtype), bb = (size_t)Cb * dtype_size(dtype);
+    dispatch_mover(ba | bb, [&](auto tag, int w) {      // (ba | bb) % w == 0  <=>  both divisible (w a power of two)
+        using V = decltype(tag);
+        const size_t total = rows * ((ba + bb) / w);
+        hipLaunchKernelGGL(concat2_kernel<V>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, (const V *)a,
+                           (const V *)b, (V *)y, total, (int)(ba / w), (int)(bb / w));
+    });
     return check_launch("concat2");
 }
 
 extern "C" int dlwpcs_split2(const void *y, void *a, void *b, size_t rows, int Ca, int Cb, int dtype,
                              dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "split2");
+    REQUIRE_DTYPE(dtype, "split2");
     REQUIRE(y && (a || b) && Ca >= 1 && Cb >= 1, "split2: bad arguments");
     if (rows == 0) return DLWPCS_OK;
-    if (Ca % 4 == 0 && Cb % 4 == 0) {
-        const size_t total = rows * ((Ca + Cb) / 4);
-        hipLaunchKernelGGL(split2_kernel<float4>, stream_grid(total), dim3(256), 0, (hipStream_t)stream,
-                           (const float4 *)y, (float4 *)a, (float4 *)b, total, Ca / 4, Cb / 4);
-    } else {
-        const size_t total = rows * (Ca + Cb);
-        hipLaunchKernelGGL(split2_kernel<float>, stream_grid(total), dim3(256), 0, (hipStream_t)stream,
-                           (const float *)y, (float *)a, (float *)b, total, Ca, Cb);
-    }
+    const size_t ba = (size_t)Ca * dtype_size(dtype), bb = (size_t)Cb * dtype_size(dtype);
+    dispatch_mover(ba | bb, [&](auto tag, int w) {
+        using V = decltype(tag);
+        const size_t total = rows * ((ba + bb) / w);
+        hipLaunchKernelGGL(split2_kernel<V>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, (const V *)y, (V *)a,
+                           (V *)b, total, (int)(ba / w), (int)(bb / w));
+    });
     return check_launch("split2");
 }
 
-static int launch_transpose(const void *x, void *y, int batch, size_t R, size_t Ccols, hipStream_t s, const char *who) {
+template <typename S>
+static int launch_transpose_t(const void *x, void *y, dim3 grid, int R, size_t Ccols, hipStream_t s, const char *who) {
+    hipLaunchKernelGGL(transpose_kernel<S>, grid, dim3(256), 0, s, (const S *)x, (S *)y, R, Ccols);
+    return check_launch(who);
+}
+
+static int launch_transpose(const void *x, void *y, int batch, size_t R, size_t Ccols, int dtype, hipStream_t s,
+                            const char *who) {
     if (batch == 0 || R == 0 || Ccols == 0) return DLWPCS_OK;
     if (R > 0x7fffffffu) return fail(DLWPCS_E_INVALID, "%s: too many rows", who);
     dim3 grid((unsigned)((Ccols + 31) / 32), (unsigned)((R + 31) / 32), (unsigned)batch);
     if (grid.y > 65535 || grid.z > 65535) return fail(DLWPCS_E_UNSUPPORTED, "%s: grid too large", who);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, (const float *)x, (float *)y, (int)R, Ccols);
-    return check_launch(who);
+    return dtype == DLWPCS_BF16 ? launch_transpose_t<uint16_t>(x, y, grid, (int)R, Ccols, s, who)
+                                : launch_transpose_t<uint32_t>(x, y, grid, (int)R, Ccols, s, who);
 }
 
 extern "C" int dlwpcs_cf_to_cl(const void *x, void *y, int B, int C, size_t S, int dtype, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "cf_to_cl");
+    REQUIRE_DTYPE(dtype, "cf_to_cl");
     REQUIRE(x && y && B >= 0 && C >= 1, "cf_to_cl: bad arguments");
-    return launch_transpose(x, y, B, (size_t)C, S, (hipStream_t)stream, "cf_to_cl");   // (B,C,S) -> (B,S,C)
+    return launch_transpose(x, y, B, (size_t)C, S, dtype, (hipStream_t)stream, "cf_to_cl");   // (B,C,S) -> (B,S,C)
 }
 extern "C" int dlwpcs_cl_to_cf(const void *x, void *y, int B, int C, size_t S, int dtype, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "cl_to_cf");
+    REQUIRE_DTYPE(dtype, "cl_to_cf");
     REQUIRE(x && y && B >= 0 && C >= 1, "cl_to_cf: bad arguments");
-    // (B,S,C) -> (B,C,S): rows = S may exceed 65535*32, so put S on grid.x by swapping roles
-    if (B == 0 || S == 0) return DLWPCS_OK;
-    dim3 grid((unsigned)((C + 31) / 32), (unsigned)((S + 31) / 32), (unsigned)B);
-    if (grid.y > 65535) {
-        // fall back: treat as batch of S-chunks is not possible generically; S per sample is 6*H*W < 2M in practice
-        return fail(DLWPCS_E_UNSUPPORTED, "cl_to_cf: spatial size too large");
-    }
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float *)x, (float *)y, (int)S,
-                       (size_t)C);
-    return check_launch("cl_to_cf");
+    return launch_transpose(x, y, B, S, (size_t)C, dtype, (hipStream_t)stream, "cl_to_cf");   // (B,S,C) -> (B,C,S)
 }
 
 extern "C" int dlwpcs_add(const void *a, const void *b, void *y, size_t n, int dtype, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "add");
+    REQUIRE_DTYPE(dtype, "add");
     REQUIRE(a && b && y, "add: null pointer");
     if (n == 0) return DLWPCS_OK;
-    hipLaunchKernelGGL(add_kernel, stream_grid(n / 4 + 1), dim3(256), 0, (hipStream_t)stream, (const float *)a,
-                       (const float *)b, (float *)y, n);
+    if (dtype == DLWPCS_BF16)
+        hipLaunchKernelGGL((add_kernel<H8, bf16_t>), stream_grid(n / 8 + 1), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t *)a, (const bf16_t *)b, (bf16_t *)y, n);
+    else
+        hipLaunchKernelGGL((add_kernel<float4, float>), stream_grid(n / 4 + 1), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)a, (const float *)b, (float *)y, n);
     return check_launch("add");
 }
 
@@ -576,13 +646,22 @@ extern "C" size_t dlwpcs_mse_scratch_bytes(void) { return (size_t)MSE_BLOCKS * 2
 
 extern "C" int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float *loss_out, size_t n, float weight,
                                   int dtype, void *scratch, dlwpcs_stream_t stream) {
-    REQUIRE_F32(dtype, "mse_fwd_bwd");
+    const bool t_f32 = (dtype & DLWPCS_MSE_TARGET_F32) != 0;
+    dtype &= ~DLWPCS_MSE_TARGET_F32;
+    REQUIRE_DTYPE(dtype, "mse_fwd_bwd");
     REQUIRE(y && t && loss_out && scratch && n > 0, "mse_fwd_bwd: bad arguments");
     size_t g = (n + 255) / 256;
     if (g > MSE_BLOCKS) g = MSE_BLOCKS;
     const float gscale = weight * 2.f / (float)n;
-    hipLaunchKernelGGL(mse_stage1_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float *)y,
-                       (const float *)t, (float *)dy, (float *)scratch, n, gscale);
+    if (dtype == DLWPCS_BF16 && t_f32)
+        hipLaunchKernelGGL((mse_stage1_kernel<bf16_t, float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t *)y, (const float *)t, (bf16_t *)dy, (float *)scratch, n, gscale);
+    else if (dtype == DLWPCS_BF16)
+        hipLaunchKernelGGL((mse_stage1_kernel<bf16_t, bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t *)y, (const bf16_t *)t, (bf16_t *)dy, (float *)scratch, n, gscale);
+    else
+        hipLaunchKernelGGL((mse_stage1_kernel<float, float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)y, (const float *)t, (float *)dy, (float *)scratch, n, gscale);
     hipLaunchKernelGGL(mse_stage2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)scratch, loss_out,
                        (int)g, 1.f / (float)n, weight);
     return check_launch("mse_fwd_bwd");

@@ -15,7 +15,12 @@
  *   - tensors on the hot path are `channels_last`:  x[b][face][row][col][channel]  (face axis = 6,
  *     faces 0-3 equatorial going east, 4 = south pole, 5 = north pole; reference DLWP/custom.py:1057-1070).
  *     `channels_first` (B,C,6,H,W) callers convert with dlwpcs_cf_to_cl / dlwpcs_cl_to_cf.
- *   - dtype: DLWPCS_F32 (this round).  Arithmetic is exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.
+ *   - dtype: DLWPCS_F32 -- every tensor fp32, arithmetic is exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.
+ *            DLWPCS_BF16 -- mixed precision (the reference trains under TF's AMP graph rewrite, Azure/train_cs.py:429):
+ *            ACTIVATIONS and their gradients (src*, y, dy, dsrc*, x/dx of the stock ops, mse y/t/dy) are bfloat16 in
+ *            HBM; PARAMETERS and their gradients (w_*, b_*, dw_*, db_*, Adam state) stay fp32 master copies; the
+ *            contraction runs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, fp32 accumulate), every
+ *            elementwise kernel computes in fp32 and rounds once on store (round-to-nearest-even).
  *
  * Reference interfaces replaced (paths relative to the reference repository root):
  *   CubeSpherePadding2D.call        DLWP/custom.py:1082-1308   -> dlwpcs_halo_table, dlwpcs_pad_fwd/_bwd
@@ -45,7 +50,8 @@ extern "C" {
 #define DLWPCS_E_LAUNCH      -4       /* HIP launch error */
 
 /* dtype tags */
-#define DLWPCS_F32 0
+#define DLWPCS_F32  0
+#define DLWPCS_BF16 1                 /* activations / activation gradients stored as bfloat16 (see "dtype" above) */
 
 /* activation tags (epilogue of conv_fwd, mask of the backward kernels) */
 #define DLWPCS_ACT_NONE        0
@@ -106,7 +112,7 @@ typedef struct dlwpcs_conv_desc {
     int32_t flip_north_pole;
     int32_t act;            /* DLWPCS_ACT_* */
     float   alpha, vmax;    /* parameters of DLWPCS_ACT_LEAKY_CLIP */
-    int32_t dtype;          /* DLWPCS_F32 */
+    int32_t dtype;          /* DLWPCS_F32 | DLWPCS_BF16 (dtype of src*, y, dy, dsrc*; parameters are always fp32) */
     int32_t flags;          /* DLWPCS_CONV_* bits */
 } dlwpcs_conv_desc;
 
@@ -189,7 +195,10 @@ int dlwpcs_add(const void *a, const void *b, void *y, size_t n, int dtype, dlwpc
  * Training-step tail (Azure/train_cs.py:424-430): keras 'mse' with a loss weight, metric 'mae', and Adam.
  * ------------------------------------------------------------------------------------------------------------- */
 /* loss_out[0] += weight*mean((y-t)^2), loss_out[1] += mean(|y-t|);  dy = weight*2*(y-t)/n  (dy may be NULL).
- * scratch: >= dlwpcs_mse_scratch_bytes() bytes.  Deterministic two-stage reduction. */
+ * scratch: >= dlwpcs_mse_scratch_bytes() bytes.  Deterministic two-stage reduction, fp32 arithmetic.
+ * dtype = dtype of y and dy; t has the same dtype unless DLWPCS_MSE_TARGET_F32 is OR-ed in (bf16 prediction scored
+ * against the fp32 target, as TF's AMP does: the loss is computed in fp32). */
+#define DLWPCS_MSE_TARGET_F32 0x100
 size_t dlwpcs_mse_scratch_bytes(void);
 int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float *loss_out, size_t n, float weight, int dtype,
                        void *scratch, dlwpcs_stream_t stream);
