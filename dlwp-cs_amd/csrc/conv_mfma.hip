@@ -814,6 +814,272 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix cores (hot-path shapes of the bf16 mode: every channel count a multiple of 8).
+//
+// Same worker structure as wgrad_mfma_kernel (persistent, 4 consumer + 4 producer waves, one partial per worker, static
+// strided item lists per face class), but the contraction runs on v_mfma_f32_32x32x16_bf16 with K = 16 PIXELS per
+// instruction.  Both operands are stored channels-contiguous ([pixel][32 channels] bf16, 64 B per pixel, as they arrive
+// from HBM) while the instruction wants, per lane, 8 consecutive K values of ONE channel: the transposition is done by
+// the LDS itself with ds_read_b64_tr_b16 -- the 16 lanes of a group each pass the address of 4 contiguous channels of one
+// of 4 pixels and receive one channel of those 4 pixels (probed on the MI355X with tools/probe_tr.hip: lane n gets
+// column n, element j = row j).  The K -> pixel mapping is free as long as X and dZ agree, so pixels are taken in flat
+// band order and every lane computes its own two pixel addresses; the 64-B pixel stride makes each 32-lane access group
+// (4 pixels x 32 channels = 256 B) hit all 64 banks exactly once.
+// dZ = dy * act'(y) is rounded to bf16 by the producers (it is a bf16 tensor in this mode); bias gradients are summed
+// from those rounded values in fp32.  Items are <= 384 pixels (16-pixel K slabs; rows beyond npix are zero-filled).
+// ------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr16(const char *p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+
+template <int KS, bool MASK>
+__global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
+    constexpr int TAPS = KS * KS;
+    constexpr int PB = 64;                  // LDS bytes per pixel: 32 channels bf16 (X tile and dZ tile alike)
+    constexpr int NCT = 256;                // consumer threads == producer threads
+    constexpr int IT_X = 10;                // X 16-B vectors per producer thread per item: capacity 640 tile pixels
+    constexpr int IT_DY = 6;                // dZ 16-B vectors per producer thread per item: capacity 384 pixels
+    const ConvKParams &P = W.c;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pix_cap = (P.pix_per_block + 15) & ~15;
+    const int x_bytes = P.tile_rows_max * P.W2 * PB;
+    const int buf_bytes = x_bytes + pix_cap * PB;
+    // the 16 KB cross-wave reduction scratch (+ 8 KB bias staging) aliases the buffers after the main loop
+
+    const int worker = blockIdx.x;
+    const int cit = blockIdx.y, cot = blockIdx.z;
+    int j, nj, nfaces, fbase;
+    if (worker < W.n_eq) { j = worker; nj = W.n_eq; nfaces = 4; fbase = 0; }
+    else if (worker < W.n_eq + W.n_4) { j = worker - W.n_eq; nj = W.n_4; nfaces = 1; fbase = 4; }
+    else { j = worker - W.n_eq - W.n_4; nj = W.n_5; nfaces = 1; fbase = 5; }
+    const int nbands = P.nblk_face;
+    const int total_items = P.B * nfaces * nbands;
+    const int n_my = j < total_items ? (total_items - j + nj - 1) / nj : 0;
+    const int face_pix = P.No * P.No;
+    const int tid = threadIdx.x;
+
+    struct Item { int b, f, m0, npix, y0, nitems; };
+    auto item_of = [&](int k) {
+        Item it;
+        const int t = j + max(min(k, n_my - 1), 0) * nj;
+        const int band = t % nbands;
+        const int r = t / nbands;
+        it.f = fbase + r % nfaces;
+        it.b = r / nfaces;
+        it.m0 = band * P.pix_per_block;
+        it.npix = min(P.pix_per_block, face_pix - it.m0);
+        it.y0 = __umulhi((uint32_t)it.m0, P.magicNo);
+        const int ylast = __umulhi((uint32_t)(it.m0 + it.npix - 1), P.magicNo);
+        it.nitems = (ylast - it.y0 + KS) * P.W2 * 4;        // 4 vectors of 8 channels per tile pixel
+        return it;
+    };
+
+    if (tid >= NCT) {
+        // =========================================== producers ===========================================
+        const int ptid = tid - NCT;
+        const int qx = ptid & 3;                            // this thread's 8-channel group: fixed for the whole kernel
+        const int cx = cit * 32 + qx * 8;
+        const bool cx_ok = cx < P.Cin;
+        const bool from0 = cx < P.C0;
+        const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
+        const int cs = from0 ? cx : cx - P.C0;
+        const int cstride = from0 ? P.C0 : P.C1;
+        const bool up = from0 && P.up0;
+        const int M = P.Nin + KS - 1;
+        const int co = cot * 32 + qx * 8;
+        const bool co_ok = co < P.Cout;
+        const bool want_bias = W.bpartial != nullptr && cit == 0;
+        float bsum[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bsum[u] = 0.f;
+        int sidx[IT_X], sidx_n[IT_X];
+        auto lookup = [&](const Item &it, int (&sx)[IT_X]) {
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int e = min(ptid + i * NCT, it.nitems - 1);
+                const int pix = e >> 2;
+                const int ty = __umulhi((uint32_t)pix, P.magicW2);
+                const int tx = pix - ty * P.W2;
+                const int iy = it.y0 + ty;
+                int v0;
+                if (P.mode == MODE_HALO) v0 = P.table[(it.f * M + iy) * M + tx];
+                else v0 = (it.f * P.Nin + iy) * P.Nin + tx;
+                sx[i] = (ptid + i * NCT < it.nitems) ? v0 : -1;
+            }
+        };
+        Item cur = item_of(0);
+        if (n_my > 0) lookup(cur, sidx);
+        for (int k = 0; k < n_my; ++k) {
+            char *buf = smem + (k & 1) * buf_bytes;
+            const Item nxt = item_of(k + 1);
+            const bf16_t *sb = from0 ? reinterpret_cast<const bf16_t *>(P.src0) + (size_t)cur.b * 6 * g0 * g0 * P.C0
+                                     : reinterpret_cast<const bf16_t *>(P.src1) + (size_t)cur.b * 6 * P.Nin * P.Nin * P.C1;
+            // ---- X tile: every load in flight at once
+            uint4 xv[IT_X];
+            bool xok[IT_X];
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int idx = sidx[i];
+                const bool ok = cx_ok && idx >= 0;
+                const int ii = ok ? idx : 0;
+                const int vf = __umulhi((uint32_t)ii, P.magicN2);
+                const int rem = ii - vf * P.Nin * P.Nin;
+                const int vy = __umulhi((uint32_t)rem, P.magicN);
+                const int vx = rem - vy * P.Nin;
+                const int pix_up = (vf * g0 + (vy >> 1)) * g0 + (vx >> 1);
+                const int pix = up ? pix_up : ii;
+                xv[i] = *reinterpret_cast<const uint4 *>(sb + (ok ? (size_t)pix * cstride + cs : 0));
+                xok[i] = ok;
+            }
+            // ---- dZ tile [pix][32 output channels of tile cot] = dy * act'(y), zero beyond npix / Cout
+            const size_t rowbase = (((size_t)cur.b * 6 + cur.f) * face_pix + cur.m0) * P.Cout;
+            const bf16_t *dyb = reinterpret_cast<const bf16_t *>(W.dy) + rowbase;
+            const bf16_t *yb = MASK ? reinterpret_cast<const bf16_t *>(W.y) + rowbase : nullptr;
+            uint4 dv[IT_DY], yv[MASK ? IT_DY : 1];
+            bool dok[IT_DY];
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) {
+                const int kk = (ptid + i * NCT) >> 2;
+                const bool ok = kk < cur.npix && co_ok;
+                const size_t o = ok ? (size_t)kk * P.Cout + co : 0;
+                dv[i] = *reinterpret_cast<const uint4 *>(dyb + o);
+                if (MASK) yv[i] = *reinterpret_cast<const uint4 *>(yb + o);
+                dok[i] = ok;
+            }
+            lookup(nxt, sidx_n);                                   // next item's halo-table entries ride along
+            // dZ = dy * act'(y), applied only after EVERY load of the item has been issued
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) {
+                if (MASK) vmask(dv[i], yv[i], P.alpha, P.vmax);
+                dv[i] = vsel(dok[i], dv[i]);
+            }
+            // ---- registers -> LDS
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int e = ptid + i * NCT;
+                if (e < cur.nitems) *reinterpret_cast<uint4 *>(buf + (size_t)e * 16) = vsel(xok[i], xv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) {
+                const int e = ptid + i * NCT;
+                if (e < pix_cap * 4) *reinterpret_cast<uint4 *>(buf + x_bytes + (size_t)e * 16) = dv[i];
+                if (want_bias) {
+                    bsum[0] += bf_lo(dv[i].x); bsum[1] += bf_hi(dv[i].x); bsum[2] += bf_lo(dv[i].y); bsum[3] += bf_hi(dv[i].y);
+                    bsum[4] += bf_lo(dv[i].z); bsum[5] += bf_hi(dv[i].z); bsum[6] += bf_lo(dv[i].w); bsum[7] += bf_hi(dv[i].w);
+                }
+            }
+            __syncthreads();            // B_k: item k is in LDS
+            cur = nxt;
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) sidx[i] = sidx_n[i];
+        }
+        // ---- bias partial: thread (q = ptid & 3, 64 pixel phases) holds sums of channels 8q..8q+7 -> fixed-order sum
+        __syncthreads();                // consumers are done with the buffers (matches the consumers' final barrier)
+        float *red = reinterpret_cast<float *>(smem) + 4096;   // behind the consumers' 4 x 1024-float reduction scratch
+        if (want_bias) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) red[ptid * 8 + u] = bsum[u];
+        }
+        __syncthreads();
+        if (want_bias && ptid < 32) {
+            float sum = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < 64; ++ph) sum += red[(ph * 4 + (ptid >> 3)) * 8 + (ptid & 7)];
+            W.bpartial[(size_t)worker * W.CoutP + cot * 32 + ptid] = sum;
+        }
+        // the consumers' tap loop below executes 2 barriers per tap: keep the barrier counts of both halves equal
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) { __syncthreads(); __syncthreads(); }
+        return;
+    }
+
+    // ============================================= consumers =============================================
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int li = lane & 15;
+    const int choff = ((((lane >> 4) & 1) * 16) + (li & 3) * 4) * 2;   // byte offset of this lane's 4 contiguous channels
+    const int prow = li >> 2;                                            // which of the 4 pixels of a transpose block
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int tapoff[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) tapoff[t] = ((t / KS) * P.W2 + (t % KS)) * PB;
+
+    const int nslab = pix_cap / 16;             // K slabs (16 pixels) per item
+    const int S = (((nslab + 3) / 4) + 1) & ~1; // slabs per consumer wave, rounded up to even (extra slabs add zero)
+    for (int k = 0; k < n_my; ++k) {
+        __syncthreads();                        // B_k
+        const char *lds_x = smem + (k & 1) * buf_bytes, *lds_dy = lds_x + x_bytes;
+        const Item it = item_of(k);
+        // operands of slab si of this wave: K index kk = 8*half + 4*jj + prow (jj = 0, 1) <-> flat pixel 16*s + kk.
+        // Branch-free: out-of-range slabs / pixels read a clamped (valid) X address and a zero dZ.
+        auto frag = [&](int si, uint4 (&a)[TAPS], uint4 &bq) {
+            const int s = wave + 4 * si;
+            const int sc = min(s, nslab - 1);
+            const bool live = s < nslab;
+            int xaddr[2], daddr[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int m = 16 * sc + 8 * half + 4 * jj + prow;
+                const int gm = it.m0 + min(m, it.npix - 1);
+                const int oy = __umulhi((uint32_t)gm, P.magicNo);
+                xaddr[jj] = ((oy - it.y0) * P.W2 + (gm - oy * P.No)) * PB + choff;
+                daddr[jj] = m * PB + choff;
+            }
+            const uint2 b0 = lds_tr16(lds_dy + daddr[0]), b1 = lds_tr16(lds_dy + daddr[1]);
+            bq = vsel(live, make_uint4(b0.x, b0.y, b1.x, b1.y));
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const uint2 a0 = lds_tr16(lds_x + xaddr[0] + tapoff[tap]), a1 = lds_tr16(lds_x + xaddr[1] + tapoff[tap]);
+                a[tap] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            }
+        };
+        uint4 fa[2][TAPS], fb[2];
+        frag(0, fa[0], fb[0]);
+        for (int si = 0; si < S; si += 2) {
+            frag(si + 1, fa[1], fb[1]);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fa[0][tap], fb[0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TAPS + 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);
+            frag(si + 2, fa[0], fb[0]);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fa[1][tap], fb[1]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TAPS + 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);
+        }
+    }
+    __syncthreads();                            // all consumers finished reading the last buffer
+    __syncthreads();                            // (producers stage their bias sums between these two)
+
+    // cross-wave reduction through LDS (fixed order w = 0..3), one tap at a time
+    float *red = reinterpret_cast<float *>(smem);
+    float *pout = W.partial + (size_t)worker * TAPS * W.CinP * W.CoutP;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[wave * 1024 + ci * 32 + l31] = acc[tap][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * NCT;
+            const float sum = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+            const int ci = e >> 5, co = e & 31;
+            pout[((size_t)tap * W.CinP + cit * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
+        }
+        __syncthreads();
+    }
+}
+
 // Sum the per-slot partials in a fixed order and route them to the weight groups.  Workgroup = 16 outputs x 16 slot
 // phases: thread (o, ph) adds slots ph, ph+16, ... (fixed order), the 16 phases are then combined through LDS in a fixed
 // tree -> bitwise reproducible, and enough workgroups (outputs/16) to fill the chip.  accumulate != 0: add to the
@@ -1051,10 +1317,22 @@ struct WsLayout {
 };
 
 // persistent weight-gradient launch geometry: pixels per work item, items (bands) per face, workers per face class
+// bf16 matrix-core weight gradient (wgrad_bf16_kernel): bf16 tensors whose channel counts are all multiples of 8
+static bool wgrad_bf16_eligible(const dlwpcs_conv_desc *d) {
+    return d->dtype == DLWPCS_BF16 && d->C0 % 8 == 0 && d->C1 % 8 == 0 && d->Cout % 8 == 0;
+}
+
 static void wgrad_tiling(const dlwpcs_conv_desc *d, int &pix, int &nblk, int &n_eq, int &n_4, int &n_5) {
     const int No = out_size(d);
     const int face_pix = No * No;
-    const int CAP = 192;     // pixels per work item: 2 LDS buffers of (X tile + dZ tile) in one CU's 160 KB
+    // pixels per work item: 2 LDS buffers of (X tile + dZ tile) in one CU's 160 KB (bf16 tiles are half the bytes)
+    int CAP = 192;
+    if (wgrad_bf16_eligible(d)) {
+        CAP = 384;
+        // the X tile (item rows + k-1 halo rows, full padded width) must fit the producers' 640-pixel register capacity
+        while (CAP > 96 && (long)(tile_rows_for(No <= CAP ? (CAP / No) * No : CAP, No) + d->ksize - 1) * (No + d->ksize - 1) > 640)
+            CAP -= 96;
+    }
     pix = CAP;
     if (No <= CAP) pix = (CAP / No) * No;
     if (pix > face_pix) pix = face_pix;
@@ -1252,6 +1530,41 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
 #endif
     if (P.C1 == 0) P.src1 = P.src0;
     const bool mask = d->act != DLWPCS_ACT_NONE;
+    dim3 grid((unsigned)(L.n_eq + L.n_4 + L.n_5), (unsigned)(CinP / 32), (unsigned)(CoutP / 32));
+    const int nout = TAPS * Cin * d->Cout + (want_bias ? d->Cout : 0);
+    if (wgrad_bf16_eligible(d) && (size_t)P.tile_rows_max * P.W2 <= 640 && L.wg_pix <= 384) {
+        const int pcap = (L.wg_pix + 15) & ~15;
+        size_t lds = 2 * ((size_t)P.tile_rows_max * P.W2 * 64 + (size_t)pcap * 64);
+        if (lds < (4096 + 2048) * 4) lds = (4096 + 2048) * 4;   // cross-wave reduction scratch + bias staging alias the buffers
+        if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
+        if ((long)P.Nin * P.Nin >= (1l << 16))
+            return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: face size %d too large for the 16-bit index arithmetic", P.Nin);
+#define WGB_LAUNCH(KSV, MASKV)                                                                                            \
+    do {                                                                                                                  \
+        auto kern = wgrad_bf16_kernel<KSV, MASKV>;                                                                        \
+        if (lds > 64 * 1024) {                                                                                            \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));    \
+        }                                                                                                                 \
+        int pidx = -1;                                                                                                    \
+        if (prof_enabled()) {                                                                                             \
+            const Work wk = conv_work(d);                                                                                 \
+            pidx = prof_begin("wgrad_bf16_kernel<" #KSV ", " #MASKV ">", wk.flops, wk.bytes, s);                          \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, W);                                                             \
+        if (pidx >= 0) prof_end(pidx, s);                                                                                 \
+    } while (0)
+        if (KS == 3) { if (mask) WGB_LAUNCH(3, true); else WGB_LAUNCH(3, false); }
+        else { if (mask) WGB_LAUNCH(1, true); else WGB_LAUNCH(1, false); }
+#undef WGB_LAUNCH
+        rc = check_launch("wgrad_bf16");
+        if (rc) return rc;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(nout, 16)), dim3(256), 0, s, W.partial, W.bpartial,
+                           (float *)dw_eq, (float *)dw_pol, (float *)dw_np, (float *)db_eq, (float *)db_pol, (float *)db_np,
+                           KS, Cin, d->Cout, CinP, CoutP, L.n_eq, L.n_4, L.n_5, d->flip_north_pole,
+                           (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0);
+        return check_launch("wgrad_reduce");
+    }
     const int pix_cap = (L.wg_pix + 1) & ~1;
     const int vw = vec_width(d->C0, d->C1, d->dtype);
     const bool bf = d->dtype == DLWPCS_BF16;
@@ -1263,7 +1576,6 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     size_t lds = 2 * bufb;
     if (lds < (4096 + 1024) * 4) lds = (4096 + 1024) * 4;     // cross-wave reduction scratch + bias staging alias the buffers
     if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
-    dim3 grid((unsigned)(L.n_eq + L.n_4 + L.n_5), (unsigned)(CinP / 32), (unsigned)(CoutP / 32));
 #define WG_LAUNCH(TV, TS, KSV, VWV, MASKV)                                                                                \
     do {                                                                                                                  \
         auto kern = wgrad_mfma_kernel<TV, KSV, VWV, MASKV>;                                                               \
@@ -1297,7 +1609,6 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
 #undef WG_LAUNCH
     rc = check_launch("wgrad_mfma");
     if (rc) return rc;
-    const int nout = TAPS * Cin * d->Cout + (want_bias ? d->Cout : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(nout, 16)), dim3(256), 0, s, W.partial, W.bpartial,
                        (float *)dw_eq, (float *)dw_pol, (float *)dw_np, (float *)db_eq, (float *)db_pol, (float *)db_np,
                        KS, Cin, d->Cout, CinP, CoutP, L.n_eq, L.n_4, L.n_5, d->flip_north_pole,

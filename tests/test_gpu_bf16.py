@@ -301,7 +301,7 @@ def test_unet2_train_step_bf16_tracks_fp64_oracle():
     y = model.predict(x)
     assert y.dtype == np.float32
     pr = [{k: v.clone().requires_grad_(True) for k, v in prm.items()} for prm in params]
-    yr = orc.unet2_forward(torch.tensor(x), pr)
+    yr = orc.unet2_forward(torch.tensor(x, dtype=torch.float64), pr)
     assert rel_err(y, yr.detach().numpy()) < 3e-2
     loss = orc.mse_loss(yr, torch.tensor(tgt, dtype=torch.float64))
     loss.backward()
