@@ -21,6 +21,8 @@ MSE_TARGET_F32 = 0x100
 ACT_NONE = 0
 ACT_LEAKY_CLIP = 1
 CONV_ACCUMULATE_WGRAD = 1
+CONV_PREPACKED = 2
+PACK_FWD, PACK_BWD, PACK_BIAS = 0, 1, 2
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -33,6 +35,13 @@ class ConvDesc(ctypes.Structure):
                 ('up0', ctypes.c_int32), ('flip_north_pole', ctypes.c_int32), ('act', ctypes.c_int32),
                 ('alpha', ctypes.c_float), ('vmax', ctypes.c_float), ('dtype', ctypes.c_int32),
                 ('flags', ctypes.c_int32)]
+
+
+class PackItem(ctypes.Structure):
+    """struct dlwpcs_pack_item (include/dlwpcs.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('w_eq', 'w_pol', 'w_np', 'b_eq', 'b_pol', 'b_np', 'wpk_fwd', 'wpk_bwd',
+                                                'bias_pk')] + \
+               [(n, ctypes.c_int32) for n in ('ksize', 'Cin', 'Cout', 'flip_north_pole', 'dtype', 'reserved')]
 
 
 class GConvDesc(ctypes.Structure):
@@ -51,6 +60,8 @@ PROTOTYPES = {
     'dlwpcs_pad_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dlwpcs_pad_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dlwpcs_conv_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    'dlwpcs_conv_packed_bytes': (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
+    'dlwpcs_pack_batch': (c_int, [c_void_p, c_int, c_void_p]),
     'dlwpcs_conv_fwd': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_void_p, c_void_p, c_void_p, c_size_t,
                                                                                  c_void_p]),
     'dlwpcs_conv_bwd_data': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 5 + [c_void_p, c_void_p, c_void_p,

@@ -55,6 +55,7 @@ class Model(object):
         self.use_graphs = os.environ.get('DLWPCS_GRAPHS', '1') != '0'
         # activation dtype on the device ('float32' | 'bfloat16'); parameters / gradients / Adam state are always fp32
         self.compute_dtype = backend.compute_dtype()
+        self.prepack_weights = os.environ.get('DLWPCS_PREPACK', '1') != '0'
         self._compiled = False
         self._flat_params = self._flat_grads = None
         self._graphs = {}
@@ -149,9 +150,49 @@ class Model(object):
         self._plan = steps
         self.n_fused = len(fused)
 
+    def _pack_state(self, device):
+        """Packed-weight buffers + the device item table of every matrix-core convolution layer (built once per
+        (device, compute dtype); the parameter tensors never move after _flatten_parameters)."""
+        from ..custom import CubeSphereConv2D
+        from .. import _native as nat
+        tag = nat.BF16 if self.compute_dtype == 'bfloat16' else nat.F32
+        key = (str(device), tag, self._flat_params.data_ptr() if self._flat_params is not None else 0)
+        st = getattr(self, '_pack_cache', None)
+        if st is not None and st['key'] == key:
+            return st
+        entries, table = [], {}
+        for lay in self.layers:
+            if not isinstance(lay, CubeSphereConv2D) or not lay.built or not lay._is_mfma_config():
+                continue
+            we = lay.equatorial_kernel
+            if we.device != device or id(we) in table:
+                continue
+            bufs = ops.conv_packed_buffers(lay.kernel_size[0], we.shape[2], we.shape[3], tag, device,
+                                           bias=lay.equatorial_bias is not None)
+            entries.append((we, lay.polar_kernel, lay.north_pole_kernel, lay.equatorial_bias, lay.polar_bias,
+                            lay.north_pole_bias, bufs, lay.kernel_size[0], lay.flip_north_pole, tag))
+            table[id(we)] = (tag, bufs[0], bufs[1], bufs[2])
+        st = {'key': key, 'items': ops.make_pack_items(entries, device) if entries else None, 'n': len(entries),
+              'table': table, 'keep': entries}
+        self._pack_cache = st
+        return st
+
     def _forward(self, inputs):
         want = backend.torch_dtype(self.compute_dtype)
         inputs = [v if v.dtype == want else v.to(want) for v in inputs]
+        if inputs and inputs[0].is_cuda and self.prepack_weights:
+            # one launch packs the weights of every layer for this pass (they changed with the last optimizer step)
+            st = self._pack_state(inputs[0].device)
+            if st['n']:
+                ops.pack_batch(st['items'], st['n'])
+            ops.PREPACKED = st['table']
+            try:
+                return self._run_plan(inputs)
+            finally:
+                ops.PREPACKED = {}
+        return self._run_plan(inputs)
+
+    def _run_plan(self, inputs):
         values = {t.uid: v for t, v in zip(self.inputs, inputs)}
         for st in self._plan:
             if st[0] == 'fused_conv':

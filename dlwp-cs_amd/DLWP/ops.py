@@ -15,6 +15,11 @@ from ._native import ConvDesc, GConvDesc, check, lib, ptr, require_device, strea
 # (DLWP.keras.Model turns this on around its training step; plain autograd use keeps the standard semantics).
 DIRECT_PARAM_GRADS = False
 
+# Pre-packed weights (dlwpcs_pack_batch): id(equatorial kernel tensor) -> (dtype tag, wpk_fwd, bias_pk | None, wpk_bwd).
+# DLWP.keras.Model fills this around its forward pass after packing every layer with ONE launch; a convolution whose
+# kernel is not listed (or listed for another dtype) packs its weights itself, per call, into the workspace.
+PREPACKED = {}
+
 # workspace: one growing byte buffer per device (caller-owned from the library's point of view)
 _workspaces = {}
 
@@ -124,9 +129,19 @@ class _CSConv(torch.autograd.Function):
             table, inv = nat.halo_tables(N, (ksize - 1) // 2, src0.device)
         nbytes = lib().dlwpcs_conv_workspace_bytes(ctypes.byref(d))
         ws = _workspace(nbytes, src0.device)
-        check(lib().dlwpcs_conv_fwd(ctypes.byref(d), ptr(src0), ptr(src1), ptr(w_eq), ptr(w_pol), ptr(w_np),
-                                    ptr(b_eq), ptr(b_pol), ptr(b_np), ptr(y), ptr(table), ptr(ws), ws.numel(),
-                                    stream_ptr()), 'dlwpcs_conv_fwd')
+        packed = PREPACKED.get(id(w_eq))
+        if packed is not None and packed[0] != d.dtype:
+            packed = None
+        if packed is not None:
+            d.flags |= nat.CONV_PREPACKED
+            check(lib().dlwpcs_conv_fwd(ctypes.byref(d), ptr(src0), ptr(src1), ptr(packed[1]), 0, 0,
+                                        ptr(packed[2]) if b_eq is not None else 0, 0, 0, ptr(y), ptr(table), ptr(ws),
+                                        ws.numel(), stream_ptr()), 'dlwpcs_conv_fwd')
+        else:
+            check(lib().dlwpcs_conv_fwd(ctypes.byref(d), ptr(src0), ptr(src1), ptr(w_eq), ptr(w_pol), ptr(w_np),
+                                        ptr(b_eq), ptr(b_pol), ptr(b_np), ptr(y), ptr(table), ptr(ws), ws.numel(),
+                                        stream_ptr()), 'dlwpcs_conv_fwd')
+        ctx.packed = packed
         ctx.desc = d
         ctx.tables = (table, inv)
         ctx.has = (src1 is not None, w_np is not None, b_eq is not None, b_np is not None)
@@ -149,7 +164,9 @@ class _CSConv(torch.autograd.Function):
         dsrc0 = torch.empty_like(src0) if need[0] else None
         dsrc1 = torch.empty_like(src1) if (has_src1 and need[1]) else None
         if dsrc0 is not None or dsrc1 is not None:
-            check(lib().dlwpcs_conv_bwd_data(ctypes.byref(d), ptr(dy), ptr(y), ptr(w_eq), ptr(w_pol), ptr(w_np),
+            # (d.flags carries CONV_PREPACKED from the forward when packed buffers were used)
+            wq = ctx.packed[3] if ctx.packed is not None else w_eq
+            check(lib().dlwpcs_conv_bwd_data(ctypes.byref(d), ptr(dy), ptr(y), ptr(wq), ptr(w_pol), ptr(w_np),
                                              ptr(dsrc0), ptr(dsrc1), ptr(inv), ptr(ws), ws.numel(), stream_ptr()),
                   'dlwpcs_conv_bwd_data')
         dw_eq = dw_pol = dw_np = db_eq = db_pol = db_np = None
@@ -179,6 +196,41 @@ class _CSConv(torch.autograd.Function):
                                                 ptr(table), ptr(ws), ws.numel(), stream_ptr()),
                   'dlwpcs_conv_bwd_weights')
         return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 7
+
+
+def conv_packed_buffers(ksize, cin, cout, dtype_tag, device, bias=True):
+    """Allocate (wpk_fwd, bias_pk | None, wpk_bwd) for one layer; sizes from dlwpcs_conv_packed_bytes."""
+    d = _make_desc(1, max(ksize, 2), cin, 0, cout, ksize, False, False, True, nat.ACT_NONE, 0.0, 0.0, dtype_tag)
+    out = []
+    for which in (nat.PACK_FWD, nat.PACK_BIAS, nat.PACK_BWD):
+        n = lib().dlwpcs_conv_packed_bytes(ctypes.byref(d), which)
+        if n == 0:
+            check(-1, 'dlwpcs_conv_packed_bytes')
+        out.append(torch.empty(n, dtype=torch.uint8, device=device))
+    if not bias:
+        out[1] = None
+    return tuple(out)
+
+
+def make_pack_items(entries, device):
+    """
+    entries: list of (w_eq, w_pol, w_np, b_eq, b_pol, b_np, (wpk_fwd, bias_pk, wpk_bwd), ksize, flip, dtype_tag).
+    Returns the device-resident dlwpcs_pack_item array (uint8 tensor) for dlwpcs_pack_batch.
+    """
+    arr = (nat.PackItem * len(entries))()
+    for it, (we, wp, wn, be, bp, bn, bufs, ksize, flip, tag) in zip(arr, entries):
+        it.w_eq, it.w_pol, it.w_np = ptr(we), ptr(wp), ptr(wn)
+        it.b_eq, it.b_pol, it.b_np = ptr(be), ptr(bp), ptr(bn)
+        it.wpk_fwd, it.bias_pk, it.wpk_bwd = ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2])
+        it.ksize, it.Cin, it.Cout = int(ksize), int(we.shape[2]), int(we.shape[3])
+        it.flip_north_pole, it.dtype, it.reserved = int(flip), int(tag), 0
+    raw = bytes(arr)
+    host = torch.frombuffer(bytearray(raw), dtype=torch.uint8) if raw else torch.empty(0, dtype=torch.uint8)
+    return host.to(device)
+
+
+def pack_batch(items_dev, n_items):
+    check(lib().dlwpcs_pack_batch(ptr(items_dev), int(n_items), stream_ptr()), 'dlwpcs_pack_batch')
 
 
 def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1=None, ksize=3, halo=True, up0=False,

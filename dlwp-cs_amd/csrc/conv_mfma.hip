@@ -455,13 +455,13 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 // T = MFMA operand type: float -> 4 values per 16-B lane entry (K group of 8), bf16_t -> 8 values (K group of 16; the
 // fp32 master weights are rounded to bf16 here, once per call).
 template <typename T>
-__global__ void __launch_bounds__(256) pack_weights_kernel(const float *__restrict__ w_eq, const float *__restrict__ w_pol,
-                                                           const float *__restrict__ w_np, T *__restrict__ out,
-                                                           int KS, int Cin, int Cout, int K, int Ncol, int CG, int NTtot,
-                                                           int flip, int transposed, size_t total) {
+__device__ __forceinline__ void pack_weights_range(const float *__restrict__ w_eq, const float *__restrict__ w_pol,
+                                                   const float *__restrict__ w_np, T *__restrict__ out,
+                                                   int KS, int Cin, int Cout, int K, int Ncol, int CG, int NTtot,
+                                                   int flip, int transposed, size_t total, size_t first, size_t stride) {
     constexpr int J = 16 / (int)sizeof(T);
     const int TAPS = KS * KS;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    for (size_t e = first; e < total; e += stride) {
         size_t r = e;
         const int j = r % J; r /= J;
         const int n = r % 32; r /= 32;
@@ -481,6 +481,51 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float *__restri
             val = w[((size_t)(ty * KS + tx) * Cin + ci) * Cout + co];
         }
         if constexpr (sizeof(T) == 4) out[e] = val; else out[e] = f2bf(val);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_weights_kernel(const float *__restrict__ w_eq, const float *__restrict__ w_pol,
+                                                           const float *__restrict__ w_np, T *__restrict__ out,
+                                                           int KS, int Cin, int Cout, int K, int Ncol, int CG, int NTtot,
+                                                           int flip, int transposed, size_t total) {
+    pack_weights_range<T>(w_eq, w_pol, w_np, out, KS, Cin, Cout, K, Ncol, CG, NTtot, flip, transposed, total,
+                          (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+
+// Every layer of a model in ONE launch (dlwpcs_pack_batch): block (x, item) packs item `blockIdx.y`'s forward weights,
+// data-gradient weights and biases with a grid-stride loop over x.
+__global__ void __launch_bounds__(256) pack_batch_kernel(const dlwpcs_pack_item *__restrict__ items) {
+    const dlwpcs_pack_item it = items[blockIdx.y];
+    const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    const int KS = it.ksize, TAPS = KS * KS;
+    const bool bf = it.dtype == DLWPCS_BF16;
+    const int cgw = bf ? 16 : 8, per_lane = bf ? 8 : 4;
+    const float *w_eq = (const float *)it.w_eq, *w_pol = (const float *)it.w_pol, *w_np = (const float *)it.w_np;
+    if (it.wpk_fwd) {
+        const int CG = (it.Cin + cgw - 1) / cgw, NTtot = (it.Cout + 31) / 32;
+        const size_t total = (size_t)3 * NTtot * CG * TAPS * 64 * per_lane;
+        if (bf) pack_weights_range<bf16_t>(w_eq, w_pol, w_np, (bf16_t *)it.wpk_fwd, KS, it.Cin, it.Cout, it.Cin, it.Cout, CG, NTtot,
+                                           it.flip_north_pole, 0, total, first, stride);
+        else pack_weights_range<float>(w_eq, w_pol, w_np, (float *)it.wpk_fwd, KS, it.Cin, it.Cout, it.Cin, it.Cout, CG, NTtot,
+                                       it.flip_north_pole, 0, total, first, stride);
+    }
+    if (it.wpk_bwd) {
+        const int CG = (it.Cout + cgw - 1) / cgw, NTtot = (it.Cin + 31) / 32;
+        const size_t total = (size_t)3 * NTtot * CG * TAPS * 64 * per_lane;
+        if (bf) pack_weights_range<bf16_t>(w_eq, w_pol, w_np, (bf16_t *)it.wpk_bwd, KS, it.Cin, it.Cout, it.Cout, it.Cin, CG, NTtot,
+                                           it.flip_north_pole, 1, total, first, stride);
+        else pack_weights_range<float>(w_eq, w_pol, w_np, (float *)it.wpk_bwd, KS, it.Cin, it.Cout, it.Cout, it.Cin, CG, NTtot,
+                                       it.flip_north_pole, 1, total, first, stride);
+    }
+    if (it.bias_pk && it.b_eq) {
+        const int CoutP = ((it.Cout + 31) / 32) * 32;
+        const float *b_eq = (const float *)it.b_eq, *b_pol = (const float *)it.b_pol, *b_np = (const float *)it.b_np;
+        for (size_t e = first; e < (size_t)3 * CoutP; e += stride) {
+            const int v = (int)(e / CoutP), co = (int)(e % CoutP);
+            const float *bsrc = v == 0 ? b_eq : (v == 1 ? b_pol : (b_np ? b_np : b_pol));
+            ((float *)it.bias_pk)[e] = co < it.Cout ? bsrc[co] : 0.f;
+        }
     }
 }
 
@@ -1401,6 +1446,24 @@ extern "C" size_t dlwpcs_conv_workspace_bytes(const dlwpcs_conv_desc *d) {
     return ws_layout(d).total;
 }
 
+extern "C" size_t dlwpcs_conv_packed_bytes(const dlwpcs_conv_desc *d, int which) {
+    if (validate(d, "conv_packed_bytes") != DLWPCS_OK) return 0;
+    const WsLayout L = ws_layout(d);
+    if (which == DLWPCS_PACK_FWD) return L.bias - L.wpk_f;
+    if (which == DLWPCS_PACK_BIAS) return L.wpk_b - L.bias;
+    if (which == DLWPCS_PACK_BWD) return L.dxv - L.wpk_b;
+    fail(DLWPCS_E_INVALID, "conv_packed_bytes: which = %d", which);
+    return 0;
+}
+
+extern "C" int dlwpcs_pack_batch(const dlwpcs_pack_item *items_dev, int n_items, dlwpcs_stream_t stream) {
+    if (n_items < 0 || (n_items > 0 && !items_dev)) return fail(DLWPCS_E_INVALID, "pack_batch: bad arguments");
+    if (n_items == 0) return DLWPCS_OK;
+    if (n_items > 65535) return fail(DLWPCS_E_UNSUPPORTED, "pack_batch: more than 65535 items");
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(48, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
+    return check_launch("pack_batch");
+}
+
 extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
                                const void *w_eq, const void *w_pol, const void *w_np,
                                const void *b_eq, const void *b_pol, const void *b_np,
@@ -1408,24 +1471,26 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
                                void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
     int rc = validate(d, "conv_fwd");
     if (rc) return rc;
-    if (!src0 || !w_eq || !w_pol || !y || !workspace) return fail(DLWPCS_E_INVALID, "conv_fwd: null pointer");
+    if (!src0 || !w_eq || (!w_pol && !(d->flags & DLWPCS_CONV_PREPACKED)) || !y || !workspace)
+        return fail(DLWPCS_E_INVALID, "conv_fwd: null pointer");
     if (d->C1 > 0 && !src1) return fail(DLWPCS_E_INVALID, "conv_fwd: C1 > 0 but src1 is null");
     if (d->halo && !table_dev) return fail(DLWPCS_E_INVALID, "conv_fwd: halo requested without table");
-    if ((b_eq == nullptr) != (b_pol == nullptr)) return fail(DLWPCS_E_INVALID, "conv_fwd: b_eq and b_pol must both be given or both be null");
+    const bool prepacked = (d->flags & DLWPCS_CONV_PREPACKED) != 0;
+    if (!prepacked && (b_eq == nullptr) != (b_pol == nullptr)) return fail(DLWPCS_E_INVALID, "conv_fwd: b_eq and b_pol must both be given or both be null");
     const WsLayout L = ws_layout(d);
     if (workspace_bytes < L.total) return fail(DLWPCS_E_WORKSPACE, "conv_fwd: workspace %zu < %zu bytes", workspace_bytes, L.total);
     if (d->B == 0) return DLWPCS_OK;
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)workspace;
     const int Cin = d->C0 + d->C1;
-    void *wpk = ws + L.wpk_f;
-    float *bpk = (float *)(ws + L.bias);
-    launch_pack(w_eq, w_pol, w_np, wpk, d->ksize, Cin, d->Cout, 0, d->flip_north_pole, d->dtype, s);
+    const void *wpk = prepacked ? w_eq : ws + L.wpk_f;      // PREPACKED: w_eq / b_eq are dlwpcs_pack_batch outputs
+    const float *bpk = prepacked ? (const float *)b_eq : (const float *)(ws + L.bias);
+    if (!prepacked) launch_pack(w_eq, w_pol, w_np, ws + L.wpk_f, d->ksize, Cin, d->Cout, 0, d->flip_north_pole, d->dtype, s);
     const int NTtot = ceil_div(d->Cout, 32);
-    if (b_eq) {
+    if (b_eq && !prepacked) {
         const int n = 3 * NTtot * 32;
         hipLaunchKernelGGL(pack_bias_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, (const float *)b_eq,
-                           (const float *)b_pol, (const float *)b_np, bpk, d->Cout, NTtot * 32);
+                           (const float *)b_pol, (const float *)b_np, (float *)(ws + L.bias), d->Cout, NTtot * 32);
     }
     ConvKParams P{};
     P.src0 = src0; P.src1 = src1; P.ymask = nullptr;
@@ -1444,7 +1509,8 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
                                     void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
     int rc = validate(d, "conv_bwd_data");
     if (rc) return rc;
-    if (!dy || !w_eq || !w_pol || !workspace) return fail(DLWPCS_E_INVALID, "conv_bwd_data: null pointer");
+    const bool prepacked = (d->flags & DLWPCS_CONV_PREPACKED) != 0;
+    if (!dy || !w_eq || (!w_pol && !prepacked) || !workspace) return fail(DLWPCS_E_INVALID, "conv_bwd_data: null pointer");
     if (d->act != DLWPCS_ACT_NONE && !y) return fail(DLWPCS_E_INVALID, "conv_bwd_data: activation needs the saved output y");
     if (d->halo && !inv_table_dev) return fail(DLWPCS_E_INVALID, "conv_bwd_data: halo requested without inverse table");
     if (!dsrc0 && !dsrc1) return DLWPCS_OK;
@@ -1454,8 +1520,9 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)workspace;
     const int Cin = d->C0 + d->C1;
-    void *wpk = ws + L.wpk_b, *dxv = ws + L.dxv;
-    launch_pack(w_eq, w_pol, w_np, wpk, d->ksize, Cin, d->Cout, 1, d->flip_north_pole, d->dtype, s);
+    const void *wpk = prepacked ? w_eq : ws + L.wpk_b;      // PREPACKED: w_eq is the wpk_bwd output of dlwpcs_pack_batch
+    void *dxv = ws + L.dxv;
+    if (!prepacked) launch_pack(w_eq, w_pol, w_np, ws + L.wpk_b, d->ksize, Cin, d->Cout, 1, d->flip_north_pole, d->dtype, s);
     const int No = out_size(d);
     ConvKParams P{};
     P.src0 = dy; P.src1 = nullptr; P.ymask = d->act != DLWPCS_ACT_NONE ? y : nullptr;

@@ -100,6 +100,9 @@ int dlwpcs_pad_bwd(const void *dy, void *dx, int B, int N, int C, int p, int dty
  * ------------------------------------------------------------------------------------------------------------- */
 /* dlwpcs_conv_desc.flags */
 #define DLWPCS_CONV_ACCUMULATE_WGRAD 1   /* bwd_weights ADDS to dw_* / db_* (shared layers, flat gradient buffer) */
+#define DLWPCS_CONV_PREPACKED        2   /* conv_fwd: w_eq = wpk_fwd, b_eq = bias_pk (or NULL); conv_bwd_data: w_eq = wpk_bwd,
+                                          * all produced by dlwpcs_pack_batch; the other kernel / bias pointers are ignored.
+                                          * Without the flag every call re-packs its weights into the workspace. */
 
 typedef struct dlwpcs_conv_desc {
     int32_t B;              /* batch */
@@ -117,6 +120,24 @@ typedef struct dlwpcs_conv_desc {
 } dlwpcs_conv_desc;
 
 size_t dlwpcs_conv_workspace_bytes(const dlwpcs_conv_desc *d);      /* max over fwd / bwd_data / bwd_weights */
+
+/* Weight packing hoisted out of the per-call path: the kernels consume the HWIO fp32 weights in matrix-core fragment
+ * order (3 face variants, rounded to bf16 in DLWPCS_BF16 mode).  A model packs ALL its layers with one launch per step
+ * (after the optimizer update) and passes the packed buffers with DLWPCS_CONV_PREPACKED.
+ * dlwpcs_conv_packed_bytes: size of one packed buffer of the layer described by d (only ksize, C0+C1, Cout, dtype matter).
+ * dlwpcs_pack_batch: items_dev is a DEVICE array of n_items descriptors (caller-owned; pointers inside are device
+ * pointers); wpk_fwd / wpk_bwd / bias_pk may individually be NULL to skip that output. */
+#define DLWPCS_PACK_FWD  0
+#define DLWPCS_PACK_BWD  1
+#define DLWPCS_PACK_BIAS 2
+typedef struct dlwpcs_pack_item {
+    const void *w_eq, *w_pol, *w_np;      /* HWIO fp32 kernels (w_np NULL unless independent north pole) */
+    const void *b_eq, *b_pol, *b_np;      /* fp32 biases or NULL */
+    void *wpk_fwd, *wpk_bwd, *bias_pk;    /* outputs */
+    int32_t ksize, Cin, Cout, flip_north_pole, dtype, reserved;
+} dlwpcs_pack_item;
+size_t dlwpcs_conv_packed_bytes(const dlwpcs_conv_desc *d, int which);
+int dlwpcs_pack_batch(const dlwpcs_pack_item *items_dev, int n_items, dlwpcs_stream_t stream);
 
 int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d,
                     const void *src0, const void *src1,
