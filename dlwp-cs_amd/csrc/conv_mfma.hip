@@ -193,30 +193,39 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         int pli = 0;
         long long *plp = (P.dbg && ptid == 0 && blockIdx.y == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
 #endif
-        // (address of the table entry | direct flat source index) of tile item slot i; select-only arithmetic
-        auto table_addr = [&](const Geo &gq, int i) -> int {
-            const int e = min(ptid + i * NCT, gq.nitems - 1);
+        // Tile-invariant slot constants: slot i of this thread is tile pixel (ty, tx) in EVERY tile (only the band's first
+        // row y0, the face and the sample change), so the divisions happen once per kernel.  Packed per slot:
+        //   bits 4:0 = ty, bit 5 = column valid (MODE_ZERO border), bits 31:6 = OFF + offset of (ty, tx) from the band's
+        //   first row on the source grid (halo table row stride M / source row stride Nin).
+        constexpr int PADZ = (MODE == MODE_ZERO) ? KS - 1 : 0;
+        const int rstride = (MODE == MODE_HALO) ? P.Nin + KS - 1 : P.Nin;
+        const int OFF = PADZ * (rstride + 1);
+        const int nitems_cap = P.tile_rows_max * P.W2 * Q;
+        int slot_c[ITS];
+#pragma unroll
+        for (int i = 0; i < ITS; ++i) {
+            const int e = min(ptid + i * NCT, nitems_cap - 1);
             const int pix = e / Q;
             const int ty = __umulhi((uint32_t)pix, P.magicW2);
             const int tx = pix - ty * P.W2;
-            const int iy = gq.y0 + ty;
-            if (MODE == MODE_HALO) {
-                const int M = P.Nin + KS - 1;
-                return (gq.f * M + iy) * M + tx;
-            } else if (MODE == MODE_DIRECT) {
-                return (gq.f * P.Nin + iy) * P.Nin + tx;
-            } else {
-                const int vy = iy - (KS - 1), vx = tx - (KS - 1);
-                const bool ok = (vy >= 0) & (vy < P.Nin) & (vx >= 0) & (vx < P.Nin);
-                return ok ? (gq.f * P.Nin + vy) * P.Nin + vx : -1;
-            }
-        };
+            const int vx = tx - PADZ;
+            const int xok = (vx >= 0) & (vx < P.Nin);
+            slot_c[i] = (((ty - PADZ) * rstride + vx + OFF) << 6) | (xok << 5) | ty;
+        }
         // flat source index on the Nin grid (-1 = zero cell) of every item slot of a tile, all loads in flight at once
         auto lookup = [&](const Geo &gq, int (&sidx)[ITS]) {
+            const int base = (gq.f * rstride + gq.y0) * rstride - OFF;
 #pragma unroll
             for (int i = 0; i < ITS; ++i) {
-                const int a = table_addr(gq, i);
-                const int v0 = (MODE == MODE_HALO) ? P.table[a] : a;
+                const int sc = slot_c[i];
+                const int a = base + (sc >> 6);
+                int v0;
+                if (MODE == MODE_HALO) v0 = P.table[a];
+                else if (MODE == MODE_DIRECT) v0 = a;
+                else {
+                    const int vy = gq.y0 + (sc & 31) - PADZ;
+                    v0 = ((vy >= 0) & (vy < P.Nin) & ((sc >> 5) & 1)) ? a : -1;
+                }
                 sidx[i] = (ptid + i * NCT < gq.nitems) ? v0 : -1;
             }
         };
@@ -257,12 +266,10 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 const int idx = sidx[i];
                 const bool ok = c_ok && idx >= 0;
                 const int ii = ok ? idx : 0;
-                // nearest-upsampled source: (face, y, x) on the Nin grid -> (face, y/2, x/2) on the Nin/2 grid
-                const int vf = __umulhi((uint32_t)ii, P.magicN2);
-                const int rem = ii - vf * P.Nin * P.Nin;
-                const int vy = __umulhi((uint32_t)rem, P.magicN);
-                const int vx = rem - vy * P.Nin;
-                const int pix_up = (vf * g0 + (vy >> 1)) * g0 + (vx >> 1);
+                // nearest-upsampled source: row r = face*Nin + y of the Nin grid -> row r/2 = face*g0 + y/2 of the Nin/2 grid
+                // (Nin = 2*g0 is even), column x -> x/2
+                const int r = __umulhi((uint32_t)ii, P.magicN);
+                const int pix_up = (r >> 1) * g0 + ((ii - r * P.Nin) >> 1);
                 const int pix = up ? pix_up : ii;
                 const size_t oo = ok ? (size_t)pix * cstride + cs : 0;
                 val[i] = *reinterpret_cast<const V *>(sb + oo);
@@ -312,17 +319,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     // NOTE: no s_setprio(1) here: a prioritised wave waiting for the busy matrix pipe still wins its SIMD's issue
     // arbitration and starves the co-resident producer wave's address arithmetic.
 
-    float bias_v[3][NT];
-#pragma unroll
-    for (int vv = 0; vv < 3; ++vv)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = (nt0 + wn * NT + nt) * 32 + l31;
-            bias_v[vv][nt] = (P.bias && co < P.Cout) ? P.bias[(size_t)vv * P.NTtot * 32 + co] : 0.f;
-        }
-
     f32x16 acc[MT][NT];
-    float *stage = reinterpret_cast<float *>(smem + 2 * buf_bytes) + wave * (16 * 36);
     int g = 0;
 #ifdef DLWPCS_TIMELINE
     int tli = 0;
@@ -350,6 +347,16 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        // this tile's bias quads (face variant gq.v): issued here so that the latency is covered by the chunk loop.
+        // (The packed bias vector is zero-padded to NTtot*32 floats, so every quad is readable.)
+        float4 bq[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq)
+                bq[nt][jq] = P.bias ? *reinterpret_cast<const float4 *>(P.bias + (size_t)gq.v * P.NTtot * 32 +
+                                                                         (nt0 + wn * NT + nt) * 32 + 8 * jq + 4 * half)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
 
         for (int ch = 0; ch < nchunks; ++ch, ++g) {
             TL_MARK();
@@ -380,63 +387,49 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) frag_mma<T>(acc[mt][nt], fa[cur][mt], fb[cur][nt]);
+                    for (int nt = 0; nt < NT; ++nt) frag_mma<T>(acc[mt][nt], fb[cur][nt], fa[cur][mt]);   // D[co][pixel]
                 __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);                          // DS reads of step s+1 first
                 __builtin_amdgcn_sched_group_barrier(0x008, MmaPerFrag<T>::N * MT * NT, 0);       // then the MFMAs of step s
             }
         }
 
-        // ---- tile epilogue: bias + activation + stores (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
-        // Wide path (C_out % 4 == 0): each half M tile (16 pixels x 32 channels) is transposed through a wave-private
-        // 16 x 36-float LDS patch so that every lane stores 4 channels (16 B fp32 / 8 B bf16) and 8 lanes cover one
-        // pixel's 32 channels: 4 wide stores per M tile instead of 16 scalar stores (the epilogue is store-issue bound).
+        // ---- tile epilogue: bias + activation + stores.  The MFMA ran as D[co][pixel] (weights as the A operand), so in
+        // the C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) a lane owns ONE pixel and, per r>>2, FOUR
+        // CONSECUTIVE output channels: they leave as one 16-B (fp32) / 8-B (bf16) store straight from the accumulators,
+        // no LDS transposition.
         TL_MARK();
         T *outp = reinterpret_cast<T *>(P.out) + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
         const bool wide = (P.Cout & 3) == 0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int cot = (nt0 + wn * NT + nt) * 32;
-            const int co = cot + l31;
-            const float bv = gq.v == 0 ? bias_v[0][nt] : (gq.v == 1 ? bias_v[1][nt] : bias_v[2][nt]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                if (wide) {
+                const int m = (wm * MT + mt) * 32 + l31;
+                if (m >= gq.npix) continue;
+                T *dst = outp + (size_t)(gq.m0 + m) * P.Cout + cot + 4 * half;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                        for (int rr = 0; rr < 8; ++rr) {
-                            const int r = h * 8 + rr;
-                            float val = acc[mt][nt][r] + bv;
-                            if (P.act == DLWPCS_ACT_LEAKY_CLIP) val = act_leaky_clip(val, P.alpha, P.vmax);
-                            stage[((rr & 3) + 8 * (rr >> 2) + 4 * half) * 36 + l31] = val;
-                        }
-                        // wave-private patch: the wave runs in lock step and its LDS ops complete in order -> no barrier
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int row = (lane >> 3) + 8 * j;
-                            const int quad = lane & 7;
-                            const float4 v4 = *reinterpret_cast<const float4 *>(stage + row * 36 + quad * 4);
-                            const int m = (wm * MT + mt) * 32 + h * 16 + row;
-                            const int c4 = cot + quad * 4;
-                            if (m < gq.npix && c4 < P.Cout) {
-                                T *dst = outp + (size_t)(gq.m0 + m) * P.Cout + c4;
-                                if constexpr (ES == 4) *reinterpret_cast<float4 *>(dst) = v4;
-                                else *reinterpret_cast<uint2 *>(dst) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
-                            }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int jq = 0; jq < 4; ++jq) {
+                    const int co = cot + 8 * jq + 4 * half;
+                    float4 v4 = make_float4(acc[mt][nt][4 * jq] + bq[nt][jq].x, acc[mt][nt][4 * jq + 1] + bq[nt][jq].y,
+                                            acc[mt][nt][4 * jq + 2] + bq[nt][jq].z, acc[mt][nt][4 * jq + 3] + bq[nt][jq].w);
+                    if (P.act == DLWPCS_ACT_LEAKY_CLIP) {
+                        v4.x = act_leaky_clip(v4.x, P.alpha, P.vmax); v4.y = act_leaky_clip(v4.y, P.alpha, P.vmax);
+                        v4.z = act_leaky_clip(v4.z, P.alpha, P.vmax); v4.w = act_leaky_clip(v4.w, P.alpha, P.vmax);
                     }
-                } else if (co < P.Cout) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (m < gq.npix) {
-                            float val = acc[mt][nt][r] + bv;
-                            if (P.act == DLWPCS_ACT_LEAKY_CLIP) val = act_leaky_clip(val, P.alpha, P.vmax);
-                            if constexpr (ES == 4) outp[(size_t)(gq.m0 + m) * P.Cout + co] = val;
-                            else outp[(size_t)(gq.m0 + m) * P.Cout + co] = f2bf(val);
+                    if (wide) {
+                        if (co < P.Cout) {
+                            if constexpr (ES == 4) *reinterpret_cast<float4 *>(dst + 8 * jq) = v4;
+                            else *reinterpret_cast<uint2 *>(dst + 8 * jq) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
                         }
+                    } else {
+                        const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (co + u < P.Cout) {
+                                if constexpr (ES == 4) dst[8 * jq + u] = vs[u];
+                                else dst[8 * jq + u] = f2bf(vs[u]);
+                            }
                     }
                 }
             }
@@ -1243,9 +1236,11 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
     const size_t buf = (size_t)P.tile_rows_max * P.W2 * (KC * ES + 16) + (size_t)NTB * (KC / CGW) * KS * KS * 1024;
-    const size_t lds = 2 * buf + (size_t)(WM * WN) * 16 * 36 * sizeof(float);     // + wave-private epilogue patches
+    const size_t lds = 2 * buf;
     if (lds > 160 * 1024)
         return fail(DLWPCS_E_UNSUPPORTED, "conv: LDS tile of %zu bytes exceeds 160 KiB (face size %d)", lds, P.No);
+    if (P.tile_rows_max > 32)
+        return fail(DLWPCS_E_UNSUPPORTED, "conv: %d tile rows exceed the producers' 5-bit row field", P.tile_rows_max);
     if ((size_t)P.tile_rows_max * P.W2 > (size_t)3 * NTHREADS)
         return fail(DLWPCS_E_UNSUPPORTED, "conv: tile of %d x %d pixels exceeds the producers' register capacity", P.tile_rows_max, P.W2);
     if ((long)P.Nin * P.Nin * 6 >= (1l << 16) * 6 && (long)P.Nin * P.Nin >= (1l << 16))
