@@ -56,6 +56,7 @@ class Model(object):
         # activation dtype on the device ('float32' | 'bfloat16'); parameters / gradients / Adam state are always fp32
         self.compute_dtype = backend.compute_dtype()
         self.prepack_weights = os.environ.get('DLWPCS_PREPACK', '1') != '0'
+        self.wgrad_side_stream = os.environ.get('DLWPCS_SIDE_STREAM', '0') == '1'   # measured slower on MI355X: off
         self._compiled = False
         self._flat_params = self._flat_grads = None
         self._graphs = {}
@@ -341,10 +342,13 @@ class Model(object):
         if train:
             ones = [torch.ones(2, dtype=torch.float32, device=stats[0].device) for _ in stats]
             ops.DIRECT_PARAM_GRADS = True       # weight gradients accumulate straight into the flat gradient buffer
+            ops.WGRAD_SIDE_STREAM = self.wgrad_side_stream
             try:
                 torch.autograd.backward(stats, ones)
             finally:
                 ops.DIRECT_PARAM_GRADS = False
+                ops.WGRAD_SIDE_STREAM = False
+                ops.join_side_stream(stats[0].device)
         return torch.stack([s.detach() for s in stats])
 
     def _apply_gradients(self):

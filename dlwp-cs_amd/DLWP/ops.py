@@ -20,12 +20,36 @@ DIRECT_PARAM_GRADS = False
 # kernel is not listed (or listed for another dtype) packs its weights itself, per call, into the workspace.
 PREPACKED = {}
 
-# workspace: one growing byte buffer per device (caller-owned from the library's point of view)
+# When True (DLWP.keras.Model training step), weight-gradient kernels are enqueued on a second HIP stream: they depend
+# only on (src, dy) and nothing before the optimizer consumes them, so they overlap the data-gradient chain of the layers
+# below (fills launch gaps and the tails of the persistent kernels).  Whoever sets this must call join_side_stream()
+# before the gradients are read.
+WGRAD_SIDE_STREAM = False
+_side_streams = {}
+
+
+def side_stream(device):
+    key = str(device)
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
+def join_side_stream(device):
+    """Make the current stream wait for everything enqueued on the weight-gradient side stream."""
+    st = _side_streams.get(str(device))
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
+
+
+# workspace: one growing byte buffer per (device, role) (caller-owned from the library's point of view)
 _workspaces = {}
 
 
-def _workspace(nbytes, device):
-    key = str(device)
+def _workspace(nbytes, device, role='main'):
+    key = (str(device), role)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
@@ -177,13 +201,26 @@ class _CSConv(torch.autograd.Function):
             pe, pp, pn, be, bp, bn = ctx.params
             d2 = ConvDesc.from_buffer_copy(d)
             d2.flags = d.flags | nat.CONV_ACCUMULATE_WGRAD
-            check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d2), ptr(src0), ptr(src1), ptr(dy), ptr(y), ptr(pe.grad),
-                                                ptr(pp.grad), ptr(None if pn is None else pn.grad),
-                                                ptr(None if be is None else be.grad),
-                                                ptr(None if bp is None else bp.grad),
-                                                ptr(None if bn is None else bn.grad),
-                                                ptr(table), ptr(ws), ws.numel(), stream_ptr()),
-                  'dlwpcs_conv_bwd_weights')
+
+            def launch(wsx):
+                check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d2), ptr(src0), ptr(src1), ptr(dy), ptr(y), ptr(pe.grad),
+                                                    ptr(pp.grad), ptr(None if pn is None else pn.grad),
+                                                    ptr(None if be is None else be.grad),
+                                                    ptr(None if bp is None else bp.grad),
+                                                    ptr(None if bn is None else bn.grad),
+                                                    ptr(table), ptr(wsx), wsx.numel(), stream_ptr()),
+                      'dlwpcs_conv_bwd_weights')
+            if WGRAD_SIDE_STREAM:
+                side = side_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))      # dy and the saved activations are ready
+                ws2 = _workspace(nbytes, dev, 'side')                 # own workspace: the main stream keeps using `ws`
+                with torch.cuda.stream(side):
+                    launch(ws2)
+                for t in (src0, src1, dy, y):                         # keep their memory until the side stream is done
+                    if t is not None:
+                        t.record_stream(side)
+            else:
+                launch(ws)
         elif need[2] or need[3] or need[4] or need[5] or need[6] or need[7]:
             dw_eq, dw_pol = torch.empty_like(w_eq), torch.empty_like(w_pol)
             dw_np = torch.empty_like(w_np) if has_np else None

@@ -873,12 +873,16 @@ __device__ __forceinline__ uint2 lds_tr16(const char *p) {
     return __builtin_bit_cast(uint2, v);
 }
 
-template <int KS, bool MASK>
+// XV = channels per X load (8 = 16-B vectors; 2 = 4-B vectors for channel counts that are only even, e.g. the 14-channel
+// network input), QX = X vectors staged per tile pixel (QX * XV channels of the 32-wide ci tile; the rest of the LDS row
+// is never written and only feeds accumulator rows >= C_in, which the reduction ignores).
+template <int KS, bool MASK, int XV, int QX>
 __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     constexpr int TAPS = KS * KS;
     constexpr int PB = 64;                  // LDS bytes per pixel: 32 channels bf16 (X tile and dZ tile alike)
     constexpr int NCT = 256;                // consumer threads == producer threads
-    constexpr int IT_X = 10;                // X 16-B vectors per producer thread per item: capacity 640 tile pixels
+    constexpr int IT_X = XV == 8 ? 10 : 20; // X vectors per producer thread per item: capacity IT_X * 256 / QX tile pixels
+    typedef typename VecT<bf16_t, XV>::type XVec;
     constexpr int IT_DY = 6;                // dZ 16-B vectors per producer thread per item: capacity 384 pixels
     const ConvKParams &P = W.c;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -911,15 +915,15 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         it.npix = min(P.pix_per_block, face_pix - it.m0);
         it.y0 = __umulhi((uint32_t)it.m0, P.magicNo);
         const int ylast = __umulhi((uint32_t)(it.m0 + it.npix - 1), P.magicNo);
-        it.nitems = (ylast - it.y0 + KS) * P.W2 * 4;        // 4 vectors of 8 channels per tile pixel
+        it.nitems = (ylast - it.y0 + KS) * P.W2 * QX;       // QX channel vectors per tile pixel
         return it;
     };
 
     if (tid >= NCT) {
         // =========================================== producers ===========================================
         const int ptid = tid - NCT;
-        const int qx = ptid & 3;                            // this thread's 8-channel group: fixed for the whole kernel
-        const int cx = cit * 32 + qx * 8;
+        const int qx = ptid & 3;                            // this thread's 8-channel dZ group: fixed for the whole kernel
+        const int cx = cit * 32 + (ptid % QX) * XV;         // this thread's X channels: fixed as well (256 % QX == 0)
         const bool cx_ok = cx < P.Cin;
         const bool from0 = cx < P.C0;
         const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
@@ -938,7 +942,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int e = min(ptid + i * NCT, it.nitems - 1);
-                const int pix = e >> 2;
+                const int pix = e / QX;
                 const int ty = __umulhi((uint32_t)pix, P.magicW2);
                 const int tx = pix - ty * P.W2;
                 const int iy = it.y0 + ty;
@@ -956,20 +960,17 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             const bf16_t *sb = from0 ? reinterpret_cast<const bf16_t *>(P.src0) + (size_t)cur.b * 6 * g0 * g0 * P.C0
                                      : reinterpret_cast<const bf16_t *>(P.src1) + (size_t)cur.b * 6 * P.Nin * P.Nin * P.C1;
             // ---- X tile: every load in flight at once
-            uint4 xv[IT_X];
+            XVec xv[IT_X];
             bool xok[IT_X];
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int idx = sidx[i];
                 const bool ok = cx_ok && idx >= 0;
                 const int ii = ok ? idx : 0;
-                const int vf = __umulhi((uint32_t)ii, P.magicN2);
-                const int rem = ii - vf * P.Nin * P.Nin;
-                const int vy = __umulhi((uint32_t)rem, P.magicN);
-                const int vx = rem - vy * P.Nin;
-                const int pix_up = (vf * g0 + (vy >> 1)) * g0 + (vx >> 1);
+                const int r = __umulhi((uint32_t)ii, P.magicN);      // row face*Nin + y of the Nin grid -> row r/2 of Nin/2
+                const int pix_up = (r >> 1) * g0 + ((ii - r * P.Nin) >> 1);
                 const int pix = up ? pix_up : ii;
-                xv[i] = *reinterpret_cast<const uint4 *>(sb + (ok ? (size_t)pix * cstride + cs : 0));
+                xv[i] = *reinterpret_cast<const XVec *>(sb + (ok ? (size_t)pix * cstride + cs : 0));
                 xok[i] = ok;
             }
             // ---- dZ tile [pix][32 output channels of tile cot] = dy * act'(y), zero beyond npix / Cout
@@ -998,7 +999,8 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int e = ptid + i * NCT;
-                if (e < cur.nitems) *reinterpret_cast<uint4 *>(buf + (size_t)e * 16) = vsel(xok[i], xv[i]);
+                if (e < cur.nitems)
+                    *reinterpret_cast<XVec *>(buf + (size_t)(e / QX) * PB + (ptid % QX) * (XV * 2)) = vsel(xok[i], xv[i]);
             }
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
@@ -1359,7 +1361,13 @@ struct WsLayout {
 // persistent weight-gradient launch geometry: pixels per work item, items (bands) per face, workers per face class
 // bf16 matrix-core weight gradient (wgrad_bf16_kernel): bf16 tensors whose channel counts are all multiples of 8
 static bool wgrad_bf16_eligible(const dlwpcs_conv_desc *d) {
-    return d->dtype == DLWPCS_BF16 && d->C0 % 8 == 0 && d->C1 % 8 == 0 && d->Cout % 8 == 0;
+    return d->dtype == DLWPCS_BF16 && d->C0 % 2 == 0 && d->C1 % 2 == 0 && d->Cout % 8 == 0;
+}
+// X staging of wgrad_bf16_kernel: channels per load, vectors per tile pixel, tile-pixel capacity of the producers
+static void wgrad_bf16_xcfg(const dlwpcs_conv_desc *d, int &xv, int &qx, int &cap_px) {
+    if (d->C0 % 8 == 0 && d->C1 % 8 == 0) { xv = 8; qx = 4; cap_px = 640; }
+    else if (d->C0 + d->C1 <= 16) { xv = 2; qx = 8; cap_px = 640; }
+    else { xv = 2; qx = 16; cap_px = 320; }
 }
 
 static void wgrad_tiling(const dlwpcs_conv_desc *d, int &pix, int &nblk, int &n_eq, int &n_4, int &n_5) {
@@ -1369,8 +1377,10 @@ static void wgrad_tiling(const dlwpcs_conv_desc *d, int &pix, int &nblk, int &n_
     int CAP = 192;
     if (wgrad_bf16_eligible(d)) {
         CAP = 384;
-        // the X tile (item rows + k-1 halo rows, full padded width) must fit the producers' 640-pixel register capacity
-        while (CAP > 96 && (long)(tile_rows_for(No <= CAP ? (CAP / No) * No : CAP, No) + d->ksize - 1) * (No + d->ksize - 1) > 640)
+        int xv, qx, cap_px;
+        wgrad_bf16_xcfg(d, xv, qx, cap_px);
+        // the X tile (item rows + k-1 halo rows, full padded width) must fit the producers' register capacity
+        while (CAP > 96 && (long)(tile_rows_for(No <= CAP ? (CAP / No) * No : CAP, No) + d->ksize - 1) * (No + d->ksize - 1) > cap_px)
             CAP -= 96;
     }
     pix = CAP;
@@ -1594,16 +1604,18 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     const bool mask = d->act != DLWPCS_ACT_NONE;
     dim3 grid((unsigned)(L.n_eq + L.n_4 + L.n_5), (unsigned)(CinP / 32), (unsigned)(CoutP / 32));
     const int nout = TAPS * Cin * d->Cout + (want_bias ? d->Cout : 0);
-    if (wgrad_bf16_eligible(d) && (size_t)P.tile_rows_max * P.W2 <= 640 && L.wg_pix <= 384) {
+    int xv = 0, qx = 0, cap_px = 0;
+    if (wgrad_bf16_eligible(d)) wgrad_bf16_xcfg(d, xv, qx, cap_px);
+    if (xv && (size_t)P.tile_rows_max * P.W2 <= (size_t)cap_px && L.wg_pix <= 384) {
         const int pcap = (L.wg_pix + 15) & ~15;
         size_t lds = 2 * ((size_t)P.tile_rows_max * P.W2 * 64 + (size_t)pcap * 64);
         if (lds < (4096 + 2048) * 4) lds = (4096 + 2048) * 4;   // cross-wave reduction scratch + bias staging alias the buffers
         if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
         if ((long)P.Nin * P.Nin >= (1l << 16))
             return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: face size %d too large for the 16-bit index arithmetic", P.Nin);
-#define WGB_LAUNCH(KSV, MASKV)                                                                                            \
+#define WGB_LAUNCH(KSV, MASKV, XVV, QXV)                                                                                  \
     do {                                                                                                                  \
-        auto kern = wgrad_bf16_kernel<KSV, MASKV>;                                                                        \
+        auto kern = wgrad_bf16_kernel<KSV, MASKV, XVV, QXV>;                                                              \
         if (lds > 64 * 1024) {                                                                                            \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));    \
@@ -1611,13 +1623,19 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
         int pidx = -1;                                                                                                    \
         if (prof_enabled()) {                                                                                             \
             const Work wk = conv_work(d);                                                                                 \
-            pidx = prof_begin("wgrad_bf16_kernel<" #KSV ", " #MASKV ">", wk.flops, wk.bytes, s);                          \
+            pidx = prof_begin("wgrad_bf16_kernel<" #KSV ", " #MASKV ", " #XVV ", " #QXV ">", wk.flops, wk.bytes, s);      \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, W);                                                             \
         if (pidx >= 0) prof_end(pidx, s);                                                                                 \
     } while (0)
-        if (KS == 3) { if (mask) WGB_LAUNCH(3, true); else WGB_LAUNCH(3, false); }
-        else { if (mask) WGB_LAUNCH(1, true); else WGB_LAUNCH(1, false); }
+#define WGB_X(KSV, MASKV)                                                                                                 \
+    do {                                                                                                                  \
+        if (xv == 8) WGB_LAUNCH(KSV, MASKV, 8, 4); else if (qx == 8) WGB_LAUNCH(KSV, MASKV, 2, 8);                        \
+        else WGB_LAUNCH(KSV, MASKV, 2, 16);                                                                               \
+    } while (0)
+        if (KS == 3) { if (mask) WGB_X(3, true); else WGB_X(3, false); }
+        else { if (mask) WGB_X(1, true); else WGB_X(1, false); }
+#undef WGB_X
 #undef WGB_LAUNCH
         rc = check_launch("wgrad_bf16");
         if (rc) return rc;

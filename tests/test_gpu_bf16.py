@@ -171,6 +171,9 @@ BF16_CONV_CASES = [
     (1, 20, 5, 0, 7, 1, False, False, True, False, True),      # odd sizes everywhere
     (3, 9, 6, 0, 33, 3, True, False, True, False, True),       # odd face size, partial N tile
     (1, 96, 8, 0, 32, 3, True, False, True, False, True),      # C96
+    (1, 24, 26, 0, 32, 3, True, False, True, False, True),     # 13 vars x 2 steps (cfg 5): even channels, 16 x 4-B vectors
+    (2, 16, 6, 10, 16, 3, True, True, True, False, True),      # even channels from two sources (upsample + concat)
+    (1, 96, 26, 0, 32, 3, True, False, True, False, True),     # C96 first layer of cfg 5
 ]
 
 
