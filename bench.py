@@ -3,12 +3,14 @@
 bench.py -- headline benchmark of the MI355X-native DLWP-CS engine.
 
 Metric (BASELINE.json): cubed-sphere samples/sec, forward + backward (+ Adam step), 6x48x48 U-Net `unet2` with 7
-variables x 2 time steps = 14 input/output channels (BASELINE config 3 geometry), batch 32 per GPU, synthetic data,
-random-init weights.  One "step" = one optimisation step (fwd + bwd + gradient all-reduce when N > 1 + Adam) on one batch
+variables x 2 time steps = 14 input/output channels (BASELINE config 3: geometry AND dtype -- bf16 compute with fp32
+master weights), batch 32 per GPU, synthetic data, random-init weights.  At N = 1 the same workload is also measured in
+the exact-fp32 mode (the 1e-5 parity mode) and reported under the key "f32".  One "step" = one optimisation step (fwd + bwd + gradient all-reduce when N > 1 + Adam) on one batch
 already resident in HBM.  One process per GPU; N > 1 is launched by torch.distributed.run (RCCL).
 
 Prints ONE JSON line on rank 0 (see the task contract): value = whole-job samples/s, plus
-  roofline     -- dominant MFMA kernel: algorithmic FLOPs per launch / HIP-event time per launch vs the fp32 MFMA peak
+  roofline     -- dominant convolution kernel: algorithmic FLOPs and bytes per launch / HIP-event time per launch against
+                  the roofline that bounds it (matrix peak of the instruction it issues, or HBM)
   cpu_baseline -- the CPU restatement of the reference path (oracle/, torch-CPU fp32, reference-structured) timed on the
                   host cores of this box on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -135,19 +137,110 @@ def roofline_pass(model, dx, dt, steps=3):
     return agg
 
 
+def measure(args, dtype, rank, world, local_rank, with_roofline):
+    """Build the model in `dtype`, warm up, time exactly args.steps steps (barrier + synchronize on both sides, MAX over
+    ranks), optionally run the per-launch roofline pass.  Returns the result dict on rank 0, None elsewhere."""
+    from DLWP.keras import backend
+    N, C, base, B = args.face, args.channels, args.base, args.batch
+    backend.set_compute_dtype('bfloat16' if dtype == 'bf16' else 'float32')
+    np.random.seed(1)
+    model = build_model(args.workload, N, C, C, base)
+    backend.set_compute_dtype('float32')
+    model.use_graphs = not args.no_graphs
+    model.compile(optimizer='adam', loss='mse')
+    adt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    rng = np.random.default_rng(1000 + rank)
+    dev = backend.device()
+    dx = [torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(adt)]
+    with torch.no_grad():
+        oshape = model.predict_on_device(dx[0][:1]).shape[1:]
+    dt = [torch.tensor(rng.standard_normal((B,) + tuple(oshape)), dtype=torch.float32, device=dev)]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 3)):      # >= 3: eager warm-up, graph capture, first replay
+        model.train_on_device_batch(dx, dt)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.train_on_device_batch(dx, dt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    # the roofline pass runs eager optimisation steps (gradient all-reduce included): EVERY rank takes part
+    agg = roofline_pass(model, dx, dt) if with_roofline else None
+    if rank != 0:
+        return None
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = B * world * args.steps / elapsed
+    fps = flops_per_sample(args.workload, N, C, C, base)
+    prec = ('bf16 activations + bf16 MFMA, fp32 master weights / gradients / Adam' if dtype == 'bf16'
+            else 'exact-fp32 MFMA')
+    result = {
+        'metric': 'cubed-sphere samples/sec (fwd+bwd)', 'value': round(value, 2), 'unit': 'samples/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+        'config': {'workload': '%s C%d: x (%d,6,%d,%d,%d) per GPU, %d out channels, base %d, MSE + Adam, '
+                               'fwd+bwd+update, %s' % (args.workload, N, B, N, N, C, C, base, prec),
+                   'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                   'hip_graphs': bool(model.use_graphs)},
+        'model_tflops': round(3 * fps * value / 1e12, 3),
+    }
+    if with_roofline:
+        if agg:
+            # per kernel: the roofline that bounds it = the larger of (algorithmic flops / matrix peak of the instruction
+            # it issues) and (algorithmic bytes / HBM peak); frac = that bound time / measured time
+            def bound_of(name, cnt, ms, fl, by):
+                peak_f = PEAK_BF16_MFMA_TFLOPS if name.startswith(BF16_MFMA_KERNELS) else PEAK_FP32_MFMA_TFLOPS
+                t_f, t_b = fl / (peak_f * 1e12), by / (PEAK_HBM_GBS * 1e9)
+                t = ms * 1e-3
+                if t_f >= t_b:
+                    return {'bound': 'mfma', 'achieved': round(fl / t / 1e12, 3), 'peak': peak_f, 'unit': 'TFLOP/s',
+                            'frac': round(t_f / t, 4)}
+                return {'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round(t_b / t, 4)}
+            name, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
+            rf = bound_of(name, cnt, ms, fl, by)
+            rf.update({'traffic': None, 'kernel': name, 'launches': cnt, 'avg_launch_us': round(1e3 * ms / cnt, 2),
+                       'algorithmic_gflop_per_launch': round(fl / cnt / 1e9, 3),
+                       'algorithmic_mbytes_per_launch': round(by / cnt / 1e6, 3)})
+            tot_ms = sum(v[1] for v in agg.values())
+            tot_fl = sum(v[2] for v in agg.values())
+            rf['all_mfma_kernels_tflops'] = round(tot_fl / (tot_ms * 1e-3) / 1e12, 3)
+            rf['per_kernel'] = {}
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                bk = bound_of(k, *v)
+                rf['per_kernel'][k] = {'launches': v[0], 'avg_us': round(1e3 * v[1] / v[0], 2),
+                                       'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2), 'bound': bk['bound'],
+                                       'frac': bk['frac']}
+            result['roofline'] = rf
+    del model
+    torch.cuda.empty_cache()
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='unet2', choices=['unet2', 'encoder6'])
     ap.add_argument('--batch', type=int, default=32, help='samples per GPU per step')
     ap.add_argument('--face', type=int, default=48)
     ap.add_argument('--channels', type=int, default=14, help='input (= output) channels: 7 variables x 2 time steps')
     ap.add_argument('--base', type=int, default=32)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
-                    help='activation dtype: f32 = exact-fp32 MFMA everywhere; bf16 = bf16 activations + bf16 MFMA, '
-                         'fp32 master weights / gradients / Adam (BASELINE config 3)')
+    ap.add_argument('--dtype', default='bf16', choices=['f32', 'bf16'],
+                    help='activation dtype of the headline number.  bf16 (default; BASELINE config 3 names bf16 compute, '
+                         'the reference trains under TF AMP): bf16 activations + bf16 MFMA, fp32 master weights / '
+                         'gradients / Adam.  f32: exact-fp32 MFMA everywhere (the 1e-5 parity mode).')
+    ap.add_argument('--no-companion', action='store_true',
+                    help='skip the second measurement in the other dtype (N = 1 only) reported under "f32" / "bf16"')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graphs', action='store_true')
@@ -179,88 +272,16 @@ def main():
 
     from DLWP.keras import backend
     backend.set_device('cuda:%d' % local_rank)
-    N, C, base, B = args.face, args.channels, args.base, args.batch
-    np.random.seed(1)
-    backend.set_compute_dtype('bfloat16' if args.dtype == 'bf16' else 'float32')
-    model = build_model(args.workload, N, C, C, base)
-    model.use_graphs = not args.no_graphs
-    adt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    model.compile(optimizer='adam', loss='mse')
-    rng = np.random.default_rng(1000 + rank)
-    dev = backend.device()
-    dx = [torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(adt)]
-    with torch.no_grad():
-        oshape = model.predict_on_device(dx[0][:1]).shape[1:]
-    dt = [torch.tensor(rng.standard_normal((B,) + tuple(oshape)), dtype=torch.float32, device=dev)]
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(max(args.warmup, 3)):      # >= 3: eager warm-up, graph capture, first replay
-        model.train_on_device_batch(dx, dt)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.train_on_device_batch(dx, dt)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    result = None
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = B * world * args.steps / elapsed
-        fps = flops_per_sample(args.workload, N, C, C, base)
-        result = {
-            'metric': 'cubed-sphere samples/sec (fwd+bwd)', 'value': round(value, 2), 'unit': 'samples/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': '%s C%d: x (%d,6,%d,%d,%d) per GPU, %d out channels, base %d, MSE + Adam, '
-                                   'fwd+bwd+update' % (args.workload, N, B, N, N, C, C, base),
-                       'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                       'hip_graphs': bool(model.use_graphs)},
-            'model_tflops': round(3 * fps * value / 1e12, 3),
-        }
-    if rank == 0 and not args.no_roofline:
-        agg = roofline_pass(model, dx, dt)
-        if agg:
-            # per kernel: the roofline that bounds it = the larger of (algorithmic flops / matrix peak of the instruction
-            # it issues) and (algorithmic bytes / HBM peak); frac = that bound time / measured time
-            def bound_of(name, cnt, ms, fl, by):
-                peak_f = PEAK_BF16_MFMA_TFLOPS if name.startswith(BF16_MFMA_KERNELS) else PEAK_FP32_MFMA_TFLOPS
-                t_f, t_b = fl / (peak_f * 1e12), by / (PEAK_HBM_GBS * 1e9)
-                t = ms * 1e-3
-                if t_f >= t_b:
-                    return {'bound': 'mfma', 'achieved': round(fl / t / 1e12, 3), 'peak': peak_f, 'unit': 'TFLOP/s',
-                            'frac': round(t_f / t, 4)}
-                return {'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': round(t_b / t, 4)}
-            name, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
-            rf = bound_of(name, cnt, ms, fl, by)
-            rf.update({'traffic': None, 'kernel': name, 'launches': cnt, 'avg_launch_us': round(1e3 * ms / cnt, 2),
-                       'algorithmic_gflop_per_launch': round(fl / cnt / 1e9, 3),
-                       'algorithmic_mbytes_per_launch': round(by / cnt / 1e6, 3)})
-            tot_ms = sum(v[1] for v in agg.values())
-            tot_fl = sum(v[2] for v in agg.values())
-            rf['all_mfma_kernels_tflops'] = round(tot_fl / (tot_ms * 1e-3) / 1e12, 3)
-            rf['per_kernel'] = {}
-            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                bk = bound_of(k, *v)
-                rf['per_kernel'][k] = {'launches': v[0], 'avg_us': round(1e3 * v[1] / v[0], 2),
-                                       'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2), 'bound': bk['bound'],
-                                       'frac': bk['frac']}
-            result['roofline'] = rf
-    elif world > 1 and not args.no_roofline:
-        pass
+    result = measure(args, args.dtype, rank, world, local_rank, with_roofline=not args.no_roofline)
     if world > 1:
         torch.distributed.barrier()
+    if world == 1 and not args.no_companion:
+        other = 'f32' if args.dtype == 'bf16' else 'bf16'
+        comp = measure(args, other, rank, world, local_rank, with_roofline=not args.no_roofline)
+        keep = ('value', 'unit', 'ms_per_step', 'dtype', 'model_tflops', 'roofline')
+        result[other] = {k: comp[k] for k in keep if k in comp}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(args.workload, N, C, C, base)
+        result['cpu_baseline'] = cpu_baseline(args.workload, args.face, args.channels, args.channels, args.base)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

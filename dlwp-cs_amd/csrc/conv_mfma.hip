@@ -1465,7 +1465,8 @@ extern "C" int dlwpcs_pack_batch(const dlwpcs_pack_item *items_dev, int n_items,
     if (n_items < 0 || (n_items > 0 && !items_dev)) return fail(DLWPCS_E_INVALID, "pack_batch: bad arguments");
     if (n_items == 0) return DLWPCS_OK;
     if (n_items > 65535) return fail(DLWPCS_E_UNSUPPORTED, "pack_batch: more than 65535 items");
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(48, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
+    // 256 x n_items workgroups: the largest U-Net layer packs ~0.9 M values per direction, small layers exit at once
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(256, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
     return check_launch("pack_batch");
 }
 
