@@ -514,6 +514,8 @@ class Model(object):
                 vals = self._evaluate_impl(validation_data, None, batch_size, validation_steps)
                 logs.update({'val_' + k: v for k, v in zip(names, vals)})
             cbl.call('on_epoch_end', epoch, logs)
+            if y is None and hasattr(x, 'on_epoch_end'):
+                x.on_epoch_end()           # keras.utils.Sequence contract (re-shuffles an ArrayDataGenerator)
             if verbose:
                 msg = ' - '.join('%s: %.4f' % (k, v) for k, v in logs.items())
                 print('Epoch %d/%d - %ds - %s' % (epoch + 1, epochs, int(time.time() - t0), msg))

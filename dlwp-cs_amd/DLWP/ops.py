@@ -577,3 +577,29 @@ def add(a, b):
     y = torch.empty_like(a)
     check(lib().dlwpcs_add(ptr(a), ptr(b), ptr(y), a.numel(), nat.dtype_tag(a), stream_ptr()), 'dlwpcs_add')
     return y
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# Batch feed (reference DLWP/model/generators.py:872-984): gather a batch window out of the HBM-resident data array
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def batch_gather(array, samples, var_idx, out, n_steps, t_off, t_stride, c_off, c_stride, channels_last=True):
+    """
+    array (T, V, *space) fp32 device tensor; samples (B,) / var_idx (nv,) int32 device tensors; out (B, *space, Ctot) or
+    (B, Ctot, *space), float32 or bfloat16, written in place: channel c_off + n*c_stride + j <- array[samples + t_off +
+    n*t_stride, var_idx[j]].
+    """
+    for t in (array, out):
+        require_device(t, 'batch_gather')
+    if array.dtype != torch.float32 or not array.is_contiguous() or not out.is_contiguous():
+        raise TypeError('batch_gather: array must be contiguous float32, out contiguous')
+    T, V = int(array.shape[0]), int(array.shape[1])
+    S = int(array[0, 0].numel())
+    B = int(samples.numel())
+    Ctot = int(out.shape[-1] if channels_last else out.shape[1])
+    if out.numel() != B * S * Ctot:
+        raise ValueError('batch_gather: out shape %s does not match batch %d, space %d' % (tuple(out.shape), B, S))
+    check(lib().dlwpcs_batch_gather(ptr(array), T, V, S, ptr(samples), B, ptr(var_idx), int(var_idx.numel()),
+                                    int(n_steps), int(t_off), int(t_stride), ptr(out), Ctot, int(c_off), int(c_stride),
+                                    1 if channels_last else 0, nat.dtype_tag(out), stream_ptr()), 'dlwpcs_batch_gather')
+    return out

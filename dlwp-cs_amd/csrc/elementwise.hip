@@ -369,6 +369,57 @@ __global__ void __launch_bounds__(256) transpose_kernel(const S *__restrict__ x,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Batch assembly (reference ArrayDataGenerator.generate, DLWP/model/generators.py:872-984): the whole
+// (time, variable, space) data array lives in HBM and a training batch is ONE gather
+//     out[b][s][c_off + n*c_stride + j] = array[samples[b] + t_off + n*t_stride][var_idx[j]][s]        (channels_last)
+//     out[b][c_off + n*c_stride + j][s] = ...                                                          (channels_first)
+// instead of host fancy-indexing + transpose + upload.  Source rows are contiguous in s, the channels_last destination
+// is contiguous in c: 64 pixels x all gathered channels go through a padded LDS tile so both sides are coalesced.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename OT>
+__global__ void __launch_bounds__(256) batch_gather_cl_kernel(const float *__restrict__ array, size_t S, int V,
+                                                              const int32_t *__restrict__ samples,
+                                                              const int32_t *__restrict__ var_idx, int nv, int n_steps,
+                                                              int t_off, int t_stride, OT *__restrict__ out, int Ctot,
+                                                              int c_off, int c_stride) {
+    extern __shared__ float tile[];                 // [nch][65]
+    const int nch = n_steps * nv;
+    const size_t s0 = (size_t)blockIdx.x * 64;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long t0 = (long)samples[b] + t_off;
+    for (int cc = w; cc < nch; cc += 4) {
+        const int n = cc / nv, j = cc - n * nv;
+        const float *src = array + ((size_t)(t0 + (long)n * t_stride) * V + var_idx[j]) * S;
+        tile[cc * 65 + lane] = (s0 + lane < S) ? src[s0 + lane] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * nch; idx += 256) {
+        const int px = idx / nch, cc = idx - px * nch;
+        if (s0 + px >= S) break;
+        const int n = cc / nv, j = cc - n * nv;
+        Acc<1> v; v.v[0] = tile[cc * 65 + px];
+        VT<OT>::st(out + ((size_t)b * S + s0 + px) * Ctot + c_off + n * c_stride + j, v);
+    }
+}
+
+template <typename OT>
+__global__ void __launch_bounds__(256) batch_gather_cf_kernel(const float *__restrict__ array, size_t S, int V,
+                                                              const int32_t *__restrict__ samples,
+                                                              const int32_t *__restrict__ var_idx, int nv, int n_steps,
+                                                              int t_off, int t_stride, OT *__restrict__ out, int Ctot,
+                                                              int c_off, int c_stride) {
+    const int cc = blockIdx.y, b = blockIdx.z;
+    const int n = cc / nv, j = cc - n * nv;
+    const float *src = array + ((size_t)((long)samples[b] + t_off + (long)n * t_stride) * V + var_idx[j]) * S;
+    OT *dst = out + ((size_t)b * Ctot + c_off + n * c_stride + j) * S;
+    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (size_t)gridDim.x * blockDim.x) {
+        Acc<1> v; v.v[0] = src[s];
+        VT<OT>::st(dst + s, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // keras 'mse' (+ 'mae' metric) with gradient, two-stage fixed-order reduction          (Azure/train_cs.py:424-430)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int MSE_BLOCKS = 1024;
@@ -675,4 +726,42 @@ extern "C" int dlwpcs_adam_step(float *p, const float *g, float *m, float *v, si
                            beta1, beta2, eps, grad_scale);
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
     return check_launch("adam_step");
+}
+
+extern "C" int dlwpcs_batch_gather(const void *array, int64_t T, int V, int64_t S, const int32_t *samples_dev, int B,
+                                   const int32_t *var_idx_dev, int nv, int n_steps, int t_off, int t_stride, void *out,
+                                   int Ctot, int c_off, int c_stride, int channels_last, int dtype,
+                                   dlwpcs_stream_t stream) {
+    REQUIRE_DTYPE(dtype, "batch_gather");
+    REQUIRE(array && samples_dev && var_idx_dev && out, "batch_gather: null pointer");
+    REQUIRE(T >= 1 && V >= 1 && S >= 1 && B >= 0 && nv >= 1 && n_steps >= 1 && Ctot >= 1 && c_off >= 0 && c_stride >= 0,
+            "batch_gather: bad shape T=%lld V=%d S=%lld B=%d nv=%d n_steps=%d", (long long)T, V, (long long)S, B, nv, n_steps);
+    REQUIRE(c_off + (n_steps - 1) * c_stride + nv <= Ctot, "batch_gather: channel window exceeds Ctot=%d", Ctot);
+    if (B == 0) return DLWPCS_OK;
+    if (B > 65535) return fail(DLWPCS_E_UNSUPPORTED, "batch_gather: batch > 65535");
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = n_steps * nv;
+    if (channels_last) {
+        const size_t lds = (size_t)nch * 65 * sizeof(float);
+        if (lds > 64 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "batch_gather: %d gathered channels exceed the LDS tile", nch);
+        dim3 grid((unsigned)((S + 63) / 64), (unsigned)B);
+        if (dtype == DLWPCS_BF16)
+            hipLaunchKernelGGL(batch_gather_cl_kernel<bf16_t>, grid, dim3(256), lds, s, (const float *)array, (size_t)S, V,
+                               samples_dev, var_idx_dev, nv, n_steps, t_off, t_stride, (bf16_t *)out, Ctot, c_off, c_stride);
+        else
+            hipLaunchKernelGGL(batch_gather_cl_kernel<float>, grid, dim3(256), lds, s, (const float *)array, (size_t)S, V,
+                               samples_dev, var_idx_dev, nv, n_steps, t_off, t_stride, (float *)out, Ctot, c_off, c_stride);
+    } else {
+        if (nch > 65535) return fail(DLWPCS_E_UNSUPPORTED, "batch_gather: too many channels");
+        size_t gx = (S + 255) / 256;
+        if (gx > 64) gx = 64;
+        dim3 grid((unsigned)gx, (unsigned)nch, (unsigned)B);
+        if (dtype == DLWPCS_BF16)
+            hipLaunchKernelGGL(batch_gather_cf_kernel<bf16_t>, grid, dim3(256), 0, s, (const float *)array, (size_t)S, V,
+                               samples_dev, var_idx_dev, nv, n_steps, t_off, t_stride, (bf16_t *)out, Ctot, c_off, c_stride);
+        else
+            hipLaunchKernelGGL(batch_gather_cf_kernel<float>, grid, dim3(256), 0, s, (const float *)array, (size_t)S, V,
+                               samples_dev, var_idx_dev, nv, n_steps, t_off, t_stride, (float *)out, Ctot, c_off, c_stride);
+    }
+    return check_launch("batch_gather");
 }

@@ -230,6 +230,19 @@ int dlwpcs_adam_step(float *p, const float *g, float *m, float *v, size_t n, int
                      float lr, float beta1, float beta2, float eps, float grad_scale, dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
+ * Batch feed (reference ArrayDataGenerator.generate, DLWP/model/generators.py:872-984): with the whole data array
+ * (T, V, S) fp32 resident in HBM (S = flattened space, e.g. 6*N*N), one launch assembles a batch window
+ *   channels_last : out[b][s][c_off + n*c_stride + j] = array[samples[b] + t_off + n*t_stride][var_idx[j]][s]
+ *   channels_first: out[b][c_off + n*c_stride + j][s] = (same)
+ * for n < n_steps, j < nv.  out is (B, S, Ctot) or (B, Ctot, S) of `dtype` (fp32 source rounded to bf16 on the fly).
+ * The caller guarantees samples[b] + t_off + (n_steps-1)*t_stride < T.  Predictors, insolation channels and targets
+ * of a batch are three calls with different (array, var_idx, c_off, c_stride, t_off).
+ * ------------------------------------------------------------------------------------------------------------- */
+int dlwpcs_batch_gather(const void *array, int64_t T, int V, int64_t S, const int32_t *samples_dev, int B,
+                        const int32_t *var_idx_dev, int nv, int n_steps, int t_off, int t_stride, void *out,
+                        int Ctot, int c_off, int c_stride, int channels_last, int dtype, dlwpcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------- *
  * Opt-in launch profiler (bench.py `roofline`): when enabled, every MFMA convolution kernel launch is bracketed by two
  * HIP events recorded on the launch stream.  Off by default; do not enable while a stream is being graph-captured.
  * dlwpcs_prof_get: tag = kernel name as rocprofv3 prints it (template arguments included), ms = event-elapsed time,
