@@ -22,6 +22,7 @@ ACT_NONE = 0
 ACT_LEAKY_CLIP = 1
 CONV_ACCUMULATE_WGRAD = 1
 CONV_PREPACKED = 2
+CONV_REUSE_DZ = 4
 PACK_FWD, PACK_BWD, PACK_BIAS = 0, 1, 2
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t

@@ -187,12 +187,23 @@ class _CSConv(torch.autograd.Function):
         need = ctx.needs_input_grad
         dsrc0 = torch.empty_like(src0) if need[0] else None
         dsrc1 = torch.empty_like(src1) if (has_src1 and need[1]) else None
-        if dsrc0 is not None or dsrc1 is not None:
-            # (d.flags carries CONV_PREPACKED from the forward when packed buffers were used)
-            wq = ctx.packed[3] if ctx.packed is not None else w_eq
-            check(lib().dlwpcs_conv_bwd_data(ctypes.byref(d), ptr(dy), ptr(y), ptr(wq), ptr(w_pol), ptr(w_np),
-                                             ptr(dsrc0), ptr(dsrc1), ptr(inv), ptr(ws), ws.numel(), stream_ptr()),
-                  'dlwpcs_conv_bwd_data')
+        want_w = any(need[2:8])
+        reuse_dz = ((dsrc0 is not None or dsrc1 is not None) and want_w and d.act != nat.ACT_NONE
+                    and not WGRAD_SIDE_STREAM)
+        if reuse_dz:
+            # the weight-gradient kernel computes dz = dy * act'(y) anyway: launched FIRST, it leaves dz in the workspace
+            # for the data-gradient kernel right behind it (which then reads neither y nor does the act' arithmetic)
+            d.flags |= nat.CONV_REUSE_DZ
+
+        def run_bwd_data():
+            if dsrc0 is not None or dsrc1 is not None:
+                # (d.flags carries CONV_PREPACKED from the forward when packed buffers were used)
+                wq = ctx.packed[3] if ctx.packed is not None else w_eq
+                check(lib().dlwpcs_conv_bwd_data(ctypes.byref(d), ptr(dy), ptr(y), ptr(wq), ptr(w_pol), ptr(w_np),
+                                                 ptr(dsrc0), ptr(dsrc1), ptr(inv), ptr(ws), ws.numel(), stream_ptr()),
+                      'dlwpcs_conv_bwd_data')
+        if not reuse_dz:
+            run_bwd_data()
         dw_eq = dw_pol = dw_np = db_eq = db_pol = db_np = None
         if DIRECT_PARAM_GRADS and (need[2] or need[3]) and all(
                 p is None or (p.is_leaf and p.grad is not None and p.grad.is_contiguous()) for p in ctx.params):
@@ -232,6 +243,8 @@ class _CSConv(torch.autograd.Function):
                                                 ptr(dw_pol), ptr(dw_np), ptr(db_eq), ptr(db_pol), ptr(db_np),
                                                 ptr(table), ptr(ws), ws.numel(), stream_ptr()),
                   'dlwpcs_conv_bwd_weights')
+        if reuse_dz:
+            run_bwd_data()
         return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 7
 
 

@@ -548,6 +548,8 @@ struct WgradKParams {
     float *bpartial;        // [nworkers][CoutP] or nullptr
     int CinP, CoutP;        // multiples of 32
     int n_eq, n_4, n_5;     // workers per face class (equatorial faces 0-3 / face 4 / face 5); grid.x = their sum
+    uint32_t magicB, magicNb;   // exact-division magics of the batch size and of the bands per face (wgrad_bf16_kernel)
+    void *dz_out;               // wgrad_bf16_kernel with MASK: ci-tile-0 workers also store dz (same shape as dy), or nullptr
 };
 
 // Weight-gradient kernel: persistent + wave-specialised.  GEMM view per tap:
@@ -881,7 +883,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     constexpr int TAPS = KS * KS;
     constexpr int PB = 64;                  // LDS bytes per pixel: 32 channels bf16 (X tile and dZ tile alike)
     constexpr int NCT = 256;                // consumer threads == producer threads
-    constexpr int IT_X = XV == 8 ? 10 : 20; // X vectors per producer thread per item: capacity IT_X * 256 / QX tile pixels
+    constexpr int IT_X = XV == 8 ? 8 : 16;  // X vectors per producer thread per item: capacity IT_X * 256 / QX tile pixels
     typedef typename VecT<bf16_t, XV>::type XVec;
     constexpr int IT_DY = 6;                // dZ 16-B vectors per producer thread per item: capacity 384 pixels
     const ConvKParams &P = W.c;
@@ -898,19 +900,25 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     else if (worker < W.n_eq + W.n_4) { j = worker - W.n_eq; nj = W.n_4; nfaces = 1; fbase = 4; }
     else { j = worker - W.n_eq - W.n_4; nj = W.n_5; nfaces = 1; fbase = 5; }
     const int nbands = P.nblk_face;
+    // Items in (face, band)-major, SAMPLE-minor order; worker j of its class owns one contiguous range.  Consecutive items
+    // of a worker are then the same tile position in consecutive samples: every gather offset, validity flag and LDS
+    // address stays the same and only a scalar sample base moves (offsets are rebuilt at the <= 2 combo changes per worker).
     const int total_items = P.B * nfaces * nbands;
-    const int n_my = j < total_items ? (total_items - j + nj - 1) / nj : 0;
+    const int t_first = (int)(((long)total_items * j) / nj), t_last = (int)(((long)total_items * (j + 1)) / nj);
+    const int n_my = t_last - t_first;
     const int face_pix = P.No * P.No;
     const int tid = threadIdx.x;
 
-    struct Item { int b, f, m0, npix, y0, nitems; };
+    struct Item { int b, f, combo, m0, npix, y0, nitems; };
     auto item_of = [&](int k) {
         Item it;
-        const int t = j + max(min(k, n_my - 1), 0) * nj;
-        const int band = t % nbands;
-        const int r = t / nbands;
-        it.f = fbase + r % nfaces;
-        it.b = r / nfaces;
+        const int t = t_first + max(min(k, n_my - 1), 0);
+        // (div_magic(1) does not fit 32 bits: a divisor of 1 is passed as magic 0)
+        it.combo = W.magicB ? __umulhi((uint32_t)t, W.magicB) : t;                    // t / B
+        it.b = t - it.combo * P.B;
+        const int fl = W.magicNb ? __umulhi((uint32_t)it.combo, W.magicNb) : it.combo;   // combo / nbands
+        const int band = it.combo - fl * nbands;
+        it.f = fbase + fl;
         it.m0 = band * P.pix_per_block;
         it.npix = min(P.pix_per_block, face_pix - it.m0);
         it.y0 = __umulhi((uint32_t)it.m0, P.magicNo);
@@ -937,8 +945,11 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         float bsum[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) bsum[u] = 0.f;
-        int sidx[IT_X], sidx_n[IT_X];
-        auto lookup = [&](const Item &it, int (&sx)[IT_X]) {
+        // Per-slot gather offsets (elements, relative to the sample's base pointer; -1 = zero cell), valid for one
+        // (face, band) combination: halo-table lookup + upsample decode happen here, once per combo, not once per item.
+        int xoff[IT_X];
+        int cur_combo = -1;
+        auto rebuild = [&](const Item &it) {
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int e = min(ptid + i * NCT, it.nitems - 1);
@@ -946,75 +957,107 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                 const int ty = __umulhi((uint32_t)pix, P.magicW2);
                 const int tx = pix - ty * P.W2;
                 const int iy = it.y0 + ty;
-                int v0;
-                if (P.mode == MODE_HALO) v0 = P.table[(it.f * M + iy) * M + tx];
-                else v0 = (it.f * P.Nin + iy) * P.Nin + tx;
-                sx[i] = (ptid + i * NCT < it.nitems) ? v0 : -1;
-            }
-        };
-        Item cur = item_of(0);
-        if (n_my > 0) lookup(cur, sidx);
-        for (int k = 0; k < n_my; ++k) {
-            char *buf = smem + (k & 1) * buf_bytes;
-            const Item nxt = item_of(k + 1);
-            const bf16_t *sb = from0 ? reinterpret_cast<const bf16_t *>(P.src0) + (size_t)cur.b * 6 * g0 * g0 * P.C0
-                                     : reinterpret_cast<const bf16_t *>(P.src1) + (size_t)cur.b * 6 * P.Nin * P.Nin * P.C1;
-            // ---- X tile: every load in flight at once
-            XVec xv[IT_X];
-            bool xok[IT_X];
-#pragma unroll
-            for (int i = 0; i < IT_X; ++i) {
-                const int idx = sidx[i];
-                const bool ok = cx_ok && idx >= 0;
-                const int ii = ok ? idx : 0;
+                int ii;                                              // flat cell on the Nin grid INSIDE the face plane set
+                if (P.mode == MODE_HALO) ii = P.table[(it.f * M + iy) * M + tx];
+                else ii = (it.f * P.Nin + iy) * P.Nin + tx;
                 const int r = __umulhi((uint32_t)ii, P.magicN);      // row face*Nin + y of the Nin grid -> row r/2 of Nin/2
                 const int pix_up = (r >> 1) * g0 + ((ii - r * P.Nin) >> 1);
-                const int pix = up ? pix_up : ii;
-                xv[i] = *reinterpret_cast<const XVec *>(sb + (ok ? (size_t)pix * cstride + cs : 0));
-                xok[i] = ok;
+                const int spix = up ? pix_up : ii;
+                xoff[i] = (cx_ok && ptid + i * NCT < it.nitems) ? spix * cstride + cs : -1;
             }
-            // ---- dZ tile [pix][32 output channels of tile cot] = dy * act'(y), zero beyond npix / Cout
-            const size_t rowbase = (((size_t)cur.b * 6 + cur.f) * face_pix + cur.m0) * P.Cout;
+            cur_combo = it.combo;
+        };
+        // dZ slot offsets never change: slot i is pixel kk = (ptid + i*NCT) / 4 of the band, channels co..co+7
+        int doff[IT_DY];
+#pragma unroll
+        for (int i = 0; i < IT_DY; ++i) doff[i] = ((ptid + i * NCT) >> 2) * P.Cout + co;
+        const size_t sample_elems = from0 ? (size_t)6 * g0 * g0 * P.C0 : (size_t)6 * P.Nin * P.Nin * P.C1;
+        const bf16_t *src_base = reinterpret_cast<const bf16_t *>(from0 ? P.src0 : P.src1);
+        // Two register sets, prefetch distance 2: the loads of item k+1 are issued BEFORE the loads of item k are waited for,
+        // so a full item's worth of loads is always in flight and the HBM/L2 latency never shows (with one set the
+        // producers spent more than half of every item waiting; the consumers, 16x faster than in the fp32 kernel, idled).
+        struct Stage {
+            XVec xv[IT_X];
+            uint4 dv[IT_DY], yv[MASK ? IT_DY : 1];
+            bool xok[IT_X], dok[IT_DY];
+        };
+        auto issue = [&](const Item &it, Stage &st) {
+            if (it.combo != cur_combo) rebuild(it);                 // uniform, <= 2-3 times per worker
+            const bf16_t *sb = src_base + (size_t)it.b * sample_elems;
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int o = xoff[i];
+                st.xv[i] = *reinterpret_cast<const XVec *>(sb + (uint32_t)max(o, 0));
+                st.xok[i] = o >= 0;
+            }
+            // dZ tile [pix][32 output channels of tile cot] = dy * act'(y), zero beyond npix / Cout
+            const size_t rowbase = (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * P.Cout;
             const bf16_t *dyb = reinterpret_cast<const bf16_t *>(W.dy) + rowbase;
             const bf16_t *yb = MASK ? reinterpret_cast<const bf16_t *>(W.y) + rowbase : nullptr;
-            uint4 dv[IT_DY], yv[MASK ? IT_DY : 1];
-            bool dok[IT_DY];
+            const int dlim = it.npix * P.Cout;                      // slot valid <=> its pixel < npix
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
-                const int kk = (ptid + i * NCT) >> 2;
-                const bool ok = kk < cur.npix && co_ok;
-                const size_t o = ok ? (size_t)kk * P.Cout + co : 0;
-                dv[i] = *reinterpret_cast<const uint4 *>(dyb + o);
-                if (MASK) yv[i] = *reinterpret_cast<const uint4 *>(yb + o);
-                dok[i] = ok;
+                const bool ok = co_ok && doff[i] < dlim;
+                const uint32_t o = ok ? (uint32_t)doff[i] : 0u;
+                st.dv[i] = *reinterpret_cast<const uint4 *>(dyb + o);
+                if (MASK) st.yv[i] = *reinterpret_cast<const uint4 *>(yb + o);
+                st.dok[i] = ok;
             }
-            lookup(nxt, sidx_n);                                   // next item's halo-table entries ride along
-            // dZ = dy * act'(y), applied only after EVERY load of the item has been issued
+        };
+#ifdef DLWPCS_TIMELINE
+        int pli = 0;
+        long long *plp = (P.dbg && ptid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
+#endif
+        auto commit = [&](const Item &it, int k, Stage &st) {
+            char *buf = smem + (k & 1) * buf_bytes;
+            PL_MARK();
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
-                if (MASK) vmask(dv[i], yv[i], P.alpha, P.vmax);
-                dv[i] = vsel(dok[i], dv[i]);
+                if (MASK) vmask(st.dv[i], st.yv[i], P.alpha, P.vmax);
+                st.dv[i] = vsel(st.dok[i], st.dv[i]);
             }
-            // ---- registers -> LDS
+            // DLWPCS_CONV_REUSE_DZ: the workers of ci tile 0 see every dZ element exactly once -> they hand dz to the
+            // data-gradient kernel that follows (which then needs neither y nor the act' arithmetic)
+            if (MASK && W.dz_out != nullptr && cit == 0) {
+                bf16_t *dzb = reinterpret_cast<bf16_t *>(W.dz_out) + (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * P.Cout;
+#pragma unroll
+                for (int i = 0; i < IT_DY; ++i)
+                    if (st.dok[i]) *reinterpret_cast<uint4 *>(dzb + (uint32_t)doff[i]) = st.dv[i];
+            }
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int e = ptid + i * NCT;
-                if (e < cur.nitems)
-                    *reinterpret_cast<XVec *>(buf + (size_t)(e / QX) * PB + (ptid % QX) * (XV * 2)) = vsel(xok[i], xv[i]);
+                if (e < it.nitems)
+                    *reinterpret_cast<XVec *>(buf + (size_t)(e / QX) * PB + (ptid % QX) * (XV * 2)) = vsel(st.xok[i], st.xv[i]);
             }
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
                 const int e = ptid + i * NCT;
-                if (e < pix_cap * 4) *reinterpret_cast<uint4 *>(buf + x_bytes + (size_t)e * 16) = dv[i];
+                if (e < pix_cap * 4) *reinterpret_cast<uint4 *>(buf + x_bytes + (size_t)e * 16) = st.dv[i];
                 if (want_bias) {
-                    bsum[0] += bf_lo(dv[i].x); bsum[1] += bf_hi(dv[i].x); bsum[2] += bf_lo(dv[i].y); bsum[3] += bf_hi(dv[i].y);
-                    bsum[4] += bf_lo(dv[i].z); bsum[5] += bf_hi(dv[i].z); bsum[6] += bf_lo(dv[i].w); bsum[7] += bf_hi(dv[i].w);
+                    bsum[0] += bf_lo(st.dv[i].x); bsum[1] += bf_hi(st.dv[i].x); bsum[2] += bf_lo(st.dv[i].y); bsum[3] += bf_hi(st.dv[i].y);
+                    bsum[4] += bf_lo(st.dv[i].z); bsum[5] += bf_hi(st.dv[i].z); bsum[6] += bf_lo(st.dv[i].w); bsum[7] += bf_hi(st.dv[i].w);
                 }
             }
+            PL_MARK();
             __syncthreads();            // B_k: item k is in LDS
-            cur = nxt;
-#pragma unroll
-            for (int i = 0; i < IT_X; ++i) sidx[i] = sidx_n[i];
+            PL_MARK();
+        };
+        if (n_my > 0) {
+            Stage A, B;
+            Item i0 = item_of(0), i1 = item_of(1);          // item_of clamps: prefetches past the end re-read the last item
+            issue(i0, A);
+            for (int k = 0; k < n_my; k += 2) {
+                // invariant: A holds item k (in flight)
+                const Item i2 = item_of(k + 2);
+                issue(i1, B);
+                commit(i0, k, A);
+                if (k + 1 >= n_my) break;
+                const Item i3 = item_of(k + 3);
+                issue(i2, A);
+                commit(i1, k + 1, B);
+                i0 = i2; i1 = i3;
+            }
         }
         // ---- bias partial: thread (q = ptid & 3, 64 pixel phases) holds sums of channels 8q..8q+7 -> fixed-order sum
         __syncthreads();                // consumers are done with the buffers (matches the consumers' final barrier)
@@ -1053,8 +1096,14 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
 
     const int nslab = pix_cap / 16;             // K slabs (16 pixels) per item
     const int S = (((nslab + 3) / 4) + 1) & ~1; // slabs per consumer wave, rounded up to even (extra slabs add zero)
+#ifdef DLWPCS_TIMELINE
+    int tli = 0;
+    long long *tlp = (P.dbg && tid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
+#endif
     for (int k = 0; k < n_my; ++k) {
+        TL_MARK();
         __syncthreads();                        // B_k
+        TL_MARK();
         const char *lds_x = smem + (k & 1) * buf_bytes, *lds_dy = lds_x + x_bytes;
         const Item it = item_of(k);
         // operands of slab si of this wave: K index kk = 8*half + 4*jj + prow (jj = 0, 1) <-> flat pixel 16*s + kk.
@@ -1354,7 +1403,7 @@ static inline int out_size(const dlwpcs_conv_desc *d) { return d->halo ? d->N : 
 
 // workspace layout (bytes, 256-aligned regions)
 struct WsLayout {
-    size_t wpk_f, bias, wpk_b, dxv, partial, bpartial, total;
+    size_t wpk_f, bias, wpk_b, dxv, dz, partial, bpartial, total;
     int n_eq, n_4, n_5, wg_pix, wg_nblk;
 };
 
@@ -1365,10 +1414,14 @@ static bool wgrad_bf16_eligible(const dlwpcs_conv_desc *d) {
 }
 // X staging of wgrad_bf16_kernel: channels per load, vectors per tile pixel, tile-pixel capacity of the producers
 static void wgrad_bf16_xcfg(const dlwpcs_conv_desc *d, int &xv, int &qx, int &cap_px) {
-    if (d->C0 % 8 == 0 && d->C1 % 8 == 0) { xv = 8; qx = 4; cap_px = 640; }
-    else if (d->C0 + d->C1 <= 16) { xv = 2; qx = 8; cap_px = 640; }
-    else { xv = 2; qx = 16; cap_px = 320; }
+    if (d->C0 % 8 == 0 && d->C1 % 8 == 0) { xv = 8; qx = 4; cap_px = 512; }
+    else if (d->C0 + d->C1 <= 16) { xv = 2; qx = 8; cap_px = 512; }
+    else { xv = 2; qx = 16; cap_px = 256; }
 }
+
+// DLWPCS_CONV_REUSE_DZ hand-over happens iff the flag is set, there is an activation, and conv_bwd_weights takes the
+// wgrad_bf16_kernel path (evaluated identically by conv_bwd_weights, which writes dz, and conv_bwd_data, which reads it)
+static bool dz_handover(const dlwpcs_conv_desc *d);
 
 static void wgrad_tiling(const dlwpcs_conv_desc *d, int &pix, int &nblk, int &n_eq, int &n_4, int &n_5) {
     const int No = out_size(d);
@@ -1399,6 +1452,10 @@ static void wgrad_tiling(const dlwpcs_conv_desc *d, int &pix, int &nblk, int &n_
     n_eq = wpp - n_4 - n_5; if (n_eq < 1) n_eq = 1;
 }
 
+static WsLayout ws_layout(const dlwpcs_conv_desc *d);
+// wgrad_bf16_kernel applies: eligible dtype / channel counts and the item's X tile fits the producers' registers
+static bool wgrad_bf16_fits(const dlwpcs_conv_desc *d, const struct WsLayout &L);
+
 static WsLayout ws_layout(const dlwpcs_conv_desc *d) {
     WsLayout L{};
     const int Cin = d->C0 + d->C1, TAPS = d->ksize * d->ksize;
@@ -1412,6 +1469,7 @@ static WsLayout ws_layout(const dlwpcs_conv_desc *d) {
     L.wpk_b = off; off += align_up((size_t)3 * NTb * CGb * TAPS * 256 * 4, 256);
     const int Nv = d->halo ? d->N + d->ksize - 1 : d->N;      // face size of the virtual-input gradient
     L.dxv = off;   off += align_up((size_t)d->B * 6 * Nv * Nv * Cin * dtype_size(d->dtype), 256);
+    L.dz = off;    off += align_up((size_t)d->B * 6 * No * No * d->Cout * dtype_size(d->dtype), 256);   // REUSE_DZ hand-over
     int pix, nblk;
     wgrad_tiling(d, pix, nblk, L.n_eq, L.n_4, L.n_5);
     L.wg_pix = pix; L.wg_nblk = nblk;
@@ -1423,6 +1481,19 @@ static WsLayout ws_layout(const dlwpcs_conv_desc *d) {
     (void)No;
     L.total = off;
     return L;
+}
+
+static bool wgrad_bf16_fits(const dlwpcs_conv_desc *d, const WsLayout &L) {
+    if (!wgrad_bf16_eligible(d)) return false;
+    int xv, qx, cap_px;
+    wgrad_bf16_xcfg(d, xv, qx, cap_px);
+    const int No = out_size(d), KS = d->ksize;
+    const long tile_px = (long)(tile_rows_for(L.wg_pix, No) + KS - 1) * (No + KS - 1);
+    return tile_px <= cap_px && L.wg_pix <= 384;
+}
+static bool dz_handover(const dlwpcs_conv_desc *d) {
+    if (!(d->flags & DLWPCS_CONV_REUSE_DZ) || d->act == DLWPCS_ACT_NONE || d->B == 0) return false;
+    return wgrad_bf16_fits(d, ws_layout(d));
 }
 
 static void launch_pack(const void *w_eq, const void *w_pol, const void *w_np, void *out, int KS, int Cin, int Cout,
@@ -1531,7 +1602,10 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     if (!prepacked) launch_pack(w_eq, w_pol, w_np, ws + L.wpk_b, d->ksize, Cin, d->Cout, 1, d->flip_north_pole, d->dtype, s);
     const int No = out_size(d);
     ConvKParams P{};
-    P.src0 = dy; P.src1 = nullptr; P.ymask = d->act != DLWPCS_ACT_NONE ? y : nullptr;
+    // DLWPCS_CONV_REUSE_DZ: the weight-gradient call that ran just before left dz = dy * act'(y) in the workspace
+    const bool dz_ready = dz_handover(d);
+    P.src0 = dz_ready ? (const void *)(ws + L.dz) : dy; P.src1 = nullptr;
+    P.ymask = (d->act != DLWPCS_ACT_NONE && !dz_ready) ? y : nullptr;
     P.wpk = wpk; P.bias = nullptr; P.out = dxv; P.table = nullptr;
     P.B = d->B; P.Nin = No; P.No = No + d->ksize - 1;     // full correlation: output = input + k - 1
     P.C0 = d->Cout; P.C1 = 0; P.Cin = d->Cout; P.Cout = Cin;
@@ -1591,12 +1665,14 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     P.W2 = P.No + KS - 1; P.magicW2 = div_magic(P.W2); P.magicNo = div_magic(P.No);
     P.tile_rows_max = tile_rows_for(L.wg_pix, P.No) + (KS - 1);
     W.dy = dy; W.y = y;
+    W.dz_out = dz_handover(d) ? ws + L.dz : nullptr;
     W.partial = (float *)(ws + L.partial);
     const bool want_bias = db_eq || db_pol || db_np;
     W.bpartial = want_bias ? (float *)(ws + L.bpartial) : nullptr;
     W.CinP = CinP; W.CoutP = CoutP;
     W.n_eq = L.n_eq; W.n_4 = L.n_4; W.n_5 = L.n_5;
     P.magicN = div_magic(P.Nin); P.magicN2 = div_magic(P.Nin * P.Nin);
+    W.magicB = P.B > 1 ? div_magic(P.B) : 0; W.magicNb = P.nblk_face > 1 ? div_magic(P.nblk_face) : 0;
     P.dbg = nullptr;
 #ifdef DLWPCS_TIMELINE
     { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
@@ -1607,7 +1683,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     const int nout = TAPS * Cin * d->Cout + (want_bias ? d->Cout : 0);
     int xv = 0, qx = 0, cap_px = 0;
     if (wgrad_bf16_eligible(d)) wgrad_bf16_xcfg(d, xv, qx, cap_px);
-    if (xv && (size_t)P.tile_rows_max * P.W2 <= (size_t)cap_px && L.wg_pix <= 384) {
+    if (wgrad_bf16_fits(d, L)) {
         const int pcap = (L.wg_pix + 15) & ~15;
         size_t lds = 2 * ((size_t)P.tile_rows_max * P.W2 * 64 + (size_t)pcap * 64);
         if (lds < (4096 + 2048) * 4) lds = (4096 + 2048) * 4;   // cross-wave reduction scratch + bias staging alias the buffers

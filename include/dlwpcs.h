@@ -103,6 +103,10 @@ int dlwpcs_pad_bwd(const void *dy, void *dx, int B, int N, int C, int p, int dty
 #define DLWPCS_CONV_PREPACKED        2   /* conv_fwd: w_eq = wpk_fwd, b_eq = bias_pk (or NULL); conv_bwd_data: w_eq = wpk_bwd,
                                           * all produced by dlwpcs_pack_batch; the other kernel / bias pointers are ignored.
                                           * Without the flag every call re-packs its weights into the workspace. */
+#define DLWPCS_CONV_REUSE_DZ         4   /* set on BOTH conv_bwd_weights and the conv_bwd_data call that FOLLOWS it on the
+                                          * same stream with the same desc and workspace (act != NONE): where the bf16
+                                          * weight-gradient kernel applies it leaves dz = dy * act'(y) in the workspace
+                                          * and bwd_data reads that instead of dy and y; otherwise the flag is ignored */
 
 typedef struct dlwpcs_conv_desc {
     int32_t B;              /* batch */

@@ -247,6 +247,29 @@ def test_conv_forward_and_backward_bf16(case):
             assert rel_err(host(db[n].grad), tb[n].grad.numpy()) < 5e-3, 'db ' + n
 
 
+@pytest.mark.parametrize('C0,Cout', [(14, 32), (32, 32), (5, 8)])
+def test_conv_weight_gradient_only_bf16(C0, Cout):
+    """First-layer situation: the input needs no gradient, so the weight-gradient kernel applies act' itself (no dz
+    hand-over to a data-gradient kernel) -- must agree with the path that hands dz over."""
+    from DLWP import ops
+    from DLWP._native import ACT_LEAKY_CLIP
+    rng = np.random.default_rng(C0)
+    x = to_bf(rng.standard_normal((3, 6, 16, 16, C0)) * 3)
+    w, b = _rand_conv_params(rng, 3, C0, Cout)
+    gy = to_bf(rng.standard_normal((3, 6, 16, 16, Cout)))
+    grads = []
+    for need_x in (False, True):
+        xx = x.clone().requires_grad_(need_x)
+        dw = {n: to_f32(v).requires_grad_(True) for n, v in w.items() if v is not None}
+        db = {n: to_f32(v).requires_grad_(True) for n, v in b.items() if v is not None}
+        y = ops.cs_conv(xx, dw['eq'], dw['pol'], None, db['eq'], db['pol'], None, ksize=3, halo=True, act=ACT_LEAKY_CLIP,
+                        alpha=0.1, vmax=10.0)
+        y.backward(gy)
+        grads.append([dw['eq'].grad, dw['pol'].grad, db['eq'].grad, db['pol'].grad])
+    for a, bb in zip(*grads):
+        assert torch.equal(a, bb)
+
+
 def test_conv_wgrad_is_deterministic_bf16():
     from DLWP import ops
     rng = np.random.default_rng(11)
