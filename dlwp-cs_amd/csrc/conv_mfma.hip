@@ -46,6 +46,8 @@ struct ConvKParams {
     int nblk_face;              // workgroups per (sample, face)
     int W2;                     // tile width = No + KS - 1
     uint32_t magicW2, magicNo, magicN, magicN2;
+    uint32_t magicB, magicNblk; // exact-division magics of B and nblk_face (0 when the divisor is 1)
+    int patches;                // LDS holds the wave-private epilogue patches (0: no room -> direct quad stores)
     int tile_rows_max;          // rows reserved in LDS
     int ntiles;                 // B * 6 * nblk_face (persistent kernel)
     long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
@@ -166,13 +168,19 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     const int G = gridDim.x;
     const int nchunks = (P.CG + KCG - 1) / KCG;
 
-    struct Geo { int b, f, v, m0, npix, y0, nitems; };
+    // Tiles in (face, band)-major, SAMPLE-minor order; every workgroup owns one contiguous range (the ranges themselves
+    // are laid out XCD-aware: neighbouring ranges on the same XCD's L2).  Consecutive tiles of a workgroup are then the same
+    // tile position in consecutive samples: gather offsets, validity flags and LDS addresses stay put, only a scalar sample
+    // base moves; they are rebuilt at the few (face, band) changes.
+    const uint32_t lw = xcd_remap(blockIdx.x, (uint32_t)G);
+    const int t_first = (int)(((long)P.ntiles * lw) / G), t_last = (int)(((long)P.ntiles * (lw + 1)) / G);
+    struct Geo { int b, f, v, combo, m0, npix, y0, nitems; };
     auto geo_of = [&](int t) {
         Geo gq;
-        const uint32_t L = xcd_remap((uint32_t)t, (uint32_t)P.ntiles);
-        const int blk = L % P.nblk_face;
-        gq.f = (L / P.nblk_face) % 6;
-        gq.b = L / (P.nblk_face * 6);
+        gq.combo = P.magicB ? __umulhi((uint32_t)t, P.magicB) : t;                      // t / B   (magic 0 <=> divisor 1)
+        gq.b = t - gq.combo * P.B;
+        gq.f = P.magicNblk ? __umulhi((uint32_t)gq.combo, P.magicNblk) : gq.combo;     // combo / nblk_face
+        const int blk = gq.combo - gq.f * P.nblk_face;
         gq.v = gq.f < 4 ? 0 : (gq.f == 4 ? 1 : 2);
         gq.m0 = blk * P.pix_per_block;
         gq.npix = min(P.pix_per_block, face_pix - gq.m0);
@@ -187,8 +195,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         const int ptid = tid - NCT;
         const int qv = (ptid % Q) * VW;
         const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.wpk);
-        int t = blockIdx.x;
-        if (t >= P.ntiles) return;
+        if (t_first >= t_last) return;
 #ifdef DLWPCS_TIMELINE
         int pli = 0;
         long long *plp = (P.dbg && ptid == 0 && blockIdx.y == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
@@ -229,13 +236,11 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 sidx[i] = (ptid + i * NCT < gq.nitems) ? v0 : -1;
             }
         };
-        int sidx[ITS], sidx_n[ITS];
-        Geo gq = geo_of(t);
-        lookup(gq, sidx);
+        int sidx[ITS];
         int g = 0;
 
-        // one chunk: weights + input tile (+ optionally the next tile's table entries) -> LDS, straight-line
-        auto fill = [&](const Geo &gc, const Geo &gn, int ch, bool prefetch_next) {
+        // one chunk: weights + input tile -> LDS, straight-line
+        auto fill = [&](const Geo &gc, int ch) {
             char *buf = smem + (g & 1) * buf_bytes;
             const T *s0b = reinterpret_cast<const T *>(P.src0) + (size_t)gc.b * 6 * g0 * g0 * P.C0;
             const T *s1b = P.C1 > 0 ? reinterpret_cast<const T *>(P.src1) + (size_t)gc.b * 6 * P.Nin * P.Nin * P.C1 : s0b;
@@ -276,7 +281,6 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 if (MASK) ymv[i] = *reinterpret_cast<const V *>(ymb + oo);
                 okv[i] = ok;
             }
-            if (prefetch_next) lookup(gn, sidx_n);
             PL_MARK();
             // act' mask only after EVERY load has been issued (a use right behind its load makes hipcc wait per load)
             if (MASK) {
@@ -298,16 +302,11 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             ++g;
         };
 
-        while (true) {
-            const bool have_next = t + G < P.ntiles;
-            const Geo gn = geo_of(have_next ? t + G : t);
-            fill(gq, gn, 0, true);                              // first chunk + next tile's table entries
-            for (int ch = 1; ch < nchunks; ++ch) fill(gq, gn, ch, false);
-            if (!have_next) break;
-            t += G;
-            gq = gn;
-#pragma unroll
-            for (int i = 0; i < ITS; ++i) sidx[i] = sidx_n[i];
+        int cur_combo = -1;
+        for (int t = t_first; t < t_last; ++t) {
+            const Geo gq = geo_of(t);
+            if (gq.combo != cur_combo) { lookup(gq, sidx); cur_combo = gq.combo; }      // uniform; a few times per workgroup
+            for (int ch = 0; ch < nchunks; ++ch) fill(gq, ch);
         }
         return;
     }
@@ -326,20 +325,24 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     long long *tlp = (P.dbg && tid == 0 && blockIdx.y == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
 #endif
     TL_MARK();
-    for (int t = blockIdx.x; t < P.ntiles; t += G) {
+    int abase[MT];
+    int cur_combo = -1;
+    for (int t = t_first; t < t_last; ++t) {
         const Geo gq = geo_of(t);
-        int abase[MT];
+        if (gq.combo != cur_combo) {            // LDS addresses of this lane's pixels: the same for every sample of a combo
+            cur_combo = gq.combo;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = (wm * MT + mt) * 32 + l31;
-            int base = 0;
-            if (m < gq.npix) {
-                const int gm = gq.m0 + m;
-                const int oy = __umulhi((uint32_t)gm, P.magicNo);
-                const int ox = gm - oy * P.No;
-                base = ((oy - gq.y0) * P.W2 + ox) * RB;
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = (wm * MT + mt) * 32 + l31;
+                int base = 0;
+                if (m < gq.npix) {
+                    const int gm = gq.m0 + m;
+                    const int oy = __umulhi((uint32_t)gm, P.magicNo);
+                    const int ox = gm - oy * P.No;
+                    base = ((oy - gq.y0) * P.W2 + ox) * RB;
+                }
+                abase[mt] = base + half * 16;
             }
-            abase[mt] = base + half * 16;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -395,10 +398,19 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 
         // ---- tile epilogue: bias + activation + stores.  The MFMA ran as D[co][pixel] (weights as the A operand), so in
         // the C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) a lane owns ONE pixel and, per r>>2, FOUR
-        // CONSECUTIVE output channels: they leave as one 16-B (fp32) / 8-B (bf16) store straight from the accumulators,
-        // no LDS transposition.
+        // CONSECUTIVE output channels.  Storing those quads directly costs one L2 write request per lane and quad (8 per
+        // 64-B line; measured: ~1 request/clk/CU, 3 k of a 5 k-cycle epilogue), so each M tile goes through a wave-private
+        // LDS patch [32 pixels][32 channels + 16 B pad] instead: 4 quad writes per lane in, 16 B per lane out with the
+        // lanes of a pixel contiguous -> every store instruction writes whole lines.  No fence: the LDS executes one wave's
+        // instructions in order; wave_barrier only pins the compiler's schedule (a release fence here waits vmcnt(0),
+        // i.e. for the previous stores to land -- that was the cost of the first LDS epilogue).
         TL_MARK();
         T *outp = reinterpret_cast<T *>(P.out) + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
+        constexpr int PROW = 32 * ES + 16;          // patch row: one pixel's 32 channels + pad
+        constexpr int LPP = 32 * ES / 16;           // lanes per pixel on the way out (16 B each): 8 fp32 / 4 bf16
+        constexpr int PPP = 64 / LPP;               // pixels per store pass
+        char *patch = smem + 2 * buf_bytes + wave * (32 * PROW);
+        const bool lines = P.patches && (P.Cout % (16 / ES)) == 0;
         const bool wide = (P.Cout & 3) == 0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -406,7 +418,6 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = (wm * MT + mt) * 32 + l31;
-                if (m >= gq.npix) continue;
                 T *dst = outp + (size_t)(gq.m0 + m) * P.Cout + cot + 4 * half;
 #pragma unroll
                 for (int jq = 0; jq < 4; ++jq) {
@@ -417,20 +428,39 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                         v4.x = act_leaky_clip(v4.x, P.alpha, P.vmax); v4.y = act_leaky_clip(v4.y, P.alpha, P.vmax);
                         v4.z = act_leaky_clip(v4.z, P.alpha, P.vmax); v4.w = act_leaky_clip(v4.w, P.alpha, P.vmax);
                     }
-                    if (wide) {
-                        if (co < P.Cout) {
-                            if constexpr (ES == 4) *reinterpret_cast<float4 *>(dst + 8 * jq) = v4;
-                            else *reinterpret_cast<uint2 *>(dst + 8 * jq) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
-                        }
-                    } else {
-                        const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (co + u < P.Cout) {
-                                if constexpr (ES == 4) dst[8 * jq + u] = vs[u];
-                                else dst[8 * jq + u] = f2bf(vs[u]);
+                    if (lines) {
+                        char *pp = patch + l31 * PROW + (8 * jq + 4 * half) * ES;
+                        if constexpr (ES == 4) *reinterpret_cast<float4 *>(pp) = v4;
+                        else *reinterpret_cast<uint2 *>(pp) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
+                    } else if (m < gq.npix) {
+                        if (wide) {
+                            if (co < P.Cout) {
+                                if constexpr (ES == 4) *reinterpret_cast<float4 *>(dst + 8 * jq) = v4;
+                                else *reinterpret_cast<uint2 *>(dst + 8 * jq) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
                             }
+                        } else {
+                            const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (co + u < P.Cout) {
+                                    if constexpr (ES == 4) dst[8 * jq + u] = vs[u];
+                                    else dst[8 * jq + u] = f2bf(vs[u]);
+                                }
+                        }
                     }
+                }
+                if (lines) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int ps = 0; ps < 32 / PPP; ++ps) {
+                        const int px = ps * PPP + lane / LPP, q = lane % LPP;
+                        const uint4 v = *reinterpret_cast<const uint4 *>(patch + px * PROW + q * 16);
+                        const int mm = (wm * MT + mt) * 32 + px;
+                        const int c = cot + q * (16 / ES);
+                        if (mm < gq.npix && c < P.Cout)
+                            *reinterpret_cast<uint4 *>(outp + (size_t)(gq.m0 + mm) * P.Cout + c) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
@@ -1280,6 +1310,8 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     P.magicNo = div_magic(P.No);
     P.magicN = div_magic(P.Nin);
     P.magicN2 = div_magic(P.Nin * P.Nin);
+    P.magicB = P.B > 1 ? div_magic(P.B) : 0;
+    P.magicNblk = P.nblk_face > 1 ? div_magic(P.nblk_face) : 0;
     P.tile_rows_max = tile_rows_for(pix, P.No) + (KS - 1);
     P.ntiles = P.B * 6 * P.nblk_face;
     P.dbg = nullptr;
@@ -1287,7 +1319,9 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
     const size_t buf = (size_t)P.tile_rows_max * P.W2 * (KC * ES + 16) + (size_t)NTB * (KC / CGW) * KS * KS * 1024;
-    const size_t lds = 2 * buf;
+    size_t lds = 2 * buf + (size_t)(WM * WN) * 32 * (32 * ES + 16);            // + wave-private epilogue patches
+    P.patches = 1;
+    if (lds > 160 * 1024) { lds = 2 * buf; P.patches = 0; }                     // large faces: direct quad stores instead
     if (lds > 160 * 1024)
         return fail(DLWPCS_E_UNSUPPORTED, "conv: LDS tile of %zu bytes exceeds 160 KiB (face size %d)", lds, P.No);
     if (P.tile_rows_max > 32)
