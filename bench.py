@@ -207,7 +207,9 @@ def measure(args, dtype, rank, world, local_rank, with_roofline):
                         'frac': round(t_b / t, 4)}
             name, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
             rf = bound_of(name, cnt, ms, fl, by)
-            rf.update({'traffic': None, 'kernel': name, 'launches': cnt, 'avg_launch_us': round(1e3 * ms / cnt, 2),
+            # HBM-side bytes need PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass): collected with
+            # this same command and committed per kernel in profiles/r01_bench_unet2_b32_hbm_pmc.txt
+            rf.update({'traffic': None, 'traffic_profile': 'profiles/r01_bench_unet2_b32_hbm_pmc.txt', 'kernel': name, 'launches': cnt, 'avg_launch_us': round(1e3 * ms / cnt, 2),
                        'algorithmic_gflop_per_launch': round(fl / cnt / 1e9, 3),
                        'algorithmic_mbytes_per_launch': round(by / cnt / 1e6, 3)})
             tot_ms = sum(v[1] for v in agg.values())
