@@ -908,18 +908,27 @@ __device__ __forceinline__ uint2 lds_tr16(const char *p) {
 // XV = channels per X load (8 = 16-B vectors; 2 = 4-B vectors for channel counts that are only even, e.g. the 14-channel
 // network input), QX = X vectors staged per tile pixel (QX * XV channels of the 32-wide ci tile; the rest of the LDS row
 // is never written and only feeds accumulator rows >= C_in, which the reduction ignores).
-template <int KS, bool MASK, int XV, int QX>
+// CT = ci tiles (of 32 channels) per worker.  CT = 2 (C_in a multiple of 64): the worker stages 64 input channels per pixel
+// (two [pixel][32 ch] planes) against ONE dZ tile and its consumer waves split as (ci tile, slab parity) instead of four
+// slab phases -- each dZ element is loaded, masked and written to LDS once per 64 input channels instead of once per 32,
+// which is what the producers, the bottleneck of this kernel, spend most of their time on.  Items are then <= 192 pixels.
+template <int KS, bool MASK, int XV, int QX, int CT>
 __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     constexpr int TAPS = KS * KS;
-    constexpr int PB = 64;                  // LDS bytes per pixel: 32 channels bf16 (X tile and dZ tile alike)
+    constexpr int PB = 64;                  // LDS bytes per pixel and plane: 32 channels bf16 (X planes and dZ tile alike)
     constexpr int NCT = 256;                // consumer threads == producer threads
-    constexpr int IT_X = XV == 8 ? 8 : 16;  // X vectors per producer thread per item: capacity IT_X * 256 / QX tile pixels
+    constexpr int QXT = QX * CT;            // X vectors staged per tile pixel
+    // X vectors per producer thread per item: capacity IT_X * 256 / QXT tile pixels (512 / 320 / 512|256)
+    constexpr int IT_X = XV == 8 ? (CT == 2 ? 10 : 8) : 16;
     typedef typename VecT<bf16_t, XV>::type XVec;
-    constexpr int IT_DY = 6;                // dZ 16-B vectors per producer thread per item: capacity 384 pixels
+    constexpr int IT_DY = CT == 2 ? 3 : 6;  // dZ 16-B vectors per producer thread per item: capacity 192 / 384 pixels
+    constexpr int NPH = 4 / CT;             // consumer waves sharing the slabs of one ci tile
+    static_assert(CT == 1 || (XV == 8 && QX == 4), "two ci tiles per worker need full 16-B X vectors");
     const ConvKParams &P = W.c;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pix_cap = (P.pix_per_block + 15) & ~15;
-    const int x_bytes = P.tile_rows_max * P.W2 * PB;
+    const int plane_bytes = P.tile_rows_max * P.W2 * PB;
+    const int x_bytes = CT * plane_bytes;
     const int buf_bytes = x_bytes + pix_cap * PB;
     // the 16 KB cross-wave reduction scratch (+ 8 KB bias staging) aliases the buffers after the main loop
 
@@ -953,7 +962,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         it.npix = min(P.pix_per_block, face_pix - it.m0);
         it.y0 = __umulhi((uint32_t)it.m0, P.magicNo);
         const int ylast = __umulhi((uint32_t)(it.m0 + it.npix - 1), P.magicNo);
-        it.nitems = (ylast - it.y0 + KS) * P.W2 * QX;       // QX channel vectors per tile pixel
+        it.nitems = (ylast - it.y0 + KS) * P.W2 * QXT;      // QXT channel vectors per tile pixel
         return it;
     };
 
@@ -961,7 +970,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         // =========================================== producers ===========================================
         const int ptid = tid - NCT;
         const int qx = ptid & 3;                            // this thread's 8-channel dZ group: fixed for the whole kernel
-        const int cx = cit * 32 + (ptid % QX) * XV;         // this thread's X channels: fixed as well (256 % QX == 0)
+        const int cx = cit * 32 * CT + (ptid % QXT) * XV;   // this thread's X channels: fixed as well (256 % QXT == 0)
         const bool cx_ok = cx < P.Cin;
         const bool from0 = cx < P.C0;
         const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
@@ -983,7 +992,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int e = min(ptid + i * NCT, it.nitems - 1);
-                const int pix = e / QX;
+                const int pix = e / QXT;
                 const int ty = __umulhi((uint32_t)pix, P.magicW2);
                 const int tx = pix - ty * P.W2;
                 const int iy = it.y0 + ty;
@@ -1058,7 +1067,8 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             for (int i = 0; i < IT_X; ++i) {
                 const int e = ptid + i * NCT;
                 if (e < it.nitems)
-                    *reinterpret_cast<XVec *>(buf + (size_t)(e / QX) * PB + (ptid % QX) * (XV * 2)) = vsel(st.xok[i], st.xv[i]);
+                    *reinterpret_cast<XVec *>(buf + ((ptid % QXT) / QX) * plane_bytes + (size_t)(e / QXT) * PB +
+                                              ((ptid % QXT) % QX) * (XV * 2)) = vsel(st.xok[i], st.xv[i]);
             }
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
@@ -1125,7 +1135,8 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     for (int t = 0; t < TAPS; ++t) tapoff[t] = ((t / KS) * P.W2 + (t % KS)) * PB;
 
     const int nslab = pix_cap / 16;             // K slabs (16 pixels) per item
-    const int S = (((nslab + 3) / 4) + 1) & ~1; // slabs per consumer wave, rounded up to even (extra slabs add zero)
+    const int S = (((nslab + NPH - 1) / NPH) + 1) & ~1;   // slabs per consumer wave, rounded up to even (extras add zero)
+    const int ct = wave % CT, ph = wave / CT;   // this wave's ci tile and slab phase
 #ifdef DLWPCS_TIMELINE
     int tli = 0;
     long long *tlp = (P.dbg && tid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
@@ -1134,12 +1145,12 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         TL_MARK();
         __syncthreads();                        // B_k
         TL_MARK();
-        const char *lds_x = smem + (k & 1) * buf_bytes, *lds_dy = lds_x + x_bytes;
+        const char *lds_x0 = smem + (k & 1) * buf_bytes, *lds_dy = lds_x0 + x_bytes, *lds_x = lds_x0 + ct * plane_bytes;
         const Item it = item_of(k);
         // operands of slab si of this wave: K index kk = 8*half + 4*jj + prow (jj = 0, 1) <-> flat pixel 16*s + kk.
         // Branch-free: out-of-range slabs / pixels read a clamped (valid) X address and a zero dZ.
         auto frag = [&](int si, uint4 (&a)[TAPS], uint4 &bq) {
-            const int s = wave + 4 * si;
+            const int s = ph + NPH * si;
             const int sc = min(s, nslab - 1);
             const bool live = s < nslab;
             int xaddr[2], daddr[2];
@@ -1177,7 +1188,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     __syncthreads();                            // all consumers finished reading the last buffer
     __syncthreads();                            // (producers stage their bias sums between these two)
 
-    // cross-wave reduction through LDS (fixed order w = 0..3), one tap at a time
+    // cross-wave reduction through LDS (fixed order over the slab phases of each ci tile), one tap at a time
     float *red = reinterpret_cast<float *>(smem);
     float *pout = W.partial + (size_t)worker * TAPS * W.CinP * W.CoutP;
 #pragma unroll
@@ -1189,11 +1200,14 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * NCT;
-            const float sum = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
-            const int ci = e >> 5, co = e & 31;
-            pout[((size_t)tap * W.CinP + cit * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
+        for (int i = 0; i < 4 * CT; ++i) {
+            const int e = tid + i * NCT;                    // (ci tile, ci, co) = (e / 1024, (e / 32) % 32, e % 32)
+            const int t2 = e >> 10, e10 = e & 1023;
+            float sum;
+            if (CT == 1) sum = (red[e10] + red[1024 + e10]) + (red[2048 + e10] + red[3072 + e10]);
+            else sum = red[t2 * 1024 + e10] + red[(t2 + 2) * 1024 + e10];       // waves t2 and t2 + 2 share ci tile t2
+            const int ci = e10 >> 5, co = e10 & 31;
+            pout[((size_t)tap * W.CinP + (cit * CT + t2) * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
         }
         __syncthreads();
     }
@@ -1447,8 +1461,12 @@ static bool wgrad_bf16_eligible(const dlwpcs_conv_desc *d) {
     return d->dtype == DLWPCS_BF16 && d->C0 % 2 == 0 && d->C1 % 2 == 0 && d->Cout % 8 == 0;
 }
 // X staging of wgrad_bf16_kernel: channels per load, vectors per tile pixel, tile-pixel capacity of the producers
-static void wgrad_bf16_xcfg(const dlwpcs_conv_desc *d, int &xv, int &qx, int &cap_px) {
-    if (d->C0 % 8 == 0 && d->C1 % 8 == 0) { xv = 8; qx = 4; cap_px = 512; }
+static void wgrad_bf16_xcfg(const dlwpcs_conv_desc *d, int &xv, int &qx, int &cap_px, int &ct) {
+    ct = 1;
+    if (d->C0 % 8 == 0 && d->C1 % 8 == 0) {
+        xv = 8; qx = 4; cap_px = 512;
+        if ((d->C0 + d->C1) % 64 == 0) { ct = 2; cap_px = 320; }     // two ci tiles per worker, items <= 192 pixels
+    }
     else if (d->C0 + d->C1 <= 16) { xv = 2; qx = 8; cap_px = 512; }
     else { xv = 2; qx = 16; cap_px = 256; }
 }
@@ -1462,10 +1480,12 @@ static void wgrad_tiling(const dlwpcs_conv_desc *d, int &pix, int &nblk, int &n_
     const int face_pix = No * No;
     // pixels per work item: 2 LDS buffers of (X tile + dZ tile) in one CU's 160 KB (bf16 tiles are half the bytes)
     int CAP = 192;
+    int ci_tile = 32;                    // input channels per worker
     if (wgrad_bf16_eligible(d)) {
-        CAP = 384;
-        int xv, qx, cap_px;
-        wgrad_bf16_xcfg(d, xv, qx, cap_px);
+        int xv, qx, cap_px, ct;
+        wgrad_bf16_xcfg(d, xv, qx, cap_px, ct);
+        CAP = ct == 2 ? 192 : 384;
+        ci_tile = 32 * ct;
         // the X tile (item rows + k-1 halo rows, full padded width) must fit the producers' register capacity
         while (CAP > 96 && (long)(tile_rows_for(No <= CAP ? (CAP / No) * No : CAP, No) + d->ksize - 1) * (No + d->ksize - 1) > cap_px)
             CAP -= 96;
@@ -1475,7 +1495,7 @@ static void wgrad_tiling(const dlwpcs_conv_desc *d, int &pix, int &nblk, int &n_
     if (pix > face_pix) pix = face_pix;
     nblk = ceil_div(face_pix, pix);
     const int CinP = ceil_div(d->C0 + d->C1, 32) * 32, CoutP = ceil_div(d->Cout, 32) * 32;
-    const int pairs = (CinP / 32) * (CoutP / 32);
+    const int pairs = ceil_div(CinP, ci_tile) * (CoutP / 32);
     int wpp = 256 / pairs;               // one worker per CU (256 CUs) spread over the (ci, co) tile pairs
     if (wpp < 3) wpp = 3;
     const long items_per_face = (long)(d->B > 0 ? d->B : 1) * nblk;
@@ -1519,8 +1539,8 @@ static WsLayout ws_layout(const dlwpcs_conv_desc *d) {
 
 static bool wgrad_bf16_fits(const dlwpcs_conv_desc *d, const WsLayout &L) {
     if (!wgrad_bf16_eligible(d)) return false;
-    int xv, qx, cap_px;
-    wgrad_bf16_xcfg(d, xv, qx, cap_px);
+    int xv, qx, cap_px, ct;
+    wgrad_bf16_xcfg(d, xv, qx, cap_px, ct);
     const int No = out_size(d), KS = d->ksize;
     const long tile_px = (long)(tile_rows_for(L.wg_pix, No) + KS - 1) * (No + KS - 1);
     return tile_px <= cap_px && L.wg_pix <= 384;
@@ -1715,18 +1735,19 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     const bool mask = d->act != DLWPCS_ACT_NONE;
     dim3 grid((unsigned)(L.n_eq + L.n_4 + L.n_5), (unsigned)(CinP / 32), (unsigned)(CoutP / 32));
     const int nout = TAPS * Cin * d->Cout + (want_bias ? d->Cout : 0);
-    int xv = 0, qx = 0, cap_px = 0;
-    if (wgrad_bf16_eligible(d)) wgrad_bf16_xcfg(d, xv, qx, cap_px);
+    int xv = 0, qx = 0, cap_px = 0, ct = 1;
+    if (wgrad_bf16_eligible(d)) wgrad_bf16_xcfg(d, xv, qx, cap_px, ct);
     if (wgrad_bf16_fits(d, L)) {
         const int pcap = (L.wg_pix + 15) & ~15;
-        size_t lds = 2 * ((size_t)P.tile_rows_max * P.W2 * 64 + (size_t)pcap * 64);
+        size_t lds = 2 * ((size_t)ct * P.tile_rows_max * P.W2 * 64 + (size_t)pcap * 64);
+        grid.y = (unsigned)(CinP / (32 * ct));
         if (lds < (4096 + 2048) * 4) lds = (4096 + 2048) * 4;   // cross-wave reduction scratch + bias staging alias the buffers
         if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
         if ((long)P.Nin * P.Nin >= (1l << 16))
             return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: face size %d too large for the 16-bit index arithmetic", P.Nin);
-#define WGB_LAUNCH(KSV, MASKV, XVV, QXV)                                                                                  \
+#define WGB_LAUNCH(KSV, MASKV, XVV, QXV, CTV)                                                                             \
     do {                                                                                                                  \
-        auto kern = wgrad_bf16_kernel<KSV, MASKV, XVV, QXV>;                                                              \
+        auto kern = wgrad_bf16_kernel<KSV, MASKV, XVV, QXV, CTV>;                                                         \
         if (lds > 64 * 1024) {                                                                                            \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));    \
@@ -1734,15 +1755,17 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
         int pidx = -1;                                                                                                    \
         if (prof_enabled()) {                                                                                             \
             const Work wk = conv_work(d);                                                                                 \
-            pidx = prof_begin("wgrad_bf16_kernel<" #KSV ", " #MASKV ", " #XVV ", " #QXV ">", wk.flops, wk.bytes, s);      \
+            pidx = prof_begin("wgrad_bf16_kernel<" #KSV ", " #MASKV ", " #XVV ", " #QXV ", " #CTV ">", wk.flops, wk.bytes, s); \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, W);                                                             \
         if (pidx >= 0) prof_end(pidx, s);                                                                                 \
     } while (0)
 #define WGB_X(KSV, MASKV)                                                                                                 \
     do {                                                                                                                  \
-        if (xv == 8) WGB_LAUNCH(KSV, MASKV, 8, 4); else if (qx == 8) WGB_LAUNCH(KSV, MASKV, 2, 8);                        \
-        else WGB_LAUNCH(KSV, MASKV, 2, 16);                                                                               \
+        if (xv == 8 && ct == 2) WGB_LAUNCH(KSV, MASKV, 8, 4, 2);                                                          \
+        else if (xv == 8) WGB_LAUNCH(KSV, MASKV, 8, 4, 1);                                                                \
+        else if (qx == 8) WGB_LAUNCH(KSV, MASKV, 2, 8, 1);                                                                \
+        else WGB_LAUNCH(KSV, MASKV, 2, 16, 1);                                                                            \
     } while (0)
         if (KS == 3) { if (mask) WGB_X(3, true); else WGB_X(3, false); }
         else { if (mask) WGB_X(1, true); else WGB_X(1, false); }
