@@ -1213,22 +1213,26 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     }
 }
 
-// Sum the per-slot partials in a fixed order and route them to the weight groups.  Workgroup = 16 outputs x 16 slot
+// Sum the per-slot partials in a fixed order and route them to the weight groups.  Workgroup = 16 output groups x 16 slot
 // phases: thread (o, ph) adds slots ph, ph+16, ... (fixed order), the 16 phases are then combined through LDS in a fixed
-// tree -> bitwise reproducible, and enough workgroups (outputs/16) to fill the chip.  accumulate != 0: add to the
-// destination instead of overwriting it (shared layers / direct accumulation into the flat gradient buffer).
+// tree -> bitwise reproducible, and enough workgroups to fill the chip.  VEC = outputs per thread: 4 consecutive output
+// channels as one 16-B load per slot when C_out % 4 == 0 (the 16 threads of a phase then read 256 contiguous bytes per
+// slot instead of 64), else 1.  accumulate != 0: add to the destination instead of overwriting it (shared layers / direct
+// accumulation into the flat gradient buffer).
+template <int VEC>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bpartial,
                                                            float *__restrict__ dw_eq, float *__restrict__ dw_pol,
                                                            float *__restrict__ dw_np, float *__restrict__ db_eq,
                                                            float *__restrict__ db_pol, float *__restrict__ db_np,
                                                            int KS, int Cin, int Cout, int CinP, int CoutP,
                                                            int n_eq, int n_4, int n_5, int flip, int accumulate) {
+    typedef float VT __attribute__((ext_vector_type(VEC)));
     const int TAPS = KS * KS;
     const int nW = TAPS * Cin * Cout;
     const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
-    const int e = blockIdx.x * 16 + o;
+    const int e = (blockIdx.x * 16 + o) * VEC;         // first of this thread's VEC consecutive outputs
     const size_t slot_stride = (size_t)TAPS * CinP * CoutP;
-    float s_eq = 0.f, s_4 = 0.f, s_5 = 0.f;
+    VT s_eq = 0.f, s_4 = 0.f, s_5 = 0.f;
     const bool is_w = e < nW, is_b = (!is_w) && bpartial && e < nW + Cout;
     const int e4 = n_eq, e5 = n_eq + n_4, e6 = n_eq + n_4 + n_5;
     if (is_w) {
@@ -1237,16 +1241,16 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
         const int ty = tap / KS, tx = tap % KS;
         // face 5 ran with the row-reversed kernel: its partial for tap row r belongs to kernel row KS-1-r
         const size_t o5 = flip ? ((size_t)((KS - 1 - ty) * KS + tx) * CinP + ci) * CoutP + co : off;
-        for (int s = ph; s < e4; s += 16) s_eq += partial[(size_t)s * slot_stride + off];
-        for (int s = e4 + ph; s < e5; s += 16) s_4 += partial[(size_t)s * slot_stride + off];
-        for (int s = e5 + ph; s < e6; s += 16) s_5 += partial[(size_t)s * slot_stride + o5];
+        for (int s = ph; s < e4; s += 16) s_eq += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + off);
+        for (int s = e4 + ph; s < e5; s += 16) s_4 += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + off);
+        for (int s = e5 + ph; s < e6; s += 16) s_5 += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + o5);
     } else if (is_b) {
         const int co = e - nW;
-        for (int s = ph; s < e4; s += 16) s_eq += bpartial[(size_t)s * CoutP + co];
-        for (int s = e4 + ph; s < e5; s += 16) s_4 += bpartial[(size_t)s * CoutP + co];
-        for (int s = e5 + ph; s < e6; s += 16) s_5 += bpartial[(size_t)s * CoutP + co];
+        for (int s = ph; s < e4; s += 16) s_eq += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
+        for (int s = e4 + ph; s < e5; s += 16) s_4 += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
+        for (int s = e5 + ph; s < e6; s += 16) s_5 += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
     }
-    __shared__ float red[3][256];
+    __shared__ VT red[3][256];
     red[0][threadIdx.x] = s_eq; red[1][threadIdx.x] = s_4; red[2][threadIdx.x] = s_5;
     __syncthreads();
     for (int st = 8; st > 0; st >>= 1) {
@@ -1259,24 +1263,35 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
     }
     if (ph != 0) return;
     s_eq = red[0][o]; s_4 = red[1][o]; s_5 = red[2][o];
+    auto put = [&](float *dst, int idx, VT v) {
+        VT *p = reinterpret_cast<VT *>(dst + idx);
+        *p = accumulate ? *p + v : v;
+    };
     if (is_w) {
-        if (accumulate) {
-            dw_eq[e] += s_eq;
-            if (dw_np) { dw_pol[e] += s_4; dw_np[e] += s_5; } else dw_pol[e] += s_4 + s_5;
-        } else {
-            dw_eq[e] = s_eq;
-            if (dw_np) { dw_pol[e] = s_4; dw_np[e] = s_5; } else dw_pol[e] = s_4 + s_5;
-        }
+        put(dw_eq, e, s_eq);
+        if (dw_np) { put(dw_pol, e, s_4); put(dw_np, e, s_5); } else put(dw_pol, e, s_4 + s_5);
     } else if (is_b) {
         const int co = e - nW;
-        if (accumulate) {
-            if (db_eq) db_eq[co] += s_eq;
-            if (db_np) { if (db_pol) db_pol[co] += s_4; db_np[co] += s_5; } else if (db_pol) db_pol[co] += s_4 + s_5;
-        } else {
-            if (db_eq) db_eq[co] = s_eq;
-            if (db_np) { if (db_pol) db_pol[co] = s_4; db_np[co] = s_5; } else if (db_pol) db_pol[co] = s_4 + s_5;
-        }
+        if (db_eq) put(db_eq, co, s_eq);
+        if (db_np) { if (db_pol) put(db_pol, co, s_4); put(db_np, co, s_5); } else if (db_pol) put(db_pol, co, s_4 + s_5);
     }
+}
+
+// VEC = 4 needs every vector to stay inside one row of C_out values and 16-B aligned destinations
+static void launch_wgrad_reduce(hipStream_t s, const float *partial, const float *bpartial, void *dw_eq, void *dw_pol,
+                                void *dw_np, void *db_eq, void *db_pol, void *db_np, int KS, int Cin, int Cout, int CinP,
+                                int CoutP, int n_eq, int n_4, int n_5, int flip, int accumulate, bool want_bias) {
+    const int nout = KS * KS * Cin * Cout + (want_bias ? Cout : 0);
+    auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    const bool vec = Cout % 4 == 0 && al16(dw_eq) && al16(dw_pol) && al16(dw_np) && al16(db_eq) && al16(db_pol) && al16(db_np);
+    if (vec)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(ceil_div(nout / 4, 16)), dim3(256), 0, s, partial, bpartial,
+                           (float *)dw_eq, (float *)dw_pol, (float *)dw_np, (float *)db_eq, (float *)db_pol, (float *)db_np,
+                           KS, Cin, Cout, CinP, CoutP, n_eq, n_4, n_5, flip, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(ceil_div(nout, 16)), dim3(256), 0, s, partial, bpartial,
+                           (float *)dw_eq, (float *)dw_pol, (float *)dw_np, (float *)db_eq, (float *)db_pol, (float *)db_np,
+                           KS, Cin, Cout, CinP, CoutP, n_eq, n_4, n_5, flip, accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1773,10 +1788,8 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
 #undef WGB_LAUNCH
         rc = check_launch("wgrad_bf16");
         if (rc) return rc;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(nout, 16)), dim3(256), 0, s, W.partial, W.bpartial,
-                           (float *)dw_eq, (float *)dw_pol, (float *)dw_np, (float *)db_eq, (float *)db_pol, (float *)db_np,
-                           KS, Cin, d->Cout, CinP, CoutP, L.n_eq, L.n_4, L.n_5, d->flip_north_pole,
-                           (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0);
+        launch_wgrad_reduce(s, W.partial, W.bpartial, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, KS, Cin, d->Cout, CinP, CoutP,
+                            L.n_eq, L.n_4, L.n_5, d->flip_north_pole, (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0, want_bias);
         return check_launch("wgrad_reduce");
     }
     const int pix_cap = (L.wg_pix + 1) & ~1;
@@ -1823,9 +1836,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
 #undef WG_LAUNCH
     rc = check_launch("wgrad_mfma");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(nout, 16)), dim3(256), 0, s, W.partial, W.bpartial,
-                       (float *)dw_eq, (float *)dw_pol, (float *)dw_np, (float *)db_eq, (float *)db_pol, (float *)db_np,
-                       KS, Cin, d->Cout, CinP, CoutP, L.n_eq, L.n_4, L.n_5, d->flip_north_pole,
-                       (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0);
+    launch_wgrad_reduce(s, W.partial, W.bpartial, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, KS, Cin, d->Cout, CinP, CoutP,
+                        L.n_eq, L.n_4, L.n_5, d->flip_north_pole, (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0, want_bias);
     return check_launch("wgrad_reduce");
 }

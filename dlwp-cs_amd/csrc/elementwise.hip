@@ -70,6 +70,19 @@ template <> struct VT<H8> {
     }
 };
 
+struct alignas(16) F8 { float4 a, b; };     // 8 x fp32
+template <> struct VT<F8> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ Acc<8> ld(const F8 *p) {
+        const float4 a = p->a, b = p->b; Acc<8> r;
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+        return r;
+    }
+    static __device__ __forceinline__ void st(F8 *p, const Acc<8> &r) {
+        p->a = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]); p->b = make_float4(r.v[4], r.v[5], r.v[6], r.v[7]);
+    }
+};
+
 // f(tag, width): widest storage vector that divides every channel count in play (g = their gcd-like common divisor)
 template <typename F> static inline void dispatch_vec(int dtype, int g, F &&f) {
     if (dtype == DLWPCS_BF16) {
@@ -445,6 +458,35 @@ __global__ void __launch_bounds__(256) mse_stage1_kernel(const S *__restrict__ y
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s_sq[0]; partial[2 * blockIdx.x + 1] = s_ab[0]; }
 }
 
+// 8 elements per lane and iteration (n % 8 == 0): YV / TV = storage vectors of 8 predictions / 8 targets
+template <typename YV, typename TV8>
+__global__ void __launch_bounds__(256) mse_stage1_vec_kernel(const YV *__restrict__ y, const TV8 *__restrict__ t,
+                                                             YV *__restrict__ dy, float *__restrict__ partial, size_t n8,
+                                                             float gscale) {
+    float sq = 0.f, ab = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const Acc<8> yv = VT<YV>::ld(y + i);
+        const Acc<8> tv = VT<TV8>::ld(t + i);
+        Acc<8> g;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d = yv.v[k] - tv.v[k];
+            sq += d * d;
+            ab += fabsf(d);
+            g.v[k] = gscale * d;
+        }
+        if (dy) VT<YV>::st(dy + i, g);
+    }
+    __shared__ float s_sq[256], s_ab[256];
+    s_sq[threadIdx.x] = sq; s_ab[threadIdx.x] = ab;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { s_sq[threadIdx.x] += s_sq[threadIdx.x + s]; s_ab[threadIdx.x] += s_ab[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s_sq[0]; partial[2 * blockIdx.x + 1] = s_ab[0]; }
+}
+
 __global__ void __launch_bounds__(256) mse_stage2_kernel(const float *__restrict__ partial, float *__restrict__ loss_out,
                                                          int nblocks, float inv_n, float weight) {
     __shared__ double s_sq[256], s_ab[256];
@@ -704,7 +746,21 @@ extern "C" int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float 
     size_t g = (n + 255) / 256;
     if (g > MSE_BLOCKS) g = MSE_BLOCKS;
     const float gscale = weight * 2.f / (float)n;
-    if (dtype == DLWPCS_BF16 && t_f32)
+    const bool al = (((uintptr_t)y | (uintptr_t)t | (uintptr_t)dy) & 31) == 0;
+    if (n % 8 == 0 && al) {
+        const size_t n8 = n / 8;
+        g = (n8 + 255) / 256;
+        if (g > MSE_BLOCKS) g = MSE_BLOCKS;
+        if (dtype == DLWPCS_BF16 && t_f32)
+            hipLaunchKernelGGL((mse_stage1_vec_kernel<H8, F8>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                               (const H8 *)y, (const F8 *)t, (H8 *)dy, (float *)scratch, n8, gscale);
+        else if (dtype == DLWPCS_BF16)
+            hipLaunchKernelGGL((mse_stage1_vec_kernel<H8, H8>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                               (const H8 *)y, (const H8 *)t, (H8 *)dy, (float *)scratch, n8, gscale);
+        else
+            hipLaunchKernelGGL((mse_stage1_vec_kernel<F8, F8>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                               (const F8 *)y, (const F8 *)t, (F8 *)dy, (float *)scratch, n8, gscale);
+    } else if (dtype == DLWPCS_BF16 && t_f32)
         hipLaunchKernelGGL((mse_stage1_kernel<bf16_t, float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t *)y, (const float *)t, (bf16_t *)dy, (float *)scratch, n, gscale);
     else if (dtype == DLWPCS_BF16)
