@@ -48,6 +48,7 @@ struct ConvKParams {
     uint32_t magicW2, magicNo, magicN, magicN2;
     uint32_t magicB, magicNblk; // exact-division magics of B and nblk_face (0 when the divisor is 1)
     int patches;                // LDS holds the wave-private epilogue patches (0: no room -> direct quad stores)
+    int abl;                    // development only (-DDLWPCS_TIMELINE): epilogue ablation bits
     int tile_rows_max;          // rows reserved in LDS
     int ntiles;                 // B * 6 * nblk_face (persistent kernel)
     long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
@@ -412,27 +413,60 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         char *patch = smem + 2 * buf_bytes + wave * (32 * PROW);
         const bool lines = P.patches && (P.Cout % (16 / ES)) == 0;
         const bool wide = (P.Cout & 3) == 0;
+        // no activation == ReLU(alpha = 1, max = +inf): the epilogue applies the activation unconditionally and stays
+        // straight-line (a branch per quad chops it into 5-instruction blocks whose dependent chains cannot interleave)
+        const float e_alpha = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.alpha : 1.f;
+        const float e_vmax = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.vmax : __builtin_inff();
+        auto quad = [&](int mt, int nt, int jq) {
+            float4 v4 = make_float4(acc[mt][nt][4 * jq] + bq[nt][jq].x, acc[mt][nt][4 * jq + 1] + bq[nt][jq].y,
+                                    acc[mt][nt][4 * jq + 2] + bq[nt][jq].z, acc[mt][nt][4 * jq + 3] + bq[nt][jq].w);
+            v4.x = act_leaky_clip(v4.x, e_alpha, e_vmax); v4.y = act_leaky_clip(v4.y, e_alpha, e_vmax);
+            v4.z = act_leaky_clip(v4.z, e_alpha, e_vmax); v4.w = act_leaky_clip(v4.w, e_alpha, e_vmax);
+            return v4;
+        };
+        if (lines) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int cot = (nt0 + wn * NT + nt) * 32;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cot = (nt0 + wn * NT + nt) * 32;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = (wm * MT + mt) * 32 + l31;
-                T *dst = outp + (size_t)(gq.m0 + m) * P.Cout + cot + 4 * half;
+                for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int jq = 0; jq < 4; ++jq) {
-                    const int co = cot + 8 * jq + 4 * half;
-                    float4 v4 = make_float4(acc[mt][nt][4 * jq] + bq[nt][jq].x, acc[mt][nt][4 * jq + 1] + bq[nt][jq].y,
-                                            acc[mt][nt][4 * jq + 2] + bq[nt][jq].z, acc[mt][nt][4 * jq + 3] + bq[nt][jq].w);
-                    if (P.act == DLWPCS_ACT_LEAKY_CLIP) {
-                        v4.x = act_leaky_clip(v4.x, P.alpha, P.vmax); v4.y = act_leaky_clip(v4.y, P.alpha, P.vmax);
-                        v4.z = act_leaky_clip(v4.z, P.alpha, P.vmax); v4.w = act_leaky_clip(v4.w, P.alpha, P.vmax);
-                    }
-                    if (lines) {
+                    for (int jq = 0; jq < 4; ++jq) {
+                        const float4 v4 = quad(mt, nt, jq);
                         char *pp = patch + l31 * PROW + (8 * jq + 4 * half) * ES;
                         if constexpr (ES == 4) *reinterpret_cast<float4 *>(pp) = v4;
                         else *reinterpret_cast<uint2 *>(pp) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
-                    } else if (m < gq.npix) {
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int ps = 0; ps < 32 / PPP; ++ps) {
+                        const int px = ps * PPP + lane / LPP, q = lane % LPP;
+                        const uint4 v = *reinterpret_cast<const uint4 *>(patch + px * PROW + q * 16);
+                        const int mm = (wm * MT + mt) * 32 + px;
+                        const int c = cot + q * (16 / ES);
+#ifdef DLWPCS_TIMELINE
+                        if (P.abl & 1) continue;            // ablation: no global stores
+#endif
+                        if (mm < gq.npix && c < P.Cout)
+                            *reinterpret_cast<uint4 *>(outp + (size_t)(gq.m0 + mm) * P.Cout + c) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        } else {
+            // fallback (odd channel counts, or no LDS room for the patches): quads / scalars straight from the accumulators
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cot = (nt0 + wn * NT + nt) * 32;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = (wm * MT + mt) * 32 + l31;
+                    T *dst = outp + (size_t)(gq.m0 + m) * P.Cout + cot + 4 * half;
+#pragma unroll
+                    for (int jq = 0; jq < 4; ++jq) {
+                        const int co = cot + 8 * jq + 4 * half;
+                        const float4 v4 = quad(mt, nt, jq);
+                        if (m >= gq.npix) continue;
                         if (wide) {
                             if (co < P.Cout) {
                                 if constexpr (ES == 4) *reinterpret_cast<float4 *>(dst + 8 * jq) = v4;
@@ -448,19 +482,6 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                                 }
                         }
                     }
-                }
-                if (lines) {
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int ps = 0; ps < 32 / PPP; ++ps) {
-                        const int px = ps * PPP + lane / LPP, q = lane % LPP;
-                        const uint4 v = *reinterpret_cast<const uint4 *>(patch + px * PROW + q * 16);
-                        const int mm = (wm * MT + mt) * 32 + px;
-                        const int c = cot + q * (16 / ES);
-                        if (mm < gq.npix && c < P.Cout)
-                            *reinterpret_cast<uint4 *>(outp + (size_t)(gq.m0 + mm) * P.Cout + c) = v;
-                    }
-                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
@@ -1346,6 +1367,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     P.dbg = nullptr;
 #ifdef DLWPCS_TIMELINE
     { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
+    { const char *e = getenv("DLWPCS_ABL"); P.abl = e ? atoi(e) : 0; }
 #endif
     const size_t buf = (size_t)P.tile_rows_max * P.W2 * (KC * ES + 16) + (size_t)NTB * (KC / CGW) * KS * KS * 1024;
     size_t lds = 2 * buf + (size_t)(WM * WN) * 32 * (32 * ES + 16);            // + wave-private epilogue patches
