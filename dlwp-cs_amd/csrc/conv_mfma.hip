@@ -48,6 +48,12 @@ struct ConvKParams {
     uint32_t magicW2, magicNo, magicN, magicN2;
     uint32_t magicB, magicNblk; // exact-division magics of B and nblk_face (0 when the divisor is 1)
     int patches;                // LDS holds the wave-private epilogue patches (0: no room -> direct quad stores)
+    // Data-gradient direct mode (MODE_ZERO, k = 3, halo): output channels [0, dsplit) belong to source 0, the rest to source
+    // 1; where d0 / d1 is non-null the INTERIOR cells of the padded gradient go straight to that source's gradient tensor
+    // (B,6,No-2,No-2,channels of the source) and only the halo ring is written to `out`
+    void *d0, *d1;
+    int dsplit;
+    int *direct_done;           // HOST pointer: set to 1 by launch_conv_cfg when the kernel it launched honours d0 / d1
     int abl;                    // development only (-DDLWPCS_TIMELINE): epilogue ablation bits
     int tile_rows_max;          // rows reserved in LDS
     int ntiles;                 // B * 6 * nblk_face (persistent kernel)
@@ -447,8 +453,22 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 #ifdef DLWPCS_TIMELINE
                         if (P.abl & 1) continue;            // ablation: no global stores
 #endif
-                        if (mm < gq.npix && c < P.Cout)
-                            *reinterpret_cast<uint4 *>(outp + (size_t)(gq.m0 + mm) * P.Cout + c) = v;
+                        if (mm < gq.npix && c < P.Cout) {
+                            T *dst = outp + (size_t)(gq.m0 + mm) * P.Cout + c;
+                            if constexpr (MODE == MODE_ZERO && KS == 3) {
+                                // direct mode: an interior cell of the padded gradient IS cell (oy-1, ox-1) of the source
+                                const int gm = gq.m0 + mm;
+                                const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
+                                const int Ns = P.No - 2;
+                                const bool in0 = c < P.dsplit;
+                                T *sbase = reinterpret_cast<T *>(in0 ? P.d0 : P.d1);
+                                const int cs = in0 ? c : c - P.dsplit, CS = in0 ? P.dsplit : P.Cout - P.dsplit;
+                                const bool interior = ((uint32_t)(oy - 1) < (uint32_t)Ns) & ((uint32_t)(ox - 1) < (uint32_t)Ns);
+                                T *direct = sbase + ((((size_t)gq.b * 6 + gq.f) * Ns + (oy - 1)) * Ns + (ox - 1)) * CS + cs;
+                                dst = (interior && sbase != nullptr) ? direct : dst;
+                            }
+                            *reinterpret_cast<uint4 *>(dst) = v;
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -1320,6 +1340,8 @@ static void launch_wgrad_reduce(hipStream_t s, const float *partial, const float
 // ------------------------------------------------------------------------------------------------------------------
 int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int up,
                     int halo, int dtype, hipStream_t s);
+int launch_ring_fix(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int dtype,
+                    hipStream_t s);
 
 struct Work { double flops, bytes; };   // algorithmic work of one launch (for the opt-in profiler)
 
@@ -1373,6 +1395,11 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     size_t lds = 2 * buf + (size_t)(WM * WN) * 32 * (32 * ES + 16);            // + wave-private epilogue patches
     P.patches = 1;
     if (lds > 160 * 1024) { lds = 2 * buf; P.patches = 0; }                     // large faces: direct quad stores instead
+    if (MODE == MODE_ZERO && KS == 3 && P.patches && P.Cout % (16 / ES) == 0 && P.dsplit % (16 / ES) == 0) {
+        if (P.direct_done) *P.direct_done = (P.d0 || P.d1) ? 1 : 0;             // the line-store epilogue honours d0 / d1
+    } else {
+        P.d0 = P.d1 = nullptr;
+    }
     if (lds > 160 * 1024)
         return fail(DLWPCS_E_UNSUPPORTED, "conv: LDS tile of %zu bytes exceeds 160 KiB (face size %d)", lds, P.No);
     if (P.tile_rows_max > 32)
@@ -1703,16 +1730,26 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     P.CG = ceil_div(d->Cout, cgw_of(d->dtype)); P.NTtot = ceil_div(Cin, 32); P.up0 = 0;
     P.mode = MODE_ZERO;
     P.act = DLWPCS_ACT_NONE; P.alpha = d->alpha; P.vmax = d->vmax;
+    // direct mode: interior cells of the padded gradient go straight to the (non-upsampled) sources' gradient tensors, only
+    // the halo ring is materialised in dxv and a border fix-up replaces the full inverse-gather pass
+    int direct_done = 0;
+    const bool can_direct = d->halo && d->ksize == 3;
+    P.d0 = (can_direct && dsrc0 && !d->up0) ? dsrc0 : nullptr;
+    P.d1 = (can_direct && dsrc1 && d->C1 > 0) ? dsrc1 : nullptr;
+    P.dsplit = d->C0;
+    P.direct_done = &direct_done;
     rc = dispatch_conv(d->dtype, d->ksize, vec_width(d->Cout, 0, d->dtype), P, conv_work(d), s);
     if (rc) return rc;
     // dxv is the gradient of the (halo-padded, if halo) virtual input: (B,6,Nv,Nv,Cin), Nv = No + k - 1
     // halo: Nv = N + 2; plain: Nv = N.  Route to the sources (inverse halo gather, upsample adjoint, channel split).
     if (dsrc0) {
-        rc = launch_src_grad(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->up0, d->halo, d->dtype, s);
+        if (direct_done && P.d0) rc = launch_ring_fix(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->dtype, s);
+        else rc = launch_src_grad(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->up0, d->halo, d->dtype, s);
         if (rc) return rc;
     }
     if (dsrc1 && d->C1 > 0) {
-        rc = launch_src_grad(dxv, dsrc1, inv_table_dev, d->B, d->N, Cin, d->C0, d->C1, 0, d->halo, d->dtype, s);
+        if (direct_done && P.d1) rc = launch_ring_fix(dxv, dsrc1, inv_table_dev, d->B, d->N, Cin, d->C0, d->C1, d->dtype, s);
+        else rc = launch_src_grad(dxv, dsrc1, inv_table_dev, d->B, d->N, Cin, d->C0, d->C1, 0, d->halo, d->dtype, s);
         if (rc) return rc;
     }
     return DLWPCS_OK;

@@ -177,6 +177,40 @@ __global__ void __launch_bounds__(256) pad_bwd_src_kernel(const V *__restrict__ 
     }
 }
 
+// Border fix-up after a data-gradient kernel that wrote the INTERIOR cells of dxpad straight into dsrc (conv_mfma.hip,
+// direct mode): only the halo ring of dxpad was materialised; every border cell of the source (row/column 0 or N-1) still
+// lacks the <= 4 ring cells that gathered from it.  One thread per (sample, border cell, channel vector); p = 1.
+template <typename V>
+__global__ void __launch_bounds__(256) pad_ring_fix_kernel(const V *__restrict__ dxpad, V *__restrict__ dsrc,
+                                                           const int32_t *__restrict__ inv, size_t total, int CSV,
+                                                           int CTV, int choffV, int N) {
+    const int M = N + 2;
+    const int nb = N > 1 ? 4 * N - 4 : 1;              // border cells per face
+    const int dst_cells = 6 * M * M;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(e % CSV);
+        size_t r = e / CSV;
+        const int k = (int)(r % nb); r /= nb;
+        const int f = (int)(r % 6);
+        const size_t b = r / 6;
+        int yy, xx;                                    // k-th border cell: top row, bottom row, then the two side columns
+        if (k < N) { yy = 0; xx = k; }
+        else if (k < 2 * N) { yy = N - 1; xx = k - N; }
+        else if (k < 3 * N - 2) { yy = k - 2 * N + 1; xx = 0; }
+        else { yy = k - (3 * N - 2) + 1; xx = N - 1; }
+        const int src = (f * N + yy) * N + xx;
+        const V *base = dxpad + b * dst_cells * (size_t)CTV + choffV + cv;
+        V *dst = dsrc + (b * 6 * N * N + src) * (size_t)CSV + cv;
+        auto acc = VT<V>::ld(dst);
+        const int4 t = *reinterpret_cast<const int4 *>(inv + (size_t)src * 4);
+        if (t.x >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.x * CTV));
+        if (t.y >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.y * CTV));
+        if (t.z >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.z * CTV));
+        if (t.w >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.w * CTV));
+        VT<V>::st(dst, acc);
+    }
+}
+
 // gradient of one source of a halo==0 convolution input (no padding): channel window copy, optional 2x2 sum
 template <typename V>
 __global__ void __launch_bounds__(256) window_src_kernel(const V *__restrict__ dxv, V *__restrict__ dsrc, size_t total,
@@ -584,6 +618,22 @@ int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int 
                                CS / w, CT / w, choff / w, N, up);
     });
     return check_launch("src_grad");
+}
+
+// border fix-up of a source whose interior gradient was written directly by the data-gradient kernel (halo, p = 1, no
+// upsampling): adds the halo-ring cells of dxv that gathered from each border cell
+int launch_ring_fix(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int dtype,
+                    hipStream_t s) {
+    int g = 8;
+    while (g > 1 && (CT % g || choff % g || CS % g)) g >>= 1;
+    const int nb = N > 1 ? 4 * N - 4 : 1;
+    dispatch_vec(dtype, g, [&](auto tag, int w) {
+        using V = decltype(tag);
+        const size_t total = (size_t)B * 6 * nb * (CS / w);
+        hipLaunchKernelGGL(pad_ring_fix_kernel<V>, stream_grid(total), dim3(256), 0, s, (const V *)dxv, (V *)dsrc, inv, total,
+                           CS / w, CT / w, choff / w, N);
+    });
+    return check_launch("ring_fix");
 }
 }  // namespace dlwpcs
 
