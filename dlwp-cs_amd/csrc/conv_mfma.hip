@@ -953,8 +953,13 @@ __device__ __forceinline__ uint2 lds_tr16(const char *p) {
 // (two [pixel][32 ch] planes) against ONE dZ tile and its consumer waves split as (ci tile, slab parity) instead of four
 // slab phases -- each dZ element is loaded, masked and written to LDS once per 64 input channels instead of once per 32,
 // which is what the producers, the bottleneck of this kernel, spend most of their time on.  Items are then <= 192 pixels.
-template <int KS, bool MASK, int XV, int QX, int CT>
+// DV = channels per dZ load: 8 (16-B vectors), or 2 for output-channel counts that are only even and <= 16 (the 14-channel
+// 1x1 head): 8 four-byte vectors per pixel, columns 16..31 of the dZ tile are never written and only feed accumulator
+// columns >= C_out.
+template <int KS, bool MASK, int XV, int QX, int CT, int DV>
 __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
+    constexpr int QD = DV == 8 ? 4 : 8;     // dZ vectors staged per pixel
+    typedef typename VecT<bf16_t, DV>::type DVec;
     constexpr int TAPS = KS * KS;
     constexpr int PB = 64;                  // LDS bytes per pixel and plane: 32 channels bf16 (X planes and dZ tile alike)
     constexpr int NCT = 256;                // consumer threads == producer threads
@@ -962,7 +967,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     // X vectors per producer thread per item: capacity IT_X * 256 / QXT tile pixels (512 / 320 / 512|256)
     constexpr int IT_X = XV == 8 ? (CT == 2 ? 10 : 8) : 16;
     typedef typename VecT<bf16_t, XV>::type XVec;
-    constexpr int IT_DY = CT == 2 ? 3 : 6;  // dZ 16-B vectors per producer thread per item: capacity 192 / 384 pixels
+    constexpr int IT_DY = (CT == 2 ? 3 : 6) * (QD / 4);   // dZ vectors per producer thread per item: capacity 192 / 384 pixels
     constexpr int NPH = 4 / CT;             // consumer waves sharing the slabs of one ci tile
     static_assert(CT == 1 || (XV == 8 && QX == 4), "two ci tiles per worker need full 16-B X vectors");
     const ConvKParams &P = W.c;
@@ -1010,7 +1015,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     if (tid >= NCT) {
         // =========================================== producers ===========================================
         const int ptid = tid - NCT;
-        const int qx = ptid & 3;                            // this thread's 8-channel dZ group: fixed for the whole kernel
+        const int qx = ptid % QD;                           // this thread's dZ channel group: fixed for the whole kernel
         const int cx = cit * 32 * CT + (ptid % QXT) * XV;   // this thread's X channels: fixed as well (256 % QXT == 0)
         const bool cx_ok = cx < P.Cin;
         const bool from0 = cx < P.C0;
@@ -1019,12 +1024,12 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         const int cstride = from0 ? P.C0 : P.C1;
         const bool up = from0 && P.up0;
         const int M = P.Nin + KS - 1;
-        const int co = cot * 32 + qx * 8;
+        const int co = cot * 32 + qx * DV;
         const bool co_ok = co < P.Cout;
         const bool want_bias = W.bpartial != nullptr && cit == 0;
-        float bsum[8];
+        float bsum[DV];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) bsum[u] = 0.f;
+        for (int u = 0; u < DV; ++u) bsum[u] = 0.f;
         // Per-slot gather offsets (elements, relative to the sample's base pointer; -1 = zero cell), valid for one
         // (face, band) combination: halo-table lookup + upsample decode happen here, once per combo, not once per item.
         int xoff[IT_X];
@@ -1047,10 +1052,10 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             }
             cur_combo = it.combo;
         };
-        // dZ slot offsets never change: slot i is pixel kk = (ptid + i*NCT) / 4 of the band, channels co..co+7
+        // dZ slot offsets never change: slot i is pixel kk = (ptid + i*NCT) / QD of the band, channels co..co+DV-1
         int doff[IT_DY];
 #pragma unroll
-        for (int i = 0; i < IT_DY; ++i) doff[i] = ((ptid + i * NCT) >> 2) * P.Cout + co;
+        for (int i = 0; i < IT_DY; ++i) doff[i] = ((ptid + i * NCT) / QD) * P.Cout + co;
         const size_t sample_elems = from0 ? (size_t)6 * g0 * g0 * P.C0 : (size_t)6 * P.Nin * P.Nin * P.C1;
         const bf16_t *src_base = reinterpret_cast<const bf16_t *>(from0 ? P.src0 : P.src1);
         // Two register sets, prefetch distance 2: the loads of item k+1 are issued BEFORE the loads of item k are waited for,
@@ -1058,7 +1063,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         // producers spent more than half of every item waiting; the consumers, 16x faster than in the fp32 kernel, idled).
         struct Stage {
             XVec xv[IT_X];
-            uint4 dv[IT_DY], yv[MASK ? IT_DY : 1];
+            DVec dv[IT_DY], yv[MASK ? IT_DY : 1];
             bool xok[IT_X], dok[IT_DY];
         };
         auto issue = [&](const Item &it, Stage &st) {
@@ -1079,8 +1084,8 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             for (int i = 0; i < IT_DY; ++i) {
                 const bool ok = co_ok && doff[i] < dlim;
                 const uint32_t o = ok ? (uint32_t)doff[i] : 0u;
-                st.dv[i] = *reinterpret_cast<const uint4 *>(dyb + o);
-                if (MASK) st.yv[i] = *reinterpret_cast<const uint4 *>(yb + o);
+                st.dv[i] = *reinterpret_cast<const DVec *>(dyb + o);
+                if (MASK) st.yv[i] = *reinterpret_cast<const DVec *>(yb + o);
                 st.dok[i] = ok;
             }
         };
@@ -1102,7 +1107,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                 bf16_t *dzb = reinterpret_cast<bf16_t *>(W.dz_out) + (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * P.Cout;
 #pragma unroll
                 for (int i = 0; i < IT_DY; ++i)
-                    if (st.dok[i]) *reinterpret_cast<uint4 *>(dzb + (uint32_t)doff[i]) = st.dv[i];
+                    if (st.dok[i]) *reinterpret_cast<DVec *>(dzb + (uint32_t)doff[i]) = st.dv[i];
             }
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
@@ -1114,10 +1119,15 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
                 const int e = ptid + i * NCT;
-                if (e < pix_cap * 4) *reinterpret_cast<uint4 *>(buf + x_bytes + (size_t)e * 16) = st.dv[i];
+                if (e < pix_cap * QD)
+                    *reinterpret_cast<DVec *>(buf + x_bytes + (size_t)(e / QD) * PB + (e % QD) * (DV * 2)) = st.dv[i];
                 if (want_bias) {
-                    bsum[0] += bf_lo(st.dv[i].x); bsum[1] += bf_hi(st.dv[i].x); bsum[2] += bf_lo(st.dv[i].y); bsum[3] += bf_hi(st.dv[i].y);
-                    bsum[4] += bf_lo(st.dv[i].z); bsum[5] += bf_hi(st.dv[i].z); bsum[6] += bf_lo(st.dv[i].w); bsum[7] += bf_hi(st.dv[i].w);
+                    if constexpr (DV == 8) {
+                        bsum[0] += bf_lo(st.dv[i].x); bsum[1] += bf_hi(st.dv[i].x); bsum[2] += bf_lo(st.dv[i].y); bsum[3] += bf_hi(st.dv[i].y);
+                        bsum[4] += bf_lo(st.dv[i].z); bsum[5] += bf_hi(st.dv[i].z); bsum[6] += bf_lo(st.dv[i].w); bsum[7] += bf_hi(st.dv[i].w);
+                    } else {
+                        bsum[0] += bf_lo(st.dv[i]); bsum[1] += bf_hi(st.dv[i]);
+                    }
                 }
             }
             PL_MARK();
@@ -1140,18 +1150,20 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                 i0 = i2; i1 = i3;
             }
         }
-        // ---- bias partial: thread (q = ptid & 3, 64 pixel phases) holds sums of channels 8q..8q+7 -> fixed-order sum
+        // ---- bias partial: thread (q = ptid % QD, 256/QD pixel phases) holds sums of channels DV*q.. -> fixed-order sum
         __syncthreads();                // consumers are done with the buffers (matches the consumers' final barrier)
         float *red = reinterpret_cast<float *>(smem) + 4096;   // behind the consumers' 4 x 1024-float reduction scratch
         if (want_bias) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) red[ptid * 8 + u] = bsum[u];
+            for (int u = 0; u < DV; ++u) red[ptid * DV + u] = bsum[u];
         }
         __syncthreads();
         if (want_bias && ptid < 32) {
             float sum = 0.f;
+            if (ptid < QD * DV) {
 #pragma unroll
-            for (int ph = 0; ph < 64; ++ph) sum += red[(ph * 4 + (ptid >> 3)) * 8 + (ptid & 7)];
+                for (int ph = 0; ph < NCT / QD; ++ph) sum += red[(ph * QD + ptid / DV) * DV + (ptid % DV)];
+            }
             W.bpartial[(size_t)worker * W.CoutP + cot * 32 + ptid] = sum;
         }
         // the consumers' tap loop below executes 2 barriers per tap: keep the barrier counts of both halves equal
@@ -1282,13 +1294,19 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
         const int ty = tap / KS, tx = tap % KS;
         // face 5 ran with the row-reversed kernel: its partial for tap row r belongs to kernel row KS-1-r
         const size_t o5 = flip ? ((size_t)((KS - 1 - ty) * KS + tx) * CinP + ci) * CoutP + co : off;
+#pragma unroll 8
         for (int s = ph; s < e4; s += 16) s_eq += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + off);
+#pragma unroll 4
         for (int s = e4 + ph; s < e5; s += 16) s_4 += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + off);
+#pragma unroll 4
         for (int s = e5 + ph; s < e6; s += 16) s_5 += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + o5);
     } else if (is_b) {
         const int co = e - nW;
+#pragma unroll 8
         for (int s = ph; s < e4; s += 16) s_eq += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
+#pragma unroll 4
         for (int s = e4 + ph; s < e5; s += 16) s_4 += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
+#pragma unroll 4
         for (int s = e5 + ph; s < e6; s += 16) s_5 += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
     }
     __shared__ VT red[3][256];
@@ -1522,14 +1540,17 @@ struct WsLayout {
 // persistent weight-gradient launch geometry: pixels per work item, items (bands) per face, workers per face class
 // bf16 matrix-core weight gradient (wgrad_bf16_kernel): bf16 tensors whose channel counts are all multiples of 8
 static bool wgrad_bf16_eligible(const dlwpcs_conv_desc *d) {
-    return d->dtype == DLWPCS_BF16 && d->C0 % 2 == 0 && d->C1 % 2 == 0 && d->Cout % 8 == 0;
+    // dZ vectors: 8 channels, or (1x1 kernels only, e.g. the 14-channel head) 2 channels with C_out <= 16
+    const bool dz_ok = d->Cout % 8 == 0 || (d->ksize == 1 && d->Cout % 2 == 0 && d->Cout <= 16);
+    if (d->Cout % 8 != 0 && (d->C0 % 8 != 0 || d->C1 % 8 != 0)) return false;      // 4-B vectors on one side only
+    return d->dtype == DLWPCS_BF16 && d->C0 % 2 == 0 && d->C1 % 2 == 0 && dz_ok;
 }
 // X staging of wgrad_bf16_kernel: channels per load, vectors per tile pixel, tile-pixel capacity of the producers
 static void wgrad_bf16_xcfg(const dlwpcs_conv_desc *d, int &xv, int &qx, int &cap_px, int &ct) {
     ct = 1;
     if (d->C0 % 8 == 0 && d->C1 % 8 == 0) {
         xv = 8; qx = 4; cap_px = 512;
-        if ((d->C0 + d->C1) % 64 == 0) { ct = 2; cap_px = 320; }     // two ci tiles per worker, items <= 192 pixels
+        if ((d->C0 + d->C1) % 64 == 0 && d->Cout % 8 == 0) { ct = 2; cap_px = 320; }   // two ci tiles per worker, items <= 192 px
     }
     else if (d->C0 + d->C1 <= 16) { xv = 2; qx = 8; cap_px = 512; }
     else { xv = 2; qx = 16; cap_px = 256; }
@@ -1819,9 +1840,9 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
         if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
         if ((long)P.Nin * P.Nin >= (1l << 16))
             return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: face size %d too large for the 16-bit index arithmetic", P.Nin);
-#define WGB_LAUNCH(KSV, MASKV, XVV, QXV, CTV)                                                                             \
+#define WGB_LAUNCH(KSV, MASKV, XVV, QXV, CTV, DVV)                                                                        \
     do {                                                                                                                  \
-        auto kern = wgrad_bf16_kernel<KSV, MASKV, XVV, QXV, CTV>;                                                         \
+        auto kern = wgrad_bf16_kernel<KSV, MASKV, XVV, QXV, CTV, DVV>;                                                    \
         if (lds > 64 * 1024) {                                                                                            \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));    \
@@ -1829,19 +1850,25 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
         int pidx = -1;                                                                                                    \
         if (prof_enabled()) {                                                                                             \
             const Work wk = conv_work(d);                                                                                 \
-            pidx = prof_begin("wgrad_bf16_kernel<" #KSV ", " #MASKV ", " #XVV ", " #QXV ", " #CTV ">", wk.flops, wk.bytes, s); \
+            pidx = prof_begin("wgrad_bf16_kernel<" #KSV ", " #MASKV ", " #XVV ", " #QXV ", " #CTV ", " #DVV ">", wk.flops,    \
+                              wk.bytes, s);                                                                               \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, W);                                                             \
         if (pidx >= 0) prof_end(pidx, s);                                                                                 \
     } while (0)
 #define WGB_X(KSV, MASKV)                                                                                                 \
     do {                                                                                                                  \
-        if (xv == 8 && ct == 2) WGB_LAUNCH(KSV, MASKV, 8, 4, 2);                                                          \
-        else if (xv == 8) WGB_LAUNCH(KSV, MASKV, 8, 4, 1);                                                                \
-        else if (qx == 8) WGB_LAUNCH(KSV, MASKV, 2, 8, 1);                                                                \
-        else WGB_LAUNCH(KSV, MASKV, 2, 16, 1);                                                                            \
+        if (xv == 8 && ct == 2) WGB_LAUNCH(KSV, MASKV, 8, 4, 2, 8);                                                       \
+        else if (xv == 8) WGB_LAUNCH(KSV, MASKV, 8, 4, 1, 8);                                                             \
+        else if (qx == 8) WGB_LAUNCH(KSV, MASKV, 2, 8, 1, 8);                                                             \
+        else WGB_LAUNCH(KSV, MASKV, 2, 16, 1, 8);                                                                         \
     } while (0)
-        if (KS == 3) { if (mask) WGB_X(3, true); else WGB_X(3, false); }
+        if (d->Cout % 8 != 0) {
+            // 1x1 kernel with an even C_out <= 16: 4-B dZ vectors; X must take the plain 16-B path
+            if (xv != 8) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: even-only C_in and C_out together");
+            if (mask) WGB_LAUNCH(1, true, 8, 4, 1, 2); else WGB_LAUNCH(1, false, 8, 4, 1, 2);
+        }
+        else if (KS == 3) { if (mask) WGB_X(3, true); else WGB_X(3, false); }
         else { if (mask) WGB_X(1, true); else WGB_X(1, false); }
 #undef WGB_X
 #undef WGB_LAUNCH
