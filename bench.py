@@ -147,6 +147,7 @@ def measure(args, dtype, rank, world, local_rank, with_roofline):
     model = build_model(args.workload, N, C, C, base)
     backend.set_compute_dtype('float32')
     model.use_graphs = not args.no_graphs
+    model.static_batch_buffers = True      # the batch lives in the same HBM tensors every step (inputs resident in HBM)
     model.compile(optimizer='adam', loss='mse')
     adt = torch.bfloat16 if dtype == 'bf16' else torch.float32
     rng = np.random.default_rng(1000 + rank)

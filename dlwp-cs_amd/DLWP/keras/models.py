@@ -57,6 +57,10 @@ class Model(object):
         self.compute_dtype = backend.compute_dtype()
         self.prepack_weights = os.environ.get('DLWPCS_PREPACK', '1') != '0'
         self.wgrad_side_stream = os.environ.get('DLWPCS_SIDE_STREAM', '0') == '1'   # measured slower on MI355X: off
+        # True: the caller feeds every step through the SAME device tensors (e.g. a generator that assembles each batch in
+        # place): the captured graphs read them directly instead of copying each batch into private static buffers
+        self.static_batch_buffers = False
+        self._ones = {}
         self._compiled = False
         self._flat_params = self._flat_grads = None
         self._graphs = {}
@@ -340,7 +344,12 @@ class Model(object):
                              % (len(outs), len(targets)))
         stats = [ops.mse_mae(o, t, w) for o, t, w in zip(outs, targets, self.loss_weights)]
         if train:
-            ones = [torch.ones(2, dtype=torch.float32, device=stats[0].device) for _ in stats]
+            dev = stats[0].device
+            if dev not in self._ones:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('first training step must run eagerly (graph capture allocates nothing)')
+                self._ones[dev] = torch.ones(2, dtype=torch.float32, device=dev)
+            ones = [self._ones[dev] for _ in stats]
             ops.DIRECT_PARAM_GRADS = True       # weight gradients accumulate straight into the flat gradient buffer
             ops.WGRAD_SIDE_STREAM = self.wgrad_side_stream
             try:
@@ -387,8 +396,11 @@ class Model(object):
         return g['stats']
 
     def _capture(self, key, inputs, targets):
-        static_in = [torch.empty_like(t).copy_(t) for t in inputs]
-        static_tg = [torch.empty_like(t).copy_(t) for t in targets]
+        if self.static_batch_buffers:
+            static_in, static_tg = list(inputs), list(targets)
+        else:
+            static_in = [torch.empty_like(t).copy_(t) for t in inputs]
+            static_tg = [torch.empty_like(t).copy_(t) for t in targets]
         self.optimizer._ensure_state(self._flat_params)
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
