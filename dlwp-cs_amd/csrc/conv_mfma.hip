@@ -684,19 +684,23 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
     else if (worker < W.n_eq + W.n_4) { j = worker - W.n_eq; nj = W.n_4; nfaces = 1; fbase = 4; }
     else { j = worker - W.n_eq - W.n_4; nj = W.n_5; nfaces = 1; fbase = 5; }
     const int nbands = P.nblk_face;
+    // Items in (face, band)-major, SAMPLE-minor order, one contiguous range per worker (see wgrad_bf16_kernel): gather
+    // offsets are rebuilt only at the few (face, band) changes, per item only a scalar sample base moves.
     const int total_items = P.B * nfaces * nbands;
-    const int n_my = j < total_items ? (total_items - j + nj - 1) / nj : 0;
+    const int t_first = (int)(((long)total_items * j) / nj), t_last = (int)(((long)total_items * (j + 1)) / nj);
+    const int n_my = t_last - t_first;
     const int face_pix = P.No * P.No;
     const int tid = threadIdx.x;
 
-    struct Item { int b, f, m0, npix, y0, nitems; };
+    struct Item { int b, f, combo, m0, npix, y0, nitems; };
     auto item_of = [&](int k) {
         Item it;
-        const int t = j + max(min(k, n_my - 1), 0) * nj;
-        const int band = t % nbands;
-        const int r = t / nbands;
-        it.f = fbase + r % nfaces;
-        it.b = r / nfaces;
+        const int t = t_first + max(min(k, n_my - 1), 0);
+        it.combo = W.magicB ? __umulhi((uint32_t)t, W.magicB) : t;                    // t / B   (magic 0 <=> divisor 1)
+        it.b = t - it.combo * P.B;
+        const int fl = W.magicNb ? __umulhi((uint32_t)it.combo, W.magicNb) : it.combo;   // combo / nbands
+        const int band = it.combo - fl * nbands;
+        it.f = fbase + fl;
         it.m0 = band * P.pix_per_block;
         it.npix = min(P.pix_per_block, face_pix - it.m0);
         it.y0 = __umulhi((uint32_t)it.m0, P.magicNo);
@@ -719,8 +723,10 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
         const bool vec_dy = (P.Cout % 4 == 0);      // block-uniform
         const bool want_bias = W.bpartial != nullptr && cit == 0;
         float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);     // dZ column sums of this thread's (pixel subset, 4 channels)
-        int sidx[IT_X], sidx_n[IT_X];
-        auto lookup = [&](const Item &it, int (&sx)[IT_X]) {
+        // per-slot gather offsets (elements relative to the sample's base; -1 = zero cell), valid for one (face, band)
+        int xoff[IT_X];
+        int cur_combo = -1;
+        auto rebuild = [&](const Item &it) {
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int e = min(ptid + i * NCT, it.nitems - 1);
@@ -728,14 +734,19 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
                 const int ty = __umulhi((uint32_t)pix, P.magicW2);
                 const int tx = pix - ty * P.W2;
                 const int iy = it.y0 + ty;
-                int v0;
-                if (P.mode == MODE_HALO) v0 = P.table[(it.f * M + iy) * M + tx];
-                else v0 = (it.f * P.Nin + iy) * P.Nin + tx;
-                sx[i] = (ptid + i * NCT < it.nitems) ? v0 : -1;
+                int ii;
+                if (P.mode == MODE_HALO) ii = P.table[(it.f * M + iy) * M + tx];
+                else ii = (it.f * P.Nin + iy) * P.Nin + tx;
+                const int r = __umulhi((uint32_t)ii, P.magicN);      // row face*Nin + y of the Nin grid -> row r/2 of Nin/2
+                const int pix_up = (r >> 1) * g0 + ((ii - r * P.Nin) >> 1);
+                const int spix = up ? pix_up : ii;
+                xoff[i] = (cx_ok && ptid + i * NCT < it.nitems) ? spix * cstride + cs : -1;
             }
+            cur_combo = it.combo;
         };
+        const size_t sample_elems = from0 ? (size_t)6 * g0 * g0 * P.C0 : (size_t)6 * P.Nin * P.Nin * P.C1;
+        const T *src_base = reinterpret_cast<const T *>(from0 ? P.src0 : P.src1);
         Item cur = item_of(0);
-        if (n_my > 0) lookup(cur, sidx);
 #ifdef DLWPCS_TIMELINE
         int pli = 0;
         long long *plp = (P.dbg && ptid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
@@ -744,24 +755,16 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
             PL_MARK();
             float *buf = smem + (k & 1) * buf_floats;
             const Item nxt = item_of(k + 1);
-            const T *sb = from0 ? reinterpret_cast<const T *>(P.src0) + (size_t)cur.b * 6 * g0 * g0 * P.C0
-                                : reinterpret_cast<const T *>(P.src1) + (size_t)cur.b * 6 * P.Nin * P.Nin * P.C1;
+            if (cur.combo != cur_combo) rebuild(cur);              // uniform, a few times per worker
+            const T *sb = src_base + (size_t)cur.b * sample_elems;
             // ---- X tile: every load in flight at once
             V xv[IT_X];
             bool xok[IT_X];
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
-                const int idx = sidx[i];
-                const bool ok = cx_ok && idx >= 0;
-                const int ii = ok ? idx : 0;
-                const int vf = __umulhi((uint32_t)ii, P.magicN2);
-                const int rem = ii - vf * P.Nin * P.Nin;
-                const int vy = __umulhi((uint32_t)rem, P.magicN);
-                const int vx = rem - vy * P.Nin;
-                const int pix_up = (vf * g0 + (vy >> 1)) * g0 + (vx >> 1);
-                const int pix = up ? pix_up : ii;
-                xv[i] = *reinterpret_cast<const V *>(sb + (ok ? (size_t)pix * cstride + cs : 0));
-                xok[i] = ok;
+                const int o = xoff[i];
+                xv[i] = *reinterpret_cast<const V *>(sb + (uint32_t)max(o, 0));
+                xok[i] = o >= 0;
             }
             // ---- dZ tile [pix][32 output channels of tile cot] = dy * act'(y), zero beyond npix / Cout
             const size_t rowbase = (((size_t)cur.b * 6 + cur.f) * face_pix + cur.m0) * P.Cout;
@@ -800,7 +803,6 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
                     dok[i] = true;
                 }
             }
-            lookup(nxt, sidx_n);                                   // next item's halo-table entries ride along
             PL_MARK();
             // dZ = dy * act'(y), applied only after EVERY load of the item has been issued
 #pragma unroll
@@ -824,8 +826,6 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
             PL_MARK();
             __syncthreads();            // B_k: item k is in LDS
             cur = nxt;
-#pragma unroll
-            for (int i = 0; i < IT_X; ++i) sidx[i] = sidx_n[i];
         }
         // ---- bias partial: thread (q = ptid & 7, 32 pixel phases) holds sums of channels 4q..4q+3 -> fixed-order tree
         __syncthreads();                // consumers are done with the buffers (matches the consumers' final barrier)
