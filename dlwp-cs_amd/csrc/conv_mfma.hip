@@ -811,6 +811,19 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
                 if (MASK) { yv[i] = to_f4(yvr[i]); vmask(dv[i], yv[i], P.alpha, P.vmax); }
                 dv[i] = vsel(dok[i], dv[i]);
             }
+            // DLWPCS_CONV_REUSE_DZ (fp32 tensors, C_out % 4 == 0): the workers of ci tile 0 see every dZ element exactly
+            // once -> they hand dz to the data-gradient kernel that follows
+            if constexpr (MASK && sizeof(T) == 4) {
+                if (W.dz_out != nullptr && cit == 0 && vec_dy) {
+                    float *dzb = reinterpret_cast<float *>(W.dz_out) + rowbase;
+#pragma unroll
+                    for (int i = 0; i < IT_DY; ++i) {
+                        const int e = ptid + i * NCT;
+                        const int kk = e >> 3, co = cot * 32 + (e & 7) * 4;
+                        if (kk < cur.npix && co < P.Cout) *reinterpret_cast<float4 *>(dzb + (size_t)kk * P.Cout + co) = dv[i];
+                    }
+                }
+            }
             // ---- registers -> LDS
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
@@ -1632,6 +1645,7 @@ static bool wgrad_bf16_fits(const dlwpcs_conv_desc *d, const WsLayout &L) {
 }
 static bool dz_handover(const dlwpcs_conv_desc *d) {
     if (!(d->flags & DLWPCS_CONV_REUSE_DZ) || d->act == DLWPCS_ACT_NONE || d->B == 0) return false;
+    if (d->dtype == DLWPCS_F32) return d->Cout % 4 == 0;        // wgrad_mfma_kernel<float>, vector dZ path
     return wgrad_bf16_fits(d, ws_layout(d));
 }
 
