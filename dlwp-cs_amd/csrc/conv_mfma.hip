@@ -45,7 +45,7 @@ struct ConvKParams {
     int pix_per_block;          // valid pixels per workgroup (<= 32*MT*WM)
     int nblk_face;              // workgroups per (sample, face)
     int W2;                     // tile width = No + KS - 1
-    uint32_t magicW2, magicNo, magicN, magicN2;
+    uint32_t magicW2, magicNo, magicN;
     uint32_t magicB, magicNblk; // exact-division magics of B and nblk_face (0 when the divisor is 1)
     int patches;                // LDS holds the wave-private epilogue patches (0: no room -> direct quad stores)
     // Data-gradient direct mode (MODE_ZERO, k = 3, halo): output channels [0, dsplit) belong to source 0, the rest to source
@@ -1412,7 +1412,6 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     P.magicW2 = div_magic(P.W2);
     P.magicNo = div_magic(P.No);
     P.magicN = div_magic(P.Nin);
-    P.magicN2 = div_magic(P.Nin * P.Nin);
     P.magicB = P.B > 1 ? div_magic(P.B) : 0;
     P.magicNblk = P.nblk_face > 1 ? div_magic(P.nblk_face) : 0;
     P.tile_rows_max = tile_rows_for(pix, P.No) + (KS - 1);
@@ -1834,7 +1833,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     W.bpartial = want_bias ? (float *)(ws + L.bpartial) : nullptr;
     W.CinP = CinP; W.CoutP = CoutP;
     W.n_eq = L.n_eq; W.n_4 = L.n_4; W.n_5 = L.n_5;
-    P.magicN = div_magic(P.Nin); P.magicN2 = div_magic(P.Nin * P.Nin);
+    P.magicN = div_magic(P.Nin);
     W.magicB = P.B > 1 ? div_magic(P.B) : 0; W.magicNb = P.nblk_face > 1 ? div_magic(P.nblk_face) : 0;
     P.dbg = nullptr;
 #ifdef DLWPCS_TIMELINE
@@ -1843,7 +1842,6 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     if (P.C1 == 0) P.src1 = P.src0;
     const bool mask = d->act != DLWPCS_ACT_NONE;
     dim3 grid((unsigned)(L.n_eq + L.n_4 + L.n_5), (unsigned)(CinP / 32), (unsigned)(CoutP / 32));
-    const int nout = TAPS * Cin * d->Cout + (want_bias ? d->Cout : 0);
     int xv = 0, qx = 0, cap_px = 0, ct = 1;
     if (wgrad_bf16_eligible(d)) wgrad_bf16_xcfg(d, xv, qx, cap_px, ct);
     if (wgrad_bf16_fits(d, L)) {

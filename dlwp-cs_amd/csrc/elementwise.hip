@@ -456,6 +456,7 @@ __global__ void __launch_bounds__(256) batch_gather_cf_kernel(const float *__res
                                                               const int32_t *__restrict__ var_idx, int nv, int n_steps,
                                                               int t_off, int t_stride, OT *__restrict__ out, int Ctot,
                                                               int c_off, int c_stride) {
+    (void)n_steps;                                  // grid.y enumerates the n_steps * nv gathered channels
     const int cc = blockIdx.y, b = blockIdx.z;
     const int n = cc / nv, j = cc - n * nv;
     const float *src = array + ((size_t)((long)samples[b] + t_off + (long)n * t_stride) * V + var_idx[j]) * S;

@@ -129,7 +129,7 @@ def conv2d_tf(x, kernel, strides=(1, 1), padding='valid', dilation=(1, 1)):
     (B, H, W, C) [channels_last], kernel is HWIO (kh, kw, C_in, C_out).  Returns (B, H', W', C_out).
     """
     xc = x.permute(0, 3, 1, 2)
-    w = kernel.permute(3, 2, 0, 1)
+    w = kernel.permute(3, 2, 0, 1).contiguous()      # (torch-CPU's slow_conv2d backward needs a contiguous weight)
     if padding == 'same':
         pt, pb = _same_pads(xc.shape[2], w.shape[2], strides[0], dilation[0])
         pl, pr = _same_pads(xc.shape[3], w.shape[3], strides[1], dilation[1])
