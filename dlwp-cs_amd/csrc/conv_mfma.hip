@@ -233,14 +233,17 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             for (int i = 0; i < ITS; ++i) {
                 const int sc = slot_c[i];
                 const int a = base + (sc >> 6);
+                const bool live = ptid + i * NCT < gq.nitems;
                 int v0;
-                if (MODE == MODE_HALO) v0 = P.table[a];
+                // (a slot beyond THIS band's rows would index past the band -- for the last band of face 5 past the end of
+                // the table: dead slots read entry 0)
+                if (MODE == MODE_HALO) v0 = P.table[live ? a : 0];
                 else if (MODE == MODE_DIRECT) v0 = a;
                 else {
                     const int vy = gq.y0 + (sc & 31) - PADZ;
                     v0 = ((vy >= 0) & (vy < P.Nin) & ((sc >> 5) & 1)) ? a : -1;
                 }
-                sidx[i] = (ptid + i * NCT < gq.nitems) ? v0 : -1;
+                sidx[i] = live ? v0 : -1;
             }
         };
         int sidx[ITS];
