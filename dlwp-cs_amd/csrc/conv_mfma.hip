@@ -367,8 +367,9 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int jq = 0; jq < 4; ++jq)
+                // (an N tile beyond C_out -- NTtot not a multiple of the workgroup's N tiles -- re-reads the last tile's quads)
                 bq[nt][jq] = P.bias ? *reinterpret_cast<const float4 *>(P.bias + (size_t)gq.v * P.NTtot * 32 +
-                                                                         (nt0 + wn * NT + nt) * 32 + 8 * jq + 4 * half)
+                                                                         min(nt0 + wn * NT + nt, P.NTtot - 1) * 32 + 8 * jq + 4 * half)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
 
         for (int ch = 0; ch < nchunks; ++ch, ++g) {
