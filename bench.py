@@ -110,6 +110,22 @@ def cpu_baseline(workload, N, c_in, c_out, base, budget_s=20.0, batch=4):
                       '(materialised halo padding, 6 per-face conv2d per layer)' % (iters, batch, workload)}
 
 
+PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r01_bench_unet2_b32_hbm_pmc.txt')
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC summary (tools/make_profiles.py), or (None, reason)."""
+    try:
+        for line in open(PMC_PROFILE):
+            if line.startswith(kernel + ' ') or line.startswith(kernel[:84] + ' '):
+                cols = line[84:].split()
+                if len(cols) >= 4:
+                    return int((float(cols[2]) + float(cols[3])) * 1024), os.path.relpath(PMC_PROFILE, ROOT)
+    except (OSError, ValueError):
+        pass
+    return None, 'no PMC record for this kernel in profiles/'
+
+
 def roofline_pass(model, dx, dt, steps=3):
     """Eager steps with the library's per-launch HIP-event profiler on; aggregate per kernel name."""
     from DLWP import _native as nat
@@ -208,9 +224,12 @@ def measure(args, dtype, rank, world, local_rank, with_roofline):
                         'frac': round(t_b / t, 4)}
             name, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
             rf = bound_of(name, cnt, ms, fl, by)
-            # HBM-side bytes need PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass): collected with
-            # this same command and committed per kernel in profiles/r01_bench_unet2_b32_hbm_pmc.txt
-            rf.update({'traffic': None, 'traffic_profile': 'profiles/r01_bench_unet2_b32_hbm_pmc.txt', 'kernel': name, 'launches': cnt, 'avg_launch_us': round(1e3 * ms / cnt, 2),
+            # HBM-side bytes need PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass, cannot run inside
+            # this process): they are collected with this same command and committed per kernel in profiles/; `traffic` is
+            # that measurement for the dominant kernel (FETCH_SIZE x 2 per the gfx950 calibration + WRITE_SIZE), bytes/launch
+            traffic, tsrc = pmc_traffic(name)
+            rf.update({'traffic': traffic, 'traffic_source': tsrc, 'kernel': name, 'launches': cnt,
+                       'avg_launch_us': round(1e3 * ms / cnt, 2),
                        'algorithmic_gflop_per_launch': round(fl / cnt / 1e9, 3),
                        'algorithmic_mbytes_per_launch': round(by / cnt / 1e6, 3)})
             tot_ms = sum(v[1] for v in agg.values())
