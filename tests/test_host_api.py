@@ -251,3 +251,29 @@ def test_model_log_names_match_keras():
         m2.compile(loss='mse', loss_weights=[1.0])
     with pytest.raises(NotImplementedError):
         m1.compile(loss='mae')
+
+
+def test_mixed_precision_policy_and_exports():
+    """the counterpart of the reference's AMP switch (Azure/train_cs.py:429) and the DLWP.model exports"""
+    from DLWP.keras import Input, Model, backend, mixed_precision
+    from DLWP.keras.optimizers import Adam
+    from DLWP.model import ArrayDataGenerator, DLWPFunctional, tf_data_generator   # noqa: F401
+    from DLWP.model.cs_unet import CubeSphereNet
+    assert mixed_precision.global_policy().name == 'float32' and backend.compute_dtype() == 'float32'
+    opt = Adam()
+    try:
+        assert mixed_precision.enable_mixed_precision_graph_rewrite(opt) is opt
+        pol = mixed_precision.global_policy()
+        assert (pol.name, pol.compute_dtype, pol.variable_dtype) == ('mixed_bfloat16', 'bfloat16', 'float32')
+        inp = Input(shape=(6, 8, 8, 3))
+        model = Model(inputs=inp, outputs=CubeSphereNet(base_filter_number=4, output_channels=3).unet2(inp))
+        assert model.compute_dtype == 'bfloat16'
+        import torch
+        assert all(w.dtype == torch.float32 for lay in model.layers for w in getattr(lay, 'weights', []))
+    finally:
+        mixed_precision.disable_mixed_precision_graph_rewrite()
+    assert backend.compute_dtype() == 'float32'
+    with pytest.raises(ValueError):
+        mixed_precision.set_policy('mixed_float16')
+    inp = Input(shape=(6, 8, 8, 3))
+    assert Model(inputs=inp, outputs=CubeSphereNet(base_filter_number=4, output_channels=3).unet2(inp)).compute_dtype == 'float32'
