@@ -13,6 +13,8 @@ import pickle
 import re
 from copy import copy
 
+import numpy as np
+
 
 def make_keras_picklable():
     """No-op: DLWP.keras models are plain Python objects (the reference patched keras.Model, util.py:28-80)."""
@@ -100,3 +102,44 @@ def is_channels_last(model):
         if hasattr(layer, 'data_format'):
             return layer.data_format == 'channels_last'
     return False
+
+
+def insolation(dates, lat, lon, S=1., daily=False):
+    """
+    Approximate top-of-atmosphere solar insolation, the `solar` input channel of the DLWP-CS models (reference
+    DLWP/util.py:306-364; pinned to the reference by tests/golden/g6_insolation.npz).
+
+    :param dates: 1-d sequence of datetimes / Timestamps / datetime64
+    :param lat, lon: both 1-d (a regular grid is formed) or both N-d of equal shape (e.g. cubed-sphere (6, N, N)); degrees,
+        lon in 0-360
+    :param S: solar constant scaling
+    :param daily: True -> daily maximum (local noon) instead of the instantaneous value
+    :return: float32 array (date, *grid)
+    """
+    import pandas as pd
+    lat, lon = np.asarray(lat), np.asarray(lon)
+    if lat.ndim != lon.ndim:
+        raise ValueError("'lat' and 'lon' must either both be 1d or both be 2d'")
+    if lat.ndim >= 2 and lat.shape != lon.shape:
+        raise ValueError("shape mismatch between lat (%s) and lon (%s)" % (lat.shape, lon.shape))
+    if lat.ndim == 1:
+        lon, lat = np.meshgrid(lon, lat)
+    # fractional day of the year (leap days ignored), float32 like the reference: the hour angle below inherits its rounding
+    stamps = pd.DatetimeIndex(pd.to_datetime(list(dates)))
+    start = pd.DatetimeIndex([pd.Timestamp(d.year, 1, 1) for d in stamps])
+    day = ((stamps - start).total_seconds() / 86400.).values.astype(np.float32)
+    day = day.reshape((-1,) + (1,) * lat.ndim)
+    lon32 = lon.astype(np.float32)
+    if daily:
+        day = 0.5 + np.round(day)
+        lon32 = np.zeros_like(lon32)
+    # orbital constants of 1995
+    obliquity, ecc, perihelion = np.deg2rad(23.4441), 0.016715, np.deg2rad(282.7)
+    mean_lon = ecc * (1. + np.sqrt(1 - ecc ** 2.)) * np.sin(perihelion) + 2. * np.pi * (day - 80.5) / 365.
+    true_lon = mean_lon + 2. * ecc * np.sin(mean_lon - perihelion)
+    decl = np.arcsin(np.sin(obliquity) * np.sin(true_lon))
+    hour = 2 * np.pi * (day + lon32 / 360.)
+    dist = (1. - ecc ** 2.) / (1. + ecc * np.cos(true_lon - perihelion))
+    phi = np.deg2rad(lat)[None, ...]
+    sol = S * (np.sin(phi) * np.sin(decl) - np.cos(phi) * np.cos(decl) * np.cos(hour)) * dist ** -2.
+    return np.maximum(sol, 0.).astype(np.float32)

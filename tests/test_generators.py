@@ -117,3 +117,17 @@ def test_fit_generator_from_device_batches(golden_dir):
     dlwp.fit_generator(gen, epochs=3, verbose=0)          # returns None, like the reference (models.py:398-406)
     losses = dlwp.model.history.history['loss']
     assert len(losses) == 3 and np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_insolation_matches_reference(golden_dir):
+    import pandas as pd
+    from DLWP.util import insolation
+    g = np.load(os.path.join(golden_dir, 'g6_insolation.npz'))
+    dates = pd.to_datetime(list(g['dates']))
+    for got, ref in ((insolation(dates, g['lat1'], g['lon1']), g['sol_1d']),
+                     (insolation(dates, g['lat2'], g['lon2'], S=1361.), g['sol_2d']),
+                     (insolation(dates, g['lat1'], g['lon1'], daily=True), g['sol_daily'])):
+        assert got.dtype == np.float32 and got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    with pytest.raises(ValueError):
+        insolation(dates, g['lat1'], g['lon2'])
