@@ -1,24 +1,28 @@
 // Fused cubed-sphere convolution for gfx950 (MI355X): implicit-GEMM direct convolution on the matrix cores.
 //
-// One kernel template serves
+// One kernel template (conv_mfma_ws_kernel) serves
 //   * forward            y  = act( conv_valid( halo_pad(V), W_face ) + b_face )        (DLWP/custom.py:921-1002 with
 //                                                                                       :1082-1308 fused into the load)
-//   * data gradient      dVpad = conv_full( dy * act'(y), W_face^T )                   (same kernel, mode ZERO border)
-// and a second kernel computes the weight gradient.  No im2col, nothing padded is ever materialised in HBM.
+//   * data gradient      dVpad = conv_full( dz, W_face^T ), dz = dy * act'(y)          (same kernel, mode ZERO border)
+// and two more compute the weight gradient (wgrad_mfma_kernel: fp32 MFMA; wgrad_bf16_kernel: bf16 MFMA with LDS transpose
+// reads) followed by a fixed-order reduction.  No im2col, nothing padded is ever materialised in HBM.
 //
-// GEMM view per face:  M = pixels, N = C_out, K = k*k*C_in.  Matrix instruction: v_mfma_f32_32x32x2_f32 (exact fp32,
-// 64 FLOP/clk/SIMD = the chip's 157.3 TFLOP/s fp32 peak).  Per workgroup:
+// Element type T of the activations: float (v_mfma_f32_32x32x2_f32, exact fp32, 157.3 TFLOP/s) or bf16
+// (v_mfma_f32_32x32x16_bf16, ~2.5 PFLOP/s, fp32 accumulate; parameters stay fp32 and are rounded while packing).
+// GEMM view per face:  M = pixels, N = C_out, K = k*k*C_in.  Per workgroup (one per CU, persistent, 4 consumer + 4 producer
+// waves):
 //   - a band of BM <= 32*MT*WM consecutive pixels (flat row-major index inside one face of one sample) times
 //     BN = 32*NT*WN output channels; wave (wm, wn) owns MT x NT accumulator tiles of 32x32 (16 VGPRs each);
-//   - the input tile (band rows + k-1 halo rows, full width + k-1) is staged through LDS in chunks of KC channels,
-//     channels_last, row stride KC+4 floats so that the 16-lane groups of ds_read_b128 hit distinct 16-B slots;
-//   - the cube-sphere halo is resolved while staging: interior cells address their own face, border cells go through
-//     the (6,N+2,N+2) gather table (L2 resident, 60 KB at N=48); nearest-upsampling (x2) and the channel concat of the
-//     U-Net decoder are folded into the same address computation, so none of pad / upsample / concat costs a pass;
-//   - weights are pre-packed (tiny kernel, once per call) in MFMA-B fragment order, so a lane's ds_read_b128 returns
-//     the 4 consecutive K values it feeds to 4 successive MFMAs; face 5's row-reversed kernel is a packing variant.
-//   - A operand: one ds_read_b128 per (tap, 8-channel group, M tile) = 4 MFMAs' worth; K order inside a group is
-//     {lanes 0-31: c0..c3, lanes 32-63: c4..c7} x step j, identical on the A and B side.
+//   - the input tile (band rows + k-1 halo rows, full width + k-1) is staged through LDS in 64-B channel chunks (16 fp32 /
+//     32 bf16 channels), channels_last, pixel stride 80 B so that the 16-lane groups of ds_read_b128 hit distinct slots;
+//   - the cube-sphere halo is resolved while staging: border cells go through the (6,N+2,N+2) gather table (L2 resident,
+//     60 KB at N=48); nearest-upsampling (x2) and the channel concat of the U-Net decoder are folded into the same address
+//     computation, so none of pad / upsample / concat costs a pass;
+//   - weights arrive pre-packed in MFMA fragment order (dlwpcs_pack_batch: every layer of a model in one launch per pass,
+//     or per call into the workspace): a lane's ds_read_b128 returns the K values of 4 fp32 MFMAs / 1 bf16 MFMA; face 5's
+//     row-reversed kernel is a packing variant;
+//   - the MFMA runs as D[co][pixel] (weights = A operand), the epilogue (bias, activation, rounding) leaves through a
+//     wave-private LDS patch as whole-line stores; in data-gradient mode interior cells go straight to the sources.
 #include <stdlib.h>
 #include "common.h"
 

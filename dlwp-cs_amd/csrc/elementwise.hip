@@ -1,7 +1,8 @@
 // HBM-bound helper kernels of the DLWP-CS hot path (gfx950): stand-alone halo gather / inverse gather, activation,
-// 2x2 pooling / upsampling, concat / split, layout converters, loss and Adam.  All are pure streaming kernels:
-// channels_last rows are moved as float4 (16 B / lane, coalesced) whenever C % 4 == 0, grid-stride loops capped at
-// ~2048 workgroups (cdna_hip_programming.md, Guideline 11/13).  No atomics anywhere -> bitwise deterministic.
+// 2x2 pooling / upsampling, concat / split, layout converters, batch gather (feed), loss and Adam.  All are pure streaming
+// kernels: channels_last rows are moved 16 B per lane whenever the channel count allows (fp32 and bf16 storage vectors
+// with an fp32 register image), grid-stride loops capped at ~2048 workgroups (cdna_hip_programming.md, Guideline 11/13).
+// No atomics anywhere -> bitwise deterministic.
 #include "common.h"
 
 namespace dlwpcs {
