@@ -687,7 +687,7 @@ class Model(object):
         if not overwrite and os.path.exists(filepath):
             return
         payload = {'format': 'dlwpcs-model-1', 'config': self.get_config(), 'weights': self.get_weights(),
-                   'compile': None}
+                   'compile': None, 'compute_dtype': self.compute_dtype}
         if self._compiled:
             payload['compile'] = {'loss': self.loss, 'loss_weights': self.loss_weights, 'metrics': self.metrics,
                                   'optimizer': self.optimizer.get_config(),
@@ -723,6 +723,7 @@ def load_model(filepath, custom_objects=None, compile=True):
         raise ValueError('%s is not a dlwpcs model file (HDF5 models written by TensorFlow need h5py + TF to convert)'
                          % filepath)
     model = Model.from_config(payload['config'], custom_objects=custom_objects)
+    model.compute_dtype = payload.get('compute_dtype', model.compute_dtype)      # the mixed-precision mode travels with it
     model.set_weights(payload['weights'])
     cmp = payload.get('compile')
     if compile and cmp:
@@ -734,5 +735,6 @@ def load_model(filepath, custom_objects=None, compile=True):
 
 def clone_model(model):
     new = Model.from_config(model.get_config())
+    new.compute_dtype = model.compute_dtype
     new.set_weights(model.get_weights())
     return new

@@ -277,3 +277,19 @@ def test_mixed_precision_policy_and_exports():
         mixed_precision.set_policy('mixed_float16')
     inp = Input(shape=(6, 8, 8, 3))
     assert Model(inputs=inp, outputs=CubeSphereNet(base_filter_number=4, output_channels=3).unet2(inp)).compute_dtype == 'float32'
+
+
+def test_saved_model_keeps_its_compute_dtype(tmp_path):
+    from DLWP.keras import Input, Model, backend
+    from DLWP.keras.models import clone_model, load_model
+    from DLWP.model.cs_unet import CubeSphereNet
+    backend.set_compute_dtype('bfloat16')
+    try:
+        inp = Input(shape=(6, 8, 8, 3))
+        model = Model(inputs=inp, outputs=CubeSphereNet(base_filter_number=4, output_channels=3).unet2(inp))
+    finally:
+        backend.set_compute_dtype('float32')
+    path = str(tmp_path / 'm.keras')
+    model.save(path)
+    assert load_model(path, compile=False).compute_dtype == 'bfloat16'
+    assert clone_model(model).compute_dtype == 'bfloat16'
