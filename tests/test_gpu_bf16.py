@@ -365,3 +365,26 @@ def test_graph_replay_matches_eager_bf16():
         torch.cuda.synchronize()
         results.append(np.concatenate([w.ravel() for w in model.get_weights()]))
     assert np.array_equal(results[0], results[1])
+
+
+def test_predict_timeseries_bf16_equals_stepwise_predict():
+    """device-resident rollout (state stays in HBM, bf16) == feeding predict()'s output back by hand"""
+    from DLWP.keras import Input, Model, backend
+    from DLWP.model import DLWPFunctional
+    from DLWP.model.cs_unet import CubeSphereNet
+    backend.set_compute_dtype('bfloat16')
+    try:
+        inp = Input(shape=(6, 8, 8, 4), name='main_input')
+        model = Model(inputs=inp, outputs=CubeSphereNet(base_filter_number=8, output_channels=4).unet2(inp))
+    finally:
+        backend.set_compute_dtype('float32')
+    dlwp = DLWPFunctional(is_convolutional=True, time_dim=1)
+    dlwp.build_model(model, loss='mse', optimizer='adam')
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((3, 6, 8, 8, 4)).astype(np.float32)
+    series = dlwp.predict_timeseries(x, 4)
+    assert series.shape == (4, 3, 6, 8, 8, 4) and series.dtype == np.float32 and np.isfinite(series).all()
+    state = x
+    for t in range(4):
+        state = dlwp.predict(state)
+        assert np.array_equal(series[t], state), t
