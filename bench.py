@@ -21,6 +21,9 @@ import os
 import sys
 import time
 
+# the host driver only supports dmabuf IPC: RCCL's cross-process buffer sharing needs this (already exported on the boxes)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'dlwp-cs_amd'))
 sys.path.insert(0, ROOT)
