@@ -620,6 +620,10 @@ __global__ void __launch_bounds__(256) pack_bias_kernel(const float *__restrict_
 // bitwise reproducible) and applies the weight-group map (faces 0-3 -> equatorial, 4 -> polar, 5 -> polar or north
 // pole, tap rows reversed when flip_north_pole).
 // ------------------------------------------------------------------------------------------------------------------
+// taps summed across the consumer waves per LDS round of the weight-gradient epilogue (scratch = WG_TG x 4 waves x 4 KB)
+constexpr int WG_TG = 3;
+constexpr int WG_SCRATCH_FLOATS = WG_TG * 4096;
+
 struct WgradKParams {
     ConvKParams c;          // description of the virtual input (src0/src1/table/mode/...), ymask unused here
     const void *dy, *y;     // (B,6,No,No,Cout), element type T; y nullable
@@ -851,21 +855,21 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
         // ---- bias partial: thread (q = ptid & 7, 32 pixel phases) holds sums of channels 4q..4q+3 -> fixed-order tree
         __syncthreads();                // consumers are done with the buffers (matches the consumers' final barrier)
         if (want_bias) {
-            float *red = smem + 4096;   // behind the consumers' 4 x 1024-float reduction scratch
+            float *red = smem + WG_SCRATCH_FLOATS;   // behind the consumers' reduction scratch
             red[ptid * 4 + 0] = bsum.x; red[ptid * 4 + 1] = bsum.y; red[ptid * 4 + 2] = bsum.z; red[ptid * 4 + 3] = bsum.w;
         }
         __syncthreads();
         if (want_bias && ptid < 32) {
             // channel c = ptid: quad q = c >> 2, component c & 3; sum over the 32 threads with (t & 7) == q
             float sum = 0.f;
-            const float *red = smem + 4096;
+            const float *red = smem + WG_SCRATCH_FLOATS;
 #pragma unroll
             for (int ph = 0; ph < 32; ++ph) sum += red[((ph * 8 + (ptid >> 2)) * 4) + (ptid & 3)];
             W.bpartial[(size_t)worker * W.CoutP + cot * 32 + ptid] = sum;
         }
-        // the consumers' tap loop below executes 2 barriers per tap: keep the barrier counts of both halves equal
+        // the consumers' reduction loop below executes 2 barriers per round: keep the barrier counts of both halves equal
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) { __syncthreads(); __syncthreads(); }
+        for (int t0 = 0; t0 < TAPS; t0 += (TAPS >= WG_TG ? WG_TG : 1)) { __syncthreads(); __syncthreads(); }
         return;
     }
 
@@ -923,25 +927,31 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
     __syncthreads();                            // all consumers finished reading the last buffer
     __syncthreads();                            // (producers stage their bias sums between these two)
 
-    // cross-wave reduction through LDS (fixed order w = 0..3), one tap at a time
+    // cross-wave reduction through LDS (fixed order w = 0..3), WG_TG taps per round (2 barriers per round, not per tap)
     float *red = smem;
     float *pout = W.partial + (size_t)worker * TAPS * W.CinP * W.CoutP;
     const int ctid = tid;
+    constexpr int TG = TAPS >= WG_TG ? WG_TG : 1;
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
+    for (int t0 = 0; t0 < TAPS; t0 += TG) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-            red[wave * 1024 + ci * 32 + l31] = acc[tap][r];
-        }
+        for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[(tt * 4 + wave) * 1024 + ci * 32 + l31] = acc[t0 + tt][r];
+            }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = ctid + i * NCT;
-            const float sum = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
-            const int ci = e >> 5, co = e & 31;
-            pout[((size_t)tap * W.CinP + cit * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
-        }
+        for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = ctid + i * NCT;
+                const float *rt = red + tt * 4096;
+                const float sum = (rt[e] + rt[1024 + e]) + (rt[2048 + e] + rt[3072 + e]);
+                const int ci = e >> 5, co = e & 31;
+                pout[((size_t)(t0 + tt) * W.CinP + cit * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
+            }
         __syncthreads();
     }
 }
@@ -1173,7 +1183,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         }
         // ---- bias partial: thread (q = ptid % QD, 256/QD pixel phases) holds sums of channels DV*q.. -> fixed-order sum
         __syncthreads();                // consumers are done with the buffers (matches the consumers' final barrier)
-        float *red = reinterpret_cast<float *>(smem) + 4096;   // behind the consumers' 4 x 1024-float reduction scratch
+        float *red = reinterpret_cast<float *>(smem) + WG_SCRATCH_FLOATS;   // behind the consumers' reduction scratch
         if (want_bias) {
 #pragma unroll
             for (int u = 0; u < DV; ++u) red[ptid * DV + u] = bsum[u];
@@ -1187,9 +1197,9 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             }
             W.bpartial[(size_t)worker * W.CoutP + cot * 32 + ptid] = sum;
         }
-        // the consumers' tap loop below executes 2 barriers per tap: keep the barrier counts of both halves equal
+        // the consumers' reduction loop below executes 2 barriers per round: keep the barrier counts of both halves equal
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) { __syncthreads(); __syncthreads(); }
+        for (int t0 = 0; t0 < TAPS; t0 += (TAPS >= WG_TG ? WG_TG : 1)) { __syncthreads(); __syncthreads(); }
         return;
     }
 
@@ -1262,27 +1272,34 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     __syncthreads();                            // all consumers finished reading the last buffer
     __syncthreads();                            // (producers stage their bias sums between these two)
 
-    // cross-wave reduction through LDS (fixed order over the slab phases of each ci tile), one tap at a time
+    // cross-wave reduction through LDS (fixed order over the slab phases of each ci tile), WG_TG taps per round (2 barriers
+    // per round, not per tap)
     float *red = reinterpret_cast<float *>(smem);
     float *pout = W.partial + (size_t)worker * TAPS * W.CinP * W.CoutP;
+    constexpr int TG = TAPS >= WG_TG ? WG_TG : 1;
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
+    for (int t0 = 0; t0 < TAPS; t0 += TG) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-            red[wave * 1024 + ci * 32 + l31] = acc[tap][r];
-        }
+        for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[(tt * 4 + wave) * 1024 + ci * 32 + l31] = acc[t0 + tt][r];
+            }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4 * CT; ++i) {
-            const int e = tid + i * NCT;                    // (ci tile, ci, co) = (e / 1024, (e / 32) % 32, e % 32)
-            const int t2 = e >> 10, e10 = e & 1023;
-            float sum;
-            if (CT == 1) sum = (red[e10] + red[1024 + e10]) + (red[2048 + e10] + red[3072 + e10]);
-            else sum = red[t2 * 1024 + e10] + red[(t2 + 2) * 1024 + e10];       // waves t2 and t2 + 2 share ci tile t2
-            const int ci = e10 >> 5, co = e10 & 31;
-            pout[((size_t)tap * W.CinP + (cit * CT + t2) * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
-        }
+        for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+            for (int i = 0; i < 4 * CT; ++i) {
+                const int e = tid + i * NCT;                    // (ci tile, ci, co) = (e / 1024, (e / 32) % 32, e % 32)
+                const int t2 = e >> 10, e10 = e & 1023;
+                const float *rt = red + tt * 4096;
+                float sum;
+                if (CT == 1) sum = (rt[e10] + rt[1024 + e10]) + (rt[2048 + e10] + rt[3072 + e10]);
+                else sum = rt[t2 * 1024 + e10] + rt[(t2 + 2) * 1024 + e10];     // waves t2 and t2 + 2 share ci tile t2
+                const int ci = e10 >> 5, co = e10 & 31;
+                pout[((size_t)(t0 + tt) * W.CinP + (cit * CT + t2) * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
+            }
         __syncthreads();
     }
 }
@@ -1856,7 +1873,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
         const int pcap = (L.wg_pix + 15) & ~15;
         size_t lds = 2 * ((size_t)ct * P.tile_rows_max * P.W2 * 64 + (size_t)pcap * 64);
         grid.y = (unsigned)(CinP / (32 * ct));
-        if (lds < (4096 + 2048) * 4) lds = (4096 + 2048) * 4;   // cross-wave reduction scratch + bias staging alias the buffers
+        if (lds < (WG_SCRATCH_FLOATS + 2048) * 4) lds = (WG_SCRATCH_FLOATS + 2048) * 4;   // reduction scratch + bias staging alias the buffers
         if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
         if ((long)P.Nin * P.Nin >= (1l << 16))
             return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: face size %d too large for the 16-bit index arithmetic", P.Nin);
@@ -1907,7 +1924,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     if ((long)P.Nin * P.Nin >= (1l << 16))
         return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: face size %d too large for the 16-bit index arithmetic", P.Nin);
     size_t lds = 2 * bufb;
-    if (lds < (4096 + 1024) * 4) lds = (4096 + 1024) * 4;     // cross-wave reduction scratch + bias staging alias the buffers
+    if (lds < (WG_SCRATCH_FLOATS + 1024) * 4) lds = (WG_SCRATCH_FLOATS + 1024) * 4;   // reduction scratch + bias staging alias the buffers
     if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
 #define WG_LAUNCH(TV, TS, KSV, VWV, MASKV)                                                                                \
     do {                                                                                                                  \
