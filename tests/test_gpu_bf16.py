@@ -388,3 +388,33 @@ def test_predict_timeseries_bf16_equals_stepwise_predict():
     for t in range(4):
         state = dlwp.predict(state)
         assert np.array_equal(series[t], state), t
+
+
+def test_bf16_training_tracks_fp32_training():
+    """60 Adam steps on a learnable synthetic map, same initial weights and batches: the mixed-precision loss curve must
+    follow the fp32 one (a systematic gradient error -- wrong hand-over, wrong mask -- shows up as divergence)."""
+    from DLWP.keras import backend
+    rng = np.random.default_rng(123)
+    N, C, base, B = 16, 8, 8, 8
+    x = rng.standard_normal((B, 6, N, N, C)).astype(np.float32)
+    t = (0.5 * np.roll(x, 1, axis=3) - 0.25 * x + 0.1 * rng.standard_normal(x.shape)).astype(np.float32)
+    params = orc.make_unet2_params(C, C, base=base, seed=4)
+    curves = {}
+    for dtype in ('float32', 'bfloat16'):
+        backend.set_compute_dtype(dtype)
+        try:
+            model, convs = _build_unet2(N, C, C, base)
+        finally:
+            backend.set_compute_dtype('float32')
+        from DLWP.keras.optimizers import Adam
+        model.compile(optimizer=Adam(learning_rate=4e-3), loss='mse')
+        _set_params(convs, params)
+        dx = [to_f32(x).to(backend.torch_dtype(dtype))]
+        dt = [to_f32(t)]
+        losses = []
+        for _ in range(60):
+            losses.append(float(model.train_on_device_batch(dx, dt)[0, 0].item()))
+        curves[dtype] = np.array(losses)
+    f, h = curves['float32'], curves['bfloat16']
+    assert f[-1] < 0.8 * f[0], (f[0], f[-1])                    # it learns
+    assert np.all(np.abs(h - f) <= 0.03 * f + 1e-3), np.abs(h - f).max()
