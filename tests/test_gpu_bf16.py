@@ -173,7 +173,8 @@ BF16_CONV_CASES = [
     (1, 96, 8, 0, 32, 3, True, False, True, False, True),      # C96
     (1, 24, 26, 0, 32, 3, True, False, True, False, True),     # 13 vars x 2 steps (cfg 5): even channels, 16 x 4-B vectors
     (2, 16, 6, 10, 16, 3, True, True, True, False, True),      # even channels from two sources (upsample + concat)
-    (1, 96, 26, 0, 32, 3, True, False, True, False, True),     # C96 first layer of cfg 5    (2, 12, 16, 0, 96, 3, True, False, True, False, True),     # 3 N tiles under a 4-N-tile workgroup
+    (1, 96, 26, 0, 32, 3, True, False, True, False, True),     # C96 first layer of cfg 5
+    (2, 12, 16, 0, 96, 3, True, False, True, False, True),     # 3 N tiles under a 4-N-tile workgroup
     (2, 24, 96, 0, 16, 3, True, False, True, False, True),     # ... and on the data-gradient side
 ]
 

@@ -127,7 +127,8 @@ CONV_CASES = [
     (2, 48, 32, 0, 14, 1, False, False, True, False, False),   # 1x1 head
     (1, 20, 5, 0, 7, 1, False, False, True, False, True),      # odd sizes everywhere
     (3, 9, 6, 0, 33, 3, True, False, True, False, True),       # odd face size, partial N tile
-    (1, 96, 8, 0, 32, 3, True, False, True, False, True),      # C96    (2, 12, 16, 0, 96, 3, True, False, True, False, True),     # 3 N tiles under a 4-N-tile workgroup
+    (1, 96, 8, 0, 32, 3, True, False, True, False, True),      # C96
+    (2, 12, 16, 0, 96, 3, True, False, True, False, True),     # 3 N tiles under a 4-N-tile workgroup
     (2, 24, 96, 0, 16, 3, True, False, True, False, True),     # ... and on the data-gradient side
 ]
 
