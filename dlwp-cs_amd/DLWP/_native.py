@@ -23,6 +23,7 @@ ACT_LEAKY_CLIP = 1
 CONV_ACCUMULATE_WGRAD = 1
 CONV_PREPACKED = 2
 CONV_REUSE_DZ = 4
+CONV_DEFER_REDUCE = 8
 PACK_FWD, PACK_BWD, PACK_BIAS = 0, 1, 2
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -43,6 +44,15 @@ class PackItem(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ('w_eq', 'w_pol', 'w_np', 'b_eq', 'b_pol', 'b_np', 'wpk_fwd', 'wpk_bwd',
                                                 'bias_pk')] + \
                [(n, ctypes.c_int32) for n in ('ksize', 'Cin', 'Cout', 'flip_north_pole', 'dtype', 'reserved')]
+
+
+class ReduceItem(ctypes.Structure):
+    """struct dlwpcs_reduce_item (include/dlwpcs.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('partial', 'bpartial', 'dw_eq', 'dw_pol', 'dw_np', 'db_eq', 'db_pol',
+                                                'db_np')] + \
+               [(n, ctypes.c_int32) for n in ('ksize', 'Cin', 'Cout', 'CinP', 'CoutP', 'n_eq', 'n_4', 'n_5',
+                                              'flip_north_pole', 'accumulate', 'vec', 'nblocks')] + \
+               [('reserved', ctypes.c_int32 * 4)]
 
 
 class GConvDesc(ctypes.Structure):
@@ -69,6 +79,9 @@ PROTOTYPES = {
                                                                                       c_void_p, c_size_t, c_void_p]),
     'dlwpcs_conv_bwd_weights': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_void_p] * 6 +
                                 [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'dlwpcs_conv_wgrad_reduce_item': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 6 +
+                                      [c_void_p, c_size_t, ctypes.POINTER(ReduceItem)]),
+    'dlwpcs_wgrad_reduce_batch': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'dlwpcs_gconv_fwd': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),
     'dlwpcs_gconv_bwd_data': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 6),
     'dlwpcs_gconv_bwd_weights': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),

@@ -57,6 +57,8 @@ class Model(object):
         self.compute_dtype = backend.compute_dtype()
         self.prepack_weights = os.environ.get('DLWPCS_PREPACK', '1') != '0'
         self.wgrad_side_stream = os.environ.get('DLWPCS_SIDE_STREAM', '0') == '1'   # measured slower on MI355X: off
+        # one reduction launch for all layers' weight-gradient partials (DLWPCS_CONV_DEFER_REDUCE)
+        self.defer_wgrad_reduce = os.environ.get('DLWPCS_DEFER_REDUCE', '1') == '1'
         # True: the caller feeds every step through the SAME device tensors (e.g. a generator that assembles each batch in
         # place): the captured graphs read them directly instead of copying each batch into private static buffers
         self.static_batch_buffers = False
@@ -352,11 +354,16 @@ class Model(object):
             ones = [self._ones[dev] for _ in stats]
             ops.DIRECT_PARAM_GRADS = True       # weight gradients accumulate straight into the flat gradient buffer
             ops.WGRAD_SIDE_STREAM = self.wgrad_side_stream
+            ops.DEFER_WGRAD_REDUCE = self.defer_wgrad_reduce    # ... through ONE reduction launch for all layers
+            ops.drop_deferred_reduce()
             try:
                 torch.autograd.backward(stats, ones)
+                ops.flush_deferred_reduce(dev)
             finally:
                 ops.DIRECT_PARAM_GRADS = False
                 ops.WGRAD_SIDE_STREAM = False
+                ops.DEFER_WGRAD_REDUCE = False
+                ops.drop_deferred_reduce()
                 ops.join_side_stream(stats[0].device)
         return torch.stack([s.detach() for s in stats])
 

@@ -46,6 +46,7 @@ def join_side_stream(device):
 
 # workspace: one growing byte buffer per (device, role) (caller-owned from the library's point of view)
 _workspaces = {}
+_retired_workspaces = []    # outgrown buffers stay allocated: hipGraphs captured earlier have their addresses baked in
 
 
 def _workspace(nbytes, device, role='main'):
@@ -54,9 +55,52 @@ def _workspace(nbytes, device, role='main'):
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise nat.NativeError('workspace would have to grow during graph capture; run one eager step first')
+        if ws is not None:
+            _retired_workspaces.append(ws)
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
+
+
+# Deferred weight-gradient reduction (DLWPCS_CONV_DEFER_REDUCE): while the flag is on, every fused-conv backward node
+# that accumulates straight into preset .grad buffers leaves its per-worker partials in a workspace of its own and
+# queues a dlwpcs_reduce_item; flush_deferred_reduce() then sums ALL layers' partials with one launch (one per
+# application round of shared layers) instead of one small launch per layer.  Whoever sets the flag must flush before
+# the gradients are read.
+DEFER_WGRAD_REDUCE = False
+_deferred = []              # [(ReduceItem, workspace tensor)] of the backward pass in flight
+_reduce_tables = {}         # (device, raw item bytes) -> device copy of the item table
+
+
+def drop_deferred_reduce():
+    del _deferred[:]
+
+
+def flush_deferred_reduce(device):
+    if not _deferred:
+        return
+    pending = list(_deferred)
+    del _deferred[:]
+    # items whose destinations coincide (a layer applied twice) go into successive launches
+    rounds, seen = [], {}
+    for item, ws in pending:
+        k = seen.get(item.dw_eq, 0)
+        seen[item.dw_eq] = k + 1
+        while len(rounds) <= k:
+            rounds.append([])
+        rounds[k].append(item)
+    for items in rounds:
+        raw = b''.join(bytes(it) for it in items)
+        key = (str(device), raw)
+        table = _reduce_tables.get(key)
+        if table is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise nat.NativeError('reduce-item table would have to be uploaded during graph capture; run one eager '
+                                      'step first')
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            _reduce_tables[key] = table
+        check(lib().dlwpcs_wgrad_reduce_batch(ptr(table), len(items), sum(it.nblocks for it in items), stream_ptr()),
+              'dlwpcs_wgrad_reduce_batch')
 
 
 def _c(t):
@@ -183,11 +227,15 @@ class _CSConv(torch.autograd.Function):
         dy = _c(dy)
         dev = dy.device
         nbytes = lib().dlwpcs_conv_workspace_bytes(ctypes.byref(d))
-        ws = _workspace(nbytes, dev)
         need = ctx.needs_input_grad
         dsrc0 = torch.empty_like(src0) if need[0] else None
         dsrc1 = torch.empty_like(src1) if (has_src1 and need[1]) else None
         want_w = any(need[2:8])
+        direct = DIRECT_PARAM_GRADS and (need[2] or need[3]) and all(
+            p is None or (p.is_leaf and p.grad is not None and p.grad.is_contiguous()) for p in ctx.params)
+        defer = direct and DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM and d.B > 0
+        # deferred reduction: the partials (and the dz hand-over next to them) live in this node's own workspace
+        ws = _workspace(nbytes, dev, 'defer%d' % len(_deferred)) if defer else _workspace(nbytes, dev)
         reuse_dz = ((dsrc0 is not None or dsrc1 is not None) and want_w and d.act != nat.ACT_NONE
                     and not WGRAD_SIDE_STREAM)
         if reuse_dz:
@@ -205,22 +253,25 @@ class _CSConv(torch.autograd.Function):
         if not reuse_dz:
             run_bwd_data()
         dw_eq = dw_pol = dw_np = db_eq = db_pol = db_np = None
-        if DIRECT_PARAM_GRADS and (need[2] or need[3]) and all(
-                p is None or (p.is_leaf and p.grad is not None and p.grad.is_contiguous()) for p in ctx.params):
+        if direct:
             # Accumulate straight into the preset .grad buffers (views of the model's flat gradient buffer, zeroed once
             # per step): no temporaries, no AccumulateGrad add kernels; shared layers simply accumulate twice.
             pe, pp, pn, be, bp, bn = ctx.params
             d2 = ConvDesc.from_buffer_copy(d)
-            d2.flags = d.flags | nat.CONV_ACCUMULATE_WGRAD
+            d2.flags = d.flags | nat.CONV_ACCUMULATE_WGRAD | (nat.CONV_DEFER_REDUCE if defer else 0)
+            grads = (ptr(pe.grad), ptr(pp.grad), ptr(None if pn is None else pn.grad),
+                     ptr(None if be is None else be.grad), ptr(None if bp is None else bp.grad),
+                     ptr(None if bn is None else bn.grad))
 
             def launch(wsx):
-                check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d2), ptr(src0), ptr(src1), ptr(dy), ptr(y), ptr(pe.grad),
-                                                    ptr(pp.grad), ptr(None if pn is None else pn.grad),
-                                                    ptr(None if be is None else be.grad),
-                                                    ptr(None if bp is None else bp.grad),
-                                                    ptr(None if bn is None else bn.grad),
+                check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d2), ptr(src0), ptr(src1), ptr(dy), ptr(y), *grads,
                                                     ptr(table), ptr(wsx), wsx.numel(), stream_ptr()),
                       'dlwpcs_conv_bwd_weights')
+                if defer:
+                    item = nat.ReduceItem()
+                    check(lib().dlwpcs_conv_wgrad_reduce_item(ctypes.byref(d2), *grads, ptr(wsx), wsx.numel(),
+                                                              ctypes.byref(item)), 'dlwpcs_conv_wgrad_reduce_item')
+                    _deferred.append((item, wsx))
             if WGRAD_SIDE_STREAM:
                 side = side_stream(dev)
                 side.wait_stream(torch.cuda.current_stream(dev))      # dy and the saved activations are ready

@@ -1311,17 +1311,17 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
 // slot instead of 64), else 1.  accumulate != 0: add to the destination instead of overwriting it (shared layers / direct
 // accumulation into the flat gradient buffer).
 template <int VEC>
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bpartial,
-                                                           float *__restrict__ dw_eq, float *__restrict__ dw_pol,
-                                                           float *__restrict__ dw_np, float *__restrict__ db_eq,
-                                                           float *__restrict__ db_pol, float *__restrict__ db_np,
-                                                           int KS, int Cin, int Cout, int CinP, int CoutP,
-                                                           int n_eq, int n_4, int n_5, int flip, int accumulate) {
+__device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ partial, const float *__restrict__ bpartial,
+                                                  float *__restrict__ dw_eq, float *__restrict__ dw_pol,
+                                                  float *__restrict__ dw_np, float *__restrict__ db_eq,
+                                                  float *__restrict__ db_pol, float *__restrict__ db_np,
+                                                  int KS, int Cin, int Cout, int CinP, int CoutP,
+                                                  int n_eq, int n_4, int n_5, int flip, int accumulate, int block) {
     typedef float VT __attribute__((ext_vector_type(VEC)));
     const int TAPS = KS * KS;
     const int nW = TAPS * Cin * Cout;
     const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
-    const int e = (blockIdx.x * 16 + o) * VEC;         // first of this thread's VEC consecutive outputs
+    const int e = (block * 16 + o) * VEC;              // first of this thread's VEC consecutive outputs
     const size_t slot_stride = (size_t)TAPS * CinP * CoutP;
     VT s_eq = 0.f, s_4 = 0.f, s_5 = 0.f;
     const bool is_w = e < nW, is_b = (!is_w) && bpartial && e < nW + Cout;
@@ -1374,19 +1374,55 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
     }
 }
 
+template <int VEC>
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bpartial,
+                                                           float *__restrict__ dw_eq, float *__restrict__ dw_pol,
+                                                           float *__restrict__ dw_np, float *__restrict__ db_eq,
+                                                           float *__restrict__ db_pol, float *__restrict__ db_np,
+                                                           int KS, int Cin, int Cout, int CinP, int CoutP,
+                                                           int n_eq, int n_4, int n_5, int flip, int accumulate) {
+    wgrad_reduce_body<VEC>(partial, bpartial, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, KS, Cin, Cout, CinP, CoutP, n_eq,
+                           n_4, n_5, flip, accumulate, (int)blockIdx.x);
+}
+
+// All layers of a backward pass in one launch (DLWPCS_CONV_DEFER_REDUCE): a workgroup finds its item by walking the
+// (short) item list — workgroup-uniform scalar loads — and runs the same body, so the summation order and therefore
+// the result bits are those of the per-layer launches.
+__global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const dlwpcs_reduce_item *__restrict__ items, int n_items) {
+    int b = (int)blockIdx.x, i = 0;
+    while (i < n_items - 1 && b >= items[i].nblocks) { b -= items[i].nblocks; ++i; }
+    const dlwpcs_reduce_item it = items[i];
+    if (b >= it.nblocks) return;
+    if (it.vec == 4)
+        wgrad_reduce_body<4>(it.partial, it.bpartial, it.dw_eq, it.dw_pol, it.dw_np, it.db_eq, it.db_pol, it.db_np, it.ksize,
+                             it.Cin, it.Cout, it.CinP, it.CoutP, it.n_eq, it.n_4, it.n_5, it.flip_north_pole, it.accumulate, b);
+    else
+        wgrad_reduce_body<1>(it.partial, it.bpartial, it.dw_eq, it.dw_pol, it.dw_np, it.db_eq, it.db_pol, it.db_np, it.ksize,
+                             it.Cin, it.Cout, it.CinP, it.CoutP, it.n_eq, it.n_4, it.n_5, it.flip_north_pole, it.accumulate, b);
+}
+
 // VEC = 4 needs every vector to stay inside one row of C_out values and 16-B aligned destinations
+static bool wgrad_reduce_vec(const void *dw_eq, const void *dw_pol, const void *dw_np, const void *db_eq, const void *db_pol,
+                             const void *db_np, int Cout) {
+    auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    return Cout % 4 == 0 && al16(dw_eq) && al16(dw_pol) && al16(dw_np) && al16(db_eq) && al16(db_pol) && al16(db_np);
+}
+static int wgrad_reduce_blocks(int KS, int Cin, int Cout, bool want_bias, bool vec) {
+    const int nout = KS * KS * Cin * Cout + (want_bias ? Cout : 0);
+    return vec ? ceil_div(nout / 4, 16) : ceil_div(nout, 16);
+}
+
 static void launch_wgrad_reduce(hipStream_t s, const float *partial, const float *bpartial, void *dw_eq, void *dw_pol,
                                 void *dw_np, void *db_eq, void *db_pol, void *db_np, int KS, int Cin, int Cout, int CinP,
                                 int CoutP, int n_eq, int n_4, int n_5, int flip, int accumulate, bool want_bias) {
-    const int nout = KS * KS * Cin * Cout + (want_bias ? Cout : 0);
-    auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
-    const bool vec = Cout % 4 == 0 && al16(dw_eq) && al16(dw_pol) && al16(dw_np) && al16(db_eq) && al16(db_pol) && al16(db_np);
+    const bool vec = wgrad_reduce_vec(dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, Cout);
+    const int nblocks = wgrad_reduce_blocks(KS, Cin, Cout, want_bias, vec);
     if (vec)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(ceil_div(nout / 4, 16)), dim3(256), 0, s, partial, bpartial,
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(nblocks), dim3(256), 0, s, partial, bpartial,
                            (float *)dw_eq, (float *)dw_pol, (float *)dw_np, (float *)db_eq, (float *)db_pol, (float *)db_np,
                            KS, Cin, Cout, CinP, CoutP, n_eq, n_4, n_5, flip, accumulate);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(ceil_div(nout, 16)), dim3(256), 0, s, partial, bpartial,
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(nblocks), dim3(256), 0, s, partial, bpartial,
                            (float *)dw_eq, (float *)dw_pol, (float *)dw_np, (float *)db_eq, (float *)db_pol, (float *)db_np,
                            KS, Cin, Cout, CinP, CoutP, n_eq, n_4, n_5, flip, accumulate);
 }
@@ -1910,7 +1946,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
 #undef WGB_X
 #undef WGB_LAUNCH
         rc = check_launch("wgrad_bf16");
-        if (rc) return rc;
+        if (rc || (d->flags & DLWPCS_CONV_DEFER_REDUCE)) return rc;
         launch_wgrad_reduce(s, W.partial, W.bpartial, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, KS, Cin, d->Cout, CinP, CoutP,
                             L.n_eq, L.n_4, L.n_5, d->flip_north_pole, (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0, want_bias);
         return check_launch("wgrad_reduce");
@@ -1958,8 +1994,51 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
 #undef WG_VW
 #undef WG_LAUNCH
     rc = check_launch("wgrad_mfma");
-    if (rc) return rc;
+    if (rc || (d->flags & DLWPCS_CONV_DEFER_REDUCE)) return rc;
     launch_wgrad_reduce(s, W.partial, W.bpartial, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, KS, Cin, d->Cout, CinP, CoutP,
                         L.n_eq, L.n_4, L.n_5, d->flip_north_pole, (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0, want_bias);
     return check_launch("wgrad_reduce");
+}
+
+extern "C" int dlwpcs_conv_wgrad_reduce_item(const dlwpcs_conv_desc *d, void *dw_eq, void *dw_pol, void *dw_np, void *db_eq,
+                                             void *db_pol, void *db_np, void *workspace, size_t workspace_bytes,
+                                             dlwpcs_reduce_item *item) {
+    int rc = validate(d, "conv_wgrad_reduce_item");
+    if (rc) return rc;
+    if (!dw_eq || !dw_pol || !workspace || !item) return fail(DLWPCS_E_INVALID, "conv_wgrad_reduce_item: null pointer");
+    if ((db_np != nullptr) != (dw_np != nullptr) && db_eq) return fail(DLWPCS_E_INVALID, "conv_wgrad_reduce_item: dw_np/db_np must match");
+    const WsLayout L = ws_layout(d);
+    if (workspace_bytes < L.total)
+        return fail(DLWPCS_E_WORKSPACE, "conv_wgrad_reduce_item: workspace %zu < %zu bytes", workspace_bytes, L.total);
+    char *ws = (char *)workspace;
+    const int Cin = d->C0 + d->C1;
+    const bool want_bias = db_eq || db_pol || db_np;
+    const bool vec = wgrad_reduce_vec(dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, d->Cout);
+    dlwpcs_reduce_item it{};
+    it.partial = (const float *)(ws + L.partial);
+    it.bpartial = want_bias ? (const float *)(ws + L.bpartial) : nullptr;
+    it.dw_eq = (float *)dw_eq; it.dw_pol = (float *)dw_pol; it.dw_np = (float *)dw_np;
+    it.db_eq = (float *)db_eq; it.db_pol = (float *)db_pol; it.db_np = (float *)db_np;
+    it.ksize = d->ksize; it.Cin = Cin; it.Cout = d->Cout;
+    it.CinP = ceil_div(Cin, 32) * 32; it.CoutP = ceil_div(d->Cout, 32) * 32;
+    it.n_eq = L.n_eq; it.n_4 = L.n_4; it.n_5 = L.n_5;
+    it.flip_north_pole = d->flip_north_pole;
+    it.accumulate = (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0;
+    it.vec = vec ? 4 : 1;
+    it.nblocks = d->B == 0 ? 0 : wgrad_reduce_blocks(d->ksize, Cin, d->Cout, want_bias, vec);   // B == 0: nothing was produced
+    *item = it;
+    return DLWPCS_OK;
+}
+
+extern "C" int dlwpcs_wgrad_reduce_batch(const dlwpcs_reduce_item *items_dev, int n_items, int total_blocks,
+                                         dlwpcs_stream_t stream) {
+    if (n_items < 0 || n_items > 256 || total_blocks < 0) return fail(DLWPCS_E_INVALID, "wgrad_reduce_batch: n_items %d, total_blocks %d", n_items, total_blocks);
+    if (n_items == 0 || total_blocks == 0) return DLWPCS_OK;
+    if (!items_dev) return fail(DLWPCS_E_INVALID, "wgrad_reduce_batch: null item table");
+    hipStream_t s = (hipStream_t)stream;
+    int pidx = -1;
+    if (prof_enabled()) pidx = prof_begin("wgrad_reduce_batch_kernel", 0.0, 0.0, s);
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, s, items_dev, n_items);
+    if (pidx >= 0) prof_end(pidx, s);
+    return check_launch("wgrad_reduce_batch");
 }

@@ -107,6 +107,11 @@ int dlwpcs_pad_bwd(const void *dy, void *dx, int B, int N, int C, int p, int dty
                                           * same stream with the same desc and workspace (act != NONE): where the bf16
                                           * weight-gradient kernel applies it leaves dz = dy * act'(y) in the workspace
                                           * and bwd_data reads that instead of dy and y; otherwise the flag is ignored */
+#define DLWPCS_CONV_DEFER_REDUCE     8   /* conv_bwd_weights: run the weight-gradient kernel only and leave the per-worker
+                                          * partial sums in the workspace (dw_* / db_* are not touched); the caller keeps
+                                          * that workspace untouched until it has run dlwpcs_wgrad_reduce_batch over the
+                                          * item dlwpcs_conv_wgrad_reduce_item describes (one reduction launch for all
+                                          * layers of a backward pass instead of one per layer) */
 
 typedef struct dlwpcs_conv_desc {
     int32_t B;              /* batch */
@@ -168,6 +173,28 @@ int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d,
                             void *db_eq, void *db_pol, void *db_np,
                             const int32_t *table_dev,
                             void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
+
+/* Deferred, batched reduction of the per-worker partial sums (DLWPCS_CONV_DEFER_REDUCE).
+ * dlwpcs_conv_wgrad_reduce_item (host only, launches nothing): fills *item with what the reduction of the layer
+ * described by d needs — the same d (flags included: ACCUMULATE_WGRAD decides add vs overwrite), destinations and
+ * workspace as the dlwpcs_conv_bwd_weights call that produced the partials.  `nblocks` is the item's share of the launch.
+ * dlwpcs_wgrad_reduce_batch: items_dev is a DEVICE copy of n_items (<= 256) items; total_blocks = sum of their nblocks.
+ * Items whose destinations overlap (a layer applied twice) must all carry ACCUMULATE_WGRAD: items run concurrently,
+ * every destination element is owned by one thread per item, so overlapping items are only safe as atomics-free adds
+ * when the caller serialises them — put them in separate launches.  Bitwise reproducible like the per-layer path
+ * (same fixed summation order). */
+typedef struct dlwpcs_reduce_item {
+    const float *partial, *bpartial;                       /* inside the layer's workspace */
+    float *dw_eq, *dw_pol, *dw_np, *db_eq, *db_pol, *db_np;
+    int32_t ksize, Cin, Cout, CinP, CoutP, n_eq, n_4, n_5, flip_north_pole, accumulate, vec, nblocks;
+    int32_t reserved[4];
+} dlwpcs_reduce_item;
+int dlwpcs_conv_wgrad_reduce_item(const dlwpcs_conv_desc *d,
+                                  void *dw_eq, void *dw_pol, void *dw_np,
+                                  void *db_eq, void *db_pol, void *db_np,
+                                  void *workspace, size_t workspace_bytes, dlwpcs_reduce_item *item);
+int dlwpcs_wgrad_reduce_batch(const dlwpcs_reduce_item *items_dev, int n_items, int total_blocks,
+                              dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
  * Generic (any kernel size / stride / dilation / 'same') per-face convolution on an ALREADY PADDED channels_last
