@@ -253,8 +253,8 @@ def measure(args, dtype, rank, world, local_rank, with_roofline):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='unet2', choices=['unet2', 'encoder6'])
     ap.add_argument('--batch', type=int, default=32, help='samples per GPU per step')
     ap.add_argument('--face', type=int, default=48)

@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libdlwpcs.so')
 F32 = 0
 BF16 = 1
 MSE_TARGET_F32 = 0x100
+MSE_OVERWRITE = 0x200
+ADAM_ZERO_GRAD = 1
 ACT_NONE = 0
 ACT_LEAKY_CLIP = 1
 CONV_ACCUMULATE_WGRAD = 1
@@ -89,6 +91,7 @@ PROTOTYPES = {
     'dlwpcs_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_int, c_void_p]),
     'dlwpcs_avgpool2_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_avgpool2_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_avgpool2_bwd_add': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_upsample2_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_upsample2_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_concat2': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
@@ -101,6 +104,8 @@ PROTOTYPES = {
                                    c_void_p]),
     'dlwpcs_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float,
                                  c_float, c_float, c_float, c_void_p]),
+    'dlwpcs_adam_step_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float,
+                                       c_float, c_float, c_float, c_int, c_void_p]),
     'dlwpcs_batch_gather': (c_int, [c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int, c_void_p, c_int,
                                     c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_prof_enable': (c_int, [c_int]),

@@ -25,7 +25,7 @@ from .. import ops, parallel
 from .._native import ACT_LEAKY_CLIP, ACT_NONE
 from . import backend, callbacks as cbks, optimizers
 from .engine import KTensor, Layer
-from .layers import Concatenate, InputLayer, ReLU, UpSampling3D
+from .layers import AveragePooling3D, Concatenate, InputLayer, ReLU, UpSampling3D
 
 
 def _as_list(x):
@@ -65,6 +65,7 @@ class Model(object):
         self._ones = {}
         self._compiled = False
         self._flat_params = self._flat_grads = None
+        self._grads_clean = False
         self._graphs = {}
         self._seen_batch = {}
         self._toposort()
@@ -151,6 +152,11 @@ class Model(object):
                 continue
             if t.uid in fused:
                 steps.append(fused[t.uid])
+            elif isinstance(t.layer, AveragePooling3D) and len(t.node_inputs) == 1 and (
+                    len(consumers.get(t.node_inputs[0].uid, [])) > 1 or t.node_inputs[0].uid in out_uids):
+                # the pooled tensor has other consumers (U-Net skip connection): they are re-routed through an alias so
+                # that both gradients reach ONE backward kernel (ops.avgpool2_skip)
+                steps.append(('pool_skip', t.uid, t.layer, t.node_inputs[0].uid))
             else:
                 steps.append(('layer', t.uid, t.layer, [i.uid for i in t.node_inputs],
                               isinstance(t.layer, Concatenate)))
@@ -206,6 +212,9 @@ class Model(object):
                 _, out_uid, lay, s0, s1, up0, act, alpha, vmax = st
                 values[out_uid] = lay.fused_call(values[s0], None if s1 is None else values[s1], up0=up0, halo=True,
                                                  act=act, alpha=alpha, vmax=vmax)
+            elif st[0] == 'pool_skip':
+                _, out_uid, lay, in_uid = st
+                values[out_uid], values[in_uid] = ops.avgpool2_skip(values[in_uid])
             else:
                 _, out_uid, lay, in_uids, takes_list = st
                 args = [values[u] for u in in_uids]
@@ -214,6 +223,7 @@ class Model(object):
 
     def __call__(self, inputs):
         """Eager application on device tensors (differentiable)."""
+        self._grads_clean = False           # a backward through this call accumulates into the flat gradient buffer
         outs = self._forward(_as_list(inputs))
         return outs[0] if self._single_output else outs
 
@@ -365,6 +375,8 @@ class Model(object):
                 ops.DEFER_WGRAD_REDUCE = False
                 ops.drop_deferred_reduce()
                 ops.join_side_stream(stats[0].device)
+        if len(stats) == 1:
+            return stats[0].detach().view(1, 2)                 # no copy launch for the single-output case
         return torch.stack([s.detach() for s in stats])
 
     def _apply_gradients(self):
@@ -373,6 +385,7 @@ class Model(object):
 
     def _train_step_eager(self, inputs, targets):
         self._flat_grads.zero_()
+        self._grads_clean = False                               # the gradients stay readable after an eager step
         stats = self._loss_and_backward(inputs, targets, True)
         self._apply_gradients()
         return stats
@@ -397,9 +410,12 @@ class Model(object):
         for dst, src in zip(g['inputs'] + g['targets'], inputs + targets):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        if not self._grads_clean:
+            self._flat_grads.zero_()                            # an eager step / manual backward ran since the last replay
         g['fwd_bwd'].replay()
         parallel.allreduce_gradients(self._flat_grads)          # between the two graphs (scale is baked into 'update')
-        g['update'].replay()
+        g['update'].replay()                                    # ... which also clears the gradient buffer
+        self._grads_clean = True
         return g['stats']
 
     def _capture(self, key, inputs, targets):
@@ -411,11 +427,14 @@ class Model(object):
         self.optimizer._ensure_state(self._flat_params)
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # the gradient buffer is cleared by the optimizer launch of the previous replay (DLWPCS_ADAM_ZERO_GRAD), once
+        # here for the first one: the step graph needs no fill launch
+        self._flat_grads.zero_()
+        self._grads_clean = True
         with torch.cuda.graph(g1):
-            self._flat_grads.zero_()
             stats = self._loss_and_backward(static_in, static_tg, True)
         with torch.cuda.graph(g2, pool=g1.pool()):
-            self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0 / self._world)
+            self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0 / self._world, zero_grads=True)
         entry = {'fwd_bwd': g1, 'update': g2, 'inputs': static_in, 'targets': static_tg, 'stats': stats}
         self._graphs[key] = entry
         return entry

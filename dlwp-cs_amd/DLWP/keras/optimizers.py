@@ -39,18 +39,18 @@ class Adam(Optimizer):
 
     @property
     def iterations(self):
-        return 0 if self._step is None else int(self._step.item())
+        return 0 if self._step is None else int(self._step[0].item())
 
     def _ensure_state(self, flat_params):
         if self._m is None or self._m.numel() != flat_params.numel() or self._m.device != flat_params.device:
             self._m = torch.zeros_like(flat_params)
             self._v = torch.zeros_like(flat_params)
-            self._step = torch.zeros(1, dtype=torch.int32, device=flat_params.device)
+            self._step = torch.zeros(2, dtype=torch.int32, device=flat_params.device)    # {t - 1, ticket}
 
-    def apply(self, flat_params, flat_grads, grad_scale=1.0):
+    def apply(self, flat_params, flat_grads, grad_scale=1.0, zero_grads=False):
         self._ensure_state(flat_params)
         ops.adam_step(flat_params, flat_grads, self._m, self._v, self._step, self.learning_rate, self.beta_1,
-                      self.beta_2, self.epsilon, grad_scale)
+                      self.beta_2, self.epsilon, grad_scale, zero_grads=zero_grads)
 
     def get_config(self):
         return {'name': self.name, 'learning_rate': self.learning_rate, 'beta_1': self.beta_1, 'beta_2': self.beta_2,
@@ -59,7 +59,7 @@ class Adam(Optimizer):
     def state_dict(self):
         if self._m is None:
             return None
-        return {'m': self._m.cpu().numpy(), 'v': self._v.cpu().numpy(), 'step': int(self._step.item())}
+        return {'m': self._m.cpu().numpy(), 'v': self._v.cpu().numpy(), 'step': int(self._step[0].item())}
 
     def load_state_dict(self, state, flat_params):
         if state is None:
@@ -67,7 +67,8 @@ class Adam(Optimizer):
         self._ensure_state(flat_params)
         self._m.copy_(torch.from_numpy(state['m']))
         self._v.copy_(torch.from_numpy(state['v']))
-        self._step.fill_(int(state['step']))
+        self._step.zero_()
+        self._step[0] = int(state['step'])
 
 
 def get(identifier):

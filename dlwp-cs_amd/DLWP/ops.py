@@ -479,6 +479,45 @@ class _AvgPool2(torch.autograd.Function):
         return dx
 
 
+class _AvgPool2Skip(torch.autograd.Function):
+    """(pooled, alias of x): x feeds the pooling AND later consumers (a U-Net skip connection).  Routing those consumers
+    through the alias hands this node both gradients at once, so the backward is ONE pass
+    dx = d_alias + avgpool2_bwd(d_pooled) instead of avgpool2_bwd + autograd's elementwise add."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, N, C = _bnc(x, 'avgpool2')
+        if N % 2:
+            raise ValueError('avgpool2: odd face size %d' % N)
+        x = _c(x)
+        y = torch.empty((B, 6, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
+        check(lib().dlwpcs_avgpool2_fwd(ptr(x), ptr(y), B, N, C, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_avgpool2_fwd')
+        ctx.shape = (B, N, C)
+        ctx.dtype = x.dtype
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        B, N, C = ctx.shape
+        if dy is None:
+            return dskip
+        dy = _c(dy)
+        dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
+        if dskip is None:
+            check(lib().dlwpcs_avgpool2_bwd(ptr(dy), ptr(dx), B, N, C, nat.dtype_tag(dy), stream_ptr()),
+                  'dlwpcs_avgpool2_bwd')
+        else:
+            dskip = _c(dskip)
+            check(lib().dlwpcs_avgpool2_bwd_add(ptr(dy), ptr(dskip), ptr(dx), B, N, C, nat.dtype_tag(dy), stream_ptr()),
+                  'dlwpcs_avgpool2_bwd_add')
+        return dx
+
+
+def avgpool2_skip(x):
+    """-> (avgpool2(x), x') where x' aliases x and must be used by x's remaining consumers."""
+    return _AvgPool2Skip.apply(x)
+
+
 class _Upsample2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -606,8 +645,9 @@ class _MSE(torch.autograd.Function):
         if scratch is None:
             scratch = torch.empty(lib().dlwpcs_mse_scratch_bytes(), dtype=torch.uint8, device=y.device)
             _mse_scratch[key] = scratch
-        out = torch.zeros(2, dtype=torch.float32, device=y.device)
+        out = torch.empty(2, dtype=torch.float32, device=y.device)
         dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
+        tag |= nat.MSE_OVERWRITE                # out = ..., no zero-fill launch
         check(lib().dlwpcs_mse_fwd_bwd(ptr(y), ptr(t), ptr(dy), ptr(out), y.numel(), weight, tag, ptr(scratch),
                                        stream_ptr()), 'dlwpcs_mse_fwd_bwd')
         ctx.save_for_backward(dy)
@@ -625,13 +665,22 @@ def mse_mae(y, t, weight=1.0):
     return _MSE.apply(y, t, float(weight))
 
 
-def adam_step(p, g, m, v, step_dev, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
-    """In-place TF2.1-keras Adam on flat fp32 device buffers; `step_dev` is an int32 device scalar (t-1)."""
+def adam_step(p, g, m, v, step_dev, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, zero_grads=False):
+    """In-place TF2.1-keras Adam on flat fp32 device buffers.  `step_dev`: int32 device tensor; with two elements
+    {t-1, ticket = 0} the update and the step increment are ONE launch (dlwpcs_adam_step_fused; zero_grads clears g
+    once it has been consumed), with one element the two-launch dlwpcs_adam_step."""
     for t in (p, g, m, v):
         require_device(t, 'adam_step')
         _f32_param(t, 'adam_step')
+    if step_dev.numel() >= 2:
+        check(lib().dlwpcs_adam_step_fused(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(step_dev), lr, beta1, beta2,
+                                           eps, grad_scale, nat.ADAM_ZERO_GRAD if zero_grads else 0, stream_ptr()),
+              'dlwpcs_adam_step_fused')
+        return
     check(lib().dlwpcs_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(step_dev), lr, beta1, beta2, eps,
                                  grad_scale, stream_ptr()), 'dlwpcs_adam_step')
+    if zero_grads:
+        g.zero_()
 
 
 def add(a, b):

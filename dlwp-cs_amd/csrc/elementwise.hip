@@ -316,6 +316,23 @@ __global__ void __launch_bounds__(256) avgpool2_bwd_kernel(const V *__restrict__
     }
 }
 
+// dx = dskip + 0.25 * dy spread over each 2x2 block: the pooled tensor's other consumer (a U-Net skip connection)
+// contributes dskip; one pass instead of avgpool2_bwd + an elementwise add (fp32 sum, one rounding)
+template <typename V>
+__global__ void __launch_bounds__(256) avgpool2_bwd_add_kernel(const V *__restrict__ dy, const V *__restrict__ dskip,
+                                                               V *__restrict__ dx, size_t total, int CV, int N) {
+    const int No = N / 2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(e % CV);
+        size_t pix = e / CV;
+        const int xx = (int)(pix % N); pix /= N;
+        const int yy = (int)(pix % N);
+        const size_t plane = pix / N;
+        VT<V>::st(dx + e, vadd(VT<V>::ld(dskip + e),
+                               vscale(VT<V>::ld(dy + ((plane * No + yy / 2) * No + xx / 2) * CV + cv), 0.25f)));
+    }
+}
+
 // y (planes,2N,2N,C) = nearest(x (planes,N,N,C))
 template <typename V>
 __global__ void __launch_bounds__(256) upsample2_fwd_kernel(const V *__restrict__ x, V *__restrict__ y, size_t total,
@@ -524,7 +541,7 @@ __global__ void __launch_bounds__(256) mse_stage1_vec_kernel(const YV *__restric
 }
 
 __global__ void __launch_bounds__(256) mse_stage2_kernel(const float *__restrict__ partial, float *__restrict__ loss_out,
-                                                         int nblocks, float inv_n, float weight) {
+                                                         int nblocks, float inv_n, float weight, int overwrite) {
     __shared__ double s_sq[256], s_ab[256];
     double sq = 0.0, ab = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += 256) { sq += partial[2 * i]; ab += partial[2 * i + 1]; }
@@ -535,8 +552,9 @@ __global__ void __launch_bounds__(256) mse_stage2_kernel(const float *__restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        loss_out[0] += (float)(s_sq[0] * inv_n) * weight;
-        loss_out[1] += (float)(s_ab[0] * inv_n);
+        const float l0 = (float)(s_sq[0] * inv_n) * weight, l1 = (float)(s_ab[0] * inv_n);
+        loss_out[0] = overwrite ? l0 : loss_out[0] + l0;
+        loss_out[1] = overwrite ? l1 : loss_out[1] + l1;
     }
 }
 
@@ -558,6 +576,33 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
     }
 }
 __global__ void step_inc_kernel(int32_t *step) { *step += 1; }
+
+// One launch: state = {t - 1, ticket}.  Every workgroup reads t - 1 when it starts; the last one to FINISH (ticket ==
+// gridDim - 1: all others have read it by then) increments it and clears the ticket.  ZERO: g is cleared once consumed.
+template <bool ZERO>
+__global__ void __launch_bounds__(256) adam_fused_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                         float *__restrict__ v, size_t n, int32_t *state, float lr, float b1,
+                                                         float b2, float eps, float gscale) {
+    const int32_t t0 = *(volatile int32_t *)state;
+    const float t = (float)(t0 + 1);
+    const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        if (ZERO) g[i] = 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = atomicAdd(state + 1, 1);
+        if (done == (int)gridDim.x - 1) {
+            state[1] = 0;
+            state[0] = t0 + 1;
+        }
+    }
+}
 
 }  // namespace dlwpcs
 
@@ -693,6 +738,20 @@ extern "C" int dlwpcs_avgpool2_bwd(const void *dy, void *dx, int B, int N, int C
     POOL_LAUNCH(avgpool2_bwd_kernel, dy, dx, (size_t)B * 6 * N * N, N)
     return check_launch("avgpool2_bwd");
 }
+extern "C" int dlwpcs_avgpool2_bwd_add(const void *dy, const void *dskip, void *dx, int B, int N, int C, int dtype,
+                                       dlwpcs_stream_t stream) {
+    REQUIRE_DTYPE(dtype, "avgpool2_bwd_add");
+    REQUIRE(dy && dskip && dx, "avgpool2_bwd_add: null pointer");
+    REQUIRE(B >= 0 && N >= 2 && N % 2 == 0 && C >= 1, "avgpool2_bwd_add: bad shape B=%d N=%d C=%d", B, N, C);
+    if (B == 0) return DLWPCS_OK;
+    dispatch_vec(dtype, C, [&](auto tag, int w) {
+        using V = decltype(tag);
+        const size_t total = (size_t)B * 6 * N * N * (C / w);
+        hipLaunchKernelGGL(avgpool2_bwd_add_kernel<V>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, (const V *)dy,
+                           (const V *)dskip, (V *)dx, total, C / w, N);
+    });
+    return check_launch("avgpool2_bwd_add");
+}
 extern "C" int dlwpcs_upsample2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream) {
     REQUIRE_DTYPE(dtype, "upsample2_fwd");
     REQUIRE(x && y, "upsample2_fwd: null pointer");
@@ -792,7 +851,8 @@ extern "C" size_t dlwpcs_mse_scratch_bytes(void) { return (size_t)MSE_BLOCKS * 2
 extern "C" int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float *loss_out, size_t n, float weight,
                                   int dtype, void *scratch, dlwpcs_stream_t stream) {
     const bool t_f32 = (dtype & DLWPCS_MSE_TARGET_F32) != 0;
-    dtype &= ~DLWPCS_MSE_TARGET_F32;
+    const int overwrite = (dtype & DLWPCS_MSE_OVERWRITE) ? 1 : 0;
+    dtype &= ~(DLWPCS_MSE_TARGET_F32 | DLWPCS_MSE_OVERWRITE);
     REQUIRE_DTYPE(dtype, "mse_fwd_bwd");
     REQUIRE(y && t && loss_out && scratch && n > 0, "mse_fwd_bwd: bad arguments");
     size_t g = (n + 255) / 256;
@@ -822,7 +882,7 @@ extern "C" int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float 
         hipLaunchKernelGGL((mse_stage1_kernel<float, float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
                            (const float *)y, (const float *)t, (float *)dy, (float *)scratch, n, gscale);
     hipLaunchKernelGGL(mse_stage2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)scratch, loss_out,
-                       (int)g, 1.f / (float)n, weight);
+                       (int)g, 1.f / (float)n, weight, overwrite);
     return check_launch("mse_fwd_bwd");
 }
 
@@ -834,6 +894,24 @@ extern "C" int dlwpcs_adam_step(float *p, const float *g, float *m, float *v, si
                            beta1, beta2, eps, grad_scale);
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
     return check_launch("adam_step");
+}
+
+extern "C" int dlwpcs_adam_step_fused(float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev, float lr,
+                                      float beta1, float beta2, float eps, float grad_scale, int flags,
+                                      dlwpcs_stream_t stream) {
+    REQUIRE(p && g && m && v && state_dev, "adam_step_fused: null pointer");
+    REQUIRE((flags & ~DLWPCS_ADAM_ZERO_GRAD) == 0, "adam_step_fused: unknown flags %d", flags);
+    if (n == 0) {
+        hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev);
+        return check_launch("adam_step_fused");
+    }
+    if (flags & DLWPCS_ADAM_ZERO_GRAD)
+        hipLaunchKernelGGL(adam_fused_kernel<true>, stream_grid(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state_dev,
+                           lr, beta1, beta2, eps, grad_scale);
+    else
+        hipLaunchKernelGGL(adam_fused_kernel<false>, stream_grid(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state_dev,
+                           lr, beta1, beta2, eps, grad_scale);
+    return check_launch("adam_step_fused");
 }
 
 extern "C" int dlwpcs_batch_gather(const void *array, int64_t T, int V, int64_t S, const int32_t *samples_dev, int B,

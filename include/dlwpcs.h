@@ -230,6 +230,10 @@ int dlwpcs_act_bwd(const void *dy, const void *y, void *dx, size_t n, int act, f
 /* x: (B,6,N,N,C) -> y: (B,6,N/2,N/2,C), 2x2 mean;  backward spreads dy/4 */
 int dlwpcs_avgpool2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
 int dlwpcs_avgpool2_bwd(const void *dy, void *dx, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
+/* dx = dskip + avgpool2_bwd(dy): the pooled tensor also feeds a skip connection whose gradient is dskip (N,N like dx);
+ * one pass instead of avgpool2_bwd + add.  dx may alias dskip. */
+int dlwpcs_avgpool2_bwd_add(const void *dy, const void *dskip, void *dx, int B, int N, int C, int dtype,
+                            dlwpcs_stream_t stream);
 /* x: (B,6,N,N,C) -> y: (B,6,2N,2N,C), nearest;  backward sums 2x2 blocks */
 int dlwpcs_upsample2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
 int dlwpcs_upsample2_bwd(const void *dy, void *dx, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
@@ -251,6 +255,7 @@ int dlwpcs_add(const void *a, const void *b, void *y, size_t n, int dtype, dlwpc
  * dtype = dtype of y and dy; t has the same dtype unless DLWPCS_MSE_TARGET_F32 is OR-ed in (bf16 prediction scored
  * against the fp32 target, as TF's AMP does: the loss is computed in fp32). */
 #define DLWPCS_MSE_TARGET_F32 0x100
+#define DLWPCS_MSE_OVERWRITE  0x200   /* OR-ed into dtype: loss_out[0..1] = ... instead of +=  (loss_out need not be zeroed) */
 size_t dlwpcs_mse_scratch_bytes(void);
 int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float *loss_out, size_t n, float weight, int dtype,
                        void *scratch, dlwpcs_stream_t stream);
@@ -259,6 +264,14 @@ int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float *loss_out, 
  * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 int dlwpcs_adam_step(float *p, const float *g, float *m, float *v, size_t n, int32_t *step_dev,
                      float lr, float beta1, float beta2, float eps, float grad_scale, dlwpcs_stream_t stream);
+/* Same update as one launch: `state_dev` points to TWO device int32 {t-1, 0}; the second is a ticket counter (must be 0
+ * between calls, the kernel leaves it 0): the last workgroup to finish increments t-1, so no second launch is needed.
+ * DLWPCS_ADAM_ZERO_GRAD: g[i] = 0 after it has been consumed (the next step's gradient accumulation starts from zeros
+ * without a fill launch). */
+#define DLWPCS_ADAM_ZERO_GRAD 1
+int dlwpcs_adam_step_fused(float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev,
+                           float lr, float beta1, float beta2, float eps, float grad_scale, int flags,
+                           dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
  * Batch feed (reference ArrayDataGenerator.generate, DLWP/model/generators.py:872-984): with the whole data array

@@ -512,3 +512,84 @@ def test_deferred_reduce_with_a_layer_applied_twice():
     orc.mse_loss(h, torch.tensor(t, dtype=torch.float64)).backward()
     for got, ref in zip(grads[1], (tw['eq'], tw['pol'], tb['eq'], tb['pol'])):
         assert rel_err(got, ref.grad.numpy()) < RTOL
+
+
+def test_adam_fused_single_launch_matches_two_launch_and_oracle():
+    """dlwpcs_adam_step_fused: ticket-counter step increment and DLWPCS_ADAM_ZERO_GRAD; bitwise equal to dlwpcs_adam_step."""
+    from DLWP import ops
+    rng = np.random.default_rng(52)
+    n = 300001                      # many workgroups, ragged tail
+    p0 = rng.standard_normal(n).astype(np.float32)
+    pa, pb = to_dev(p0), to_dev(p0)
+    ma, va, mb, vb = (torch.zeros_like(pa) for _ in range(4))
+    step1 = torch.zeros(1, dtype=torch.int32, device=pa.device)
+    step2 = torch.zeros(2, dtype=torch.int32, device=pa.device)
+    pr = torch.tensor(p0[:1000], dtype=torch.float64)
+    mr, vr = torch.zeros_like(pr), torch.zeros_like(pr)
+    for it in range(4):
+        g = rng.standard_normal(n).astype(np.float32)
+        ga, gb = to_dev(g), to_dev(g)
+        ops.adam_step(pa, ga, ma, va, step1, grad_scale=0.5)
+        ops.adam_step(pb, gb, mb, vb, step2, grad_scale=0.5, zero_grads=(it % 2 == 0))
+        orc.adam_step(pr, torch.tensor(0.5 * g[:1000].astype(np.float64)), mr, vr, it + 1)
+        assert torch.equal(gb, torch.zeros_like(gb) if it % 2 == 0 else ga)
+        assert step2.tolist() == [it + 1, 0]
+    assert step1.item() == 4
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert rel_err(pb[:1000].cpu().numpy(), pr.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_avgpool_skip_backward_is_one_pass(dtype):
+    """ops.avgpool2_skip: (pooled, alias); gradient = d_alias + avgpool2_bwd(d_pooled) in one kernel, equal to the two
+    separate ops (fp32: bitwise; bf16: the fused kernel rounds once, the separate path twice -> 1 bf16 ulp)."""
+    from DLWP import ops
+    gen = torch.Generator(device=_dev()).manual_seed(5)
+    x = torch.randn((3, 6, 12, 12, 16), generator=gen, device=_dev()).to(dtype)
+    g_pool = torch.randn((3, 6, 6, 6, 16), generator=gen, device=_dev()).to(dtype)
+    g_skip = torch.randn((3, 6, 12, 12, 16), generator=gen, device=_dev()).to(dtype)
+    xa = x.clone().requires_grad_(True)
+    y, alias = ops.avgpool2_skip(xa)
+    assert torch.equal(alias, x) and alias.data_ptr() == xa.data_ptr()
+    torch.autograd.backward([y, alias], [g_pool, g_skip])
+    xb = x.clone().requires_grad_(True)
+    yb = ops.avgpool2(xb)
+    assert torch.equal(y, yb)
+    torch.autograd.backward([yb, xb * 1.0], [g_pool, g_skip])
+    if dtype == torch.float32:
+        assert torch.equal(xa.grad, xb.grad)
+    else:
+        ref = g_skip.float() + 0.25 * g_pool.float().repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        assert torch.equal(xa.grad, ref.to(torch.bfloat16))
+    # pooled output only
+    xc = x.clone().requires_grad_(True)
+    yc, _ = ops.avgpool2_skip(xc)
+    yc.backward(g_pool)
+    xd = x.clone().requires_grad_(True)
+    ops.avgpool2(xd).backward(g_pool)
+    assert torch.equal(xc.grad, xd.grad)
+
+
+def test_graph_and_eager_steps_interleave():
+    """Graph replays rely on the optimizer launch clearing the gradient buffer; eager steps (other batch shapes) in
+    between leave gradients behind.  A mixed sequence must give bitwise the parameters of the all-eager run."""
+    rng = np.random.default_rng(74)
+    xs = {b: rng.standard_normal((b, 6, 8, 8, 3)).astype(np.float32) for b in (4, 2)}
+    ts = {b: rng.standard_normal((b, 6, 8, 8, 3)).astype(np.float32) for b in (4, 2)}
+    params = orc.make_unet2_params(3, 3, base=4, seed=4)
+    seq = [4, 4, 4, 2, 4, 2, 2, 4, 4]        # per shape: eager, capture + replay, replay ...
+    results = []
+    for use_graphs in (False, True):
+        model, convs = _build_unet2(8, 3, 3, 4)
+        model.use_graphs = use_graphs
+        model.compile(optimizer='adam', loss='mse')
+        _set_params(convs, params)
+        dev = {b: ([to_dev(xs[b])], [to_dev(ts[b])]) for b in xs}
+        losses = []
+        for b in seq:
+            losses.append(model.train_on_device_batch(*dev[b]).clone())
+        torch.cuda.synchronize()
+        results.append((np.concatenate([w.ravel() for w in model.get_weights()]), torch.stack(losses).cpu().numpy()))
+        assert model.optimizer.iterations == len(seq)
+    assert np.array_equal(results[0][0], results[1][0])
+    assert np.array_equal(results[0][1], results[1][1])

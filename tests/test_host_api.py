@@ -81,7 +81,8 @@ def test_unet2_graph_and_fusion_plan():
     plan = orc.unet2_channel_plan(4, 4, 4)
     assert model.n_fused == 10                                   # every pad -> conv3x3 -> relu is one launch
     kinds = [s[0] for s in model._plan]
-    assert kinds.count('fused_conv') == 10 and kinds.count('layer') == 3      # 2 pools + the 1x1 head
+    # the 1x1 head; both pools feed a skip connection too -> their backward is fused with the skip gradient's add
+    assert kinds.count('fused_conv') == 10 and kinds.count('layer') == 1 and kinds.count('pool_skip') == 2
     n_params = sum(2 * (k * k * ci * co + co) for ci, co, k in plan)
     assert model.count_params() == n_params
     assert model.outputs[0].shape == (None, 6, 8, 8, 4)
