@@ -413,9 +413,10 @@ class Model(object):
         if not self._grads_clean:
             self._flat_grads.zero_()                            # an eager step / manual backward ran since the last replay
         g['fwd_bwd'].replay()
-        parallel.allreduce_gradients(self._flat_grads)          # between the two graphs (scale is baked into 'update')
-        g['update'].replay()                                    # ... which also clears the gradient buffer
-        self._grads_clean = True
+        if g['update'] is not None:
+            parallel.allreduce_gradients(self._flat_grads)      # between the two graphs (scale is baked into 'update')
+            g['update'].replay()
+        self._grads_clean = True                                # the optimizer launch also cleared the gradient buffer
         return g['stats']
 
     def _capture(self, key, inputs, targets):
@@ -433,8 +434,12 @@ class Model(object):
         self._grads_clean = True
         with torch.cuda.graph(g1):
             stats = self._loss_and_backward(static_in, static_tg, True)
-        with torch.cuda.graph(g2, pool=g1.pool()):
-            self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0 / self._world, zero_grads=True)
+            if self._world == 1:        # no exchange step: the update rides in the same graph (no inter-graph gap)
+                self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0, zero_grads=True)
+                g2 = None
+        if g2 is not None:
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0 / self._world, zero_grads=True)
         entry = {'fwd_bwd': g1, 'update': g2, 'inputs': static_in, 'targets': static_tg, 'stats': stats}
         self._graphs[key] = entry
         return entry

@@ -1833,8 +1833,11 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     P.d1 = (can_direct && dsrc1 && d->C1 > 0) ? dsrc1 : nullptr;
     P.dsplit = d->C0;
     P.direct_done = &direct_done;
+    // no halo, no upsample, one source: the virtual input IS the source -> write its gradient in place (no routing pass)
+    const bool whole = !d->halo && !d->up0 && d->C1 == 0 && dsrc0;
+    if (whole) P.out = dsrc0;
     rc = dispatch_conv(d->dtype, d->ksize, vec_width(d->Cout, 0, d->dtype), P, conv_work(d), s);
-    if (rc) return rc;
+    if (rc || whole) return rc;
     // dxv is the gradient of the (halo-padded, if halo) virtual input: (B,6,Nv,Nv,Cin), Nv = No + k - 1
     // halo: Nv = N + 2; plain: Nv = N.  Route to the sources (inverse halo gather, upsample adjoint, channel split).
     if (dsrc0) {

@@ -561,6 +561,13 @@ __global__ void __launch_bounds__(256) mse_stage2_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------------------------------
 // TF2.1-keras Adam on flat buffers
 // ---------------------------------------------------------------------------------------------------------------
+// one element; contraction off so that every kernel built on it produces the same bits
+__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float lr_t, float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p = p - lr_t * m / (sqrtf(v) + eps);
+}
 __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, size_t n,
                                                    const int32_t *__restrict__ step, float lr, float b1, float b2,
@@ -568,31 +575,35 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
     const float t = (float)(*step + 1);
     const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_elem(pi, g[i] * gscale, mi, vi, lr_t, b1, b2, eps);
+        m[i] = mi; v[i] = vi; p[i] = pi;
     }
 }
 __global__ void step_inc_kernel(int32_t *step) { *step += 1; }
 
 // One launch: state = {t - 1, ticket}.  Every workgroup reads t - 1 when it starts; the last one to FINISH (ticket ==
 // gridDim - 1: all others have read it by then) increments it and clears the ticket.  ZERO: g is cleared once consumed.
-template <bool ZERO>
+template <bool ZERO, int VEC>
 __global__ void __launch_bounds__(256) adam_fused_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                          float *__restrict__ v, size_t n, int32_t *state, float lr, float b1,
                                                          float b2, float eps, float gscale) {
+    typedef float VT4 __attribute__((ext_vector_type(VEC)));
     const int32_t t0 = *(volatile int32_t *)state;
     const float t = (float)(t0 + 1);
     const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
-        if (ZERO) g[i] = 0.f;
+    const size_t nv = n / VEC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        VT4 gi = reinterpret_cast<const VT4 *>(g)[i], mi = reinterpret_cast<const VT4 *>(m)[i];
+        VT4 vi = reinterpret_cast<const VT4 *>(v)[i], pi = reinterpret_cast<const VT4 *>(p)[i];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float pk = pi[k], mk = mi[k], vk = vi[k];
+            adam_elem(pk, gi[k] * gscale, mk, vk, lr_t, b1, b2, eps);
+            pi[k] = pk; mi[k] = mk; vi[k] = vk;
+        }
+        reinterpret_cast<VT4 *>(m)[i] = mi; reinterpret_cast<VT4 *>(v)[i] = vi; reinterpret_cast<VT4 *>(p)[i] = pi;
+        if (ZERO) reinterpret_cast<VT4 *>(g)[i] = (VT4)0.f;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -905,12 +916,18 @@ extern "C" int dlwpcs_adam_step_fused(float *p, float *g, float *m, float *v, si
         hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev);
         return check_launch("adam_step_fused");
     }
-    if (flags & DLWPCS_ADAM_ZERO_GRAD)
-        hipLaunchKernelGGL(adam_fused_kernel<true>, stream_grid(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state_dev,
-                           lr, beta1, beta2, eps, grad_scale);
-    else
-        hipLaunchKernelGGL(adam_fused_kernel<false>, stream_grid(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state_dev,
-                           lr, beta1, beta2, eps, grad_scale);
+    // few, fat workgroups: every workgroup costs one serialised ticket atomic at the end
+    const bool vec = n % 4 == 0 && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    const size_t items = vec ? n / 4 : n;
+    unsigned grid = (unsigned)((items + 255) / 256);
+    if (grid > 512) grid = 512;
+    const bool zero = (flags & DLWPCS_ADAM_ZERO_GRAD) != 0;
+#define ADAM_LAUNCH(Z, V)                                                                                              \
+    hipLaunchKernelGGL((adam_fused_kernel<Z, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state_dev,  \
+                       lr, beta1, beta2, eps, grad_scale)
+    if (vec) { if (zero) ADAM_LAUNCH(true, 4); else ADAM_LAUNCH(false, 4); }
+    else { if (zero) ADAM_LAUNCH(true, 1); else ADAM_LAUNCH(false, 1); }
+#undef ADAM_LAUNCH
     return check_launch("adam_step_fused");
 }
 

@@ -518,25 +518,32 @@ def test_adam_fused_single_launch_matches_two_launch_and_oracle():
     """dlwpcs_adam_step_fused: ticket-counter step increment and DLWPCS_ADAM_ZERO_GRAD; bitwise equal to dlwpcs_adam_step."""
     from DLWP import ops
     rng = np.random.default_rng(52)
-    n = 300001                      # many workgroups, ragged tail
+    _adam_fused_case(rng, 300001)       # many workgroups, ragged tail: scalar path
+    _adam_fused_case(rng, 300000)       # 16-B vectors
+    _adam_fused_case(rng, 8)            # one workgroup
+
+
+def _adam_fused_case(rng, n):
+    from DLWP import ops
+    k = min(n, 1000)
     p0 = rng.standard_normal(n).astype(np.float32)
     pa, pb = to_dev(p0), to_dev(p0)
     ma, va, mb, vb = (torch.zeros_like(pa) for _ in range(4))
     step1 = torch.zeros(1, dtype=torch.int32, device=pa.device)
     step2 = torch.zeros(2, dtype=torch.int32, device=pa.device)
-    pr = torch.tensor(p0[:1000], dtype=torch.float64)
+    pr = torch.tensor(p0[:k], dtype=torch.float64)
     mr, vr = torch.zeros_like(pr), torch.zeros_like(pr)
     for it in range(4):
         g = rng.standard_normal(n).astype(np.float32)
         ga, gb = to_dev(g), to_dev(g)
         ops.adam_step(pa, ga, ma, va, step1, grad_scale=0.5)
         ops.adam_step(pb, gb, mb, vb, step2, grad_scale=0.5, zero_grads=(it % 2 == 0))
-        orc.adam_step(pr, torch.tensor(0.5 * g[:1000].astype(np.float64)), mr, vr, it + 1)
+        orc.adam_step(pr, torch.tensor(0.5 * g[:k].astype(np.float64)), mr, vr, it + 1)
         assert torch.equal(gb, torch.zeros_like(gb) if it % 2 == 0 else ga)
         assert step2.tolist() == [it + 1, 0]
     assert step1.item() == 4
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
-    assert rel_err(pb[:1000].cpu().numpy(), pr.numpy()) < 1e-6
+    assert rel_err(pb[:k].cpu().numpy(), pr.numpy()) < 1e-6
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
