@@ -1435,6 +1435,176 @@ int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int 
 int launch_ring_fix(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int dtype,
                     hipStream_t s);
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Pointwise head (k = 1, no halo, 32 -> 8..16 channels, bf16): the output layer of the U-Net (32 -> 14) moves 20 MB and
+// does 5 % of the FLOPs; through the tiled conv kernel it costs as much as a 3x3 layer.  Here one wave handles 16 pixels
+// per v_mfma_f32_16x16x32_bf16 (K = all 32 input channels): lane (n = lane & 15, q = lane >> 4) loads 16 B = channels
+// 8q..8q+7 of pixel n, so ONE load instruction of the wave covers 16 complete 64-B pixel rows; the weights of the three
+// face classes stay in registers (read from the dlwpcs_pack_batch fragment buffers), the bias rides in as the C operand.
+// D layout: lane holds output channels 4q..4q+3 of pixel n -> one 8-B store per lane, 16 x 2*Cout contiguous bytes/wave.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint4 uint4_a4 __attribute__((aligned(4)));
+typedef uint2 uint2_a4 __attribute__((aligned(4)));
+
+struct PwParams {
+    const bf16_t *in;        // forward: x (pix, 32); data gradient: dy (pix, Cout)
+    const bf16_t *wpk;       // forward: wpk_fwd; data gradient: wpk_bwd
+    const float *bias;       // bias_pk [3][32] or null (forward only)
+    bf16_t *out;             // forward: y (pix, Cout); data gradient: dx (pix, 32)
+    long ngroups;            // groups of 16 consecutive pixels
+    int groups_per_face;     // N * N / 16
+    int Cout;
+    float alpha, vmax;
+};
+
+constexpr int PW_U = 4;      // 16-pixel groups in flight per wave
+
+// Each wave owns a contiguous range of groups (32-bit indices throughout; the face class of a group is tracked
+// incrementally in scalar registers: no divisions in the loop, the weight fragment is re-selected only when it changes).
+struct PwRange { int g, end, rem, face; };
+__device__ __forceinline__ PwRange pw_range(const PwParams &P) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int nwaves = (int)gridDim.x * 4;
+    const int ng = (int)P.ngroups;
+    const int per = (ng + nwaves - 1) / nwaves;
+    PwRange r;
+    r.g = wave * per < ng ? wave * per : ng;
+    r.end = r.g + per < ng ? r.g + per : ng;
+    const unsigned f = (unsigned)r.g / (unsigned)P.groups_per_face;
+    r.rem = r.g - (int)f * P.groups_per_face;
+    r.face = (int)(f % 6u);
+    return r;
+}
+__device__ __forceinline__ void pw_next(PwRange &r, int gpf) {
+    ++r.g;
+    if (++r.rem == gpf) { r.rem = 0; r.face = r.face == 5 ? 0 : r.face + 1; }
+}
+
+template <bool ACT>
+__global__ void __launch_bounds__(256) pw_fwd_kernel(PwParams P) {
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+    // packed forward weights: [variant][k-group of 8 (4 of them)][32 columns][8]; column = output channel.  A wave's range
+    // rarely spans two face classes: the fragment and the bias quad are (re)loaded only when the class changes.
+    const bf16_t *wlane = P.wpk + (q * 32 + n) * 8;
+    const float *blane = P.bias ? P.bias + q * 4 : nullptr;
+    const int co0 = q * 4, Cout = P.Cout, gpf = P.groups_per_face;
+    const bool st8 = co0 + 4 <= Cout, st4 = !st8 && co0 + 2 <= Cout;
+    PwRange r = pw_range(P);
+    const bf16_t *src = P.in + (unsigned)(n * 32 + q * 8);
+    // a group's 16 output rows are 32 * Cout contiguous bytes, but a lane's 4 channels sit at a 4-B aligned offset inside
+    // them: direct 8-B stores are split and merge badly.  The wave transposes through a private 512-B LDS patch and lanes
+    // 0 .. 2*Cout-1 write aligned 16-B pieces (no fence: one wave's LDS accesses execute in order).
+    __shared__ __attribute__((aligned(16))) uint32_t pw_stage[4][128];
+    uint32_t *stage = pw_stage[threadIdx.x >> 6];
+    const int sidx = (n * Cout + co0) >> 1;
+    const bool wr16 = lane < 2 * Cout;
+    bf16_t *dst = P.out + (unsigned)(lane * 8);
+    int vcur = -1;
+    uint4 a = make_uint4(0, 0, 0, 0);
+    f32x4 b = (f32x4)0.f;
+    while (r.g < r.end) {
+        uint4 xv[PW_U];
+#pragma unroll
+        for (int u = 0; u < PW_U; ++u) {
+            const int g = r.g + u < r.end ? r.g + u : r.end - 1;
+            xv[u] = *reinterpret_cast<const uint4 *>(src + (unsigned)g * 512u);
+        }
+#pragma unroll
+        for (int u = 0; u < PW_U; ++u) {
+            if (r.g < r.end) {
+                const int v = r.face < 4 ? 0 : r.face - 3;
+                if (v != vcur) {
+                    vcur = v;
+                    a = *reinterpret_cast<const uint4 *>(wlane + v * 1024);
+                    if (blane) b = *reinterpret_cast<const f32x4 *>(blane + v * 32);
+                }
+                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, xv[u]), b, 0, 0, 0);
+                if (ACT) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const float t = d[k] < 0.f ? d[k] * P.alpha : d[k]; d[k] = fminf(t, P.vmax); }
+                }
+                uint2 o;
+                o.x = f2bf2(d[0], d[1]); o.y = f2bf2(d[2], d[3]);
+                if (st8) { stage[sidx] = o.x; stage[sidx + 1] = o.y; }
+                else if (st4) stage[sidx] = o.x;
+                __builtin_amdgcn_wave_barrier();
+                if (wr16) *reinterpret_cast<uint4 *>(dst + (unsigned)r.g * (unsigned)(16 * Cout)) = reinterpret_cast<const uint4 *>(stage)[lane];
+                __builtin_amdgcn_wave_barrier();
+                pw_next(r, gpf);
+            }
+        }
+    }
+}
+
+// dx (pix, 32) = dy (pix, Cout) . W^T: K = Cout zero-padded to 32 (lanes q >= 2 carry zeros), two 16-row M tiles
+__global__ void __launch_bounds__(256) pw_dgrad_kernel(PwParams P) {
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+    // packed data-gradient weights: [variant][k-group of 8 (2 of them, zero-padded past Cout)][32 columns][8]; column = ci
+    // (the fragments of a face class are loaded when the class changes: thousands of waves fetching all three classes'
+    // fragments from the same few cache lines up front was the slowest part of the first version)
+    const bf16_t *wlane = P.wpk + (q * 32 + n) * 8;
+    const int Cout = P.Cout, gpf = P.groups_per_face;
+    PwRange r = pw_range(P);
+    const bf16_t *src = P.in + (unsigned)(n * Cout + q * 8);
+    bf16_t *dst = P.out + (unsigned)(n * 32 + q * 4);
+    // lanes q == 1 hold channels 8 .. Cout-1: (Cout - 8) / 2 dwords
+    const bool ld0 = q == 0, l1 = q == 1 && Cout > 8, l2 = q == 1 && Cout > 10, l3 = q == 1 && Cout > 12, l4 = q == 1 && Cout > 14;
+    int vcur = -1;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    while (r.g < r.end) {
+        uint4 bv[PW_U];
+#pragma unroll
+        for (int u = 0; u < PW_U; ++u) {
+            const int g = r.g + u < r.end ? r.g + u : r.end - 1;
+            const bf16_t *sp = src + (unsigned)g * (unsigned)(16 * Cout);
+            bv[u] = make_uint4(0, 0, 0, 0);
+            if (ld0) bv[u] = *reinterpret_cast<const uint4_a4 *>(sp);
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(sp);
+            if (l1) bv[u].x = s32[0];
+            if (l2) bv[u].y = s32[1];
+            if (l3) bv[u].z = s32[2];
+            if (l4) bv[u].w = s32[3];
+        }
+#pragma unroll
+        for (int u = 0; u < PW_U; ++u) {
+            if (r.g < r.end) {
+                const int v = r.face < 4 ? 0 : r.face - 3;
+                if (v != vcur) {
+                    vcur = v;
+                    if (q < 2) {
+                        a0 = *reinterpret_cast<const uint4 *>(wlane + v * 512);
+                        a1 = *reinterpret_cast<const uint4 *>(wlane + v * 512 + 128);
+                    }
+                }
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bv[u]),
+                                                                         (f32x4)0.f, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bv[u]),
+                                                                         (f32x4)0.f, 0, 0, 0);
+                bf16_t *o_ptr = dst + (unsigned)r.g * 512u;
+                uint2 o;
+                o.x = f2bf2(d0[0], d0[1]); o.y = f2bf2(d0[2], d0[3]);
+                *reinterpret_cast<uint2 *>(o_ptr) = o;
+                o.x = f2bf2(d1[0], d1[1]); o.y = f2bf2(d1[2], d1[3]);
+                *reinterpret_cast<uint2 *>(o_ptr + 16) = o;
+                pw_next(r, gpf);
+            }
+        }
+    }
+}
+
+static bool pw_applies(const dlwpcs_conv_desc *d) {
+    return d->dtype == DLWPCS_BF16 && d->ksize == 1 && !d->halo && !d->up0 && d->C1 == 0 && d->C0 == 32 && d->Cout % 2 == 0 &&
+           d->Cout >= 8 && d->Cout <= 16 && ((long)d->N * d->N) % 16 == 0 && d->B > 0 &&
+           (long)d->B * 6 * d->N * d->N * 32 < (1l << 31);        // 32-bit element offsets
+}
+static unsigned pw_grid(long ngroups) {
+    // latency-bound streaming: as many waves in flight as the chip holds (8 per SIMD), >= PW_U groups per wave
+    long blocks = (ngroups + 4 * PW_U - 1) / (4 * PW_U);
+    return (unsigned)(blocks > 2048 ? 2048 : blocks);
+}
+
 struct Work { double flops, bytes; };   // algorithmic work of one launch (for the opt-in profiler)
 
 // rows of the face touched by `pix` consecutive flat pixels whose first pixel is a multiple of `pix`
@@ -1790,6 +1960,18 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
     P.CG = ceil_div(Cin, cgw_of(d->dtype)); P.NTtot = NTtot; P.up0 = d->up0;
     P.mode = d->halo ? MODE_HALO : MODE_DIRECT;
     P.act = d->act; P.alpha = d->alpha; P.vmax = d->vmax;
+    if (pw_applies(d)) {
+        PwParams Q{};
+        Q.in = (const bf16_t *)src0; Q.wpk = (const bf16_t *)wpk; Q.bias = b_eq ? bpk : nullptr; Q.out = (bf16_t *)y;
+        Q.ngroups = (long)d->B * 6 * d->N * d->N / 16; Q.groups_per_face = d->N * d->N / 16; Q.Cout = d->Cout;
+        Q.alpha = d->alpha; Q.vmax = d->vmax;
+        int pidx = -1;
+        if (prof_enabled()) { const Work wk = conv_work(d); pidx = prof_begin("pw_fwd_kernel", wk.flops, wk.bytes, s); }
+        if (d->act != DLWPCS_ACT_NONE) hipLaunchKernelGGL(pw_fwd_kernel<true>, dim3(pw_grid(Q.ngroups)), dim3(256), 0, s, Q);
+        else hipLaunchKernelGGL(pw_fwd_kernel<false>, dim3(pw_grid(Q.ngroups)), dim3(256), 0, s, Q);
+        if (pidx >= 0) prof_end(pidx, s);
+        return check_launch("pw_fwd");
+    }
     return dispatch_conv(d->dtype, d->ksize, vec_width(d->C0, d->C1, d->dtype), P, conv_work(d), s);
 }
 
@@ -1814,6 +1996,16 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     void *dxv = ws + L.dxv;
     if (!prepacked) launch_pack(w_eq, w_pol, w_np, ws + L.wpk_b, d->ksize, Cin, d->Cout, 1, d->flip_north_pole, d->dtype, s);
     const int No = out_size(d);
+    if (pw_applies(d) && d->act == DLWPCS_ACT_NONE && dsrc0) {
+        PwParams Q{};
+        Q.in = (const bf16_t *)dy; Q.wpk = (const bf16_t *)wpk; Q.bias = nullptr; Q.out = (bf16_t *)dsrc0;
+        Q.ngroups = (long)d->B * 6 * d->N * d->N / 16; Q.groups_per_face = d->N * d->N / 16; Q.Cout = d->Cout;
+        int pidx = -1;
+        if (prof_enabled()) { const Work wk = conv_work(d); pidx = prof_begin("pw_dgrad_kernel", wk.flops, wk.bytes, s); }
+        hipLaunchKernelGGL(pw_dgrad_kernel, dim3(pw_grid(Q.ngroups)), dim3(256), 0, s, Q);
+        if (pidx >= 0) prof_end(pidx, s);
+        return check_launch("pw_dgrad");
+    }
     ConvKParams P{};
     // DLWPCS_CONV_REUSE_DZ: the weight-gradient call that ran just before left dz = dy * act'(y) in the workspace
     const bool dz_ready = dz_handover(d);

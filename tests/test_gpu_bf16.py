@@ -176,6 +176,9 @@ BF16_CONV_CASES = [
     (1, 96, 26, 0, 32, 3, True, False, True, False, True),     # C96 first layer of cfg 5
     (2, 12, 16, 0, 96, 3, True, False, True, False, True),     # 3 N tiles under a 4-N-tile workgroup
     (2, 24, 96, 0, 16, 3, True, False, True, False, True),     # ... and on the data-gradient side
+    (2, 16, 32, 0, 16, 1, False, False, True, False, True),    # pointwise head kernels: activation (forward only)
+    (1, 12, 32, 0, 8, 1, False, False, False, True, False),    # ... independent north pole, 8 channels, fwd + dgrad
+    (3, 8, 32, 0, 10, 1, False, False, True, False, False),    # ... 10 channels (partial last k-group / store)
 ]
 
 
