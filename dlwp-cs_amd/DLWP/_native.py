@@ -83,7 +83,7 @@ PROTOTYPES = {
                                 [c_void_p, c_void_p, c_size_t, c_void_p]),
     'dlwpcs_conv_wgrad_reduce_item': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 6 +
                                       [c_void_p, c_size_t, ctypes.POINTER(ReduceItem)]),
-    'dlwpcs_wgrad_reduce_batch': (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    'dlwpcs_wgrad_reduce_batch': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'dlwpcs_gconv_fwd': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),
     'dlwpcs_gconv_bwd_data': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 6),
     'dlwpcs_gconv_bwd_weights': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),

@@ -90,7 +90,8 @@ def flush_deferred_reduce(device):
             rounds.append([])
         rounds[k].append(item)
     for items in rounds:
-        raw = b''.join(bytes(it) for it in items)
+        host = (nat.ReduceItem * len(items))(*items)
+        raw = bytes(host)
         key = (str(device), raw)
         table = _reduce_tables.get(key)
         if table is None:
@@ -99,7 +100,7 @@ def flush_deferred_reduce(device):
                                       'step first')
             table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
             _reduce_tables[key] = table
-        check(lib().dlwpcs_wgrad_reduce_batch(ptr(table), len(items), sum(it.nblocks for it in items), stream_ptr()),
+        check(lib().dlwpcs_wgrad_reduce_batch(ptr(table), ctypes.addressof(host), len(items), stream_ptr()),
               'dlwpcs_wgrad_reduce_batch')
 
 

@@ -534,7 +534,7 @@ __device__ __forceinline__ void pack_weights_range(const float *__restrict__ w_e
     constexpr int J = 16 / (int)sizeof(T);
     const int TAPS = KS * KS;
     for (size_t e = first; e < total; e += stride) {
-        size_t r = e;
+        unsigned r = (unsigned)e;             // totals are a few million at most: 32-bit divisions (64-bit ones cost ~10x)
         const int j = r % J; r /= J;
         const int n = r % 32; r /= 32;
         const int hf = r % 2; r /= 2;
@@ -1388,17 +1388,23 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
 // All layers of a backward pass in one launch (DLWPCS_CONV_DEFER_REDUCE): a workgroup finds its item by walking the
 // (short) item list — workgroup-uniform scalar loads — and runs the same body, so the summation order and therefore
 // the result bits are those of the per-layer launches.
-__global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const dlwpcs_reduce_item *__restrict__ items, int n_items) {
-    int b = (int)blockIdx.x, i = 0;
-    while (i < n_items - 1 && b >= items[i].nblocks) { b -= items[i].nblocks; ++i; }
+constexpr int REDUCE_BATCH_MAX = 32;
+struct ReduceStarts { int first[REDUCE_BATCH_MAX + 1]; };      // first[i] = first workgroup of item i, by value (kernarg)
+__global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const dlwpcs_reduce_item *__restrict__ items, int n_items,
+                                                                 ReduceStarts st) {
+    const int b = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < REDUCE_BATCH_MAX; ++k) i += (k < n_items && b >= st.first[k]) ? 1 : 0;     // registers only
     const dlwpcs_reduce_item it = items[i];
-    if (b >= it.nblocks) return;
+    const int blk = b - st.first[i];
+    if (blk >= it.nblocks) return;
     if (it.vec == 4)
         wgrad_reduce_body<4>(it.partial, it.bpartial, it.dw_eq, it.dw_pol, it.dw_np, it.db_eq, it.db_pol, it.db_np, it.ksize,
-                             it.Cin, it.Cout, it.CinP, it.CoutP, it.n_eq, it.n_4, it.n_5, it.flip_north_pole, it.accumulate, b);
+                             it.Cin, it.Cout, it.CinP, it.CoutP, it.n_eq, it.n_4, it.n_5, it.flip_north_pole, it.accumulate, blk);
     else
         wgrad_reduce_body<1>(it.partial, it.bpartial, it.dw_eq, it.dw_pol, it.dw_np, it.db_eq, it.db_pol, it.db_np, it.ksize,
-                             it.Cin, it.Cout, it.CinP, it.CoutP, it.n_eq, it.n_4, it.n_5, it.flip_north_pole, it.accumulate, b);
+                             it.Cin, it.Cout, it.CinP, it.CoutP, it.n_eq, it.n_4, it.n_5, it.flip_north_pole, it.accumulate, blk);
 }
 
 // VEC = 4 needs every vector to stay inside one row of C_out values and 16-B aligned destinations
@@ -2225,15 +2231,27 @@ extern "C" int dlwpcs_conv_wgrad_reduce_item(const dlwpcs_conv_desc *d, void *dw
     return DLWPCS_OK;
 }
 
-extern "C" int dlwpcs_wgrad_reduce_batch(const dlwpcs_reduce_item *items_dev, int n_items, int total_blocks,
-                                         dlwpcs_stream_t stream) {
-    if (n_items < 0 || n_items > 256 || total_blocks < 0) return fail(DLWPCS_E_INVALID, "wgrad_reduce_batch: n_items %d, total_blocks %d", n_items, total_blocks);
-    if (n_items == 0 || total_blocks == 0) return DLWPCS_OK;
-    if (!items_dev) return fail(DLWPCS_E_INVALID, "wgrad_reduce_batch: null item table");
+extern "C" int dlwpcs_wgrad_reduce_batch(const dlwpcs_reduce_item *items_dev, const dlwpcs_reduce_item *items_host,
+                                         int n_items, dlwpcs_stream_t stream) {
+    if (n_items < 0) return fail(DLWPCS_E_INVALID, "wgrad_reduce_batch: n_items %d", n_items);
+    if (n_items == 0) return DLWPCS_OK;
+    if (!items_dev || !items_host) return fail(DLWPCS_E_INVALID, "wgrad_reduce_batch: null item table");
     hipStream_t s = (hipStream_t)stream;
-    int pidx = -1;
-    if (prof_enabled()) pidx = prof_begin("wgrad_reduce_batch_kernel", 0.0, 0.0, s);
-    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, s, items_dev, n_items);
-    if (pidx >= 0) prof_end(pidx, s);
+    for (int base = 0; base < n_items; base += REDUCE_BATCH_MAX) {
+        const int n = n_items - base < REDUCE_BATCH_MAX ? n_items - base : REDUCE_BATCH_MAX;
+        ReduceStarts st{};
+        int total = 0;
+        for (int k = 0; k < n; ++k) {
+            if (items_host[base + k].nblocks < 0) return fail(DLWPCS_E_INVALID, "wgrad_reduce_batch: item %d has nblocks < 0", base + k);
+            st.first[k] = total;
+            total += items_host[base + k].nblocks;
+        }
+        for (int k = n; k <= REDUCE_BATCH_MAX; ++k) st.first[k] = total;
+        if (total == 0) continue;
+        int pidx = -1;
+        if (prof_enabled()) pidx = prof_begin("wgrad_reduce_batch_kernel", 0.0, 0.0, s);
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, items_dev + base, n, st);
+        if (pidx >= 0) prof_end(pidx, s);
+    }
     return check_launch("wgrad_reduce_batch");
 }

@@ -920,7 +920,7 @@ extern "C" int dlwpcs_adam_step_fused(float *p, float *g, float *m, float *v, si
     const bool vec = n % 4 == 0 && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
     const size_t items = vec ? n / 4 : n;
     unsigned grid = (unsigned)((items + 255) / 256);
-    if (grid > 512) grid = 512;
+    if (grid > 256) grid = 256;
     const bool zero = (flags & DLWPCS_ADAM_ZERO_GRAD) != 0;
 #define ADAM_LAUNCH(Z, V)                                                                                              \
     hipLaunchKernelGGL((adam_fused_kernel<Z, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state_dev,  \

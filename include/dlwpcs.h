@@ -178,7 +178,8 @@ int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d,
  * dlwpcs_conv_wgrad_reduce_item (host only, launches nothing): fills *item with what the reduction of the layer
  * described by d needs — the same d (flags included: ACCUMULATE_WGRAD decides add vs overwrite), destinations and
  * workspace as the dlwpcs_conv_bwd_weights call that produced the partials.  `nblocks` is the item's share of the launch.
- * dlwpcs_wgrad_reduce_batch: items_dev is a DEVICE copy of n_items (<= 256) items; total_blocks = sum of their nblocks.
+ * dlwpcs_wgrad_reduce_batch: items_dev is a DEVICE copy of the n_items host items (the host copy supplies the launch
+ * geometry; both must hold the same items).
  * Items whose destinations overlap (a layer applied twice) must all carry ACCUMULATE_WGRAD: items run concurrently,
  * every destination element is owned by one thread per item, so overlapping items are only safe as atomics-free adds
  * when the caller serialises them — put them in separate launches.  Bitwise reproducible like the per-layer path
@@ -193,7 +194,7 @@ int dlwpcs_conv_wgrad_reduce_item(const dlwpcs_conv_desc *d,
                                   void *dw_eq, void *dw_pol, void *dw_np,
                                   void *db_eq, void *db_pol, void *db_np,
                                   void *workspace, size_t workspace_bytes, dlwpcs_reduce_item *item);
-int dlwpcs_wgrad_reduce_batch(const dlwpcs_reduce_item *items_dev, int n_items, int total_blocks,
+int dlwpcs_wgrad_reduce_batch(const dlwpcs_reduce_item *items_dev, const dlwpcs_reduce_item *items_host, int n_items,
                               dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
