@@ -2241,15 +2241,20 @@ extern "C" int dlwpcs_wgrad_reduce_batch(const dlwpcs_reduce_item *items_dev, co
         const int n = n_items - base < REDUCE_BATCH_MAX ? n_items - base : REDUCE_BATCH_MAX;
         ReduceStarts st{};
         int total = 0;
+        double bytes = 0.0;          // algorithmic traffic: every partial read once, every gradient written once
         for (int k = 0; k < n; ++k) {
-            if (items_host[base + k].nblocks < 0) return fail(DLWPCS_E_INVALID, "wgrad_reduce_batch: item %d has nblocks < 0", base + k);
+            const dlwpcs_reduce_item &it = items_host[base + k];
+            if (it.nblocks < 0) return fail(DLWPCS_E_INVALID, "wgrad_reduce_batch: item %d has nblocks < 0", base + k);
             st.first[k] = total;
-            total += items_host[base + k].nblocks;
+            total += it.nblocks;
+            if (it.nblocks > 0)
+                bytes += 4.0 * ((double)(it.n_eq + it.n_4 + it.n_5) * it.ksize * it.ksize * it.CinP * it.CoutP +
+                                2.0 * it.ksize * it.ksize * it.Cin * it.Cout);
         }
         for (int k = n; k <= REDUCE_BATCH_MAX; ++k) st.first[k] = total;
         if (total == 0) continue;
         int pidx = -1;
-        if (prof_enabled()) pidx = prof_begin("wgrad_reduce_batch_kernel", 0.0, 0.0, s);
+        if (prof_enabled()) pidx = prof_begin("wgrad_reduce_batch_kernel", 0.0, bytes, s);
         hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, items_dev + base, n, st);
         if (pidx >= 0) prof_end(pidx, s);
     }

@@ -40,12 +40,13 @@ def summarize(sel, nsteps, title):
 
 def main():
     rows = list(csv.DictReader(open(os.path.join(R, 'gpurun_out/prof_r1/r1_kernel_trace.csv'))))
-    idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    idx = [i for i, r in enumerate(rows) if 'adam_fused_kernel' in r['Kernel_Name']]
     steps = []
-    for a, b in zip(idx[:-1], idx[1:]):           # a step = the kernels between two optimizer launches
-        seg = rows[a + 2:b + 2]
+    for a, b in zip(idx[:-1], idx[1:]):           # a step = the kernels after one optimizer launch up to the next one
+        seg = rows[a + 1:b + 1]
         bf = any('unsigned short' in r['Kernel_Name'] or 'wgrad_bf16' in r['Kernel_Name'] for r in seg)
-        steps.append((a + 2, b + 2, bf))
+        steps.append((a + 1, b + 1, bf))
     txt = []
     for want, title in ((True, 'bf16 mode (headline)'), (False, 'f32 mode (companion)')):
         st = [s for s in steps if s[2] == want][:-4][-40:]      # drop the eager roofline-pass steps at the end of each mode
@@ -57,7 +58,7 @@ def main():
     shutil.copy(os.path.join(R, 'gpurun_out/bench_default.json'), PRE + '_benchline.json')
 
     pm = {}
-    keep = ('conv_mfma', 'wgrad', 'pad_bwd_src', 'pad_ring_fix', 'pack_batch', 'avgpool', 'mse_stage1', 'adam_kernel')
+    keep = ('conv_mfma', 'wgrad', 'pw_', 'pad_bwd_src', 'pad_ring_fix', 'pack_batch', 'avgpool', 'mse_stage1', 'adam')
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         for r in csv.DictReader(open(os.path.join(R, 'gpurun_out/pmc_%s/p_counter_collection.csv' % c))):
             k = clean(r['Kernel_Name'])
