@@ -1443,7 +1443,7 @@ int launch_ring_fix(const void *dxv, void *dsrc, const int32_t *inv, int B, int 
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// Pointwise head (k = 1, no halo, 32 -> 8..16 channels, bf16): the output layer of the U-Net (32 -> 14) moves 20 MB and
+// Pointwise head (k = 1, no halo, 32 -> 8..32 channels, bf16): the output layer of the U-Net (32 -> 14) moves 20 MB and
 // does 5 % of the FLOPs; through the tiled conv kernel it costs as much as a 3x3 layer.  Here one wave handles 16 pixels
 // per v_mfma_f32_16x16x32_bf16 (K = all 32 input channels): lane (n = lane & 15, q = lane >> 4) loads 16 B = channels
 // 8q..8q+7 of pixel n, so ONE load instruction of the wave covers 16 complete 64-B pixel rows; the weights of the three
@@ -1488,28 +1488,29 @@ __device__ __forceinline__ void pw_next(PwRange &r, int gpf) {
     if (++r.rem == gpf) { r.rem = 0; r.face = r.face == 5 ? 0 : r.face + 1; }
 }
 
-template <bool ACT>
+template <bool ACT, int MT>      // MT = 16-channel output tiles: 1 (C_out <= 16) or 2 (C_out <= 32)
 __global__ void __launch_bounds__(256) pw_fwd_kernel(PwParams P) {
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
     // packed forward weights: [variant][k-group of 8 (4 of them)][32 columns][8]; column = output channel.  A wave's range
-    // rarely spans two face classes: the fragment and the bias quad are (re)loaded only when the class changes.
+    // rarely spans two face classes: the fragments and the bias quads are (re)loaded only when the class changes (every
+    // wave pre-loading all three classes — thousands of waves on the same few cache lines — tripled the kernel time).
     const bf16_t *wlane = P.wpk + (q * 32 + n) * 8;
     const float *blane = P.bias ? P.bias + q * 4 : nullptr;
-    const int co0 = q * 4, Cout = P.Cout, gpf = P.groups_per_face;
-    const bool st8 = co0 + 4 <= Cout, st4 = !st8 && co0 + 2 <= Cout;
+    const int Cout = P.Cout, gpf = P.groups_per_face;
     PwRange r = pw_range(P);
     const bf16_t *src = P.in + (unsigned)(n * 32 + q * 8);
     // a group's 16 output rows are 32 * Cout contiguous bytes, but a lane's 4 channels sit at a 4-B aligned offset inside
-    // them: direct 8-B stores are split and merge badly.  The wave transposes through a private 512-B LDS patch and lanes
+    // them: direct 8-B stores are split and merge badly.  The wave transposes through a private LDS patch and lanes
     // 0 .. 2*Cout-1 write aligned 16-B pieces (no fence: one wave's LDS accesses execute in order).
-    __shared__ __attribute__((aligned(16))) uint32_t pw_stage[4][128];
+    __shared__ __attribute__((aligned(16))) uint32_t pw_stage[4][128 * MT];
     uint32_t *stage = pw_stage[threadIdx.x >> 6];
-    const int sidx = (n * Cout + co0) >> 1;
     const bool wr16 = lane < 2 * Cout;
     bf16_t *dst = P.out + (unsigned)(lane * 8);
     int vcur = -1;
-    uint4 a = make_uint4(0, 0, 0, 0);
-    f32x4 b = (f32x4)0.f;
+    uint4 a[MT];
+    f32x4 b[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { a[t] = make_uint4(0, 0, 0, 0); b[t] = (f32x4)0.f; }
     while (r.g < r.end) {
         uint4 xv[PW_U];
 #pragma unroll
@@ -1523,18 +1524,24 @@ __global__ void __launch_bounds__(256) pw_fwd_kernel(PwParams P) {
                 const int v = r.face < 4 ? 0 : r.face - 3;
                 if (v != vcur) {
                     vcur = v;
-                    a = *reinterpret_cast<const uint4 *>(wlane + v * 1024);
-                    if (blane) b = *reinterpret_cast<const f32x4 *>(blane + v * 32);
-                }
-                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, xv[u]), b, 0, 0, 0);
-                if (ACT) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { const float t = d[k] < 0.f ? d[k] * P.alpha : d[k]; d[k] = fminf(t, P.vmax); }
+                    for (int t = 0; t < MT; ++t) {
+                        a[t] = *reinterpret_cast<const uint4 *>(wlane + v * 1024 + t * 128);
+                        if (blane) b[t] = *reinterpret_cast<const f32x4 *>(blane + v * 32 + t * 16);
+                    }
                 }
-                uint2 o;
-                o.x = f2bf2(d[0], d[1]); o.y = f2bf2(d[2], d[3]);
-                if (st8) { stage[sidx] = o.x; stage[sidx + 1] = o.y; }
-                else if (st4) stage[sidx] = o.x;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[t]), __builtin_bit_cast(bf16x8, xv[u]),
+                                                                      b[t], 0, 0, 0);
+                    if (ACT) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { const float x = d[k] < 0.f ? d[k] * P.alpha : d[k]; d[k] = fminf(x, P.vmax); }
+                    }
+                    const int co0 = t * 16 + q * 4, sidx = (n * Cout + co0) >> 1;
+                    if (co0 + 4 <= Cout) { stage[sidx] = f2bf2(d[0], d[1]); stage[sidx + 1] = f2bf2(d[2], d[3]); }
+                    else if (co0 + 2 <= Cout) stage[sidx] = f2bf2(d[0], d[1]);
+                }
                 __builtin_amdgcn_wave_barrier();
                 if (wr16) *reinterpret_cast<uint4 *>(dst + (unsigned)r.g * (unsigned)(16 * Cout)) = reinterpret_cast<const uint4 *>(stage)[lane];
                 __builtin_amdgcn_wave_barrier();
@@ -1544,19 +1551,21 @@ __global__ void __launch_bounds__(256) pw_fwd_kernel(PwParams P) {
     }
 }
 
-// dx (pix, 32) = dy (pix, Cout) . W^T: K = Cout zero-padded to 32 (lanes q >= 2 carry zeros), two 16-row M tiles
+// dx (pix, 32) = dy (pix, Cout) . W^T: K = Cout zero-padded to 32 (lane groups past Cout carry zeros), two 16-row M tiles
 __global__ void __launch_bounds__(256) pw_dgrad_kernel(PwParams P) {
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
-    // packed data-gradient weights: [variant][k-group of 8 (2 of them, zero-padded past Cout)][32 columns][8]; column = ci
-    // (the fragments of a face class are loaded when the class changes: thousands of waves fetching all three classes'
-    // fragments from the same few cache lines up front was the slowest part of the first version)
-    const bf16_t *wlane = P.wpk + (q * 32 + n) * 8;
+    // packed data-gradient weights: [variant][k-group of 8 (2 per 16 output channels, zero-padded past Cout)][32 columns][8];
+    // column = ci.  Fragments of a face class are loaded when the class changes.
     const int Cout = P.Cout, gpf = P.groups_per_face;
+    const int kgroups = ((Cout + 15) / 16) * 2;              // k-groups present in the packed buffer
+    const bool kvalid = q < kgroups && q * 8 < Cout;
+    const bf16_t *wlane = P.wpk + (q * 32 + n) * 8;
     PwRange r = pw_range(P);
     const bf16_t *src = P.in + (unsigned)(n * Cout + q * 8);
     bf16_t *dst = P.out + (unsigned)(n * 32 + q * 4);
-    // lanes q == 1 hold channels 8 .. Cout-1: (Cout - 8) / 2 dwords
-    const bool ld0 = q == 0, l1 = q == 1 && Cout > 8, l2 = q == 1 && Cout > 10, l3 = q == 1 && Cout > 12, l4 = q == 1 && Cout > 14;
+    // lane group q holds channels 8q .. min(8q + 8, Cout) - 1: up to four dwords
+    const int nch = Cout - q * 8;
+    const bool full = nch >= 8, l1 = !full && nch > 0, l2 = !full && nch > 2, l3 = !full && nch > 4, l4 = !full && nch > 6;
     int vcur = -1;
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
     while (r.g < r.end) {
@@ -1566,7 +1575,7 @@ __global__ void __launch_bounds__(256) pw_dgrad_kernel(PwParams P) {
             const int g = r.g + u < r.end ? r.g + u : r.end - 1;
             const bf16_t *sp = src + (unsigned)g * (unsigned)(16 * Cout);
             bv[u] = make_uint4(0, 0, 0, 0);
-            if (ld0) bv[u] = *reinterpret_cast<const uint4_a4 *>(sp);
+            if (full) bv[u] = *reinterpret_cast<const uint4_a4 *>(sp);
             const uint32_t *s32 = reinterpret_cast<const uint32_t *>(sp);
             if (l1) bv[u].x = s32[0];
             if (l2) bv[u].y = s32[1];
@@ -1579,9 +1588,9 @@ __global__ void __launch_bounds__(256) pw_dgrad_kernel(PwParams P) {
                 const int v = r.face < 4 ? 0 : r.face - 3;
                 if (v != vcur) {
                     vcur = v;
-                    if (q < 2) {
-                        a0 = *reinterpret_cast<const uint4 *>(wlane + v * 512);
-                        a1 = *reinterpret_cast<const uint4 *>(wlane + v * 512 + 128);
+                    if (kvalid) {
+                        a0 = *reinterpret_cast<const uint4 *>(wlane + v * kgroups * 256);
+                        a1 = *reinterpret_cast<const uint4 *>(wlane + v * kgroups * 256 + 128);
                     }
                 }
                 const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bv[u]),
@@ -1602,7 +1611,7 @@ __global__ void __launch_bounds__(256) pw_dgrad_kernel(PwParams P) {
 
 static bool pw_applies(const dlwpcs_conv_desc *d) {
     return d->dtype == DLWPCS_BF16 && d->ksize == 1 && !d->halo && !d->up0 && d->C1 == 0 && d->C0 == 32 && d->Cout % 2 == 0 &&
-           d->Cout >= 8 && d->Cout <= 16 && ((long)d->N * d->N) % 16 == 0 && d->B > 0 &&
+           d->Cout >= 8 && d->Cout <= 32 && ((long)d->N * d->N) % 16 == 0 && d->B > 0 &&
            (long)d->B * 6 * d->N * d->N * 32 < (1l << 31);        // 32-bit element offsets
 }
 static unsigned pw_grid(long ngroups) {
@@ -1973,8 +1982,15 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
         Q.alpha = d->alpha; Q.vmax = d->vmax;
         int pidx = -1;
         if (prof_enabled()) { const Work wk = conv_work(d); pidx = prof_begin("pw_fwd_kernel", wk.flops, wk.bytes, s); }
-        if (d->act != DLWPCS_ACT_NONE) hipLaunchKernelGGL(pw_fwd_kernel<true>, dim3(pw_grid(Q.ngroups)), dim3(256), 0, s, Q);
-        else hipLaunchKernelGGL(pw_fwd_kernel<false>, dim3(pw_grid(Q.ngroups)), dim3(256), 0, s, Q);
+        const bool actv = d->act != DLWPCS_ACT_NONE;
+        const dim3 pgrid(pw_grid(Q.ngroups));
+        if (d->Cout <= 16) {
+            if (actv) hipLaunchKernelGGL((pw_fwd_kernel<true, 1>), pgrid, dim3(256), 0, s, Q);
+            else hipLaunchKernelGGL((pw_fwd_kernel<false, 1>), pgrid, dim3(256), 0, s, Q);
+        } else {
+            if (actv) hipLaunchKernelGGL((pw_fwd_kernel<true, 2>), pgrid, dim3(256), 0, s, Q);
+            else hipLaunchKernelGGL((pw_fwd_kernel<false, 2>), pgrid, dim3(256), 0, s, Q);
+        }
         if (pidx >= 0) prof_end(pidx, s);
         return check_launch("pw_fwd");
     }

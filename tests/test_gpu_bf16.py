@@ -179,6 +179,9 @@ BF16_CONV_CASES = [
     (2, 16, 32, 0, 16, 1, False, False, True, False, True),    # pointwise head kernels: activation (forward only)
     (1, 12, 32, 0, 8, 1, False, False, False, True, False),    # ... independent north pole, 8 channels, fwd + dgrad
     (3, 8, 32, 0, 10, 1, False, False, True, False, False),    # ... 10 channels (partial last k-group / store)
+    (1, 16, 32, 0, 26, 1, False, False, True, False, False),   # ... 26 channels (config 5 head): two output tiles
+    (2, 8, 32, 0, 32, 1, False, False, True, False, True),     # ... 32 channels + activation
+    (1, 12, 32, 0, 20, 1, False, False, False, True, False),   # ... 20 channels, independent north pole
 ]
 
 
