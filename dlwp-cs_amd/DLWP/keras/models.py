@@ -190,14 +190,16 @@ class Model(object):
         self._pack_cache = st
         return st
 
-    def _forward(self, inputs):
+    def _forward(self, inputs, repack=True):
         want = backend.torch_dtype(self.compute_dtype)
         inputs = [v if v.dtype == want else v.to(want) for v in inputs]
         if inputs and inputs[0].is_cuda and self.prepack_weights:
-            # one launch packs the weights of every layer for this pass (they changed with the last optimizer step)
+            # one launch packs the weights of every layer for this pass (they changed with the last optimizer step);
+            # repack=False: the caller knows they have not changed since its previous pass (steps of one rollout)
             st = self._pack_state(inputs[0].device)
-            if st['n']:
+            if st['n'] and (repack or not st.get('packed')):
                 ops.pack_batch(st['items'], st['n'])
+                st['packed'] = True
             ops.PREPACKED = st['table']
             try:
                 return self._run_plan(inputs)
@@ -602,7 +604,7 @@ class Model(object):
                 dx = [self._to_device(a[s:s + bs]) for a in xs]
                 if s == 0:
                     self._check_shapes(dx, self.inputs, 'input')
-                res = self._forward(dx)
+                res = self._forward(dx, repack=(s == 0))
                 if outs is None:
                     outs = [np.empty((n,) + tuple(r.shape[1:]), dtype=np.float32) for r in res]
                 for o, r in zip(outs, res):
@@ -611,10 +613,11 @@ class Model(object):
             outs = [np.empty((0,) + tuple(o.shape[1:]), dtype=np.float32) for o in self.outputs]
         return outs[0] if self._single_output else outs
 
-    def predict_on_device(self, inputs):
-        """Forward pass on device tensors without host round trips (used by the device-resident rollout)."""
+    def predict_on_device(self, inputs, repack=True):
+        """Forward pass on device tensors without host round trips (used by the device-resident rollout).
+        repack=False skips the weight-packing launch: only for consecutive passes with unchanged weights."""
         with torch.no_grad():
-            outs = self._forward(_as_list(inputs))
+            outs = self._forward(_as_list(inputs), repack=repack)
         return outs[0] if self._single_output else outs
 
     def rollout_on_device(self, predictors, steps, n_steps, out_series, verbose=0, batch_size=None):
@@ -633,7 +636,7 @@ class Model(object):
                 for t in range(steps):
                     if verbose > 0 and s == 0:
                         print('Prediction step %d/%d' % (t + 1, steps))
-                    res = self._forward([state])
+                    res = self._forward([state], repack=(t == 0 and s == 0))       # weights are fixed during a rollout
                     if tuple(res[-1].shape) != tuple(state.shape):
                         raise ValueError('could not broadcast model output of shape %s into the input of shape %s'
                                          % (tuple(res[-1].shape), tuple(state.shape)))

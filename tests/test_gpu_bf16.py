@@ -182,6 +182,10 @@ BF16_CONV_CASES = [
     (1, 16, 32, 0, 26, 1, False, False, True, False, False),   # ... 26 channels (config 5 head): two output tiles
     (2, 8, 32, 0, 32, 1, False, False, True, False, True),     # ... 32 channels + activation
     (1, 12, 32, 0, 20, 1, False, False, False, True, False),   # ... 20 channels, independent north pole
+    (2, 12, 16, 0, 14, 3, True, False, True, False, True),     # 4-B vector loader on the data-gradient side (dy has 14 channels)
+    (1, 16, 8, 0, 26, 3, True, False, True, False, True),      # ... 26 channels
+    (2, 10, 10, 0, 16, 3, True, False, True, False, True),     # 4-B vector loader, 10 input channels
+    (1, 12, 22, 0, 8, 1, False, False, True, False, True),     # ... 1x1, 22 input channels
 ]
 
 

@@ -43,8 +43,8 @@ def main():
     def rollout():
         state = state0
         with torch.no_grad():
-            for _ in range(n_fwd):
-                state = model.predict_on_device(state)
+            for i in range(n_fwd):
+                state = model.predict_on_device(state, repack=(i == 0))       # as Model.rollout_on_device does
         return state
 
     rollout()
