@@ -1438,6 +1438,8 @@ static void launch_wgrad_reduce(hipStream_t s, const float *partial, const float
 // ------------------------------------------------------------------------------------------------------------------
 int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int up,
                     int halo, int dtype, hipStream_t s);
+int launch_src_pair(const void *dxv, void *dsrc0, void *dsrc1, const int32_t *inv, int B, int N, int C0, int C1, int up0,
+                    int dtype, hipStream_t s);
 int launch_ring_fix(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int dtype,
                     hipStream_t s);
 
@@ -2054,6 +2056,8 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     if (rc || whole) return rc;
     // dxv is the gradient of the (halo-padded, if halo) virtual input: (B,6,Nv,Nv,Cin), Nv = No + k - 1
     // halo: Nv = N + 2; plain: Nv = N.  Route to the sources (inverse halo gather, upsample adjoint, channel split).
+    if (dsrc0 && dsrc1 && d->C1 > 0 && d->halo && direct_done && !P.d0 && P.d1)       // decoder layer: both in one launch
+        return launch_src_pair(dxv, dsrc0, dsrc1, inv_table_dev, d->B, d->N, d->C0, d->C1, d->up0, d->dtype, s);
     if (dsrc0) {
         if (direct_done && P.d0) rc = launch_ring_fix(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->dtype, s);
         else rc = launch_src_grad(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->up0, d->halo, d->dtype, s);

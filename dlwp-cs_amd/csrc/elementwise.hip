@@ -144,14 +144,14 @@ __global__ void __launch_bounds__(256) pad_bwd_kernel(const V *__restrict__ dy, 
 // Adjoint of the fused conv loader: dxpad (B,6,M,M,CT) -> gradient of ONE source (channel window [choff, choff+CS))
 // on the N grid, or on the N/2 grid with the 2x2 block sum of the nearest-upsample adjoint (up != 0).  p = 1.
 template <typename V>
-__global__ void __launch_bounds__(256) pad_bwd_src_kernel(const V *__restrict__ dxpad, V *__restrict__ dsrc,
-                                                          const int32_t *__restrict__ inv, size_t total, int CSV,
-                                                          int CTV, int choffV, int N, int up) {
+__device__ __forceinline__ void pad_bwd_src_body(const V *__restrict__ dxpad, V *__restrict__ dsrc,
+                                                 const int32_t *__restrict__ inv, size_t total, int CSV, int CTV,
+                                                 int choffV, int N, int up, unsigned block, unsigned nblocks) {
     const int p = 1;
     const int M = N + 2 * p;
     const int No = up ? N / 2 : N;
     const int out_cells = 6 * No * No, dst_cells = 6 * M * M;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    for (size_t e = (size_t)block * blockDim.x + threadIdx.x; e < total; e += (size_t)nblocks * blockDim.x) {
         const int cv = (int)(e % CSV);
         const size_t pix = e / CSV;
         const int cell = (int)(pix % out_cells);
@@ -178,17 +178,24 @@ __global__ void __launch_bounds__(256) pad_bwd_src_kernel(const V *__restrict__ 
     }
 }
 
+template <typename V>
+__global__ void __launch_bounds__(256) pad_bwd_src_kernel(const V *__restrict__ dxpad, V *__restrict__ dsrc,
+                                                          const int32_t *__restrict__ inv, size_t total, int CSV,
+                                                          int CTV, int choffV, int N, int up) {
+    pad_bwd_src_body<V>(dxpad, dsrc, inv, total, CSV, CTV, choffV, N, up, blockIdx.x, gridDim.x);
+}
+
 // Border fix-up after a data-gradient kernel that wrote the INTERIOR cells of dxpad straight into dsrc (conv_mfma.hip,
 // direct mode): only the halo ring of dxpad was materialised; every border cell of the source (row/column 0 or N-1) still
 // lacks the <= 4 ring cells that gathered from it.  One thread per (sample, border cell, channel vector); p = 1.
 template <typename V>
-__global__ void __launch_bounds__(256) pad_ring_fix_kernel(const V *__restrict__ dxpad, V *__restrict__ dsrc,
-                                                           const int32_t *__restrict__ inv, size_t total, int CSV,
-                                                           int CTV, int choffV, int N) {
+__device__ __forceinline__ void pad_ring_fix_body(const V *__restrict__ dxpad, V *__restrict__ dsrc,
+                                                  const int32_t *__restrict__ inv, size_t total, int CSV, int CTV,
+                                                  int choffV, int N, unsigned block, unsigned nblocks) {
     const int M = N + 2;
     const int nb = N > 1 ? 4 * N - 4 : 1;              // border cells per face
     const int dst_cells = 6 * M * M;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    for (size_t e = (size_t)block * blockDim.x + threadIdx.x; e < total; e += (size_t)nblocks * blockDim.x) {
         const int cv = (int)(e % CSV);
         size_t r = e / CSV;
         const int k = (int)(r % nb); r /= nb;
@@ -210,6 +217,24 @@ __global__ void __launch_bounds__(256) pad_ring_fix_kernel(const V *__restrict__
         if (t.w >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.w * CTV));
         VT<V>::st(dst, acc);
     }
+}
+
+template <typename V>
+__global__ void __launch_bounds__(256) pad_ring_fix_kernel(const V *__restrict__ dxpad, V *__restrict__ dsrc,
+                                                           const int32_t *__restrict__ inv, size_t total, int CSV,
+                                                           int CTV, int choffV, int N) {
+    pad_ring_fix_body<V>(dxpad, dsrc, inv, total, CSV, CTV, choffV, N, blockIdx.x, gridDim.x);
+}
+
+// Both sources of a fused decoder convolution in ONE launch (each launch costs ~4-5 us of floor): workgroups [0, nb0) route
+// the upsampled source 0 (inverse halo gather + 2x2 block sum), the rest apply the ring fix-up to the directly written
+// source 1.
+template <typename V>
+__global__ void __launch_bounds__(256) src_pair_kernel(const V *__restrict__ dxpad, V *__restrict__ dsrc0, V *__restrict__ dsrc1,
+                                                       const int32_t *__restrict__ inv, size_t total0, size_t total1,
+                                                       int CS0V, int CS1V, int CTV, int N, int up0, unsigned nb0) {
+    if (blockIdx.x < nb0) pad_bwd_src_body<V>(dxpad, dsrc0, inv, total0, CS0V, CTV, 0, N, up0, blockIdx.x, nb0);
+    else pad_ring_fix_body<V>(dxpad, dsrc1, inv, total1, CS1V, CTV, CS0V, N, blockIdx.x - nb0, gridDim.x - nb0);
 }
 
 // gradient of one source of a halo==0 convolution input (no padding): channel window copy, optional 2x2 sum
@@ -676,6 +701,24 @@ int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int 
                                CS / w, CT / w, choff / w, N, up);
     });
     return check_launch("src_grad");
+}
+
+// source 0 through the full inverse gather (upsampled source), source 1 through the ring fix-up, one launch
+int launch_src_pair(const void *dxv, void *dsrc0, void *dsrc1, const int32_t *inv, int B, int N, int C0, int C1, int up0,
+                    int dtype, hipStream_t s) {
+    const int CT = C0 + C1;
+    int g = 8;
+    while (g > 1 && (C0 % g || C1 % g)) g >>= 1;
+    const int No = up0 ? N / 2 : N;
+    const int nb = N > 1 ? 4 * N - 4 : 1;
+    dispatch_vec(dtype, g, [&](auto tag, int w) {
+        using V = decltype(tag);
+        const size_t total0 = (size_t)B * 6 * No * No * (C0 / w), total1 = (size_t)B * 6 * nb * (C1 / w);
+        const unsigned nb0 = stream_grid(total0).x, nb1 = stream_grid(total1).x;
+        hipLaunchKernelGGL(src_pair_kernel<V>, dim3(nb0 + nb1), dim3(256), 0, s, (const V *)dxv, (V *)dsrc0, (V *)dsrc1, inv,
+                           total0, total1, C0 / w, C1 / w, CT / w, N, up0, nb0);
+    });
+    return check_launch("src_pair");
 }
 
 // border fix-up of a source whose interior gradient was written directly by the data-gradient kernel (halo, p = 1, no
