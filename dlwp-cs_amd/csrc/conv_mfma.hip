@@ -100,6 +100,15 @@ __device__ __forceinline__ uint16_t vsel(bool c, uint16_t v) { return c ? v : (u
 __device__ __forceinline__ uint32_t vsel(bool c, uint32_t v) { return c ? v : 0u; }
 __device__ __forceinline__ uint2 vsel(bool c, uint2 v) { return c ? v : make_uint2(0u, 0u); }
 __device__ __forceinline__ uint4 vsel(bool c, uint4 v) { return c ? v : make_uint4(0u, 0u, 0u, 0u); }
+typedef uint4 uint4_a4 __attribute__((aligned(4)));
+typedef uint2 uint2_a4 __attribute__((aligned(4)));
+// drop the first `sh` dwords of a 16-B vector (zeros shift in), see TAIL8
+__device__ __forceinline__ uint4 vshl_dwords(uint4 v, int sh) {
+    if (sh == 1) return make_uint4(v.y, v.z, v.w, 0u);
+    if (sh == 2) return make_uint4(v.z, v.w, 0u, 0u);
+    if (sh == 3) return make_uint4(v.w, 0u, 0u, 0u);
+    return v;
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -150,8 +159,12 @@ template <> struct MmaPerFrag<bf16_t> { static constexpr int N = 1; };
 // ------------------------------------------------------------------------------------------------------------------
 // T = element type of the activations in HBM / LDS (float, or bf16_t with bf16 MFMA); all LDS geometry is in BYTES and
 // identical for both: a pixel row holds KC channels (64 B at KC = 16 fp32 / 32 bf16) + 16 B pad.
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK>
+// TAIL8 (bf16, VW = 8, one source): the source's channel count is even and >= 8 but not a multiple of 8 (14 = 7 variables
+// x 2 steps, 26 = 13 x 2).  Pixel rows are then only 4-B aligned; the vector that would run past the last channel is loaded
+// as the pixel's LAST 8 channels (in bounds) and shifted into place, instead of falling back to 4-B loads (7 / 13 per pixel).
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false>
 __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P) {
+    static_assert(!TAIL8 || (VW == 8 && sizeof(T) == 2 && !MASK), "TAIL8: bf16 16-B vectors, forward only");
     constexpr int ES = sizeof(T);
     constexpr int CGW = 32 / ES;                    // channels per MFMA operand group (two 16-B half fragments)
     constexpr int TAPS = KS * KS;
@@ -266,6 +279,10 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             const int cs = from0 ? c : c - P.C0;              // channel inside the chosen source
             const int cstride = from0 ? P.C0 : P.C1;
             const bool up = from0 && P.up0;
+            int cs_ld = cs, sh = 0;                     // TAIL8: per-thread constants of this chunk
+            if constexpr (TAIL8) {
+                if (c_ok && cs + 8 > cstride) { sh = (cs + 8 - cstride) >> 1; cs_ld = cstride - 8; }
+            }
             PL_MARK();
             uint4 wv[ITW];
 #pragma unroll
@@ -290,12 +307,19 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 const int r = __umulhi((uint32_t)ii, P.magicN);
                 const int pix_up = (r >> 1) * g0 + ((ii - r * P.Nin) >> 1);
                 const int pix = up ? pix_up : ii;
-                const size_t oo = ok ? (size_t)pix * cstride + cs : 0;
-                val[i] = *reinterpret_cast<const V *>(sb + oo);
+                const size_t oo = ok ? (size_t)pix * cstride + cs_ld : 0;
+                if constexpr (TAIL8) val[i] = *reinterpret_cast<const uint4_a4 *>(sb + oo);
+                else val[i] = *reinterpret_cast<const V *>(sb + oo);
                 if (MASK) ymv[i] = *reinterpret_cast<const V *>(ymb + oo);
                 okv[i] = ok;
             }
             PL_MARK();
+            if constexpr (TAIL8) {
+                if (sh) {
+#pragma unroll
+                    for (int i = 0; i < ITS; ++i) val[i] = vshl_dwords(val[i], sh);
+                }
+            }
             // act' mask only after EVERY load has been issued (a use right behind its load makes hipcc wait per load)
             if (MASK) {
 #pragma unroll
@@ -1453,8 +1477,6 @@ int launch_ring_fix(const void *dxv, void *dsrc, const int32_t *inv, int B, int 
 // D layout: lane holds output channels 4q..4q+3 of pixel n -> one 8-B store per lane, 16 x 2*Cout contiguous bytes/wave.
 // ------------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint4 uint4_a4 __attribute__((aligned(4)));
-typedef uint2 uint2_a4 __attribute__((aligned(4)));
 
 struct PwParams {
     const bf16_t *in;        // forward: x (pix, 32); data gradient: dy (pix, Cout)
@@ -1648,7 +1670,7 @@ template <typename T> struct TName;
 template <> struct TName<float> { static const char *str() { return "float"; } };
 template <> struct TName<bf16_t> { static const char *str() { return "unsigned short"; } };
 
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK>
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false>
 static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     constexpr int ES = sizeof(T), CGW = 32 / ES;
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
@@ -1686,7 +1708,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
         return fail(DLWPCS_E_UNSUPPORTED, "conv: tile of %d x %d pixels exceeds the producers' register capacity", P.tile_rows_max, P.W2);
     if ((long)P.Nin * P.Nin * 6 >= (1l << 16) * 6 && (long)P.Nin * P.Nin >= (1l << 16))
         return fail(DLWPCS_E_UNSUPPORTED, "conv: face size %d too large for the 16-bit index arithmetic", P.Nin);
-    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK>;
+    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1697,8 +1719,8 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     int pidx = -1;
     if (prof_enabled()) {
         char tag[160];
-        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s>", TName<T>::str(), KS, KC, MT,
-                 NT, WM, WN, VW, MODE, MASK ? "true" : "false");
+        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s%s>", TName<T>::str(), KS, KC, MT,
+                 NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? ", true" : "");
         pidx = prof_begin(tag, W.flops, W.bytes, s);
     }
     hipLaunchKernelGGL(kern, grid, dim3(2 * NTHREADS), lds, s, P);
@@ -1995,6 +2017,16 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
         }
         if (pidx >= 0) prof_end(pidx, s);
         return check_launch("pw_fwd");
+    }
+    // the network's input layer (14 or 26 channels): 16-B vectors with a shifted tail instead of 4-B loads
+    if (d->dtype == DLWPCS_BF16 && d->ksize == 3 && d->halo && d->C1 == 0 && d->C0 >= 8 && d->C0 % 2 == 0 && d->C0 % 8 != 0 &&
+        NTtot <= 2) {
+        if (d->C0 <= 16) {      // one 16-channel operand group: half the MFMAs of a 32-channel chunk
+            if (NTtot == 1) return launch_conv_cfg<bf16_t, 3, 16, 3, 1, 4, 1, 8, MODE_HALO, false, true>(P, conv_work(d), s);
+            return launch_conv_cfg<bf16_t, 3, 16, 3, 1, 2, 2, 8, MODE_HALO, false, true>(P, conv_work(d), s);
+        }
+        if (NTtot == 1) return launch_conv_cfg<bf16_t, 3, 32, 3, 1, 4, 1, 8, MODE_HALO, false, true>(P, conv_work(d), s);
+        return launch_conv_cfg<bf16_t, 3, 32, 3, 1, 2, 2, 8, MODE_HALO, false, true>(P, conv_work(d), s);
     }
     return dispatch_conv(d->dtype, d->ksize, vec_width(d->C0, d->C1, d->dtype), P, conv_work(d), s);
 }
