@@ -28,7 +28,7 @@
  *   ReLU(0.1,10), AveragePooling3D((1,2,2)), UpSampling3D((1,2,2)), concatenate
  *                                   Azure/train_cs.py:197-199,277-305 -> epilogue/loader flags of dlwpcs_conv_*,
  *                                                                 dlwpcs_act_*, dlwpcs_avgpool2_*, dlwpcs_upsample2_*
- *   loss='mse', Adam()              Azure/train_cs.py:424-430  -> dlwpcs_mse_fwd_bwd, dlwpcs_adam_step
+ *   loss='mse', Adam()              Azure/train_cs.py:424-430  -> dlwpcs_mse_fwd_bwd, dlwpcs_adam_step, dlwpcs_adam_step_fused
  */
 #ifndef DLWPCS_H
 #define DLWPCS_H
