@@ -4,21 +4,41 @@ bench.py -- headline benchmark of the MI355X-native DLWP-CS engine.
 
 Metric (BASELINE.json): cubed-sphere samples/sec, forward + backward (+ Adam step), 6x48x48 U-Net `unet2` with 7
 variables x 2 time steps = 14 input/output channels (BASELINE config 3: geometry AND dtype -- bf16 compute with fp32
-master weights), batch 32 per GPU, synthetic data, random-init weights.  At N = 1 the same workload is also measured in
-the exact-fp32 mode (the 1e-5 parity mode) and reported under the key "f32".  One "step" = one optimisation step (fwd + bwd + gradient all-reduce when N > 1 + Adam) on one batch
-already resident in HBM.  One process per GPU; N > 1 is launched by torch.distributed.run (RCCL).
+master weights), batch 32 per GPU, synthetic data, random-init weights.  One "step" = one optimisation step (fwd + bwd +
+gradient all-reduce when N > 1 + Adam) on one batch already resident in HBM.  One process per GPU; N > 1 is launched by
+torch.distributed.run (RCCL).  At N = 1 the same workload is also measured in the exact-fp32 mode (the 1e-5 parity mode)
+and reported under the key "f32".
 
-Prints ONE JSON line on rank 0 (see the task contract): value = whole-job samples/s, plus
-  roofline     -- dominant convolution kernel: algorithmic FLOPs and bytes per launch / HIP-event time per launch against
-                  the roofline that bounds it (matrix peak of the instruction it issues, or HBM)
+Other workloads (same JSON contract, parity-test configurations of BASELINE.json timed by the driver's clock when asked):
+  --workload encoder6 --channels 7 --dtype f32     BASELINE config 2 (6-layer encoder, 7 variables, fp32)
+  --workload rollout                               BASELINE config 5 (unet2 C96, 26 channels, bf16, 40-step rollout = 20
+                                                   forwards with the state in HBM; one GPU = one independent replica)
+
+Timing: W untimed warm-up steps, then the K steps the contract names are timed between barrier + synchronize pairs; because
+K steps of a ~1 ms step are a ~20 ms window, the run continues with timed BLOCKS (>= 5 blocks of >= 0.5 s each, every one
+bracketed the same way, MAX over ranks) and `value` / `ms_per_step` are the MEDIAN block; the contract's K-step window is
+reported beside it (`k_step_window_ms_per_step`).
+
+Prints ONE JSON line on rank 0: value = whole-job samples/s, plus
+  roofline     -- dominant convolution kernel: algorithmic FLOPs and bytes per launch / HIP-event time per launch (events on
+                  the launch stream, library profiler) against the roofline that bounds it; `traffic`, `hbm_gbs` and
+                  `mfma_busy` from rocprofv3 PMC passes of THIS command's workload collected live (child processes, one
+                  counter group per pass, --kernel-trace only) -- or, when rocprofv3 is not usable, from the newest committed
+                  profiles/rNN_*_pmc.json (source and its git blob hash are stated);
   cpu_baseline -- the CPU restatement of the reference path (oracle/, torch-CPU fp32, reference-structured) timed on the
-                  host cores of this box on a bounded sample of the same workload (rank 0, N = 1 only).
+                  host cores of this box at the same batch size (rank 0, N = 1 only).
 """
 import argparse
+import csv
 import ctypes
+import glob
 import json
 import os
+import platform
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 # the host driver only supports dmabuf IPC: RCCL's cross-process buffer sharing needs this (already exported on the boxes)
@@ -33,10 +53,12 @@ import torch         # noqa: E402
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense (measured 2495)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-BF16_MFMA_KERNELS = ('conv_mfma_ws_kernel<unsigned short', 'wgrad_bf16_kernel')
+BF16_MFMA_KERNELS = ('conv_mfma_ws_kernel<unsigned short', 'wgrad_bf16_kernel', 'pw_')
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
-FLOP_PER_SAMPLE_FWD = {            # BASELINE.md section 2 (2*6*N^2*k^2*Cin*Cout summed over the conv layers)
-    'unet2': None, 'encoder6': None}
+N_SIMD = 1024                      # 256 CUs x 4 SIMDs
+N_XCC = 8
+PEAK_CLOCK_MHZ = 2400.0
+PMC_GROUPS = (('FETCH_SIZE',), ('WRITE_SIZE',), ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'))
 
 
 def conv_plan(workload, c_in, c_out, base):
@@ -50,7 +72,8 @@ def conv_plan(workload, c_in, c_out, base):
 
 
 def flops_per_sample(workload, N, c_in, c_out, base):
-    return sum(2.0 * 6 * (N // r) ** 2 * k * k * ci * co for (r, ci, co, k) in conv_plan(workload, c_in, c_out, base))
+    wl = 'unet2' if workload == 'rollout' else workload
+    return sum(2.0 * 6 * (N // r) ** 2 * k * k * ci * co for (r, ci, co, k) in conv_plan(wl, c_in, c_out, base))
 
 
 def build_model(workload, N, c_in, c_out, base):
@@ -59,28 +82,44 @@ def build_model(workload, N, c_in, c_out, base):
     from DLWP.keras.models import Model
     net = CubeSphereNet(c_out, base, 'unet2')
     x = Input(shape=(6, N, N, c_in), name='main_input')
-    y = net.unet2(x) if workload == 'unet2' else net.encoder6(x)
+    y = net.encoder6(x) if workload == 'encoder6' else net.unet2(x)
     return Model(inputs=x, outputs=y)
 
 
-def cpu_baseline(workload, N, c_in, c_out, base, budget_s=20.0, batch=4):
-    """Reference-structured CPU port (oracle/cs_oracle.py), torch-CPU fp32, all host cores; fwd + bwd + Adam."""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or 'unknown'
+
+
+def cpu_baseline(workload, N, c_in, c_out, base, batch, warmup=3, timed=10, budget_s=45.0):
+    """Reference-structured CPU port (oracle/cs_oracle.py), torch-CPU fp32, host cores of this box: >= 3 warm-up + >= 10
+    timed steps at the benchmark's own batch size (fewer only if the time budget runs out), MEDIAN step time."""
     from oracle import cs_oracle as orc
     cores = os.cpu_count() or 1
+    train = workload != 'rollout'
     params = orc.make_unet2_params(c_in, c_out, base=base, seed=1, dtype=torch.float32)
     if workload == 'encoder6':
         params = params[:6]
-    leaves = [v.requires_grad_(True) for prm in params for v in prm.values()]
+    leaves = [v.requires_grad_(train) for prm in params for v in prm.values()]
     ms = [torch.zeros_like(v) for v in leaves]
     vs = [torch.zeros_like(v) for v in leaves]
     rng = np.random.default_rng(0)
     x = torch.tensor(rng.standard_normal((batch, 6, N, N, c_in)), dtype=torch.float32)
-    fwd = orc.unet2_forward if workload == 'unet2' else orc.encoder6_forward
+    fwd = orc.encoder6_forward if workload == 'encoder6' else orc.unet2_forward
     with torch.no_grad():
         tshape = fwd(x[:1], params).shape[1:]
     tgt = torch.tensor(rng.standard_normal((batch,) + tuple(tshape)), dtype=torch.float32)
 
     def step(t):
+        if not train:                       # rollout: one forward pass (a 40-step rollout = 20 of them)
+            with torch.no_grad():
+                fwd(x, params)
+            return
         for v in leaves:
             v.grad = None
         loss = orc.mse_loss(fwd(x, params), tgt)
@@ -88,7 +127,8 @@ def cpu_baseline(workload, N, c_in, c_out, base, budget_s=20.0, batch=4):
         with torch.no_grad():
             for p, m, v in zip(leaves, ms, vs):
                 orc.adam_step(p, p.grad, m, v, t)
-    # pick the thread count that runs this workload fastest on this host (many-core boxes oversubscribe small convs)
+    # thread count: all host cores unless fewer threads run this workload faster (many-core boxes oversubscribe small convs)
+    t_start = time.perf_counter()
     best = None
     for thr in sorted({cores, min(cores, 64), min(cores, 32), min(cores, 16)}, reverse=True):
         torch.set_num_threads(thr)
@@ -100,45 +140,185 @@ def cpu_baseline(workload, N, c_in, c_out, base, budget_s=20.0, batch=4):
             best = (el, thr)
     threads = best[1]
     torch.set_num_threads(threads)
-    t0 = time.perf_counter()
-    iters = 0
-    while True:
-        step(iters + 2)
-        iters += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or iters >= 50:
-            break
-    return {'value': round(batch * iters / el, 3), 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d steps of batch %d, %s fwd+bwd+Adam, torch-CPU fp32, reference-structured oracle '
-                      '(materialised halo padding, 6 per-face conv2d per layer)' % (iters, batch, workload)}
+    for i in range(warmup):
+        step(i + 2)
+    times = []
+    while len(times) < timed and (len(times) < 3 or time.perf_counter() - t_start < budget_s):
+        t0 = time.perf_counter()
+        step(len(times) + 2)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    unit = 'samples/s' if train else 'forward-samples/s'
+    what = 'fwd+bwd+Adam' if train else 'one forward pass (a 40-step rollout is 20 of them)'
+    return {'value': round(batch / med, 3), 'unit': unit, 'cores': threads, 'host_cores': cores, 'cpu_model': _cpu_model(),
+            'torch': torch.__version__, 'kind': 'port', 'median_step_s': round(med, 4),
+            'sample': '%d warm-up + %d timed steps of batch %d (median), %s, %s, torch-CPU fp32, %d threads (fastest of '
+                      'the host\'s %d cores and smaller pools), reference-structured oracle (materialised halo padding, 6 '
+                      'per-face conv2d per layer)' % (warmup, len(times), batch, workload, what, threads, cores)}
 
 
-PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r01_bench_unet2_b32_hbm_pmc.txt')
+# ---------------------------------------------------------------------------------------------------------------------- #
+# PMC counters (rocprofv3): live child passes, or the newest committed profile
+# ---------------------------------------------------------------------------------------------------------------------- #
+
+def _clean_kernel_name(n):
+    import re
+    return re.sub(r'\(.*\)$', '', n).replace('void ', '').replace('dlwpcs::', '')
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed PMC summary (tools/make_profiles.py), or (None, reason)."""
+def parse_pmc_dir(d):
+    """per kernel name -> {counter: [launches, sum]} plus the kernel durations, from one rocprofv3 --pmc output dir."""
+    out = {}
+    for path in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(path)):
+            k = _clean_kernel_name(r['Kernel_Name'])
+            a = out.setdefault(k, {}).setdefault(r['Counter_Name'], [0, 0.0])
+            a[0] += 1
+            a[1] += float(r['Counter_Value'])
+    return out
+
+
+def pmc_record(counters):
+    """counter sums of ONE kernel -> per-launch record.  FETCH_SIZE x 2: MI355X_MICROARCH.md (HBM): on gfx950 rocprofv3
+    reports exactly half of the bytes of wide coalesced streaming reads; WRITE_SIZE as reported (KB)."""
+    rec = {}
+    f, w = counters.get('FETCH_SIZE'), counters.get('WRITE_SIZE')
+    if f and w and f[0] and w[0]:
+        rec['fetch_kb_x2'] = round(2.0 * f[1] / f[0], 1)
+        rec['write_kb'] = round(w[1] / w[0], 1)
+        rec['traffic'] = int((2.0 * f[1] / f[0] + w[1] / w[0]) * 1024)
+        rec['launches'] = f[0]
+    mb, ga = counters.get('SQ_VALU_MFMA_BUSY_CYCLES'), counters.get('GRBM_GUI_ACTIVE')
+    if mb and ga and ga[1] > 0:
+        # MfmaUtil of rocprofv3's derived counters = SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs / (GRBM_GUI_ACTIVE x
+        # SIMDs).  The CSV holds GRBM_GUI_ACTIVE SUMMED over the 8 XCCs (measured: 22.5 k counts per us of kernel time =
+        # 8 x ~2.2 GHz, plus a fixed ~17 k cycles per XCC around every dispatch), the derived metric takes the max over them.
+        rec['mfma_busy'] = round(mb[1] / (ga[1] / N_XCC * N_SIMD), 4)
+        rec['mfma_busy_cycles'] = round(mb[1] / mb[0], 1)          # per launch, summed over the 1024 SIMDs
+        rec['gui_active_cycles'] = round(ga[1] / ga[0] / N_XCC, 1)
+    sb = counters.get('SQ_BUSY_CYCLES')
+    if sb and ga and ga[1] > 0:
+        rec['sq_busy_cycles'] = round(sb[1] / sb[0], 1)
+    return rec
+
+
+def collect_pmc_live(args, dtype, timeout_s=240):
+    """Run this same workload under rocprofv3, one counter group per pass (eager steps, no graphs).  Returns
+    ({kernel: record}, source string) or (None, reason)."""
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None, 'rocprofv3 not found'
+    if os.environ.get('ROCP_TOOL_LIBRARIES') or 'rocprofiler' in os.environ.get('LD_PRELOAD', ''):
+        return None, 'already running under a profiler'
+    merged = {}
+    tmp = tempfile.mkdtemp(prefix='dlwpcs_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
     try:
-        for line in open(PMC_PROFILE):
-            if line.startswith(kernel + ' ') or line.startswith(kernel[:84] + ' '):
-                cols = line[84:].split()
-                if len(cols) >= 4:
-                    return int((float(cols[2]) + float(cols[3])) * 1024), os.path.relpath(PMC_PROFILE, ROOT)
-    except (OSError, ValueError):
-        pass
-    return None, 'no PMC record for this kernel in profiles/'
+        for i, group in enumerate(PMC_GROUPS):
+            d = os.path.join(tmp, 'pass%d' % i)
+            cmd = [exe, '--kernel-trace', '--pmc'] + list(group) + ['-d', d, '-o', 'p', '--output-format', 'csv', '--',
+                   sys.executable, os.path.abspath(__file__), '--pmc-child', '--workload', args.workload, '--dtype', dtype,
+                   '--batch', str(args.batch), '--face', str(args.face), '--channels', str(args.channels),
+                   '--base', str(args.base)]
+            try:
+                r = subprocess.run(cmd, env=env, cwd='/tmp', capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, 'rocprofv3 pass %d timed out' % i
+            if r.returncode != 0:
+                return None, 'rocprofv3 pass %d failed (rc %d): %s' % (i, r.returncode, (r.stderr or '')[-200:].replace('\n', ' '))
+            for k, cs in parse_pmc_dir(d).items():
+                merged.setdefault(k, {}).update(cs)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    recs = {k: pmc_record(v) for k, v in merged.items()}
+    return {k: v for k, v in recs.items() if v}, 'live rocprofv3 --kernel-trace --pmc passes (%s), 3 eager steps each' % (
+        ' | '.join(' '.join(g) for g in PMC_GROUPS))
 
 
-def roofline_pass(model, dx, dt, steps=3):
+def newest_committed_pmc(workload, dtype):
+    """Newest profiles/rNN_*_pmc.json holding this workload / dtype -> ({kernel: record}, 'path @ git blob')."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_*_pmc.json'))):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        recs = doc.get('%s/%s' % (workload, dtype))
+        if recs:
+            best = (path, recs)
+    if best is None:
+        return None, 'no committed profiles/rNN_*_pmc.json for %s/%s' % (workload, dtype)
+    path, recs = best
+    try:
+        blob = subprocess.run(['git', 'hash-object', path], capture_output=True, text=True, cwd=ROOT).stdout.strip()[:12]
+    except OSError:
+        blob = ''
+    return recs, '%s (git blob %s)' % (os.path.relpath(path, ROOT), blob or 'n/a')
+
+
+def pmc_child(args):
+    """Body of one rocprofv3 pass: 3 eager steps (no graphs) of the workload in --dtype, nothing else."""
+    from DLWP.keras import backend
+    backend.set_device('cuda:0')
+    state = prepare(args, args.dtype, rank=0)
+    state['model'].use_graphs = False
+    for _ in range(3):
+        run_step(state)
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------------------------- #
+# the measured step
+# ---------------------------------------------------------------------------------------------------------------------- #
+
+def prepare(args, dtype, rank):
+    from DLWP.keras import backend
+    N, C, base, B = args.face, args.channels, args.base, args.batch
+    backend.set_compute_dtype('bfloat16' if dtype == 'bf16' else 'float32')
+    try:
+        np.random.seed(1)
+        model = build_model(args.workload, N, C, C, base)
+    finally:
+        backend.set_compute_dtype('float32')
+    model.use_graphs = not args.no_graphs
+    model.static_batch_buffers = True      # the batch lives in the same HBM tensors every step (inputs resident in HBM)
+    adt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    rng = np.random.default_rng(1000 + rank)
+    dev = backend.device()
+    dx = [torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(adt)]
+    st = {'model': model, 'dx': dx, 'dev': dev, 'train': args.workload != 'rollout'}
+    if st['train']:
+        model.compile(optimizer='adam', loss='mse')
+        with torch.no_grad():
+            oshape = model.predict_on_device(dx[0][:1]).shape[1:]
+        st['dt'] = [torch.tensor(rng.standard_normal((B,) + tuple(oshape)), dtype=torch.float32, device=dev)]
+    else:
+        st['n_fwd'] = args.rollout_steps // 2          # time_dim = 2: one forward pass per two forecast steps
+    return st
+
+
+def run_step(st):
+    if st['train']:
+        st['model'].train_on_device_batch(st['dx'], st['dt'])
+        return
+    state = st['dx'][0]                    # one "step" = one 40-step rollout of the batch, state resident in HBM
+    model = st['model']
+    for i in range(st['n_fwd']):
+        state = model.predict_on_device(state, repack=(i == 0))
+    st['last'] = state
+
+
+def roofline_pass(st, steps=3):
     """Eager steps with the library's per-launch HIP-event profiler on; aggregate per kernel name."""
     from DLWP import _native as nat
     lib = nat.lib()
+    model = st['model']
     use_graphs = model.use_graphs
     model.use_graphs = False
     lib.dlwpcs_prof_reset()
     lib.dlwpcs_prof_enable(1)
     for _ in range(steps):
-        model.train_on_device_batch(dx, dt)
+        run_step(st)
     torch.cuda.synchronize()
     lib.dlwpcs_prof_enable(0)
     agg = {}
@@ -156,96 +336,161 @@ def roofline_pass(model, dx, dt, steps=3):
     return agg
 
 
-def measure(args, dtype, rank, world, local_rank, with_roofline):
-    """Build the model in `dtype`, warm up, time exactly args.steps steps (barrier + synchronize on both sides, MAX over
-    ranks), optionally run the per-launch roofline pass.  Returns the result dict on rank 0, None elsewhere."""
-    from DLWP.keras import backend
+def allreduce_probe(model, world, reps=20):
+    """Duration of the step's one exchange -- all_reduce(SUM) of the flat fp32 gradient buffer -- on its own (MAX over ranks)."""
+    if world <= 1 or model._flat_grads is None:
+        return None
+    buf = torch.zeros_like(model._flat_grads)
+    for _ in range(3):
+        torch.distributed.all_reduce(buf)
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        torch.distributed.all_reduce(buf)
+    torch.cuda.synchronize()
+    el = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=buf.device)
+    torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    return float(el.item()) * 1e6
+
+
+def measure(args, dtype, rank, world, with_roofline, with_pmc):
+    """Build the workload in `dtype`, warm up, time the contract's K steps and then >= 5 blocks of >= 0.5 s (each bracketed
+    by barrier + synchronize, MAX over ranks); optionally the per-launch roofline pass and the PMC passes.  Returns the
+    result dict on rank 0, None elsewhere."""
     N, C, base, B = args.face, args.channels, args.base, args.batch
-    backend.set_compute_dtype('bfloat16' if dtype == 'bf16' else 'float32')
-    np.random.seed(1)
-    model = build_model(args.workload, N, C, C, base)
-    backend.set_compute_dtype('float32')
-    model.use_graphs = not args.no_graphs
-    model.static_batch_buffers = True      # the batch lives in the same HBM tensors every step (inputs resident in HBM)
-    model.compile(optimizer='adam', loss='mse')
-    adt = torch.bfloat16 if dtype == 'bf16' else torch.float32
-    rng = np.random.default_rng(1000 + rank)
-    dev = backend.device()
-    dx = [torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(adt)]
-    with torch.no_grad():
-        oshape = model.predict_on_device(dx[0][:1]).shape[1:]
-    dt = [torch.tensor(rng.standard_normal((B,) + tuple(oshape)), dtype=torch.float32, device=dev)]
+    st = prepare(args, dtype, rank)
+    model, dev = st['model'], st['dev']
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            run_step(st)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el
+
     for _ in range(max(args.warmup, 3)):      # >= 3: eager warm-up, graph capture, first replay
-        model.train_on_device_batch(dx, dt)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.train_on_device_batch(dx, dt)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        run_step(st)
+    k_elapsed = timed(args.steps)             # the contract's window: exactly K steps
+    est = k_elapsed / args.steps
+    per_block = max(args.steps, int(np.ceil(args.min_block_s / max(est, 1e-9))))
+    if world > 1:                             # every rank must run the same number of steps per block
+        pb = torch.tensor([per_block], dtype=torch.int64, device=dev)
+        torch.distributed.all_reduce(pb, op=torch.distributed.ReduceOp.MAX)
+        per_block = int(pb.item())
+    blocks = [timed(per_block) / per_block for _ in range(args.blocks)]
+    step_s = float(np.median(blocks))
+    ar_us = allreduce_probe(model, world) if st['train'] else None
     # the roofline pass runs eager optimisation steps (gradient all-reduce included): EVERY rank takes part
-    agg = roofline_pass(model, dx, dt) if with_roofline else None
+    agg = roofline_pass(st) if with_roofline else None
     if rank != 0:
         return None
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = B * world * args.steps / elapsed
     fps = flops_per_sample(args.workload, N, C, C, base)
     prec = ('bf16 activations + bf16 MFMA, fp32 master weights / gradients / Adam' if dtype == 'bf16'
             else 'exact-fp32 MFMA')
+    if st['train']:
+        metric, unit = 'cubed-sphere samples/sec (fwd+bwd)', 'samples/s'
+        what = '%s C%d: x (%d,6,%d,%d,%d) per GPU, %d out channels, base %d, MSE + Adam, fwd+bwd+update, %s' % (
+            args.workload, N, B, N, N, C, C if args.workload == 'unet2' else 2 * base, base, prec)
+        flops_step = 3 * fps * B
+    else:
+        metric, unit = 'cubed-sphere rollouts/sec (%d-step, inference)' % args.rollout_steps, 'rollouts/s'
+        what = 'unet2 C%d: state (%d,6,%d,%d,%d) per GPU, %d-step rollout = %d forward passes with the state in HBM ' \
+               '(independent replicas, no communication), %s' % (N, B, N, N, C, args.rollout_steps, st['n_fwd'], prec)
+        flops_step = fps * B * st['n_fwd']
+    value = B * world / step_s
     result = {
-        'metric': 'cubed-sphere samples/sec (fwd+bwd)', 'value': round(value, 2), 'unit': 'samples/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+        'metric': metric, 'value': round(value, 2), 'unit': unit,
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * step_s, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
-        'config': {'workload': '%s C%d: x (%d,6,%d,%d,%d) per GPU, %d out channels, base %d, MSE + Adam, '
-                               'fwd+bwd+update, %s' % (args.workload, N, B, N, N, C, C, base, prec),
-                   'global_batch': B * world, 'parallelism': 'dp%d' % world,
+        'config': {'workload': what, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
                    'hip_graphs': bool(model.use_graphs)},
-        'model_tflops': round(3 * fps * value / 1e12, 3),
+        'timing': {'value_from': 'median of %d blocks of %d steps (each >= %.2f s, barrier + synchronize on both sides, '
+                                 'max over ranks)' % (args.blocks, per_block, args.min_block_s),
+                   'block_ms_per_step': [round(1e3 * b, 4) for b in blocks],
+                   'k_step_window_ms_per_step': round(1e3 * k_elapsed / args.steps, 4)},
+        'model_tflops': round(flops_step * world / step_s / 1e12, 3),
     }
-    if with_roofline:
-        if agg:
-            # per kernel: the roofline that bounds it = the larger of (algorithmic flops / matrix peak of the instruction
-            # it issues) and (algorithmic bytes / HBM peak); frac = that bound time / measured time
-            def bound_of(name, cnt, ms, fl, by):
-                peak_f = PEAK_BF16_MFMA_TFLOPS if name.startswith(BF16_MFMA_KERNELS) else PEAK_FP32_MFMA_TFLOPS
-                t_f, t_b = fl / (peak_f * 1e12), by / (PEAK_HBM_GBS * 1e9)
-                t = ms * 1e-3
-                if t_f >= t_b:
-                    return {'bound': 'mfma', 'achieved': round(fl / t / 1e12, 3), 'peak': peak_f, 'unit': 'TFLOP/s',
-                            'frac': round(t_f / t, 4)}
-                return {'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': round(t_b / t, 4)}
-            name, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
-            rf = bound_of(name, cnt, ms, fl, by)
-            # HBM-side bytes need PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass, cannot run inside
-            # this process): they are collected with this same command and committed per kernel in profiles/; `traffic` is
-            # that measurement for the dominant kernel (FETCH_SIZE x 2 per the gfx950 calibration + WRITE_SIZE), bytes/launch
-            traffic, tsrc = pmc_traffic(name)
-            rf.update({'traffic': traffic, 'traffic_source': tsrc, 'kernel': name, 'launches': cnt,
-                       'avg_launch_us': round(1e3 * ms / cnt, 2),
-                       'algorithmic_gflop_per_launch': round(fl / cnt / 1e9, 3),
-                       'algorithmic_mbytes_per_launch': round(by / cnt / 1e6, 3)})
-            tot_ms = sum(v[1] for v in agg.values())
-            tot_fl = sum(v[2] for v in agg.values())
-            rf['all_mfma_kernels_tflops'] = round(tot_fl / (tot_ms * 1e-3) / 1e12, 3)
-            rf['per_kernel'] = {}
-            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                bk = bound_of(k, *v)
-                rf['per_kernel'][k] = {'launches': v[0], 'avg_us': round(1e3 * v[1] / v[0], 2),
-                                       'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2), 'bound': bk['bound'],
-                                       'frac': bk['frac']}
-            result['roofline'] = rf
-    del model
+    if not st['train']:
+        result['model_steps_per_s'] = round(B * world * st['n_fwd'] / step_s, 1)
+        result['ms_per_forward'] = round(1e3 * step_s / st['n_fwd'], 4)
+    if world > 1:
+        result['exchange'] = {'allreduce_us': None if ar_us is None else round(ar_us, 1),
+                              'bytes': int(model._flat_grads.numel() * 4) if st['train'] else 0,
+                              'backend': torch.distributed.get_backend(), 'rccl_ranks': torch.distributed.get_world_size(),
+                              'overlap': 'none: the all-reduce runs between the fwd+bwd graph and the optimizer graph; '
+                                         'allreduce_us is therefore fully exposed in ms_per_step'}
+    if with_roofline and agg:
+        # per kernel: the roofline that bounds it = the larger of (algorithmic flops / matrix peak of the instruction it
+        # issues) and (algorithmic bytes / HBM peak); frac = that bound time / measured time
+        def bound_of(name, cnt, ms, fl, by):
+            peak_f = PEAK_BF16_MFMA_TFLOPS if name.startswith(BF16_MFMA_KERNELS) else PEAK_FP32_MFMA_TFLOPS
+            t_f, t_b = fl / (peak_f * 1e12), by / (PEAK_HBM_GBS * 1e9)
+            t = ms * 1e-3
+            if t_f >= t_b:
+                return {'bound': 'mfma', 'achieved': round(fl / t / 1e12, 3), 'peak': peak_f, 'unit': 'TFLOP/s',
+                        'frac': round(t_f / t, 4)}
+            return {'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': round(t_b / t, 4)}
+        name, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
+        rf = bound_of(name, cnt, ms, fl, by)
+        rf.update({'kernel': name, 'launches': cnt, 'avg_launch_us': round(1e3 * ms / cnt, 2),
+                   'algorithmic_gflop_per_launch': round(fl / cnt / 1e9, 3),
+                   'algorithmic_mbytes_per_launch': round(by / cnt / 1e6, 3)})
+        recs, src = (None, 'PMC passes disabled (--no-pmc)')
+        if with_pmc:
+            recs, src = collect_pmc_live(args, dtype)
+            if recs is None:
+                live_err = src
+                recs, src = newest_committed_pmc(args.workload, dtype)
+                src = '%s [live collection unavailable: %s]' % (src, live_err)
+        rec = (recs or {}).get(name)
+        if rec is None and recs:
+            rec = next((v for k, v in recs.items() if k.startswith(name[:84])), None)
+        if rec is None:
+            rf.update({'traffic': None, 'hbm_gbs': None, 'mfma_busy': None})
+            rf['pmc_error'] = 'NO PMC RECORD for the dominant kernel %r in: %s' % (name, src)
+            sys.stderr.write('bench.py: ERROR: %s\n' % rf['pmc_error'])
+        else:
+            rf['traffic'] = rec.get('traffic')
+            rf['traffic_vs_algorithmic'] = (round(rec['traffic'] / (by / cnt), 3) if rec.get('traffic') and by else None)
+            rf['hbm_gbs'] = round(rec['traffic'] / (ms / cnt * 1e-3) / 1e9, 1) if rec.get('traffic') else None
+            rf['hbm_frac_of_peak'] = round(rf['hbm_gbs'] / PEAK_HBM_GBS, 4) if rf['hbm_gbs'] else None
+            # two denominators: the profiler's own active window (GRBM_GUI_ACTIVE, includes ~8 us of dispatch overhead per
+            # launch under the profiler) and this kernel's HIP-event launch time at the 2.4 GHz peak clock
+            rf['mfma_busy'] = rec.get('mfma_busy')
+            if rec.get('mfma_busy_cycles'):
+                rf['mfma_busy_vs_launch_time_at_peak_clock'] = round(
+                    rec['mfma_busy_cycles'] / (N_SIMD * (1e3 * ms / cnt) * PEAK_CLOCK_MHZ), 4)
+        rf['pmc_source'] = src
+        tot_ms = sum(v[1] for v in agg.values())
+        tot_fl = sum(v[2] for v in agg.values())
+        rf['all_mfma_kernels_tflops'] = round(tot_fl / (tot_ms * 1e-3) / 1e12, 3)
+        rf['per_kernel'] = {}
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            bk = bound_of(k, *v)
+            pk = {'launches': v[0], 'avg_us': round(1e3 * v[1] / v[0], 2),
+                  'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2), 'bound': bk['bound'], 'frac': bk['frac']}
+            r2 = (recs or {}).get(k)
+            if r2:
+                if r2.get('traffic'):
+                    pk['traffic'] = r2['traffic']
+                if r2.get('mfma_busy') is not None:
+                    pk['mfma_busy'] = r2['mfma_busy']
+            rf['per_kernel'][k] = pk
+        result['roofline'] = rf
+    del model, st
     torch.cuda.empty_cache()
     return result
 
@@ -255,21 +500,31 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='unet2', choices=['unet2', 'encoder6'])
+    ap.add_argument('--workload', default='unet2', choices=['unet2', 'encoder6', 'rollout'])
     ap.add_argument('--batch', type=int, default=32, help='samples per GPU per step')
-    ap.add_argument('--face', type=int, default=48)
-    ap.add_argument('--channels', type=int, default=14, help='input (= output) channels: 7 variables x 2 time steps')
+    ap.add_argument('--face', type=int, default=None, help='cube face size (48; rollout: 96)')
+    ap.add_argument('--channels', type=int, default=None,
+                    help='input (= output) channels: 14 = 7 variables x 2 time steps (rollout: 26 = 13 x 2)')
     ap.add_argument('--base', type=int, default=32)
+    ap.add_argument('--rollout-steps', type=int, default=40, help='forecast steps of --workload rollout (2 per forward)')
     ap.add_argument('--dtype', default='bf16', choices=['f32', 'bf16'],
                     help='activation dtype of the headline number.  bf16 (default; BASELINE config 3 names bf16 compute, '
                          'the reference trains under TF AMP): bf16 activations + bf16 MFMA, fp32 master weights / '
                          'gradients / Adam.  f32: exact-fp32 MFMA everywhere (the 1e-5 parity mode).')
+    ap.add_argument('--blocks', type=int, default=5, help='timed blocks behind the headline value (median)')
+    ap.add_argument('--min-block-s', type=float, default=0.5, help='minimum duration of a timed block')
     ap.add_argument('--no-companion', action='store_true',
                     help='skip the second measurement in the other dtype (N = 1 only) reported under "f32" / "bf16"')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='no rocprofv3 child passes (traffic / mfma_busy stay null)')
     ap.add_argument('--no-graphs', action='store_true')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.face is None:
+        args.face = 96 if args.workload == 'rollout' else 48
+    if args.channels is None:
+        args.channels = 26 if args.workload == 'rollout' else 14
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -284,6 +539,10 @@ def main():
     if not torch.cuda.is_available():
         sys.stderr.write('bench.py: no HIP device visible; the engine has no CPU path\n')
         sys.exit(2)
+    if args.pmc_child:
+        torch.cuda.set_device(0)
+        pmc_child(args)
+        return
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -297,16 +556,18 @@ def main():
 
     from DLWP.keras import backend
     backend.set_device('cuda:%d' % local_rank)
-    result = measure(args, args.dtype, rank, world, local_rank, with_roofline=not args.no_roofline)
+    single = world == 1
+    result = measure(args, args.dtype, rank, world, with_roofline=not args.no_roofline,
+                     with_pmc=single and not args.no_pmc)
     if world > 1:
         torch.distributed.barrier()
-    if world == 1 and not args.no_companion:
+    if single and not args.no_companion:
         other = 'f32' if args.dtype == 'bf16' else 'bf16'
-        comp = measure(args, other, rank, world, local_rank, with_roofline=not args.no_roofline)
-        keep = ('value', 'unit', 'ms_per_step', 'dtype', 'model_tflops', 'roofline')
+        comp = measure(args, other, rank, world, with_roofline=not args.no_roofline, with_pmc=not args.no_pmc)
+        keep = ('value', 'unit', 'ms_per_step', 'dtype', 'model_tflops', 'timing', 'roofline')
         result[other] = {k: comp[k] for k in keep if k in comp}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(args.workload, args.face, args.channels, args.channels, args.base)
+    if rank == 0 and single and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(args.workload, args.face, args.channels, args.channels, args.base, args.batch)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -106,6 +106,8 @@ PROTOTYPES = {
                                  c_float, c_float, c_float, c_void_p]),
     'dlwpcs_adam_step_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float,
                                        c_float, c_float, c_float, c_int, c_void_p]),
+    'dlwpcs_adam_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int,
+                                     c_void_p]),
     'dlwpcs_batch_gather': (c_int, [c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int, c_void_p, c_int,
                                     c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_prof_enable': (c_int, [c_int]),

@@ -9,7 +9,8 @@ fp32 accumulation and fp32 gradients of the parameters -- bf16 keeps the fp32 ex
     # or, keras-2.4 style:
     mixed_precision.set_policy('mixed_bfloat16')
 
-The policy is read when a Model is constructed (`Model.compute_dtype`).
+The policy is read when a Model is constructed (`Model.compute_dtype`); an optimizer returned by
+`enable_mixed_precision_graph_rewrite` also switches the model it is compiled into.
 """
 from . import backend
 
@@ -33,8 +34,15 @@ def global_policy():
 
 
 def enable_mixed_precision_graph_rewrite(opt, loss_scale='dynamic'):
-    """Reference Azure/train_cs.py:429.  Returns the optimizer unchanged (no loss scaling is needed for bfloat16)."""
+    """Reference Azure/train_cs.py:429.  Returns the same optimizer object (no loss scaling is needed for bfloat16), tagged:
+    like TF's rewrite, the switch travels WITH the optimizer -- `Model.compile(optimizer=opt)` puts a model that was built
+    before this call (the reference builds its Model at train_cs.py:411, calls this at :429, compiles at :430) into the
+    bfloat16 mode as well."""
     set_policy('mixed_bfloat16')
+    try:
+        opt._mixed_precision = 'bfloat16'
+    except AttributeError:
+        pass
     return opt
 
 

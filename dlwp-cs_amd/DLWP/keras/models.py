@@ -294,6 +294,11 @@ class Model(object):
     # -------------------------------------------------------------------------------------------------------------- #
     def compile(self, optimizer='adam', loss=None, metrics=None, loss_weights=None, **kwargs):
         self.optimizer = optimizers.get(optimizer)
+        mp_dtype = getattr(self.optimizer, '_mixed_precision', None)
+        if mp_dtype is not None and mp_dtype != self.compute_dtype:
+            # optimizer came out of enable_mixed_precision_graph_rewrite() AFTER this model was constructed
+            self.compute_dtype = mp_dtype
+            self._pack_cache = None
         n_out = len(self.outputs)
         losses = _as_list(loss) if isinstance(loss, (list, tuple)) else [loss] * n_out
         for l in losses:
@@ -359,11 +364,7 @@ class Model(object):
         stats = [ops.mse_mae(o, t, w) for o, t, w in zip(outs, targets, self.loss_weights)]
         if train:
             dev = stats[0].device
-            if dev not in self._ones:
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError('first training step must run eagerly (graph capture allocates nothing)')
-                self._ones[dev] = torch.ones(2, dtype=torch.float32, device=dev)
-            ones = [self._ones[dev] for _ in stats]
+            ones = [ops.unit_seed(dev) for _ in stats]
             ops.DIRECT_PARAM_GRADS = True       # weight gradients accumulate straight into the flat gradient buffer
             ops.WGRAD_SIDE_STREAM = self.wgrad_side_stream
             ops.DEFER_WGRAD_REDUCE = self.defer_wgrad_reduce    # ... through ONE reduction launch for all layers
@@ -414,6 +415,7 @@ class Model(object):
                 dst.copy_(src, non_blocking=True)
         if not self._grads_clean:
             self._flat_grads.zero_()                            # an eager step / manual backward ran since the last replay
+        self.optimizer.sync_hyper(g['grad_scale'])             # lr / betas changed since the last replay? (20-byte copy)
         g['fwd_bwd'].replay()
         if g['update'] is not None:
             parallel.allreduce_gradients(self._flat_grads)      # between the two graphs (scale is baked into 'update')
@@ -428,6 +430,8 @@ class Model(object):
             static_in = [torch.empty_like(t).copy_(t) for t in inputs]
             static_tg = [torch.empty_like(t).copy_(t) for t in targets]
         self.optimizer._ensure_state(self._flat_params)
+        grad_scale = 1.0 / self._world
+        self.optimizer.sync_hyper(grad_scale)                   # the captured Adam launch reads them from device memory
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # the gradient buffer is cleared by the optimizer launch of the previous replay (DLWPCS_ADAM_ZERO_GRAD), once
@@ -437,12 +441,13 @@ class Model(object):
         with torch.cuda.graph(g1):
             stats = self._loss_and_backward(static_in, static_tg, True)
             if self._world == 1:        # no exchange step: the update rides in the same graph (no inter-graph gap)
-                self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0, zero_grads=True)
+                self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
                 g2 = None
         if g2 is not None:
             with torch.cuda.graph(g2, pool=g1.pool()):
-                self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0 / self._world, zero_grads=True)
-        entry = {'fwd_bwd': g1, 'update': g2, 'inputs': static_in, 'targets': static_tg, 'stats': stats}
+                self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
+        entry = {'fwd_bwd': g1, 'update': g2, 'inputs': static_in, 'targets': static_tg, 'stats': stats,
+                 'grad_scale': grad_scale}
         self._graphs[key] = entry
         return entry
 

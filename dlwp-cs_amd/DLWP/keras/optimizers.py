@@ -28,6 +28,10 @@ class Adam(Optimizer):
             raise NotImplementedError('Adam(decay != 0) is not built')
         self.name = name
         self._m = self._v = self._step = None
+        # {lr, beta1, beta2, eps, grad_scale} on the device: the Adam launch reads them from HBM, so that a step replayed
+        # from a hipGraph sees `optimizer.lr = x` / a learning-rate schedule (kernel arguments are frozen at capture)
+        self._hyper = None
+        self._hyper_host = None
 
     @property
     def lr(self):
@@ -36,6 +40,23 @@ class Adam(Optimizer):
     @lr.setter
     def lr(self, value):
         self.learning_rate = float(value)
+
+    def _hyper_values(self, grad_scale):
+        return (float(self.learning_rate), float(self.beta_1), float(self.beta_2), float(self.epsilon), float(grad_scale))
+
+    def sync_hyper(self, grad_scale=1.0):
+        """Upload the hyper-parameters if they changed since the last upload (a 20-byte copy on the current stream; never
+        inside a graph capture: callers sync before capturing / replaying)."""
+        vals = self._hyper_values(grad_scale)
+        if self._hyper is None or self._hyper_host != vals:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('optimizer hyper-parameters changed during graph capture')
+            host = torch.tensor(vals, dtype=torch.float32)
+            if self._hyper is None:
+                self._hyper = host.to(self._m.device)
+            else:
+                self._hyper.copy_(host)
+            self._hyper_host = vals
 
     @property
     def iterations(self):
@@ -46,11 +67,15 @@ class Adam(Optimizer):
             self._m = torch.zeros_like(flat_params)
             self._v = torch.zeros_like(flat_params)
             self._step = torch.zeros(2, dtype=torch.int32, device=flat_params.device)    # {t - 1, ticket}
+            self._hyper = self._hyper_host = None
 
     def apply(self, flat_params, flat_grads, grad_scale=1.0, zero_grads=False):
         self._ensure_state(flat_params)
-        ops.adam_step(flat_params, flat_grads, self._m, self._v, self._step, self.learning_rate, self.beta_1,
-                      self.beta_2, self.epsilon, grad_scale, zero_grads=zero_grads)
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper(grad_scale)
+        elif self._hyper is None or self._hyper_host[4] != float(grad_scale):
+            raise RuntimeError('call optimizer.sync_hyper(grad_scale) before capturing the update')
+        ops.adam_step_dev(flat_params, flat_grads, self._m, self._v, self._step, self._hyper, zero_grads=zero_grads)
 
     def get_config(self):
         return {'name': self.name, 'learning_rate': self.learning_rate, 'beta_1': self.beta_1, 'beta_2': self.beta_2,

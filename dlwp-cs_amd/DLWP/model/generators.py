@@ -322,6 +322,17 @@ class ArrayDataGenerator(object):
         n = len(samples)
         its, iv = self._input_time_steps, self._interval
         space = tuple(self.array.shape[2:])
+        # the gather kernels trust their indices: check every row the batch reads on the host (the host path raises
+        # IndexError from numpy's fancy indexing for the same inputs)
+        samples = np.asarray(samples)
+        T = int(self.array.shape[0])
+        if n:
+            last = max([iv * (its - 1)] + [t_off + iv * (steps - 1) for t_off, steps in self._windows()])
+            if self._sequence is not None and self._add_insolation and self._sequence > 1:
+                last = max(last, iv * (its * (self._sequence - 1) + its - 1))
+            lo, hi = int(samples.min()), int(samples.max())
+            if lo < 0 or hi + last >= T:
+                raise IndexError('index %d is out of bounds for axis 0 with size %d' % (lo if lo < 0 else hi + last, T))
         smp = torch.from_numpy(samples.astype(np.int32)).to(self.device)
         cl = self.channels_last
         vin_n, add = self._input_size, self._add_insolation

@@ -624,6 +624,20 @@ def channels_last_to_first(x):
 # ------------------------------------------------------------------------------------------------------------------ #
 
 _mse_scratch = {}
+_unit_seeds = {}
+
+
+def unit_seed(device):
+    """The cached ones(2) tensor DLWP.keras.Model seeds the backward of every loss node with: _MSE.backward recognises it
+    by address and returns the gradient the forward kernel already wrote; any other upstream gradient is applied."""
+    key = str(device)
+    t = _unit_seeds.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('first training step must run eagerly (graph capture allocates nothing)')
+        t = torch.ones(2, dtype=torch.float32, device=device)
+        _unit_seeds[key] = t
+    return t
 
 
 class _MSE(torch.autograd.Function):
@@ -657,9 +671,13 @@ class _MSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (dy,) = ctx.saved_tensors
-        # Contract: the upstream gradient of out[0] is exactly 1 (DLWP.keras.Model sums the weighted losses and calls
-        # backward with ones); the forward kernel already wrote dy = weight * 2 (y - t) / n, so no extra pass here.
-        return dy, None, None
+        # The forward kernel already wrote dy = weight * 2 (y - t) / n.  DLWP.keras.Model seeds the backward with
+        # unit_seed() (upstream gradient of out[0] exactly 1): no extra pass.  Any other upstream gradient (a scaled or
+        # combined loss built on this op) is applied here; out[1] (mae) carries no gradient.
+        seed = _unit_seeds.get(str(dout.device))
+        if seed is not None and dout.data_ptr() == seed.data_ptr():
+            return dy, None, None
+        return (dy.float() * dout[0]).to(dy.dtype), None, None
 
 
 def mse_mae(y, t, weight=1.0):
@@ -682,6 +700,18 @@ def adam_step(p, g, m, v, step_dev, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, g
                                  grad_scale, stream_ptr()), 'dlwpcs_adam_step')
     if zero_grads:
         g.zero_()
+
+
+def adam_step_dev(p, g, m, v, state_dev, hyper_dev, zero_grads=False):
+    """dlwpcs_adam_step_dev: the fused Adam launch with {lr, beta1, beta2, eps, grad_scale} read from the 5-float device
+    tensor `hyper_dev` -- the form a captured hipGraph needs to honour learning-rate changes between replays."""
+    for t in (p, g, m, v, hyper_dev):
+        require_device(t, 'adam_step_dev')
+        _f32_param(t, 'adam_step_dev')
+    if hyper_dev.numel() < 5 or state_dev.numel() < 2:
+        raise ValueError('adam_step_dev: hyper_dev needs 5 floats, state_dev 2 int32')
+    check(lib().dlwpcs_adam_step_dev(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(state_dev), ptr(hyper_dev),
+                                     nat.ADAM_ZERO_GRAD if zero_grads else 0, stream_ptr()), 'dlwpcs_adam_step_dev')
 
 
 def add(a, b):

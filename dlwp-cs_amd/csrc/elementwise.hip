@@ -609,11 +609,14 @@ __global__ void step_inc_kernel(int32_t *step) { *step += 1; }
 
 // One launch: state = {t - 1, ticket}.  Every workgroup reads t - 1 when it starts; the last one to FINISH (ticket ==
 // gridDim - 1: all others have read it by then) increments it and clears the ticket.  ZERO: g is cleared once consumed.
+// hyper != nullptr (dlwpcs_adam_step_dev): {lr, beta1, beta2, eps, grad_scale} are read from device memory, so a captured
+// hipGraph honours learning-rate changes between replays (by-value kernel arguments are frozen at capture time).
 template <bool ZERO, int VEC>
 __global__ void __launch_bounds__(256) adam_fused_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                          float *__restrict__ v, size_t n, int32_t *state, float lr, float b1,
-                                                         float b2, float eps, float gscale) {
+                                                         float b2, float eps, float gscale, const float *__restrict__ hyper) {
     typedef float VT4 __attribute__((ext_vector_type(VEC)));
+    if (hyper != nullptr) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; gscale = hyper[4]; }
     const int32_t t0 = *(volatile int32_t *)state;
     const float t = (float)(t0 + 1);
     const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
@@ -950,9 +953,9 @@ extern "C" int dlwpcs_adam_step(float *p, const float *g, float *m, float *v, si
     return check_launch("adam_step");
 }
 
-extern "C" int dlwpcs_adam_step_fused(float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev, float lr,
-                                      float beta1, float beta2, float eps, float grad_scale, int flags,
-                                      dlwpcs_stream_t stream) {
+static int adam_fused_launch(float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev, float lr,
+                             float beta1, float beta2, float eps, float grad_scale, const float *hyper_dev, int flags,
+                             dlwpcs_stream_t stream) {
     REQUIRE(p && g && m && v && state_dev, "adam_step_fused: null pointer");
     REQUIRE((flags & ~DLWPCS_ADAM_ZERO_GRAD) == 0, "adam_step_fused: unknown flags %d", flags);
     if (n == 0) {
@@ -967,11 +970,23 @@ extern "C" int dlwpcs_adam_step_fused(float *p, float *g, float *m, float *v, si
     const bool zero = (flags & DLWPCS_ADAM_ZERO_GRAD) != 0;
 #define ADAM_LAUNCH(Z, V)                                                                                              \
     hipLaunchKernelGGL((adam_fused_kernel<Z, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state_dev,  \
-                       lr, beta1, beta2, eps, grad_scale)
+                       lr, beta1, beta2, eps, grad_scale, hyper_dev)
     if (vec) { if (zero) ADAM_LAUNCH(true, 4); else ADAM_LAUNCH(false, 4); }
     else { if (zero) ADAM_LAUNCH(true, 1); else ADAM_LAUNCH(false, 1); }
 #undef ADAM_LAUNCH
     return check_launch("adam_step_fused");
+}
+
+extern "C" int dlwpcs_adam_step_fused(float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev, float lr,
+                                      float beta1, float beta2, float eps, float grad_scale, int flags,
+                                      dlwpcs_stream_t stream) {
+    return adam_fused_launch(p, g, m, v, n, state_dev, lr, beta1, beta2, eps, grad_scale, nullptr, flags, stream);
+}
+
+extern "C" int dlwpcs_adam_step_dev(float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev,
+                                    const float *hyper_dev, int flags, dlwpcs_stream_t stream) {
+    REQUIRE(hyper_dev, "adam_step_dev: null hyper-parameter buffer");
+    return adam_fused_launch(p, g, m, v, n, state_dev, 0.f, 0.f, 0.f, 0.f, 0.f, hyper_dev, flags, stream);
 }
 
 extern "C" int dlwpcs_batch_gather(const void *array, int64_t T, int V, int64_t S, const int32_t *samples_dev, int B,

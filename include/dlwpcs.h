@@ -273,6 +273,11 @@ int dlwpcs_adam_step(float *p, const float *g, float *m, float *v, size_t n, int
 int dlwpcs_adam_step_fused(float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev,
                            float lr, float beta1, float beta2, float eps, float grad_scale, int flags,
                            dlwpcs_stream_t stream);
+/* Same kernel, hyper-parameters read from DEVICE memory: hyper_dev -> five floats {lr, beta1, beta2, eps, grad_scale}.
+ * A step captured in a hipGraph then honours `optimizer.lr = x` / learning-rate schedules between replays (by-value
+ * arguments are frozen at capture).  Same element arithmetic as dlwpcs_adam_step_fused -> same bits for equal values. */
+int dlwpcs_adam_step_dev(float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev,
+                         const float *hyper_dev, int flags, dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
  * Batch feed (reference ArrayDataGenerator.generate, DLWP/model/generators.py:872-984): with the whole data array

@@ -4,6 +4,7 @@ CPU tests of the host-side mirror of the reference API (no device work): layer s
 """
 import os
 import pickle
+import sys
 
 import numpy as np
 import pytest
@@ -150,6 +151,83 @@ def test_predict_timeseries_bookkeeping(n_out, time_dim, keep):
     assert out.dtype == np.float32
 
 
+def _g7_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g7_rollout.npz'))
+    return g, [str(n) for n in g['names']]
+
+
+def test_predict_timeseries_pinned_to_reference(golden_dir):
+    """a6: DLWPFunctional.predict_timeseries against outputs of the reference's OWN method body
+    (/root/reference/DLWP/model/models.py:418-460, executed by tests/golden/gen_golden_rollout.py), both layouts,
+    n_steps x time_dim x keep_time_dim x time_steps; bit-exact (pure bookkeeping around a +1 model)."""
+    from DLWP.model import DLWPFunctional
+    g, names = _g7_cases(golden_dir)
+    assert len(names) == 32
+    for name in names:
+        layout, n, t, k, s = name.split('_')
+        n_out, time_dim, keep, steps = int(n[1:]), int(t[1:]), bool(int(k[1:])), int(s[1:])
+        dlwp = DLWPFunctional(is_convolutional=True, time_dim=time_dim)
+        dlwp.build_model(_StubModel(n_out), loss='mse')
+        x = g[name + '_x']
+        x0 = x.copy()
+        out = dlwp.predict_timeseries(x, steps, keep_time_dim=keep)
+        ref = g[name + '_y']
+        assert out.shape == ref.shape and out.dtype == ref.dtype == np.float32, name
+        assert np.array_equal(out, ref), name
+        assert np.array_equal(x, x0), name                     # the caller's array is not modified (reference copies)
+        # the oracle restatement used by the remaining tests agrees with the reference too
+        ref2 = orc.predict_timeseries_ref(dlwp.model.predict, x, steps, n_steps=n_out, time_dim=time_dim, keep_time_dim=keep)
+        assert np.array_equal(ref2, ref), name
+    errs = dict(zip([str(a) for a in g['err_labels']], [str(a) for a in g['err_types']]))
+    assert errs == {'list_input': 'NotImplementedError', 'zero_steps': 'ValueError'}
+
+
+def test_callbacks_pinned_to_reference(golden_dir):
+    """N3: EarlyStoppingMin / SaveWeightsOnEpoch traces of the reference's own on_epoch_end bodies
+    (/root/reference/DLWP/custom.py:113-191, executed by tests/golden/gen_golden_rollout.py) over scripted loss sequences."""
+    sys.path.insert(0, golden_dir)
+    try:
+        import gen_golden_rollout as gg
+    finally:
+        sys.path.remove(golden_dir)
+    from DLWP.custom import EarlyStoppingMin, SaveWeightsOnEpoch
+    g = np.load(os.path.join(golden_dir, 'g8_callbacks.npz'))
+    for i, (kw, losses) in enumerate(gg.ES_CASES):
+        assert np.array_equal(g['es%d_losses' % i], np.array(losses))
+        cb = EarlyStoppingMin(**kw)
+        model = gg.FakeModel()
+        cb.set_model(model)
+        cb.on_train_begin()
+        trace = []
+        for epoch, loss in enumerate(losses):
+            model.w = [np.array([float(epoch)])]
+            cb.on_epoch_end(epoch, {kw['monitor']: loss})
+            trace.append([float(model.stop_training), float(cb.wait), float(cb.best), float(cb.stopped_epoch),
+                          float(model.w[0][0])])
+            if model.stop_training:
+                break
+        assert np.array_equal(np.array(trace), g['es%d_trace' % i]), (i, trace, g['es%d_trace' % i])
+    assert str(g['es_bad_min_epochs']) == 'ValueError'
+    j = 0
+    while 'sw%d_saved' % j in g:
+        interval = int(g['sw%d_interval' % j])
+        cb = SaveWeightsOnEpoch('w.h5', interval=None if interval < 0 else interval)
+        model = gg.FakeModel()
+        model.fail_on = set(int(v) for v in g['sw%d_fail_on' % j])
+        cb.set_model(model)
+        raised = []
+        for epoch in range(6):
+            try:
+                cb.on_epoch_end(epoch)
+                raised.append(0)
+            except OSError:
+                raised.append(1)
+        assert [str(a) for a in g['sw%d_saved' % j]] == model.saved, j
+        assert np.array_equal(np.array(raised), g['sw%d_raised' % j]), j
+        j += 1
+    assert j == 4
+
+
 def test_dlwpfunctional_errors_and_attributes():
     from DLWP.model import DLWPFunctional
     with pytest.raises(ValueError, match="'time_dim' must be >= 1"):
@@ -278,6 +356,25 @@ def test_mixed_precision_policy_and_exports():
         mixed_precision.set_policy('mixed_float16')
     inp = Input(shape=(6, 8, 8, 3))
     assert Model(inputs=inp, outputs=CubeSphereNet(base_filter_number=4, output_channels=3).unet2(inp)).compute_dtype == 'float32'
+
+
+def test_mixed_precision_rewrite_after_model_construction():
+    """The reference order: Model(...) at Azure/train_cs.py:411, enable_mixed_precision_graph_rewrite(Adam()) at :429,
+    compile at :430 -- the optimizer carries the switch into compile()."""
+    from DLWP.keras import backend, mixed_precision
+    from DLWP.keras.optimizers import Adam
+    model = _tiny_model()
+    assert model.compute_dtype == 'float32'
+    try:
+        opt = mixed_precision.enable_mixed_precision_graph_rewrite(Adam())
+    finally:
+        mixed_precision.disable_mixed_precision_graph_rewrite()
+    assert backend.compute_dtype() == 'float32'
+    model.compile(optimizer=opt, loss='mse')
+    assert model.compute_dtype == 'bfloat16'
+    other = _tiny_model()
+    other.compile(optimizer=Adam(), loss='mse')
+    assert other.compute_dtype == 'float32'
 
 
 def test_saved_model_keeps_its_compute_dtype(tmp_path):
