@@ -13,7 +13,10 @@ import numpy as np
 import torch   # must be imported before the library so that one HIP runtime (torch's) serves both
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libdlwpcs.so')
+# development only: DLWPCS_LIB_TAG=<tag> loads lib/libdlwpcs_<tag>.so (an instrumented build made by build.py with the same
+# variable set, e.g. the -DDLWPCS_TIMELINE s_memtime build of tools/timeline_*.py); the product library has no tag
+_TAG = os.environ.get('DLWPCS_LIB_TAG', '')
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libdlwpcs%s.so' % ('_' + _TAG if _TAG else ''))
 
 F32 = 0
 BF16 = 1
@@ -106,6 +109,7 @@ PROTOTYPES = {
                                  c_float, c_float, c_float, c_void_p]),
     'dlwpcs_adam_step_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float,
                                        c_float, c_float, c_float, c_int, c_void_p]),
+    'dlwpcs_state_repack': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_adam_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int,
                                      c_void_p]),
     'dlwpcs_batch_gather': (c_int, [c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int, c_void_p, c_int,

@@ -15,7 +15,6 @@ Execution model (MI355X-first, replaces TF's graph executor):
 """
 import json
 import os
-import pickle
 import time
 
 import numpy as np
@@ -631,13 +630,17 @@ class Model(object):
         predict_timeseries loop, DLWP/model/models.py:446-454).  Fills out_series[(steps*n_steps), n, ...] in place.
         """
         if len(self.inputs) != 1:
-            raise NotImplementedError('rollout_on_device needs a single-input model')
+            raise NotImplementedError('rollout_on_device serves single-input models; models with solar / constants inputs '
+                                      'go through rollout_with_forcing (TimeSeriesEstimator)')
         n = predictors.shape[0]
         bs = 32 if batch_size is None else int(batch_size)
         with torch.no_grad():
             for s in range(0, n, bs):
                 state = self._to_device(predictors[s:s + bs])
                 self._check_shapes([state], self.inputs, 'input')
+                # the whole series of this batch is written into ONE device buffer and downloaded once: no host
+                # synchronisation inside the step loop
+                series = torch.empty((steps * n_steps,) + tuple(state.shape), dtype=torch.float32, device=state.device)
                 for t in range(steps):
                     if verbose > 0 and s == 0:
                         print('Prediction step %d/%d' % (t + 1, steps))
@@ -647,30 +650,171 @@ class Model(object):
                                          % (tuple(res[-1].shape), tuple(state.shape)))
                     state = res[-1]
                     for k in range(n_steps):
-                        out_series[t * n_steps + k, s:s + bs] = res[k].float().cpu().numpy()
+                        series[t * n_steps + k].copy_(res[k])
+                out_series[:, s:s + bs] = series.cpu().numpy()
+
+    def _input_roles(self):
+        """(main, [solar...], constants | None) indices into self.inputs: by the names the reference scripts use
+        (Azure/train_cs.py:191-194,392-396: 'main_input', 'solar_<k>', 'constants'), else by rank (solar inputs carry a
+        time axis: (B, T, 6, N, N, 1))."""
+        names = [t.layer.name for t in self.inputs]
+        main, solar, const = 0, [], None
+        for i, (t, nm) in enumerate(zip(self.inputs, names)):
+            if i == 0:
+                continue
+            if nm.startswith('solar') or len(t.shape) == len(self.inputs[0].shape) + 1:
+                solar.append(i)
+            elif nm.startswith('constant') or i == len(self.inputs) - 1:
+                const = i
+            else:
+                raise ValueError('rollout_with_forcing: cannot tell the role of input %r' % nm)
+        return main, solar, const
+
+    def rollout_with_forcing(self, predictors, sequence_steps, insolation=None, start_index=None, io_time_steps=None,
+                             verbose=0):
+        """
+        Device-resident core of the reference's TimeSeriesEstimator.predict (DLWP/model/extensions.py:252-308): iterate a
+        (multi-step) model with inputs [main_input, solar_1.., constants] on its own last output, re-injecting the known
+        forcing every step.  Between steps the state never leaves HBM: the new main input is ONE `dlwpcs_state_repack`
+        launch (last output + insolation as the last channel of every input time step -- the numpy concatenate / transpose /
+        reshape of extensions.py:281-296), the solar inputs of the later integration steps are `dlwpcs_batch_gather` launches
+        out of the HBM-resident insolation array, the constants tensor is reused.
+
+        :param predictors: the model's initial inputs (array / list of arrays or device tensors), as the generator yields them
+        :param sequence_steps: how many times the whole model is applied
+        :param insolation: (T, 6, N, N) fp32 array on the data's time grid (row r = time r * dt), or None for a model
+            without solar forcing (the main input is then the last output itself)
+        :param start_index: (B,) int: row of `insolation` of each sample's FIRST input time step
+        :param io_time_steps: input (= output) time steps folded into the channel axis; default: the time axis of the
+            solar inputs, else 1
+        :return: fp32 device tensor (sequence_steps, n_outputs, B, 6, N, N, C_out); download it once
+        """
+        sequence_steps = int(sequence_steps)
+        if sequence_steps < 1:
+            raise ValueError('sequence_steps must be a positive integer')
+        xs = self._standardize_inputs(predictors)
+        i_main, i_solar, i_const = self._input_roles()
+        n_out = len(self.outputs)
+        dev = backend.device()
+        cdt = backend.torch_dtype(self.compute_dtype)
+        with torch.no_grad():
+            cur = [self._to_device(a) for a in xs]
+            self._check_shapes(cur, self.inputs, 'input')
+            B = cur[i_main].shape[0]
+            space = tuple(cur[i_main].shape[1:-1])
+            c_main, c_out = cur[i_main].shape[-1], self.outputs[-1].shape[-1]
+            if io_time_steps is None:
+                io_time_steps = self.inputs[i_solar[0]].shape[1] if i_solar else 1
+            its = int(io_time_steps)
+            if insolation is not None:
+                if c_out % its or c_main != c_out + its:
+                    raise ValueError('rollout_with_forcing: main input has %d channels, the last output %d: expected %d '
+                                     'time steps x (variables + 1 solar channel)' % (c_main, c_out, its))
+                if start_index is None:
+                    raise ValueError('rollout_with_forcing: `start_index` is needed with `insolation`')
+                sol = insolation if isinstance(insolation, torch.Tensor) else torch.from_numpy(
+                    np.ascontiguousarray(insolation, dtype=np.float32))
+                sol = sol.to(dev, dtype=torch.float32).contiguous()
+                if tuple(sol.shape[1:]) != space:
+                    raise ValueError('rollout_with_forcing: insolation grid %s != input grid %s' % (tuple(sol.shape[1:]), space))
+                sol = sol.unsqueeze(1)                                              # (T, 1, *space): one "variable"
+                start = np.asarray(start_index, dtype=np.int64).reshape(-1)
+                if start.shape[0] != B:
+                    raise ValueError('rollout_with_forcing: start_index needs one entry per sample')
+                # every row read below, checked on the host (the gather kernels trust their indices)
+                last = int(start.max()) + (sequence_steps - 1) * its * n_out + (n_out - 1) * its + its - 1
+                if sequence_steps > 1 and (int(start.min()) < 0 or last >= sol.shape[0]):
+                    raise IndexError('rollout_with_forcing: insolation rows up to %d are needed, the array has %d'
+                                     % (last, sol.shape[0]))
+                zero = torch.zeros(1, dtype=torch.int32, device=dev)
+                steps_ar = np.arange(its, dtype=np.int64)
+            elif c_main != c_out or i_solar:
+                raise ValueError('rollout_with_forcing: without insolation the last output must have the main input\'s shape')
+            series = torch.empty((sequence_steps, n_out, B) + space + (c_out,), dtype=torch.float32, device=dev)
+            for s in range(sequence_steps):
+                if verbose > 0:
+                    print('Time step %d/%d' % (s + 1, sequence_steps))
+                res = self._forward(cur, repack=(s == 0))                           # weights are fixed during a rollout
+                for k in range(n_out):
+                    series[s, k].copy_(res[k])
+                if s + 1 == sequence_steps:
+                    break
+                if insolation is None:
+                    cur[i_main] = res[-1]
+                    continue
+                # known forcing of the next application: time rows start + (s+1)*its*n_out + n + m*its  (extensions.py:277-287)
+                nxt = []
+                for m in range(n_out):
+                    rows = (start[:, None] + (s + 1) * its * n_out + m * its + steps_ar[None, :]).reshape(-1)
+                    idx = torch.from_numpy(rows.astype(np.int32)).to(dev)
+                    buf = torch.empty((B, its) + space + (1,), dtype=cdt, device=dev)
+                    ops.batch_gather(sol, idx, zero, buf.view((B * its,) + space + (1,)), 1, 0, 1, 0, 1, True)
+                    nxt.append(buf)
+                cur[i_main] = ops.state_repack(res[-1], nxt[0], its)
+                if len(i_solar) != n_out - 1:
+                    raise ValueError('rollout_with_forcing: %d solar inputs for %d outputs' % (len(i_solar), n_out))
+                for m, i in enumerate(i_solar):
+                    cur[i] = nxt[m + 1]
+        return series
 
     def reset_states(self):
         pass
 
     # -------------------------------------------------------------------------------------------------------------- #
-    # persistence (native format; HDF5 needs h5py which this stack does not carry)
+    # persistence: native npz containers (no pickle); HDF5 files written by keras / h5py are READ by DLWP.keras.hdf5_lite
     # -------------------------------------------------------------------------------------------------------------- #
     def save_weights(self, filepath, overwrite=True, save_format=None):
+        """Native weights file: an uncompressed numpy `.npz` container (whatever the extension; `save_format` is accepted for
+        call compatibility with reference DLWP/custom.py:186) holding one array per weight plus their keras names.  Loaded
+        with allow_pickle=False -- nothing in the file can execute code."""
         if not overwrite and os.path.exists(filepath):
             return
-        payload = {'format': 'dlwpcs-weights-1', 'names': [n for l in self._weight_layers() for n in l._weight_names],
-                   'weights': self.get_weights()}
-        tmp = '%s.tmp%d' % (filepath, os.getpid())
-        with open(tmp, 'wb') as f:
-            pickle.dump(payload, f, protocol=pickle.HIGHEST_PROTOCOL)
-        os.replace(tmp, filepath)
+        from . import serialization
+        names = [n for l in self._weight_layers() for n in l._weight_names]
+        layers = [[l.name, len(l._weights)] for l in self._weight_layers()]
+        serialization.save_container(filepath, self.get_weights(), {'format': 'dlwpcs-weights-2', 'names': names,
+                                                                    'layers': layers})
+
+    def _set_weights_by_layer(self, file_layers, by_name, what):
+        """file_layers: ordered [(layer name, [arrays])] of the layers that own weights.  keras semantics
+        (`load_weights_from_hdf5_group[_by_name]`): topological order by default, layer names with by_name=True."""
+        mine = self._weight_layers()
+        file_layers = [(n, ws) for n, ws in file_layers if len(ws)]
+        if by_name:
+            table = dict(file_layers)
+            for l in mine:
+                if l.name in table:
+                    l.set_weights(table[l.name])
+            return
+        if len(file_layers) != len(mine):
+            raise ValueError('You are trying to load a weight file containing %d layers into a model with %d layers.'
+                             % (len(file_layers), len(mine)))
+        for l, (n, ws) in zip(mine, file_layers):
+            if len(ws) != len(l._weights):
+                raise ValueError('Layer #%s (named "%s") expects %d weight(s), but the saved weights (%s, layer "%s") have '
+                                 '%d element(s).' % (mine.index(l), l.name, len(l._weights), what, n, len(ws)))
+            l.set_weights(ws)
 
     def load_weights(self, filepath, by_name=False):
-        with open(filepath, 'rb') as f:
-            payload = pickle.load(f)
-        if not isinstance(payload, dict) or payload.get('format') != 'dlwpcs-weights-1':
+        """Native `.npz` container, or an HDF5 weights / model file written by Keras + h5py (the reference's
+        `model.save_weights(path, save_format='h5')`, DLWP/custom.py:184-191): read by the pure-Python HDF5 subset reader
+        DLWP.keras.hdf5_lite -- no h5py / TensorFlow needed."""
+        from . import hdf5_lite, serialization
+        if hdf5_lite.is_hdf5(filepath):
+            layers, _ = hdf5_lite.read_keras_weights(filepath)
+            self._set_weights_by_layer([(n, [a for _, a in ws]) for n, ws in layers], by_name, 'HDF5')
+            return
+        arrays, meta = serialization.load_container(filepath)
+        if meta.get('format') != 'dlwpcs-weights-2':
             raise ValueError('%s is not a dlwpcs weights file' % filepath)
-        self.set_weights(payload['weights'])
+        if by_name and meta.get('layers'):
+            k, fl = 0, []
+            for name, n in meta['layers']:
+                fl.append((name, arrays[k:k + n]))
+                k += n
+            self._set_weights_by_layer(fl, True, 'npz')
+            return
+        self.set_weights(arrays)
 
     def get_config(self):
         index = {}
@@ -723,18 +867,101 @@ class Model(object):
                    outputs=outs[0] if config.get('single_output') else outs, name=config.get('name'))
 
     def save(self, filepath, overwrite=True, include_optimizer=True, **kwargs):
+        """Model file (`.keras` of DLWP.util.save_model): npz container with the graph config (JSON, engine format and the
+        keras functional format), the weights, the compile arguments and the optimizer state."""
         if not overwrite and os.path.exists(filepath):
             return
-        payload = {'format': 'dlwpcs-model-1', 'config': self.get_config(), 'weights': self.get_weights(),
-                   'compile': None, 'compute_dtype': self.compute_dtype}
+        from . import serialization
+        meta = {'format': 'dlwpcs-model-2', 'config': self.get_config(), 'keras_config': self.to_keras_config(),
+                'compile': None, 'compute_dtype': self.compute_dtype, 'n_weights': len(self.weights)}
+        arrays = self.get_weights()
         if self._compiled:
-            payload['compile'] = {'loss': self.loss, 'loss_weights': self.loss_weights, 'metrics': self.metrics,
-                                  'optimizer': self.optimizer.get_config(),
-                                  'optimizer_state': self.optimizer.state_dict() if include_optimizer else None}
-        tmp = '%s.tmp%d' % (filepath, os.getpid())
-        with open(tmp, 'wb') as f:
-            pickle.dump(payload, f, protocol=pickle.HIGHEST_PROTOCOL)
-        os.replace(tmp, filepath)
+            meta['compile'] = {'loss': self.loss, 'loss_weights': self.loss_weights, 'metrics': self.metrics,
+                               'optimizer': self.optimizer.get_config(), 'optimizer_state': None}
+            st = self.optimizer.state_dict() if include_optimizer else None
+            if st is not None:
+                meta['compile']['optimizer_state'] = {'step': st['step']}
+                arrays = arrays + [st['m'], st['v']]
+        serialization.save_container(filepath, arrays, meta)
+
+    # -- keras functional config (what `model.to_json()` / the `model_config` attribute of a keras HDF5 file hold) ------- #
+    def to_keras_config(self):
+        node_of = {}                     # tensor uid -> (layer name, node index)
+        calls = {}
+        layers = []
+        entry = {}
+        for t in self.inputs + [n for n in self._nodes if n.uid not in {i.uid for i in self.inputs}]:
+            lay = t.layer
+            if id(lay) not in entry:
+                cfg = lay.get_config()
+                e = {'name': lay.name, 'class_name': type(lay).__name__, 'config': cfg, 'inbound_nodes': []}
+                entry[id(lay)] = e
+                layers.append(e)
+            e = entry[id(lay)]
+            k = calls.get(id(lay), 0)
+            calls[id(lay)] = k + 1
+            node_of[t.uid] = (lay.name, k)
+            if t.node_inputs:
+                e['inbound_nodes'].append([[node_of[i.uid][0], node_of[i.uid][1], 0, {}] for i in t.node_inputs])
+        return {'class_name': 'Model',
+                'config': {'name': self.name, 'layers': layers,
+                           'input_layers': [[node_of[t.uid][0], node_of[t.uid][1], 0] for t in self.inputs],
+                           'output_layers': [[node_of[t.uid][0], node_of[t.uid][1], 0] for t in self.outputs]},
+                'keras_version': '2.2.4-tf', 'backend': 'dlwpcs'}
+
+    @classmethod
+    def from_keras_config(cls, config, custom_objects=None):
+        """Rebuild the graph from a keras functional-model config (`json.loads(model.to_json())` of TF-keras 2.x, or its
+        'config' member): layers by class name from DLWP.keras.layers / DLWP.custom / custom_objects, nodes in dependency
+        order (the algorithm of keras' `Network.from_config`)."""
+        from .. import custom
+        from . import layers as klayers
+        if 'config' in config and 'layers' not in config:
+            config = config['config']
+        table = {}
+        for mod in (klayers, custom):
+            for k in dir(mod):
+                v = getattr(mod, k)
+                if isinstance(v, type) and issubclass(v, Layer):
+                    table[k] = v
+        table.update(custom_objects or {})
+        objs, pending = {}, []
+        for lc in config['layers']:
+            cname = lc['class_name']
+            if cname not in table:
+                raise ValueError('Unknown layer: %s' % cname)
+            cfg = dict(lc['config'])
+            lay = table[cname].from_config(cfg)
+            objs[lc['name']] = lay
+            for ni, node in enumerate(lc.get('inbound_nodes', [])):
+                pending.append((lc['name'], ni, node))
+        tensors = {}
+        for lc in config['layers']:
+            lay = objs[lc['name']]
+            if isinstance(lay, InputLayer):
+                tensors[(lc['name'], 0)] = KTensor(lay.batch_input_shape, layer=lay, node_inputs=(), name=lay.name)
+        counts = {}
+        while pending:
+            progressed = False
+            rest = []
+            for name, ni, node in pending:
+                refs = [(r[0], r[1]) for r in node]
+                # a layer's nodes must be created in order (node index = call count)
+                if all(r in tensors for r in refs) and counts.get(name, 0) == ni:
+                    lay = objs[name]
+                    ins = [tensors[r] for r in refs]
+                    tensors[(name, ni)] = lay(ins if (isinstance(lay, Concatenate) or len(ins) > 1) else ins[0])
+                    counts[name] = ni + 1
+                    progressed = True
+                else:
+                    rest.append((name, ni, node))
+            if not progressed:
+                raise ValueError('keras config: cannot resolve the inbound nodes of %s' % sorted({p[0] for p in rest}))
+            pending = rest
+        ins = [tensors[(r[0], r[1])] for r in config['input_layers']]
+        outs = [tensors[(r[0], r[1])] for r in config['output_layers']]
+        return cls(inputs=ins[0] if len(ins) == 1 else ins, outputs=outs[0] if len(outs) == 1 else outs,
+                   name=config.get('name'))
 
     def to_json(self, **kwargs):
         return json.dumps({'class_name': 'Model', 'config': self.get_config()}, default=lambda o: list(o), **kwargs)
@@ -755,20 +982,53 @@ class Model(object):
         print_fn('Fused cubed-sphere convolution launches per forward pass: %d' % self.n_fused)
 
 
+def _compile_from_keras_training_config(model, tc):
+    opt = tc.get('optimizer_config') or {}
+    ocfg = dict(opt.get('config', {}))
+    if opt.get('class_name', 'Adam').lower() != 'adam':
+        raise NotImplementedError('optimizer %r: the DLWP-CS engine provides Adam' % opt.get('class_name'))
+    ocfg = {k: ocfg[k] for k in ('learning_rate', 'lr', 'beta_1', 'beta_2', 'epsilon', 'amsgrad', 'decay') if k in ocfg}
+    metrics = tc.get('metrics') or []
+    flat = []
+    for m in (metrics if isinstance(metrics, (list, tuple)) else [metrics]):
+        flat += list(m) if isinstance(m, (list, tuple)) else [m]
+    metrics = ['mae' if m in ('mae', 'mean_absolute_error') else m for m in flat]
+    model.compile(optimizer=optimizers.Adam(**ocfg), loss=tc.get('loss'), loss_weights=tc.get('loss_weights'),
+                  metrics=sorted(set(metrics)) or None)
+
+
 def load_model(filepath, custom_objects=None, compile=True):
-    with open(filepath, 'rb') as f:
-        payload = pickle.load(f)
-    if not isinstance(payload, dict) or payload.get('format') != 'dlwpcs-model-1':
-        raise ValueError('%s is not a dlwpcs model file (HDF5 models written by TensorFlow need h5py + TF to convert)'
-                         % filepath)
-    model = Model.from_config(payload['config'], custom_objects=custom_objects)
-    model.compute_dtype = payload.get('compute_dtype', model.compute_dtype)      # the mixed-precision mode travels with it
-    model.set_weights(payload['weights'])
-    cmp = payload.get('compile')
+    """
+    Load a model file: the engine's npz container (Model.save), or an HDF5 file written by keras' `model.save()` under
+    TensorFlow (the `<name>.keras` of the reference's DLWP.util.save_model, util.py:139): graph from its `model_config`
+    attribute, weights from its `model_weights` group, optimizer / loss from `training_config` -- read without h5py.
+    """
+    from . import hdf5_lite, serialization
+    if hdf5_lite.is_hdf5(filepath):
+        layers, cfg = hdf5_lite.read_keras_weights(filepath)
+        if cfg is None:
+            raise ValueError('%s holds weights only (no model_config): build the model and use load_weights' % filepath)
+        model = Model.from_keras_config(json.loads(cfg), custom_objects=custom_objects)
+        model._set_weights_by_layer([(n, [a for _, a in ws]) for n, ws in layers], False, 'HDF5')
+        f = hdf5_lite.File(filepath)
+        tc = f.attrs.get('training_config')
+        if compile and tc is not None:
+            _compile_from_keras_training_config(model, json.loads(hdf5_lite._as_str(tc)))
+        return model
+    arrays, meta = serialization.load_container(filepath)
+    if meta.get('format') != 'dlwpcs-model-2':
+        raise ValueError('%s is not a dlwpcs model file' % filepath)
+    model = Model.from_config(meta['config'], custom_objects=custom_objects)
+    model.compute_dtype = meta.get('compute_dtype', model.compute_dtype)      # the mixed-precision mode travels with it
+    nw = int(meta['n_weights'])
+    model.set_weights(arrays[:nw])
+    cmp = meta.get('compile')
     if compile and cmp:
         model.compile(optimizer=optimizers.get(cmp['optimizer']), loss=cmp['loss'], loss_weights=cmp['loss_weights'],
                       metrics=cmp['metrics'])
-        model.optimizer.load_state_dict(cmp.get('optimizer_state'), model._flat_params)
+        st = cmp.get('optimizer_state')
+        if st is not None and len(arrays) >= nw + 2:
+            model.optimizer.load_state_dict({'m': arrays[nw], 'v': arrays[nw + 1], 'step': st['step']}, model._flat_params)
     return model
 
 

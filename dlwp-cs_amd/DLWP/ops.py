@@ -585,6 +585,29 @@ def concat_channels(tensors):
     return out
 
 
+def state_repack(state, extra, n_time):
+    """Next main input of a forecast step: `state` (B, *space, T*V) with `extra` (B, T, *space, E) appended as the last E
+    channels of each of the T time steps -> (B, *space, T*(V+E)).  One launch (dlwpcs_state_repack); inference only."""
+    require_device(state, 'state_repack')
+    require_device(extra, 'state_repack')
+    if state.dtype != extra.dtype:
+        raise TypeError('state_repack: state is %s but extra is %s' % (state.dtype, extra.dtype))
+    state, extra = _c(state), _c(extra)
+    B, T = state.shape[0], int(n_time)
+    space = tuple(state.shape[1:-1])
+    if state.shape[-1] % T or tuple(extra.shape[:2]) != (B, T) or tuple(extra.shape[2:-1]) != space:
+        raise ValueError('state_repack: state %s / extra %s do not match %d time steps'
+                         % (tuple(state.shape), tuple(extra.shape), T))
+    V, E = state.shape[-1] // T, extra.shape[-1]
+    S = 1
+    for v in space:
+        S *= int(v)
+    out = torch.empty((B,) + space + (T * (V + E),), dtype=state.dtype, device=state.device)
+    check(lib().dlwpcs_state_repack(ptr(state), ptr(extra), ptr(out), B, S, T, V, E, nat.dtype_tag(state), stream_ptr()),
+          'dlwpcs_state_repack')
+    return out
+
+
 class _Transpose(torch.autograd.Function):
     """(B, C, S...) <-> (B, S..., C) layout conversion for data_format='channels_first' callers."""
 

@@ -13,9 +13,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-OBJ = os.path.join(HERE, 'build')
+TAG = os.environ.get('DLWPCS_LIB_TAG', '')          # development only: instrumented side build (see DLWP/_native.py)
+OBJ = os.path.join(HERE, 'build' + ('_' + TAG if TAG else ''))
 LIBDIR = os.path.join(HERE, 'lib')
-LIB = os.path.join(LIBDIR, 'libdlwpcs.so')
+LIB = os.path.join(LIBDIR, 'libdlwpcs%s.so' % ('_' + TAG if TAG else ''))
 SOURCES = ['halo_table.cpp', 'prof.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_generic.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'

@@ -404,6 +404,28 @@ __global__ void __launch_bounds__(256) concat2_kernel(const V *__restrict__ a, c
     }
 }
 
+// Rollout state re-injection (reference DLWP/model/extensions.py:281-299 + the Reshape / Permute / Concatenate chain of
+// Azure/train_cs.py:401-406 as ONE pass): the next main input of a forecast step is the model's last output with the known
+// forcing (insolation) appended as the last channels of every time step,
+//   out[b][s][n*(V+E) + j] = j < V ? state[b][s][n*V + j] : extra[b][n][s][j - V]            (n < T time steps)
+// state (B,S,T*V) and extra (B,T,S,E) are channels_last tensors of the same element type W (raw 2- or 4-byte words).
+template <typename W>
+__global__ void __launch_bounds__(256) state_repack_kernel(const W *__restrict__ state, const W *__restrict__ extra,
+                                                           W *__restrict__ out, size_t total, unsigned S, unsigned T,
+                                                           unsigned V, unsigned E) {
+    const unsigned VE = V + E, C = T * VE;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const unsigned c = (unsigned)(e % C);
+        const size_t pix = e / C;                      // b * S + s
+        const unsigned n = c / VE, j = c - n * VE;
+        if (j < V) out[e] = state[pix * (size_t)(T * V) + n * V + j];
+        else {
+            const size_t b = pix / S, sp = pix - b * S;
+            out[e] = extra[((b * T + n) * S + sp) * E + (j - V)];
+        }
+    }
+}
+
 template <typename V>
 __global__ void __launch_bounds__(256) split2_kernel(const V *__restrict__ y, V *__restrict__ a, V *__restrict__ b,
                                                      size_t total, int CaV, int CbV) {
@@ -846,6 +868,25 @@ extern "C" int dlwpcs_concat2(const void *a, const void *b, void *y, size_t rows
                            (const V *)b, (V *)y, total, (int)(ba / w), (int)(bb / w));
     });
     return check_launch("concat2");
+}
+
+extern "C" int dlwpcs_state_repack(const void *state, const void *extra, void *out, int B, size_t S, int T, int V, int E,
+                                   int dtype, dlwpcs_stream_t stream) {
+    REQUIRE_DTYPE(dtype, "state_repack");
+    REQUIRE(state && extra && out, "state_repack: null pointer");
+    REQUIRE(B >= 0 && S >= 1 && T >= 1 && V >= 1 && E >= 1, "state_repack: bad shape B=%d S=%zu T=%d V=%d E=%d", B, S, T, V, E);
+    REQUIRE(S < (1ull << 32), "state_repack: S too large");
+    if (B == 0) return DLWPCS_OK;
+    const size_t total = (size_t)B * S * T * (V + E);
+    if (dtype == DLWPCS_BF16)
+        hipLaunchKernelGGL(state_repack_kernel<uint16_t>, stream_grid(total), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t *)state, (const uint16_t *)extra, (uint16_t *)out, total, (unsigned)S, (unsigned)T,
+                           (unsigned)V, (unsigned)E);
+    else
+        hipLaunchKernelGGL(state_repack_kernel<uint32_t>, stream_grid(total), dim3(256), 0, (hipStream_t)stream,
+                           (const uint32_t *)state, (const uint32_t *)extra, (uint32_t *)out, total, (unsigned)S, (unsigned)T,
+                           (unsigned)V, (unsigned)E);
+    return check_launch("state_repack");
 }
 
 extern "C" int dlwpcs_split2(const void *y, void *a, void *b, size_t rows, int Ca, int Cb, int dtype,

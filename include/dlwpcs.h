@@ -242,6 +242,12 @@ int dlwpcs_upsample2_bwd(const void *dy, void *dx, int B, int N, int C, int dtyp
 int dlwpcs_concat2(const void *a, const void *b, void *y, size_t rows, int Ca, int Cb, int dtype,
                    dlwpcs_stream_t stream);
 int dlwpcs_split2(const void *y, void *a, void *b, size_t rows, int Ca, int Cb, int dtype, dlwpcs_stream_t stream);
+/* Rollout state re-injection (replaces the per-step numpy concatenate / transpose / reshape of the reference's
+ * TimeSeriesEstimator.predict, DLWP/model/extensions.py:281-299, and the Reshape / Permute / Concatenate chain of
+ * Azure/train_cs.py:401-406): out (B,S,T*(V+E)) <- state (B,S,T*V) with extra (B,T,S,E) appended as the last E channels of
+ * every one of the T time steps.  All three tensors have element type `dtype`. */
+int dlwpcs_state_repack(const void *state, const void *extra, void *out, int B, size_t S, int T, int V, int E,
+                        int dtype, dlwpcs_stream_t stream);
 /* layout converters for data_format='channels_first' callers: (B,C,S) <-> (B,S,C), S = 6*H*W */
 int dlwpcs_cf_to_cl(const void *x, void *y, int B, int C, size_t S, int dtype, dlwpcs_stream_t stream);
 int dlwpcs_cl_to_cf(const void *x, void *y, int B, int C, size_t S, int dtype, dlwpcs_stream_t stream);

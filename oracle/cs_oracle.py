@@ -336,3 +336,61 @@ def predict_timeseries_ref(predict_fn, predictors, time_steps, n_steps=1, time_d
         series = series.transpose((0, 2, 1) + tuple(range(3, 3 + len(feature_shape))))
         series = series.reshape((out_steps * time_dim, sample_dim, -1) + feature_shape[1:])
     return series
+
+
+# ---------------------------------------------------------------------------------------------------------------- #
+# TimeSeriesEstimator.predict, channels_last branch for DLWPFunctional models with insolation re-injection,
+# DLWP/model/extensions.py:252-308 (loop) and :384-436 (output assembly).  xarray-free restatement: coordinates are plain arrays.
+# ---------------------------------------------------------------------------------------------------------------- #
+
+def estimator_rollout_ref(predict_fn, predictors, steps, insolation_rows, start_index, n_steps, time_dim, its, ots,
+                          constants=None, keep_time_dim=False, interval=1):
+    """
+    Restates the reference loop for a channels_last, non-recurrent generator (`_keep_time_axis` False) whose model outputs
+    every input variable (its == ots):
+      * `predict_fn(list_of_inputs) -> list of n_steps outputs`, each (B, *space, ots*V)            extensions.py:273
+      * per sequence step the known insolation of the new times is appended as the last channel of every input time step
+        (extensions.py:277-296) and the constants are re-attached (:304-306)
+      * result (B, sequence_steps, n_steps, ...) -> (B, effective_steps, ...) (:308-310), then the f_hour assembly of :384-436.
+    `insolation_rows(rows) -> (len(rows), *space)` plays `insolation(new_t + k dt, lat, lon)`; `start_index[b]` is the time row of
+    sample b's first input step, so `new_t` advances by ots * n_steps rows per sequence step (:277).
+    Returns (values, f_hour): values (f_hour, B, *space, V) or, with keep_time_dim, (f_hour, B, ots, *space, V).
+    """
+    if int(steps) < 1:
+        raise ValueError('must use positive integer for steps')
+    if ots > its:
+        raise NotImplementedError
+    es = ots
+    effective_steps = int(np.ceil(steps / es))
+    p = [np.array(a, dtype=np.float32) for a in predictors]
+    B = p[0].shape[0]
+    space = p[0].shape[1:-1]
+    rank = len(space)
+    sequence_steps = int(np.ceil(steps / n_steps / time_dim))
+    out0 = predict_fn(p)
+    t_shape = np.asarray(out0[0]).shape
+    result = np.full((B, sequence_steps, n_steps) + tuple(t_shape[1:]), np.nan, dtype=np.float32)
+    new_t = np.asarray(start_index, dtype=np.int64).copy()
+    fwd_tr = (0, rank + 1) + tuple(range(1, 1 + rank)) + (-1,)
+    bwd_tr = (0,) + tuple(range(2, 2 + rank)) + (1, -1)
+    for s in range(sequence_steps):
+        outs = out0 if s == 0 else predict_fn(p)
+        result[:, s] = np.stack([np.asarray(o, dtype=np.float32) for o in outs], axis=1)
+        new_t = new_t + ots * n_steps
+        new_ins = [np.concatenate([np.expand_dims(insolation_rows(new_t + n + m * its)[:, None], axis=-1)
+                                   for n in range(its)], axis=1) for m in range(n_steps)]
+        r = result[:, s, -1].reshape(tuple(t_shape[:-1]) + (ots, -1)).transpose(fwd_tr)
+        p = [np.concatenate([r, new_ins[0]], axis=-1).transpose(bwd_tr).reshape((B,) + tuple(space) + (-1,))] + new_ins[1:]
+        if constants is not None:
+            p.append(np.repeat(np.expand_dims(constants, axis=0), B, axis=0))
+    n_dim_1 = result.size // int(np.prod(t_shape))
+    result = result.reshape((t_shape[0], n_dim_1) + tuple(t_shape[1:]))[:, :effective_steps]
+    rv = result.reshape((B, effective_steps) + tuple(space) + (ots, -1))
+    if keep_time_dim:
+        vals = rv.transpose((1, 0, -2) + tuple(range(2, 2 + rank)) + (-1,))
+        f_hour = np.arange(1, effective_steps * (es + interval - 1) + 1, es + interval - 1)
+        return vals, f_hour
+    vals = rv.transpose((1, -2, 0) + tuple(range(2, 2 + rank)) + (-1,)).reshape(
+        (rv.shape[1] * rv.shape[-2], rv.shape[0]) + tuple(space) + (-1,))
+    f_hour = np.array([np.arange(0, es) + interval + e * (es - 1 + interval) for e in range(effective_steps)]).flatten()
+    return vals[:steps], f_hour[:steps]

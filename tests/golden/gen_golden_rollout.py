@@ -238,6 +238,48 @@ def gen_callbacks():
     print('g8:', {k: v.shape for k, v in store.items() if k.endswith('trace')})
 
 
+# ------------------------------------------------------------------------------------------------------------------ #
+# ref_wrapper.pkl / ref_wrapper.history: what the reference's DLWP.util.save_model pickles next to the keras file
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def gen_wrapper():
+    """`save_model` (/root/reference/DLWP/util.py:127-155) pickles a copy of the DLWPFunctional wrapper with `model` and
+    `base_model` set to None, and `history.history`.  The reference class (DLWP/model/models.py:320-351, cut out of the file and
+    executed in a module object named DLWP.model.models) is instantiated and pickled exactly that way; the engine's
+    DLWP.util.load_model must resurrect it through its own class of the same import path."""
+    import pickle
+    import types
+    from copy import copy
+    src = open(os.path.join(REF, 'DLWP', 'model', 'models.py')).read()
+    cls_src = _cut(src, r'^class DLWPFunctional\(object\):.*?(?=^class |\Z)')
+    saved = {k: sys.modules.get(k) for k in ('DLWP', 'DLWP.model', 'DLWP.model.models')}
+    try:
+        for name in ('DLWP', 'DLWP.model', 'DLWP.model.models'):
+            sys.modules[name] = types.ModuleType(name)
+        mod = sys.modules['DLWP.model.models']
+        mod.np = np
+        exec(compile(cls_src, 'models.py:DLWPFunctional', 'exec'), mod.__dict__)
+        obj = mod.DLWPFunctional(is_convolutional=True, is_recurrent=False, time_dim=2)
+        obj._n_steps = 2
+        obj.model = object()             # stands for the keras model; save_model drops it
+        obj.base_model = obj.model
+        model_copy = copy(obj)
+        model_copy.model = None
+        model_copy.base_model = None
+        with open(os.path.join(HERE, 'ref_wrapper.pkl'), 'wb') as f:
+            pickle.dump(model_copy, f, protocol=pickle.HIGHEST_PROTOCOL)
+        with open(os.path.join(HERE, 'ref_wrapper.history'), 'wb') as f:
+            pickle.dump({'loss': [1.5, 0.75], 'val_loss': [1.25, 0.875]}, f, protocol=pickle.HIGHEST_PROTOCOL)
+        print('ref_wrapper.pkl:', sorted(model_copy.__dict__))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 if __name__ == '__main__':
     gen_rollout()
     gen_callbacks()
+    gen_wrapper()

@@ -1,0 +1,182 @@
+"""
+TimeSeriesEstimator (reference DLWP/model/extensions.py:162-481).
+
+CPU: the estimator's bookkeeping (host loop for model objects without the device rollout, output assembly, coordinates) against
+the oracle's restatement of the reference loop, with a stub "model" whose outputs are a known function of ALL its inputs.
+GPU (`-m gpu`): the device-resident rollout of the real 2-step sequence model of build_cs_model (inputs main_input + solar_1 +
+constants) against the fp64 oracle network unrolled by hand through the same restatement, and against the host loop.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cs_oracle as orc
+
+N, V, ITS, K, T = 8, 3, 2, 2, 40
+
+
+def _data(seed=31):
+    rng = np.random.default_rng(seed)
+    arr = rng.standard_normal((T, V, 6, N, N)).astype(np.float32)
+    sol = rng.random((T, 6, N, N)).astype(np.float32)
+    const = rng.standard_normal((K, 6, N, N)).astype(np.float32)
+    return arr, sol, const
+
+
+class _StubNet(object):
+    """two-output sequence 'model': every output depends on every input (main, solar_1, constants)"""
+
+    def __init__(self, n_out):
+        self.outputs = [None] * n_out
+
+    def compile(self, **kw):
+        pass
+
+    def predict(self, x, **kw):
+        xs = x if isinstance(x, (list, tuple)) else [x]
+        main = np.asarray(xs[0], dtype=np.float32)
+        B = main.shape[0]
+        st = main.reshape(main.shape[:-1] + (ITS, V + 1))
+        state, solar = st[..., :V], st[..., V]
+        outs = []
+        for m in range(len(self.outputs)):
+            extra = solar.sum(axis=-1, keepdims=True)[..., None]
+            if m >= 1 and len(xs) > 1 and xs[1].ndim == main.ndim + 1:
+                extra = extra + np.moveaxis(xs[m][..., 0], 1, -1).sum(axis=-1, keepdims=True)[..., None]
+            if xs[-1].ndim == main.ndim and len(xs) > 1:
+                extra = extra + 0.25 * xs[-1].sum(axis=-1, keepdims=True)[..., None]
+            state = 0.5 * state + 0.1 * (m + 1) + 0.01 * extra
+            outs.append(state.reshape(main.shape[:-1] + (ITS * V,)).astype(np.float32))
+        assert outs[0].shape[0] == B
+        return outs if len(outs) > 1 else outs[0]
+
+
+def _generator(dlwp, sequence, with_const=True, device=None):
+    from DLWP.model.generators import ArrayDataGenerator
+    arr, sol, const = _data()
+    return ArrayDataGenerator(dlwp, arr, rank=3, batch_size=4, input_time_steps=ITS, output_time_steps=ITS,
+                              sequence=sequence, insolation_array=sol, constants=const if with_const else None,
+                              channels_last=True, device=device), sol, const
+
+
+@pytest.mark.parametrize('n_out', [1, 2])
+@pytest.mark.parametrize('keep', [False, True])
+@pytest.mark.parametrize('steps', [3, 8])
+def test_estimator_host_loop_matches_reference_restatement(n_out, keep, steps):
+    from DLWP.keras import backend
+    backend.set_device('cpu')
+    from DLWP.model import DLWPFunctional, TimeSeriesEstimator
+    dlwp = DLWPFunctional(is_convolutional=True, time_dim=ITS)
+    dlwp.build_model(_StubNet(n_out), loss='mse')
+    gen, sol, const = _generator(dlwp, n_out if n_out > 1 else None)
+    est = TimeSeriesEstimator(dlwp, gen)
+    samples = np.array([0, 3, 5])
+    fc = est.predict(steps, samples=samples, keep_time_dim=keep)
+    p, _ = gen.generate(samples)
+    const_cl = const.transpose(1, 2, 3, 0)
+    ref, f_hour = orc.estimator_rollout_ref(lambda xs: _as_list(dlwp.model.predict(xs)), p, steps, lambda rows: sol[rows],
+                                            samples, n_out, ITS, ITS, ITS, constants=const_cl, keep_time_dim=keep)
+    assert fc.values.shape == ref.shape and np.array_equal(fc.values, ref)
+    assert np.array_equal(fc.coords['f_hour'], f_hour.astype(np.float64))
+    assert np.array_equal(fc.coords['time'], samples + ITS - 1)
+    want_dims = ('f_hour', 'time', 'time_step', 'x0', 'x1', 'x2', 'varlev') if keep else ('f_hour', 'time', 'x0', 'x1', 'x2', 'varlev')
+    assert fc.dims == want_dims
+    if not keep:
+        assert fc.values.shape[0] == steps
+
+
+def _as_list(o):
+    return list(o) if isinstance(o, (list, tuple)) else [o]
+
+
+def test_estimator_argument_checks():
+    from DLWP.keras import backend
+    backend.set_device('cpu')
+    from DLWP.model import DLWPFunctional, TimeSeriesEstimator
+    dlwp = DLWPFunctional(is_convolutional=True, time_dim=ITS)
+    dlwp.build_model(_StubNet(2), loss='mse')
+    gen, sol, const = _generator(dlwp, 2)
+    est = TimeSeriesEstimator(dlwp, gen)
+    with pytest.raises(ValueError, match='must use positive integer for steps'):
+        est.predict(0)
+    with pytest.raises(NotImplementedError):
+        est.predict(2, impute=True)
+    with pytest.raises(IndexError):                 # the forecast runs past the generator's insolation array
+        est.predict(60, samples=[30])
+    with pytest.raises(NotImplementedError):
+        TimeSeriesEstimator(object(), gen)
+    assert est.convolution_shape == (gen._n_sample,) + tuple(gen.convolution_shape)
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
+# GPU
+# --------------------------------------------------------------------------------------------------------------------- #
+
+def _oracle_sequence_model(params, n_out):
+    """The multi-step wiring of Azure/train_cs.py:391-409 with the fp64 oracle network, unrolled by hand."""
+    def predict(xs):
+        xs = [torch.tensor(np.asarray(a), dtype=torch.float64) for a in xs]
+        main, const = xs[0], xs[-1]
+        solar = xs[1:-1]
+        outs = [orc.unet2_forward(torch.cat([main, const], dim=-1), params)]
+        for step in range(1, n_out):
+            xo = outs[-1]
+            xo = xo.reshape(tuple(xo.shape[:-1]) + (ITS, -1))
+            xo = torch.cat([xo, solar[step - 1].permute(0, 2, 3, 4, 1, 5)], dim=-1)
+            xo = xo.reshape(tuple(main.shape))
+            outs.append(orc.unet2_forward(torch.cat([xo, const], dim=-1), params))
+        return [o.numpy() for o in outs]
+    return predict
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_estimator_device_rollout_matches_oracle_and_host_loop(dtype):
+    assert torch.cuda.is_available()
+    from DLWP.keras import backend
+    backend.set_device('cuda:0')
+    from DLWP.model import DLWPFunctional, TimeSeriesEstimator
+    from DLWP.model.cs_unet import build_cs_model
+    n_out, base = 2, 4
+    dlwp = DLWPFunctional(is_convolutional=True, time_dim=ITS)
+    gen, sol, const = _generator(dlwp, n_out)
+    backend.set_compute_dtype(dtype)
+    try:
+        np.random.seed(3)
+        model = build_cs_model(gen.convolution_shape, ITS * V, 'unet2', base_filter_number=base, integration_steps=n_out,
+                               io_time_steps=ITS, insolation_shape=gen.insolation_shape, constants_shape=(6, N, N, K))
+    finally:
+        backend.set_compute_dtype('float32')
+    dlwp.build_model(model, loss='mse', optimizer='adam')
+    cin = ITS * (V + 1) + K
+    params = orc.make_unet2_params(cin, ITS * V, base=base, seed=9)
+    net = model.cs_net
+    convs = [net.conv_2d_1, net.conv_2d_1_2, net.conv_2d_2, net.conv_2d_2_2, net.conv_2d_5_2, net.conv_2d_5,
+             net.conv_2d_6_2, net.conv_2d_6, net.conv_2d_7, net.conv_2d_7_2, net.conv_2d_8]
+    for lay, prm in zip(convs, params):
+        lay.set_weights([prm['equatorial_kernel'].numpy(), prm['polar_kernel'].numpy(),
+                         prm['equatorial_bias'].numpy(), prm['polar_bias'].numpy()])
+    est = TimeSeriesEstimator(dlwp, gen)
+    samples = np.array([1, 4, 6, 9])
+    steps = 11                                           # 3 sequence steps of 2 x 2 time steps, cut to 11
+    fc = est.predict(steps, samples=samples)
+    assert fc.values.shape == (steps, 4, 6, N, N, V) and fc.values.dtype == np.float32
+    p, _ = gen.generate(samples)
+    const_cl = const.transpose(1, 2, 3, 0)
+    ref, f_hour = orc.estimator_rollout_ref(_oracle_sequence_model(params, n_out), p, steps, lambda rows: sol[rows], samples,
+                                            n_out, ITS, ITS, ITS, constants=const_cl)
+    err = np.abs(fc.values - ref).max() / np.abs(ref).max()
+    assert err < (2e-5 if dtype == 'float32' else 4e-2), err
+    assert np.array_equal(fc.coords['f_hour'], f_hour.astype(np.float64))
+    # the device-resident rollout and the reference-structured host loop (one predict() round trip per step) agree
+    host = est._host_loop(list(p), 3, sol, samples)
+    host = host.reshape((4, -1) + host.shape[3:])[:, :6]
+    rv = host.reshape((4, 6, 6, N, N, ITS, V)).transpose(1, 5, 0, 2, 3, 4, 6).reshape(12, 4, 6, N, N, V)[:steps]
+    if dtype == 'float32':
+        assert np.array_equal(rv, fc.values)
+    else:
+        assert np.abs(rv - fc.values).max() <= 2e-2 * np.abs(rv).max()     # host loop feeds fp32-rounded states back in
+    # keep_time_dim view of the same forecast
+    fk = est.predict(steps, samples=samples, keep_time_dim=True)
+    assert fk.dims[:3] == ('f_hour', 'time', 'time_step') and fk.values.shape == (6, 4, ITS, 6, N, N, V)
+    assert np.array_equal(fk.values[0, :, 0], fc.values[0])
