@@ -41,7 +41,7 @@ class ConvDesc(ctypes.Structure):
                 ('Cout', ctypes.c_int32), ('ksize', ctypes.c_int32), ('halo', ctypes.c_int32),
                 ('up0', ctypes.c_int32), ('flip_north_pole', ctypes.c_int32), ('act', ctypes.c_int32),
                 ('alpha', ctypes.c_float), ('vmax', ctypes.c_float), ('dtype', ctypes.c_int32),
-                ('flags', ctypes.c_int32)]
+                ('flags', ctypes.c_int32), ('c0_valid', ctypes.c_int32)]
 
 
 class PackItem(ctypes.Structure):
@@ -109,6 +109,8 @@ PROTOTYPES = {
                                  c_float, c_float, c_float, c_void_p]),
     'dlwpcs_adam_step_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float,
                                        c_float, c_float, c_float, c_int, c_void_p]),
+    'dlwpcs_pad_channels': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_slice_channels': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_state_repack': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_adam_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int,
                                      c_void_p]),

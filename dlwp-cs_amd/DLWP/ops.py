@@ -147,10 +147,64 @@ def cs_pad(x, p):
 # Fused cubed-sphere convolution (reference DLWP/custom.py:921-1002 + :1082-1308 + Keras ReLU/UpSampling3D/concatenate)
 # ------------------------------------------------------------------------------------------------------------------ #
 
-def _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax, dtype=nat.F32):
+def _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax, dtype=nat.F32, c0_valid=0):
     return ConvDesc(B=B, N=N, C0=C0, C1=C1, Cout=Cout, ksize=ksize, halo=int(halo), up0=int(up0),
                     flip_north_pole=int(flip), act=int(act), alpha=float(alpha), vmax=float(vmax), dtype=int(dtype),
-                    flags=0)
+                    flags=0, c0_valid=int(c0_valid))
+
+
+class _PadChannels(torch.autograd.Function):
+    """(…, C) -> (…, Cp): zero channels appended (dlwpcs_pad_channels); the backward slices them off again."""
+
+    @staticmethod
+    def forward(ctx, x, cp):
+        require_device(x, 'pad_channels')
+        x = _c(x)
+        C = x.shape[-1]
+        rows = x.numel() // C if C else 0
+        y = torch.empty(tuple(x.shape[:-1]) + (cp,), dtype=x.dtype, device=x.device)
+        check(lib().dlwpcs_pad_channels(ptr(x), ptr(y), rows, C, cp, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_pad_channels')
+        ctx.c = C
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        cp = dy.shape[-1]
+        rows = dy.numel() // cp
+        dx = torch.empty(tuple(dy.shape[:-1]) + (ctx.c,), dtype=dy.dtype, device=dy.device)
+        check(lib().dlwpcs_slice_channels(ptr(dy), ptr(dx), rows, cp, ctx.c, nat.dtype_tag(dy), stream_ptr()),
+              'dlwpcs_slice_channels')
+        return dx, None
+
+
+def pad_channels(x, cp):
+    """Append zero channels up to `cp` (no-op when the tensor already has cp channels)."""
+    if x.shape[-1] == cp:
+        return x
+    if x.shape[-1] > cp:
+        raise ValueError('pad_channels: tensor has %d channels, asked for %d' % (x.shape[-1], cp))
+    return _PadChannels.apply(x, int(cp))
+
+
+def channel_vector(dtype):
+    """channels per 16-B vector of an activation dtype: the alignment the fast kernel paths want"""
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def padded_channels(c, dtype, even_too=None):
+    """Physical channel count the engine stores a c-channel NETWORK INPUT with: odd counts (7 variables) are always padded
+    to the next 16-B vector (the scalar-load kernel paths spill registers and run at a fraction of the vector paths); even
+    counts that are not vector multiples (14 = 7 x 2) only when DLWPCS_PAD_EVEN=1 (they have 4-B-vector / shifted-tail paths)."""
+    import os
+    v = channel_vector(dtype)
+    if c % v == 0:
+        return c
+    if even_too is None:
+        even_too = os.environ.get('DLWPCS_PAD_EVEN', '0') == '1'
+    if c % 2 == 1 or even_too:
+        return (c + v - 1) // v * v
+    return c
 
 
 def _f32_param(t, what):
@@ -165,7 +219,8 @@ class _CSConv(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, ksize, halo, up0, flip, act, alpha, vmax):
+    def forward(ctx, src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, ksize, halo, up0, flip, act, alpha, vmax,
+                c0_valid=0):
         require_device(src0, 'cs_conv')
         src0 = _c(src0)
         B = src0.shape[0]
@@ -185,12 +240,12 @@ class _CSConv(torch.autograd.Function):
         for prm in (w_eq, w_pol, w_np, b_eq, b_pol, b_np):
             _f32_param(prm, 'cs_conv')
         kh, kw, cin, Cout = w_eq.shape
-        if kh != ksize or kw != ksize or cin != C0 + C1:
+        if kh != ksize or kw != ksize or cin != (c0_valid or C0) + C1:
             raise ValueError('cs_conv: kernel shape %s does not match ksize=%d, C_in=%d' % (tuple(w_eq.shape), ksize,
-                                                                                          C0 + C1))
+                                                                                          (c0_valid or C0) + C1))
         w_eq, w_pol = _c(w_eq), _c(w_pol)
         w_np = _c(w_np) if w_np is not None else None
-        d = _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax, nat.dtype_tag(src0))
+        d = _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax, nat.dtype_tag(src0), c0_valid)
         No = N if halo else N - ksize + 1
         y = torch.empty((B, 6, No, No, Cout), dtype=src0.dtype, device=src0.device)
         table = inv = None
@@ -297,7 +352,7 @@ class _CSConv(torch.autograd.Function):
                   'dlwpcs_conv_bwd_weights')
         if reuse_dz:
             run_bwd_data()
-        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 7
+        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 8
 
 
 def conv_packed_buffers(ksize, cin, cout, dtype_tag, device, bias=True):
@@ -339,8 +394,23 @@ def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1
             flip_north_pole=True, act=nat.ACT_NONE, alpha=0.0, vmax=0.0):
     if (w_np is None) != (b_np is None) and b_eq is not None:
         raise ValueError('cs_conv: north-pole kernel and bias must be given together')
+    # Network inputs with a channel count that is not a multiple of the 16-B vector (7 variables; optionally 14 = 7 x 2):
+    # stored with zero channels up to the vector width (dlwpcs_conv_desc.c0_valid), so that every kernel takes its vector
+    # path.  A caller that already holds the padded layout (Model pads its static input buffers once, the device batch feed
+    # gathers straight into it) passes it as is.
+    c0_valid = 0
+    cin_w = w_eq.shape[2]
+    if src1 is None and not up0:
+        c_phys = src0.shape[-1]
+        if c_phys == cin_w:
+            cp = padded_channels(c_phys, src0.dtype)
+            if cp != c_phys:
+                src0 = pad_channels(src0, cp)
+                c0_valid = cin_w
+        elif cin_w < c_phys <= (cin_w + channel_vector(src0.dtype) - 1) // channel_vector(src0.dtype) * channel_vector(src0.dtype):
+            c0_valid = cin_w
     return _CSConv.apply(src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, int(ksize), bool(halo), bool(up0),
-                         bool(flip_north_pole), int(act), float(alpha), float(vmax))
+                         bool(flip_north_pole), int(act), float(alpha), float(vmax), int(c0_valid))
 
 
 # ------------------------------------------------------------------------------------------------------------------ #

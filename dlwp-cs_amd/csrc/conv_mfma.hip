@@ -59,6 +59,7 @@ struct ConvKParams {
     int dsplit;
     int *direct_done;           // HOST pointer: set to 1 by launch_conv_cfg when the kernel it launched honours d0 / d1
     int abl;                    // development only (-DDLWPCS_TIMELINE): epilogue ablation bits
+    int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
     int tile_rows_max;          // rows reserved in LDS
     int ntiles;                 // B * 6 * nblk_face (persistent kernel)
     long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
@@ -129,6 +130,19 @@ template <typename T> struct MmaPerFrag;
 template <> struct MmaPerFrag<float> { static constexpr int N = 4; };
 template <> struct MmaPerFrag<bf16_t> { static constexpr int N = 1; };
 
+// Scheduling tunables, bit set.  Defaults are the measured-best values; DLWPCS_TUNE=<int> overrides them for A/B runs.
+//   1: weight-gradient kernels: producer waves run at s_setprio 2 (they are the second-dispatched, i.e. arbitration-losing,
+//      half of the workgroup and the consumers wait for them at every barrier)
+//   2: forward / data-gradient kernel: the same for its producer waves
+//   4: forward / data-gradient kernel: weight fragments stay in LDS across tiles (see `wres` in the producer)
+//   8: bf16 forward / data-gradient kernel with TWO consumer teams (see conv_mfma_ws_kernel, TEAMS)
+enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_TEAMS = 8 };
+static int tune_bits() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : TUNE_CONV_WEIGHTS_STAY; }
+    return v;
+}
+
 #ifdef DLWPCS_TIMELINE
 #define TL_MARK() do { if (tlp && tli < 32) tlp[tli++] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PL_MARK() do { if (plp && pli < 32) plp[pli++] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -162,9 +176,17 @@ template <> struct MmaPerFrag<bf16_t> { static constexpr int N = 1; };
 // TAIL8 (bf16, VW = 8, one source): the source's channel count is even and >= 8 but not a multiple of 8 (14 = 7 variables
 // x 2 steps, 26 = 13 x 2).  Pixel rows are then only 4-B aligned; the vector that would run past the last channel is loaded
 // as the pixel's LAST 8 channels (in bounds) and shifted into place, instead of falling back to 4-B loads (7 / 13 per pixel).
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false>
-__global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P) {
+// TEAMS = 2: TWO teams of consumer waves (2 x WM*WN waves + WM*WN producer waves, three waves per SIMD) take the workgroup's
+// tiles alternately: while one team runs the MFMAs of its tile the other one runs the epilogue (bias, activation, rounding,
+// LDS patch, stores) of the tile it finished before, so the matrix cores no longer idle through every epilogue -- with one
+// team a 32 -> 32 channel tile cost the consumers 2.8 k cycles of MFMA phase + 3.0 k of epilogue + 0.8 k of set-up while
+// the producers needed ~4 k (s_memtime marks).  Every wave still executes ONE workgroup barrier per chunk: a team that does
+// not own the chunk's tile arrives at the tile's first barrier at once and spreads the remaining ones over its epilogue.
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false,
+          int TEAMS = 1>
+__global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P) {
     static_assert(!TAIL8 || (VW == 8 && sizeof(T) == 2 && !MASK), "TAIL8: bf16 16-B vectors, forward only");
+    static_assert(TEAMS == 1 || TEAMS == 2, "one or two consumer teams");
     constexpr int ES = sizeof(T);
     constexpr int CGW = 32 / ES;                    // channels per MFMA operand group (two 16-B half fragments)
     constexpr int TAPS = KS * KS;
@@ -172,7 +194,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     constexpr int KCG = KC / CGW;
     constexpr int Q = KC / VW;
     constexpr int NTB = NT * WN;
-    constexpr int NCT = 64 * WM * WN;               // consumer threads == producer threads
+    constexpr int NCT = 64 * WM * WN;               // threads of one consumer team == producer threads
     constexpr int WF4 = NTB * KCG * TAPS * 64;      // 16-B entries per weight chunk
     constexpr int GF4 = TAPS * 64;
     constexpr int ITS = 3 * KC / VW;                // input vectors per producer thread per chunk (3*NCT pixels)
@@ -185,7 +207,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     const int buf_bytes = in_bytes + WF4 * 16;
 
     const int tid = threadIdx.x;
-    const bool is_producer = tid >= NCT;
+    const bool is_producer = tid >= TEAMS * NCT;
     const int nt0 = blockIdx.y * NTB;
     const int face_pix = P.No * P.No;
     const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
@@ -216,10 +238,11 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 
     if (is_producer) {
         // =========================================== producers ===========================================
-        const int ptid = tid - NCT;
+        const int ptid = tid - TEAMS * NCT;
         const int qv = (ptid % Q) * VW;
         const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.wpk);
         if (t_first >= t_last) return;
+        if (P.tune & TUNE_CONV_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(2);
 #ifdef DLWPCS_TIMELINE
         int pli = 0;
         long long *plp = (P.dbg && ptid == 0 && blockIdx.y == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
@@ -265,10 +288,20 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         };
         int sidx[ITS];
         int g = 0;
+        // Weight-stationary LDS: the weight fragments of (face variant, chunk) are the same for every tile, and consecutive
+        // tiles of a workgroup are the same (face, band) in consecutive samples.  wres[b] = what buffer b's weight area holds;
+        // a chunk whose fragments are already there skips their loads and LDS writes.  With one chunk per tile both buffers
+        // converge after two tiles, with an even chunk count chunk ch always lands in buffer ch & 1; other counts simply
+        // never match.  (Measured need: at 64 -> 64 channels the fragments were 74 of the 107 KB a tile pulled through the
+        // CU's load path, which is what bounds these kernels -- ~10 B/clk/CU -- not the matrix cores.)
+        int wres[2] = {-1, -1};
 
         // one chunk: weights + input tile -> LDS, straight-line
         auto fill = [&](const Geo &gc, int ch) {
             char *buf = smem + (g & 1) * buf_bytes;
+            const int wkey = gc.v * 1024 + ch;
+            const bool need_w = !(P.tune & TUNE_CONV_WEIGHTS_STAY) || wres[g & 1] != wkey;
+            wres[g & 1] = wkey;
             const T *s0b = reinterpret_cast<const T *>(P.src0) + (size_t)gc.b * 6 * g0 * g0 * P.C0;
             const T *s1b = P.C1 > 0 ? reinterpret_cast<const T *>(P.src1) + (size_t)gc.b * 6 * P.Nin * P.Nin * P.C1 : s0b;
             const T *ymb = MASK ? reinterpret_cast<const T *>(P.ymask) + (size_t)gc.b * 6 * g0 * g0 * P.C0 : nullptr;
@@ -284,15 +317,24 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 if (c_ok && cs + 8 > cstride) { sh = (cs + 8 - cstride) >> 1; cs_ld = cstride - 8; }
             }
             PL_MARK();
-            uint4 wv[ITW];
+            if (need_w) {
+                // uniform and rare (weights stay): the fragments are fetched and written in a block of their own, so their
+                // registers are free again before the input vectors are loaded (the two-team build has 168 VGPRs per wave)
+                uint4 wv[ITW];
 #pragma unroll
-            for (int u = 0; u < ITW; ++u) {
-                const int idx = min(ptid + u * NCT, WF4 - 1);
-                const int gg = idx / GF4, w = idx % GF4;
-                const int ntl = gg / KCG, cgl = gg % KCG;
-                const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
-                const bool ok = ntile < P.NTtot && cg < P.CG;
-                wv[u] = vsel(ok, wsrc[ok ? (((size_t)gc.v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0]);
+                for (int u = 0; u < ITW; ++u) {
+                    const int idx = min(ptid + u * NCT, WF4 - 1);
+                    const int gg = idx / GF4, w = idx % GF4;
+                    const int ntl = gg / KCG, cgl = gg % KCG;
+                    const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
+                    const bool ok = ntile < P.NTtot && cg < P.CG;
+                    wv[u] = vsel(ok, wsrc[ok ? (((size_t)gc.v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0]);
+                }
+#pragma unroll
+                for (int u = 0; u < ITW; ++u) {
+                    const int idx = ptid + u * NCT;
+                    if (idx < WF4) reinterpret_cast<uint4 *>(buf + in_bytes)[idx] = wv[u];
+                }
             }
             V val[ITS];
             V ymv[MASK ? ITS : 1];
@@ -330,11 +372,6 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 const int e = ptid + i * NCT;
                 if (e < gc.nitems) *reinterpret_cast<V *>(buf + (e / Q) * RB + qv * ES) = vsel(okv[i], val[i]);
             }
-#pragma unroll
-            for (int u = 0; u < ITW; ++u) {
-                const int idx = ptid + u * NCT;
-                if (idx < WF4) reinterpret_cast<uint4 *>(buf + in_bytes)[idx] = wv[u];
-            }
             PL_MARK();
             __syncthreads();            // B_g: chunk g is in LDS
             ++g;
@@ -350,7 +387,8 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     }
 
     // ============================================= consumers =============================================
-    const int lane = tid & 63, wave = tid >> 6;
+    const int team = tid / NCT, ctid = tid - team * NCT;            // consumer team of this wave; thread inside the team
+    const int lane = ctid & 63, wave = ctid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
     // NOTE: no s_setprio(1) here: a prioritised wave waiting for the busy matrix pipe still wins its SIMD's issue
@@ -365,8 +403,10 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     TL_MARK();
     int abase[MT];
     int cur_combo = -1;
-    for (int t = t_first; t < t_last; ++t) {
-        const Geo gq = geo_of(t);
+    float4 bq[NT][4];
+
+    // ---- per-tile set-up: LDS addresses (rebuilt at (face, band) changes), zero accumulators, this tile's bias quads
+    auto setup = [&](const Geo &gq) {
         if (gq.combo != cur_combo) {            // LDS addresses of this lane's pixels: the same for every sample of a combo
             cur_combo = gq.combo;
 #pragma unroll
@@ -390,7 +430,6 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         // this tile's bias quads (face variant gq.v): issued here so that the latency is covered by the chunk loop.
         // (The packed bias vector is zero-padded to NTtot*32 floats, so every quad is readable.)
-        float4 bq[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -399,62 +438,72 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 bq[nt][jq] = P.bias ? *reinterpret_cast<const float4 *>(P.bias + (size_t)gq.v * P.NTtot * 32 +
                                                                          min(nt0 + wn * NT + nt, P.NTtot - 1) * 32 + 8 * jq + 4 * half)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
 
-        for (int ch = 0; ch < nchunks; ++ch, ++g) {
-            TL_MARK();
-            __syncthreads();                // B_g: chunk g has been written by the producers
-            TL_MARK();
-            const char *lds_in = smem + (g & 1) * buf_bytes, *lds_w = lds_in + in_bytes;
-            // Explicit two-register-set pipeline over the (channel group, tap) steps: the fragments of step s+1 are
-            // read from LDS BEFORE the MFMAs of step s are issued (left alone, the compiler reuses one register set
-            // and stalls on lgkmcnt after every step).
-            constexpr int NSTEP = KCG * TAPS;
-            uint4 fa[2][MT], fb[2][NT];
-            auto load_frag = [&](int step, uint4 (&a)[MT], uint4 (&bq)[NT]) {
-                const int cgl = step / TAPS, tap = step % TAPS;
-                const int dy = tap / KS, dx = tap % KS;
-                const int tapoff = (dy * P.W2 + dx) * RB + cgl * 32;
+    // ---- one chunk of MFMAs out of LDS buffer g & 1 (between two barriers: fragment reads + MFMAs only)
+    auto mma_chunk = [&]() {
+        const char *lds_in = smem + (g & 1) * buf_bytes, *lds_w = lds_in + in_bytes;
+        // Explicit two-register-set pipeline over the (channel group, tap) steps: the fragments of step s+1 are
+        // read from LDS BEFORE the MFMAs of step s are issued (left alone, the compiler reuses one register set
+        // and stalls on lgkmcnt after every step).
+        constexpr int NSTEP = KCG * TAPS;
+        uint4 fa[2][MT], fb[2][NT];
+        auto load_frag = [&](int step, uint4 (&a)[MT], uint4 (&bw)[NT]) {
+            const int cgl = step / TAPS, tap = step % TAPS;
+            const int dy = tap / KS, dx = tap % KS;
+            const int tapoff = (dy * P.W2 + dx) * RB + cgl * 32;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const uint4 *>(lds_in + abase[mt] + tapoff);
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const uint4 *>(lds_in + abase[mt] + tapoff);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bq[nt] = *reinterpret_cast<const uint4 *>(
-                        lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 512 + l31 * 16);
-            };
-            load_frag(0, fa[0], fb[0]);
+            for (int nt = 0; nt < NT; ++nt)
+                bw[nt] = *reinterpret_cast<const uint4 *>(
+                    lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 512 + l31 * 16);
+        };
+        load_frag(0, fa[0], fb[0]);
 #pragma unroll
-            for (int step = 0; step < NSTEP; ++step) {
-                const int cur = step & 1;
-                if (step + 1 < NSTEP) load_frag(step + 1, fa[cur ^ 1], fb[cur ^ 1]);
+        for (int step = 0; step < NSTEP; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < NSTEP) load_frag(step + 1, fa[cur ^ 1], fb[cur ^ 1]);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) frag_mma<T>(acc[mt][nt], fb[cur][nt], fa[cur][mt]);   // D[co][pixel]
-                __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);                          // DS reads of step s+1 first
-                __builtin_amdgcn_sched_group_barrier(0x008, MmaPerFrag<T>::N * MT * NT, 0);       // then the MFMAs of step s
-            }
+                for (int nt = 0; nt < NT; ++nt) frag_mma<T>(acc[mt][nt], fb[cur][nt], fa[cur][mt]);   // D[co][pixel]
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);                          // DS reads of step s+1 first
+            __builtin_amdgcn_sched_group_barrier(0x008, MmaPerFrag<T>::N * MT * NT, 0);       // then the MFMAs of step s
         }
+    };
 
-        // ---- tile epilogue: bias + activation + stores.  The MFMA ran as D[co][pixel] (weights as the A operand), so in
-        // the C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) a lane owns ONE pixel and, per r>>2, FOUR
-        // CONSECUTIVE output channels.  Storing those quads directly costs one L2 write request per lane and quad (8 per
-        // 64-B line; measured: ~1 request/clk/CU, 3 k of a 5 k-cycle epilogue), so each M tile goes through a wave-private
-        // LDS patch [32 pixels][32 channels + 16 B pad] instead: 4 quad writes per lane in, 16 B per lane out with the
-        // lanes of a pixel contiguous -> every store instruction writes whole lines.  No fence: the LDS executes one wave's
-        // instructions in order; wave_barrier only pins the compiler's schedule (a release fence here waits vmcnt(0),
-        // i.e. for the previous stores to land -- that was the cost of the first LDS epilogue).
+    // ---- tile epilogue: bias + activation + stores.  The MFMA ran as D[co][pixel] (weights as the A operand), so in
+    // the C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) a lane owns ONE pixel and, per r>>2, FOUR
+    // CONSECUTIVE output channels.  Storing those quads directly costs one L2 write request per lane and quad (8 per
+    // 64-B line; measured: ~1 request/clk/CU, 3 k of a 5 k-cycle epilogue), so each M tile goes through a wave-private
+    // LDS patch [32 pixels][32 channels + 16 B pad] instead: 4 quad writes per lane in, 16 B per lane out with the
+    // lanes of a pixel contiguous -> every store instruction writes whole lines.  No fence: the LDS executes one wave's
+    // instructions in order; wave_barrier only pins the compiler's schedule (a release fence here waits vmcnt(0),
+    // i.e. for the previous stores to land -- that was the cost of the first LDS epilogue).
+    // `nbar` workgroup barriers are spread evenly over the (n tile, m tile) pairs: a team running this epilogue beside the other
+    // team's tile owes one barrier per chunk of that tile (TEAMS = 2); 0 for an epilogue inside the team's own interval.
+    auto epilogue = [&](const Geo &gq, int nbar) {
         TL_MARK();
         T *outp = reinterpret_cast<T *>(P.out) + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
         constexpr int PROW = 32 * ES + 16;          // patch row: one pixel's 32 channels + pad
         constexpr int LPP = 32 * ES / 16;           // lanes per pixel on the way out (16 B each): 8 fp32 / 4 bf16
         constexpr int PPP = 64 / LPP;               // pixels per store pass
-        char *patch = smem + 2 * buf_bytes + wave * (32 * PROW);
+        constexpr int NPAIR = NT * MT;
+        char *patch = smem + 2 * buf_bytes + (team * WM * WN + wave) * (32 * PROW);
         const bool lines = P.patches && (P.Cout % (16 / ES)) == 0;
         const bool wide = (P.Cout & 3) == 0;
         // no activation == ReLU(alpha = 1, max = +inf): the epilogue applies the activation unconditionally and stays
         // straight-line (a branch per quad chops it into 5-instruction blocks whose dependent chains cannot interleave)
         const float e_alpha = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.alpha : 1.f;
         const float e_vmax = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.vmax : __builtin_inff();
+        int placed = 0;
+        auto owe = [&](int pair_done) {             // barriers due after `pair_done` of the NPAIR pairs
+            if (TEAMS > 1) {
+                const int want = (pair_done * nbar) / NPAIR;
+                while (placed < want) { __syncthreads(); ++placed; }
+            }
+        };
         auto quad = [&](int mt, int nt, int jq) {
             float4 v4 = make_float4(acc[mt][nt][4 * jq] + bq[nt][jq].x, acc[mt][nt][4 * jq + 1] + bq[nt][jq].y,
                                     acc[mt][nt][4 * jq + 2] + bq[nt][jq].z, acc[mt][nt][4 * jq + 3] + bq[nt][jq].w);
@@ -503,6 +552,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
+                    owe(nt * MT + mt + 1);
                 }
             }
         } else {
@@ -534,11 +584,39 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                                 }
                         }
                     }
+                    owe(nt * MT + mt + 1);
                 }
             }
         }
+        owe(NPAIR);
         TL_MARK();
+    };
+
+    Geo pend{};
+    bool pending = false;
+    for (int t = t_first; t < t_last; ++t) {
+        const bool own = TEAMS == 1 || ((t - t_first) & (TEAMS - 1)) == team;
+        if (own) {
+            const Geo gq = geo_of(t);
+            setup(gq);
+            for (int ch = 0; ch < nchunks; ++ch, ++g) {
+                TL_MARK();
+                __syncthreads();                // B_g: chunk g has been written by the producers
+                TL_MARK();
+                mma_chunk();
+            }
+            if (TEAMS == 1) epilogue(gq, 0);
+            else { pend = gq; pending = true; }
+        } else {
+            // the other team's tile: arrive at its first barrier at once (it releases that team's MFMAs), then finish the
+            // tile computed before while paying the remaining nchunks - 1 barriers
+            __syncthreads();
+            if (pending) { epilogue(pend, nchunks - 1); pending = false; }
+            else for (int ch = 1; ch < nchunks; ++ch) __syncthreads();
+            g += nchunks;
+        }
     }
+    if (TEAMS > 1 && pending) epilogue(pend, 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -748,6 +826,7 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
     if (tid >= NCT) {
         // =========================================== producers ===========================================
         const int ptid = tid - NCT;
+        if (P.tune & TUNE_WG_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(2);
         const int cx = cit * 32 + (ptid % QX) * VW;         // this thread's input channel(s): fixed for the whole kernel
         const bool cx_ok = cx < P.Cin;
         const bool from0 = cx < P.C0;
@@ -1070,6 +1149,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     if (tid >= NCT) {
         // =========================================== producers ===========================================
         const int ptid = tid - NCT;
+        if (P.tune & TUNE_WG_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(2);
         const int qx = ptid % QD;                           // this thread's dZ channel group: fixed for the whole kernel
         const int cx = cit * 32 * CT + (ptid % QXT) * XV;   // this thread's X channels: fixed as well (256 % QXT == 0)
         const bool cx_ok = cx < P.Cin;
@@ -1156,6 +1236,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                 if (MASK) vmask(st.dv[i], st.yv[i], P.alpha, P.vmax);
                 st.dv[i] = vsel(st.dok[i], st.dv[i]);
             }
+            PL_MARK();
             // DLWPCS_CONV_REUSE_DZ: the workers of ci tile 0 see every dZ element exactly once -> they hand dz to the
             // data-gradient kernel that follows (which then needs neither y nor the act' arithmetic)
             if (MASK && W.dz_out != nullptr && cit == 0) {
@@ -1164,6 +1245,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                 for (int i = 0; i < IT_DY; ++i)
                     if (st.dok[i]) *reinterpret_cast<DVec *>(dzb + (uint32_t)doff[i]) = st.dv[i];
             }
+            PL_MARK();
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int e = ptid + i * NCT;
@@ -1171,6 +1253,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                     *reinterpret_cast<XVec *>(buf + ((ptid % QXT) / QX) * plane_bytes + (size_t)(e / QXT) * PB +
                                               ((ptid % QXT) % QX) * (XV * 2)) = vsel(st.xok[i], st.xv[i]);
             }
+            PL_MARK();
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
                 const int e = ptid + i * NCT;
@@ -1186,7 +1269,11 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                 }
             }
             PL_MARK();
-            __syncthreads();            // B_k: item k is in LDS
+            // B_k: item k is in LDS.  A RAW barrier behind an explicit LDS wait: __syncthreads() makes hipcc drain vmcnt(0)
+            // first, i.e. wait for the loads of item k+1 that were issued a moment ago -- the whole HBM latency (~4 k cycles,
+            // measured with the s_memtime marks) would be paid at every barrier, with the consumers idling behind it.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             PL_MARK();
         };
         if (n_my > 0) {
@@ -1293,8 +1380,10 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);
         }
     }
+    TL_MARK();
     __syncthreads();                            // all consumers finished reading the last buffer
     __syncthreads();                            // (producers stage their bias sums between these two)
+    TL_MARK();
 
     // cross-wave reduction through LDS (fixed order over the slab phases of each ci tile), WG_TG taps per round (2 barriers
     // per round, not per tap)
@@ -1325,7 +1414,12 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                 pout[((size_t)(t0 + tt) * W.CinP + (cit * CT + t2) * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
             }
         __syncthreads();
+        TL_MARK();
     }
+#ifdef DLWPCS_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL_MARK();
+#endif
 }
 
 // Sum the per-slot partials in a fixed order and route them to the weight groups.  Workgroup = 16 output groups x 16 slot
@@ -1334,6 +1428,13 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
 // channels as one 16-B load per slot when C_out % 4 == 0 (the 16 threads of a phase then read 256 contiguous bytes per
 // slot instead of 64), else 1.  accumulate != 0: add to the destination instead of overwriting it (shared layers / direct
 // accumulation into the flat gradient buffer).
+// A workgroup reduces RED_OG output groups (VEC floats each) x 256 / RED_OG slot phases.  Measured on the 152 MB of partials of
+// a training step (MI355X): 16 groups x 16 phases 43-46 us, 32 x 8 51 us, 64 x 4 52-53 us, 128 x 2 51 us -- longer contiguous
+// reads per slot do not pay, the slot-phase parallelism does.
+#ifndef DLWPCS_RED_OG
+#define DLWPCS_RED_OG 16
+#endif
+constexpr int RED_OG = DLWPCS_RED_OG;
 template <int VEC>
 __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ partial, const float *__restrict__ bpartial,
                                                   float *__restrict__ dw_eq, float *__restrict__ dw_pol,
@@ -1342,10 +1443,11 @@ __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ part
                                                   int KS, int Cin, int Cout, int CinP, int CoutP,
                                                   int n_eq, int n_4, int n_5, int flip, int accumulate, int block) {
     typedef float VT __attribute__((ext_vector_type(VEC)));
+    constexpr int OG = RED_OG, NPH = 256 / RED_OG;     // output groups per workgroup x slot phases
     const int TAPS = KS * KS;
     const int nW = TAPS * Cin * Cout;
-    const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
-    const int e = (block * 16 + o) * VEC;              // first of this thread's VEC consecutive outputs
+    const int o = threadIdx.x % OG, ph = threadIdx.x / OG;
+    const int e = (block * OG + o) * VEC;              // first of this thread's VEC consecutive outputs
     const size_t slot_stride = (size_t)TAPS * CinP * CoutP;
     VT s_eq = 0.f, s_4 = 0.f, s_5 = 0.f;
     const bool is_w = e < nW, is_b = (!is_w) && bpartial && e < nW + Cout;
@@ -1357,28 +1459,28 @@ __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ part
         // face 5 ran with the row-reversed kernel: its partial for tap row r belongs to kernel row KS-1-r
         const size_t o5 = flip ? ((size_t)((KS - 1 - ty) * KS + tx) * CinP + ci) * CoutP + co : off;
 #pragma unroll 8
-        for (int s = ph; s < e4; s += 16) s_eq += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + off);
+        for (int s = ph; s < e4; s += NPH) s_eq += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + off);
 #pragma unroll 4
-        for (int s = e4 + ph; s < e5; s += 16) s_4 += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + off);
+        for (int s = e4 + ph; s < e5; s += NPH) s_4 += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + off);
 #pragma unroll 4
-        for (int s = e5 + ph; s < e6; s += 16) s_5 += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + o5);
+        for (int s = e5 + ph; s < e6; s += NPH) s_5 += *reinterpret_cast<const VT *>(partial + (size_t)s * slot_stride + o5);
     } else if (is_b) {
         const int co = e - nW;
 #pragma unroll 8
-        for (int s = ph; s < e4; s += 16) s_eq += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
+        for (int s = ph; s < e4; s += NPH) s_eq += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
 #pragma unroll 4
-        for (int s = e4 + ph; s < e5; s += 16) s_4 += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
+        for (int s = e4 + ph; s < e5; s += NPH) s_4 += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
 #pragma unroll 4
-        for (int s = e5 + ph; s < e6; s += 16) s_5 += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
+        for (int s = e5 + ph; s < e6; s += NPH) s_5 += *reinterpret_cast<const VT *>(bpartial + (size_t)s * CoutP + co);
     }
     __shared__ VT red[3][256];
     red[0][threadIdx.x] = s_eq; red[1][threadIdx.x] = s_4; red[2][threadIdx.x] = s_5;
     __syncthreads();
-    for (int st = 8; st > 0; st >>= 1) {
+    for (int st = NPH / 2; st > 0; st >>= 1) {
         if (ph < st) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + st * 16];
-            red[1][threadIdx.x] += red[1][threadIdx.x + st * 16];
-            red[2][threadIdx.x] += red[2][threadIdx.x + st * 16];
+            red[0][threadIdx.x] += red[0][threadIdx.x + st * OG];
+            red[1][threadIdx.x] += red[1][threadIdx.x + st * OG];
+            red[2][threadIdx.x] += red[2][threadIdx.x + st * OG];
         }
         __syncthreads();
     }
@@ -1439,7 +1541,7 @@ static bool wgrad_reduce_vec(const void *dw_eq, const void *dw_pol, const void *
 }
 static int wgrad_reduce_blocks(int KS, int Cin, int Cout, bool want_bias, bool vec) {
     const int nout = KS * KS * Cin * Cout + (want_bias ? Cout : 0);
-    return vec ? ceil_div(nout / 4, 16) : ceil_div(nout, 16);
+    return vec ? ceil_div(nout / 4, RED_OG) : ceil_div(nout, RED_OG);
 }
 
 static void launch_wgrad_reduce(hipStream_t s, const float *partial, const float *bpartial, void *dw_eq, void *dw_pol,
@@ -1645,6 +1747,7 @@ static unsigned pw_grid(long ngroups) {
 }
 
 struct Work { double flops, bytes; };   // algorithmic work of one launch (for the opt-in profiler)
+static inline int cin_logical(const dlwpcs_conv_desc *d);
 
 // rows of the face touched by `pix` consecutive flat pixels whose first pixel is a multiple of `pix`
 static int tile_rows_for(int pix, int No) {
@@ -1670,7 +1773,8 @@ template <typename T> struct TName;
 template <> struct TName<float> { static const char *str() { return "float"; } };
 template <> struct TName<bf16_t> { static const char *str() { return "unsigned short"; } };
 
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false>
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false,
+          int TEAMS = 1>
 static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     constexpr int ES = sizeof(T), CGW = 32 / ES;
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
@@ -1686,13 +1790,14 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     P.magicNblk = P.nblk_face > 1 ? div_magic(P.nblk_face) : 0;
     P.tile_rows_max = tile_rows_for(pix, P.No) + (KS - 1);
     P.ntiles = P.B * 6 * P.nblk_face;
+    P.tune = tune_bits();
     P.dbg = nullptr;
 #ifdef DLWPCS_TIMELINE
     { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
     { const char *e = getenv("DLWPCS_ABL"); P.abl = e ? atoi(e) : 0; }
 #endif
     const size_t buf = (size_t)P.tile_rows_max * P.W2 * (KC * ES + 16) + (size_t)NTB * (KC / CGW) * KS * KS * 1024;
-    size_t lds = 2 * buf + (size_t)(WM * WN) * 32 * (32 * ES + 16);            // + wave-private epilogue patches
+    size_t lds = 2 * buf + (size_t)(TEAMS * WM * WN) * 32 * (32 * ES + 16);    // + wave-private epilogue patches
     P.patches = 1;
     if (lds > 160 * 1024) { lds = 2 * buf; P.patches = 0; }                     // large faces: direct quad stores instead
     if (MODE == MODE_ZERO && KS == 3 && P.patches && P.Cout % (16 / ES) == 0 && P.dsplit % (16 / ES) == 0) {
@@ -1708,7 +1813,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
         return fail(DLWPCS_E_UNSUPPORTED, "conv: tile of %d x %d pixels exceeds the producers' register capacity", P.tile_rows_max, P.W2);
     if ((long)P.Nin * P.Nin * 6 >= (1l << 16) * 6 && (long)P.Nin * P.Nin >= (1l << 16))
         return fail(DLWPCS_E_UNSUPPORTED, "conv: face size %d too large for the 16-bit index arithmetic", P.Nin);
-    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8>;
+    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8, TEAMS>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1719,11 +1824,11 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     int pidx = -1;
     if (prof_enabled()) {
         char tag[160];
-        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s>", TName<T>::str(), KS, KC, MT,
-                 NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? "true" : "false");
+        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %d>", TName<T>::str(), KS, KC,
+                 MT, NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? "true" : "false", TEAMS);
         pidx = prof_begin(tag, W.flops, W.bytes, s);
     }
-    hipLaunchKernelGGL(kern, grid, dim3(2 * NTHREADS), lds, s, P);
+    hipLaunchKernelGGL(kern, grid, dim3((1 + TEAMS) * NTHREADS), lds, s, P);
     if (pidx >= 0) prof_end(pidx, s);
     return check_launch("conv_mfma");
 }
@@ -1739,6 +1844,14 @@ static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
     else {
         // Measured (MI355X, batch 32): the smaller tiles (MT = 2 / MT = 1) that would even out the tile count per CU
         // lose more to halo re-staging (the producers become the bottleneck) than they gain -> fixed MT = 3 tilings.
+        // bf16: two consumer teams (epilogue of tile t beside the MFMAs of tile t+1) on the MT = 3 tilings
+        if constexpr (sizeof(T) == 2 && KS == 3) {
+            if (tune_bits() & TUNE_CONV_TEAMS) {
+                if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, 2>(P, W, s);
+                if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK, false, 2>(P, W, s);
+                if (face_pix > 320) return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK, false, 2>(P, W, s);
+            }
+        }
         if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
         if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
         if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK>(P, W, s);
@@ -1785,7 +1898,7 @@ static inline int cgw_of(int dtype) { return dtype == DLWPCS_BF16 ? 16 : 8; }
 // output touched once + the weights.
 static Work conv_work(const dlwpcs_conv_desc *d) {
     const double No = d->halo ? d->N : d->N - d->ksize + 1;
-    const double Cin = d->C0 + d->C1, taps = (double)d->ksize * d->ksize;
+    const double Cin = cin_logical(d), taps = (double)d->ksize * d->ksize;
     const double n0 = d->up0 ? d->N / 2 : d->N;
     Work w;
     w.flops = 2.0 * d->B * 6 * No * No * taps * Cin * d->Cout;
@@ -1808,10 +1921,21 @@ static int validate(const dlwpcs_conv_desc *d, const char *who) {
     if (!d->halo && d->N < d->ksize) return fail(DLWPCS_E_INVALID, "%s: N < kernel size", who);
     if (d->act != DLWPCS_ACT_NONE && d->act != DLWPCS_ACT_LEAKY_CLIP) return fail(DLWPCS_E_INVALID, "%s: unknown activation %d", who, d->act);
     if (d->N > 1024) return fail(DLWPCS_E_UNSUPPORTED, "%s: N > 1024", who);
+    if (d->c0_valid != 0) {
+        if (d->c0_valid < 1 || d->c0_valid > d->C0) return fail(DLWPCS_E_INVALID, "%s: c0_valid %d outside [1, C0 = %d]", who, d->c0_valid, d->C0);
+        if (d->C1 != 0) return fail(DLWPCS_E_INVALID, "%s: c0_valid needs a single source (C1 = 0)", who);
+        if (ceil_div(d->c0_valid, 32) != ceil_div(d->C0, 32))
+            return fail(DLWPCS_E_INVALID, "%s: c0_valid %d and C0 %d must share their last 32-channel tile", who, d->c0_valid, d->C0);
+    }
     return DLWPCS_OK;
 }
 
 static inline int out_size(const dlwpcs_conv_desc *d) { return d->halo ? d->N : d->N - d->ksize + 1; }
+// Logical input channels = rows of the HWIO kernels.  c0_valid > 0: src0 is stored with C0 channels per pixel of which only
+// the first c0_valid are real (the rest are zero padding up to the next vector width, e.g. 7 variables in an 8-channel
+// layout); the kernels keep c0_valid input rows, the packed fragments carry zeros for the padding (pack_weights_range zero-
+// fills k >= K) and the weight-gradient reduction emits the real rows only.
+static inline int cin_logical(const dlwpcs_conv_desc *d) { return (d->c0_valid > 0 ? d->c0_valid : d->C0) + d->C1; }
 
 // workspace layout (bytes, 256-aligned regions)
 struct WsLayout {
@@ -1984,7 +2108,7 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
     const int Cin = d->C0 + d->C1;
     const void *wpk = prepacked ? w_eq : ws + L.wpk_f;      // PREPACKED: w_eq / b_eq are dlwpcs_pack_batch outputs
     const float *bpk = prepacked ? (const float *)b_eq : (const float *)(ws + L.bias);
-    if (!prepacked) launch_pack(w_eq, w_pol, w_np, ws + L.wpk_f, d->ksize, Cin, d->Cout, 0, d->flip_north_pole, d->dtype, s);
+    if (!prepacked) launch_pack(w_eq, w_pol, w_np, ws + L.wpk_f, d->ksize, cin_logical(d), d->Cout, 0, d->flip_north_pole, d->dtype, s);
     const int NTtot = ceil_div(d->Cout, 32);
     if (b_eq && !prepacked) {
         const int n = 3 * NTtot * 32;
@@ -2050,7 +2174,7 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     const int Cin = d->C0 + d->C1;
     const void *wpk = prepacked ? w_eq : ws + L.wpk_b;      // PREPACKED: w_eq is the wpk_bwd output of dlwpcs_pack_batch
     void *dxv = ws + L.dxv;
-    if (!prepacked) launch_pack(w_eq, w_pol, w_np, ws + L.wpk_b, d->ksize, Cin, d->Cout, 1, d->flip_north_pole, d->dtype, s);
+    if (!prepacked) launch_pack(w_eq, w_pol, w_np, ws + L.wpk_b, d->ksize, cin_logical(d), d->Cout, 1, d->flip_north_pole, d->dtype, s);
     const int No = out_size(d);
     if (pw_applies(d) && d->act == DLWPCS_ACT_NONE && dsrc0) {
         PwParams Q{};
@@ -2122,9 +2246,10 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     const int CinP = ceil_div(Cin, 32) * 32, CoutP = ceil_div(d->Cout, 32) * 32;
     if (d->B == 0 && (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD)) return DLWPCS_OK;
     if (d->B == 0) {
-        (void)hipMemsetAsync(dw_eq, 0, (size_t)TAPS * Cin * d->Cout * 4, s);
-        (void)hipMemsetAsync(dw_pol, 0, (size_t)TAPS * Cin * d->Cout * 4, s);
-        if (dw_np) (void)hipMemsetAsync(dw_np, 0, (size_t)TAPS * Cin * d->Cout * 4, s);
+        const size_t wbytes = (size_t)TAPS * cin_logical(d) * d->Cout * 4;
+        (void)hipMemsetAsync(dw_eq, 0, wbytes, s);
+        (void)hipMemsetAsync(dw_pol, 0, wbytes, s);
+        if (dw_np) (void)hipMemsetAsync(dw_np, 0, wbytes, s);
         if (db_eq) (void)hipMemsetAsync(db_eq, 0, (size_t)d->Cout * 4, s);
         if (db_pol) (void)hipMemsetAsync(db_pol, 0, (size_t)d->Cout * 4, s);
         if (db_np) (void)hipMemsetAsync(db_np, 0, (size_t)d->Cout * 4, s);
@@ -2148,6 +2273,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     W.CinP = CinP; W.CoutP = CoutP;
     W.n_eq = L.n_eq; W.n_4 = L.n_4; W.n_5 = L.n_5;
     P.magicN = div_magic(P.Nin);
+    P.tune = tune_bits();
     W.magicB = P.B > 1 ? div_magic(P.B) : 0; W.magicNb = P.nblk_face > 1 ? div_magic(P.nblk_face) : 0;
     P.dbg = nullptr;
 #ifdef DLWPCS_TIMELINE
@@ -2200,7 +2326,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
 #undef WGB_LAUNCH
         rc = check_launch("wgrad_bf16");
         if (rc || (d->flags & DLWPCS_CONV_DEFER_REDUCE)) return rc;
-        launch_wgrad_reduce(s, W.partial, W.bpartial, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, KS, Cin, d->Cout, CinP, CoutP,
+        launch_wgrad_reduce(s, W.partial, W.bpartial, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, KS, cin_logical(d), d->Cout, CinP, CoutP,
                             L.n_eq, L.n_4, L.n_5, d->flip_north_pole, (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0, want_bias);
         return check_launch("wgrad_reduce");
     }
@@ -2248,7 +2374,7 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
 #undef WG_LAUNCH
     rc = check_launch("wgrad_mfma");
     if (rc || (d->flags & DLWPCS_CONV_DEFER_REDUCE)) return rc;
-    launch_wgrad_reduce(s, W.partial, W.bpartial, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, KS, Cin, d->Cout, CinP, CoutP,
+    launch_wgrad_reduce(s, W.partial, W.bpartial, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, KS, cin_logical(d), d->Cout, CinP, CoutP,
                         L.n_eq, L.n_4, L.n_5, d->flip_north_pole, (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0, want_bias);
     return check_launch("wgrad_reduce");
 }
@@ -2272,13 +2398,13 @@ extern "C" int dlwpcs_conv_wgrad_reduce_item(const dlwpcs_conv_desc *d, void *dw
     it.bpartial = want_bias ? (const float *)(ws + L.bpartial) : nullptr;
     it.dw_eq = (float *)dw_eq; it.dw_pol = (float *)dw_pol; it.dw_np = (float *)dw_np;
     it.db_eq = (float *)db_eq; it.db_pol = (float *)db_pol; it.db_np = (float *)db_np;
-    it.ksize = d->ksize; it.Cin = Cin; it.Cout = d->Cout;
+    it.ksize = d->ksize; it.Cin = cin_logical(d); it.Cout = d->Cout;
     it.CinP = ceil_div(Cin, 32) * 32; it.CoutP = ceil_div(d->Cout, 32) * 32;
     it.n_eq = L.n_eq; it.n_4 = L.n_4; it.n_5 = L.n_5;
     it.flip_north_pole = d->flip_north_pole;
     it.accumulate = (d->flags & DLWPCS_CONV_ACCUMULATE_WGRAD) ? 1 : 0;
     it.vec = vec ? 4 : 1;
-    it.nblocks = d->B == 0 ? 0 : wgrad_reduce_blocks(d->ksize, Cin, d->Cout, want_bias, vec);   // B == 0: nothing was produced
+    it.nblocks = d->B == 0 ? 0 : wgrad_reduce_blocks(d->ksize, cin_logical(d), d->Cout, want_bias, vec);   // B == 0: nothing was produced
     *item = it;
     return DLWPCS_OK;
 }

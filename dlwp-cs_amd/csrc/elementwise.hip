@@ -426,6 +426,27 @@ __global__ void __launch_bounds__(256) state_repack_kernel(const W *__restrict__
     }
 }
 
+// Channel padding of a channels_last tensor (dlwpcs_conv_desc.c0_valid): y[row][c] = c < C ? x[row][c] : 0 for c < Cp, and
+// its adjoint (slice).  Element type W = raw 2- or 4-byte word.
+template <typename W>
+__global__ void __launch_bounds__(256) pad_channels_kernel(const W *__restrict__ x, W *__restrict__ y, size_t total, unsigned C,
+                                                           unsigned Cp) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / Cp;
+        const unsigned c = (unsigned)(e - row * Cp);
+        y[e] = c < C ? x[row * C + c] : (W)0;
+    }
+}
+template <typename W>
+__global__ void __launch_bounds__(256) slice_channels_kernel(const W *__restrict__ y, W *__restrict__ x, size_t total, unsigned C,
+                                                             unsigned Cp) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / C;
+        const unsigned c = (unsigned)(e - row * C);
+        x[e] = y[row * Cp + c];
+    }
+}
+
 template <typename V>
 __global__ void __launch_bounds__(256) split2_kernel(const V *__restrict__ y, V *__restrict__ a, V *__restrict__ b,
                                                      size_t total, int CaV, int CbV) {
@@ -887,6 +908,34 @@ extern "C" int dlwpcs_state_repack(const void *state, const void *extra, void *o
                            (const uint32_t *)state, (const uint32_t *)extra, (uint32_t *)out, total, (unsigned)S, (unsigned)T,
                            (unsigned)V, (unsigned)E);
     return check_launch("state_repack");
+}
+
+extern "C" int dlwpcs_pad_channels(const void *x, void *y, size_t rows, int C, int Cp, int dtype, dlwpcs_stream_t stream) {
+    REQUIRE_DTYPE(dtype, "pad_channels");
+    REQUIRE(x && y && C >= 1 && Cp >= C, "pad_channels: bad arguments C=%d Cp=%d", C, Cp);
+    if (rows == 0) return DLWPCS_OK;
+    const size_t total = rows * (size_t)Cp;
+    if (dtype == DLWPCS_BF16)
+        hipLaunchKernelGGL(pad_channels_kernel<uint16_t>, stream_grid(total), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t *)x, (uint16_t *)y, total, (unsigned)C, (unsigned)Cp);
+    else
+        hipLaunchKernelGGL(pad_channels_kernel<uint32_t>, stream_grid(total), dim3(256), 0, (hipStream_t)stream,
+                           (const uint32_t *)x, (uint32_t *)y, total, (unsigned)C, (unsigned)Cp);
+    return check_launch("pad_channels");
+}
+
+extern "C" int dlwpcs_slice_channels(const void *y, void *x, size_t rows, int Cp, int C, int dtype, dlwpcs_stream_t stream) {
+    REQUIRE_DTYPE(dtype, "slice_channels");
+    REQUIRE(x && y && C >= 1 && Cp >= C, "slice_channels: bad arguments C=%d Cp=%d", C, Cp);
+    if (rows == 0) return DLWPCS_OK;
+    const size_t total = rows * (size_t)C;
+    if (dtype == DLWPCS_BF16)
+        hipLaunchKernelGGL(slice_channels_kernel<uint16_t>, stream_grid(total), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t *)y, (uint16_t *)x, total, (unsigned)C, (unsigned)Cp);
+    else
+        hipLaunchKernelGGL(slice_channels_kernel<uint32_t>, stream_grid(total), dim3(256), 0, (hipStream_t)stream,
+                           (const uint32_t *)y, (uint32_t *)x, total, (unsigned)C, (unsigned)Cp);
+    return check_launch("slice_channels");
 }
 
 extern "C" int dlwpcs_split2(const void *y, void *a, void *b, size_t rows, int Ca, int Cb, int dtype,

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DLWPCS_VERSION 100            /* 0.1.0 */
+#define DLWPCS_VERSION 101            /* 0.1.1: dlwpcs_conv_desc.c0_valid, dlwpcs_adam_step_dev, dlwpcs_state_repack */
 
 /* error codes */
 #define DLWPCS_OK             0
@@ -126,6 +126,11 @@ typedef struct dlwpcs_conv_desc {
     float   alpha, vmax;    /* parameters of DLWPCS_ACT_LEAKY_CLIP */
     int32_t dtype;          /* DLWPCS_F32 | DLWPCS_BF16 (dtype of src*, y, dy, dsrc*; parameters are always fp32) */
     int32_t flags;          /* DLWPCS_CONV_* bits */
+    int32_t c0_valid;       /* 0: every channel of src0 is real.  > 0 (C1 must be 0): src0 is stored with C0 channels per
+                             * pixel but only the first c0_valid are variables, the rest is zero padding up to the vector
+                             * width (7 variables in an 8-channel layout: 16-B loads instead of scalar ones).  The HWIO
+                             * kernels and their gradients keep c0_valid input rows; dsrc0 is written with C0 channels,
+                             * zeros in the padding. */
 } dlwpcs_conv_desc;
 
 size_t dlwpcs_conv_workspace_bytes(const dlwpcs_conv_desc *d);      /* max over fwd / bwd_data / bwd_weights */
@@ -242,6 +247,10 @@ int dlwpcs_upsample2_bwd(const void *dy, void *dx, int B, int N, int C, int dtyp
 int dlwpcs_concat2(const void *a, const void *b, void *y, size_t rows, int Ca, int Cb, int dtype,
                    dlwpcs_stream_t stream);
 int dlwpcs_split2(const void *y, void *a, void *b, size_t rows, int Ca, int Cb, int dtype, dlwpcs_stream_t stream);
+/* Channel padding for dlwpcs_conv_desc.c0_valid: y (rows, Cp) <- x (rows, C), zeros in channels C..Cp-1; slice is the adjoint
+ * (x (rows, C) <- the first C channels of y (rows, Cp)). */
+int dlwpcs_pad_channels(const void *x, void *y, size_t rows, int C, int Cp, int dtype, dlwpcs_stream_t stream);
+int dlwpcs_slice_channels(const void *y, void *x, size_t rows, int Cp, int C, int dtype, dlwpcs_stream_t stream);
 /* Rollout state re-injection (replaces the per-step numpy concatenate / transpose / reshape of the reference's
  * TimeSeriesEstimator.predict, DLWP/model/extensions.py:281-299, and the Reshape / Permute / Concatenate chain of
  * Azure/train_cs.py:401-406): out (B,S,T*(V+E)) <- state (B,S,T*V) with extra (B,T,S,E) appended as the last E channels of

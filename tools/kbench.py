@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--only', default='fwd,dgrad,wgrad')
     ap.add_argument('--layer', default='')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     lib = nat.lib()
@@ -47,13 +48,14 @@ def main():
         if args.layer and args.layer != name:
             continue
         n0 = N // 2 if up0 else N
-        src0 = torch.randn(B, 6, n0, n0, C0, device=dev).requires_grad_(True)
-        src1 = torch.randn(B, 6, N, N, C1, device=dev).requires_grad_(True) if C1 else None
+        adt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+        src0 = torch.randn(B, 6, n0, n0, C0, device=dev).to(adt).requires_grad_(True)
+        src1 = torch.randn(B, 6, N, N, C1, device=dev).to(adt).requires_grad_(True) if C1 else None
         cin = C0 + C1
         w = [(torch.randn(k, k, cin, Cout, device=dev) / (k * k * cin) ** 0.5).requires_grad_(True) for _ in range(2)]
         b = [torch.zeros(Cout, device=dev).requires_grad_(True) for _ in range(2)]
         No = N if halo else N - k + 1
-        gy = torch.randn(B, 6, No, No, Cout, device=dev)
+        gy = torch.randn(B, 6, No, No, Cout, device=dev).to(adt)
 
         def run():
             y = ops.cs_conv(src0, w[0], w[1], None, b[0], b[1], None, src1=src1, ksize=k, halo=bool(halo),
@@ -73,7 +75,8 @@ def main():
         n = lib.dlwpcs_prof_count()
         for i in range(n):
             lib.dlwpcs_prof_get(i, tag, 160, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
-            kind = ['fwd', 'dgrad', 'wgrad'][i % 3]
+            name = tag.value.decode()
+            kind = 'wgrad' if 'wgrad' in name else ('fwd' if i % 3 == 0 else 'dgrad')
             a = per.setdefault(kind, [tag.value.decode(), 0.0, 0.0, 0])
             a[1] += ms.value
             a[2] += fl.value
@@ -86,6 +89,8 @@ def main():
     tot = sum(r[2] for r in rows)
     for r in rows:
         print('%-12s %-6s %8.1f us %7.2f TF  %s' % r)
+    for kind in ('fwd', 'dgrad', 'wgrad'):
+        print('sum %-6s %.1f us' % (kind, sum(r[2] for r in rows if r[1] == kind)))
     print('total %.1f us' % tot)
 
 
