@@ -427,9 +427,8 @@ class _GConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_eq, w_pol, w_np, b_eq, b_pol, b_np, strides, padding, dilation, flip):
         require_device(x, 'cs_gconv')
-        if x.dtype != torch.float32:
-            raise NotImplementedError('cs_gconv (strides / dilation / "same"): float32 only; the bfloat16 path serves the '
-                                      'hot configuration (k in {1,3}, stride 1)')
+        for prm in (w_eq, w_pol, w_np, b_eq, b_pol, b_np):
+            _f32_param(prm, 'cs_gconv')
         x, w_eq, w_pol = _c(x), _c(w_eq), _c(w_pol)
         w_np = _c(w_np) if w_np is not None else None
         B, F6, H, W, Cin = x.shape
@@ -450,7 +449,7 @@ class _GConv(torch.autograd.Function):
         if Ho < 1 or Wo < 1:
             raise ValueError('cs_gconv: empty output')
         d = GConvDesc(B=B, H=H, W=W, Cin=Cin, Cout=Cout, kh=kh, kw=kw, sh=sh, sw=sw, dh=dh, dw=dw, pad_t=pad_t,
-                      pad_l=pad_l, Ho=Ho, Wo=Wo, flip_north_pole=int(flip), dtype=nat.F32)
+                      pad_l=pad_l, Ho=Ho, Wo=Wo, flip_north_pole=int(flip), dtype=nat.dtype_tag(x))
         y = torch.empty((B, 6, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
         check(lib().dlwpcs_gconv_fwd(ctypes.byref(d), ptr(x), ptr(w_eq), ptr(w_pol), ptr(w_np), ptr(b_eq), ptr(b_pol),
                                      ptr(b_np), ptr(y), stream_ptr()), 'dlwpcs_gconv_fwd')
@@ -474,7 +473,7 @@ class _GConv(torch.autograd.Function):
         dw_np = torch.empty_like(w_np) if has_np else None
         db_eq = db_pol = db_np = None
         if has_bias:
-            db_eq = torch.empty(d.Cout, dtype=dy.dtype, device=dy.device)
+            db_eq = torch.empty(d.Cout, dtype=torch.float32, device=dy.device)
             db_pol = torch.empty_like(db_eq)
             db_np = torch.empty_like(db_eq) if has_bnp else None
         check(lib().dlwpcs_gconv_bwd_weights(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw_eq), ptr(dw_pol), ptr(dw_np),

@@ -249,3 +249,118 @@ def test_cfg5_rollout_full_size_bf16():
     assert rel_err(series[0, 7:8], yr) < 3e-2
     y1 = model.predict(x[7:8], batch_size=1)
     assert rel_err(y1[0], series[0, 7]) < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 2: 6-layer encoder, 7 input variables, batch 32, fp32.  The 7-channel input is stored with 8 channels
+# per pixel (dlwpcs_conv_desc.c0_valid = 7: zero padding up to the 16-B vector) so that the first layer takes the float4
+# kernel paths; kernels and gradients keep 7 input rows.
+# ---------------------------------------------------------------------------------------------------------------------
+
+CFG2_FIRST = (48, 7, 0, 32, 3, True, False)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_cfg2_first_layer_full_batch(dtype):
+    """x (32,6,48,48,7): forward + input gradient of three samples and the whole-batch weight / bias gradients against the
+    fp64 oracle; adjoint identities over the full batch; the padded layout (8 or 16 channels) given directly equals the
+    7-channel call bit for bit."""
+    from DLWP import ops
+    layer = CFG2_FIRST
+    N, C0, C1, Cout, k, halo, up0 = layer
+    gen = torch.Generator(device=_dev()).manual_seed(77)
+    x0, _, gy = _inputs(gen, layer, B_FULL)
+    w, b = _params(gen, k, C0, Cout)
+    if dtype == torch.bfloat16:
+        x0, gy = x0.to(dtype), gy.to(dtype)
+    # bf16: without the activation -- act'(y) flips where the bf16-rounded y sits on the other side of 0 / 10 than the fp64 one
+    act = dtype == torch.float32
+    y, dx0, _, dw, db = _run(layer, x0, None, w, b, gy, act=act)
+    assert tuple(dx0.shape) == tuple(x0.shape) and y.dtype == dtype
+    pick = [0, 13, 31]
+    t0 = x0[pick].double().cpu().requires_grad_(True)
+    tw = {n: v.double().cpu().requires_grad_(True) for n, v in w.items()}
+    tb = {n: v.double().cpu().requires_grad_(True) for n, v in b.items()}
+    if dtype == torch.bfloat16:     # the kernels consume bf16-rounded weights
+        tw = {n: v.detach().to(torch.bfloat16).double().requires_grad_(True) for n, v in tw.items()}
+    yref = orc.cs_conv2d(orc.cs_pad(t0, 1, 'channels_last'), tw['eq'], tw['pol'], None, tb['eq'], tb['pol'], None,
+                         data_format='channels_last', flip_north_pole=True, independent_north_pole=False)
+    if act:
+        yref = orc.relu_leaky_clip(yref, 0.1, 10.0)
+    yref.backward(gy[pick].double().cpu())
+    tol_y, tol_g = (RTOL, RTOL) if dtype == torch.float32 else (2.0 ** -7, 2e-2)
+    assert rel_err(y[pick].float().cpu().numpy(), yref.detach().numpy()) < tol_y
+    assert rel_err(dx0[pick].float().cpu().numpy(), t0.grad.numpy()) < tol_g
+    # weight gradients: batch linearity against four 8-sample launches (fp64 accumulation of the parts)
+    acc_w = {n: torch.zeros_like(v, dtype=torch.float64) for n, v in dw.items()}
+    for s in range(0, B_FULL, 8):
+        _, _, _, pw, _ = _run(layer, x0[s:s + 8], None, w, b, gy[s:s + 8], act=act)
+        for n in acc_w:
+            acc_w[n] += pw[n].double()
+    for n in acc_w:
+        assert tuple(dw[n].shape) == (3, 3, 7, 32)
+        assert rel_err(dw[n].cpu().numpy(), acc_w[n].cpu().numpy()) < (RTOL if dtype == torch.float32 else 5e-3), n
+    # the physically padded layout handed over by the caller: identical bits, gradient of the padding channels is zero
+    cp = ops.padded_channels(7, dtype)
+    assert cp == (8 if dtype == torch.float32 else 8)
+    xp = torch.zeros((B_FULL, 6, N, N, cp), dtype=dtype, device=_dev())
+    xp[..., :7] = x0
+    yp, dxp, _, dwp, dbp = _run((N, cp, 0, Cout, k, halo, up0), xp, None, w, b, gy, act=act)
+    assert torch.equal(yp, y) and torch.equal(dxp[..., :7], dx0) and float(dxp[..., 7:].abs().max()) == 0.0
+    for n in dw:
+        assert torch.equal(dwp[n], dw[n]) and torch.equal(dbp[n], db[n])
+
+
+def test_cfg2_first_layer_adjoint_identities_fp32():
+    layer = CFG2_FIRST
+    N, C0, C1, Cout, k, halo, up0 = layer
+    gen = torch.Generator(device=_dev()).manual_seed(78)
+    x0, _, gy = _inputs(gen, layer, B_FULL)
+    w, b = _params(gen, k, C0, Cout)
+    y, dx0, _, dw, db = _run(layer, x0, None, w, b, gy, act=False)
+    yg = dot64(y, gy)
+    bdb = dot64(b['eq'], db['eq']) + dot64(b['pol'], db['pol'])
+    scale = float(torch.linalg.vector_norm(y.double()) * torch.linalg.vector_norm(gy.double()))
+    assert abs(yg - (dot64(x0, dx0) + bdb)) < RTOL * scale
+    assert abs(yg - (dot64(w['eq'], dw['eq']) + dot64(w['pol'], dw['pol']) + bdb)) < RTOL * scale
+
+
+def test_cfg2_encoder6_full_batch_fp32():
+    """encoder6 (first six convolutions of unet2), x (32,6,48,48,7), fp32: samples of the 32-batch prediction against the fp64
+    oracle, batch independence, and one MSE + Adam step: gradient of the 32-sample mean loss = mean of four 8-sample ones."""
+    from DLWP.keras import Input, Model
+    from DLWP.model.cs_unet import CubeSphereNet
+    rng = np.random.default_rng(606)
+    x = rng.standard_normal((B_FULL, 6, 48, 48, 7)).astype(np.float32)
+    t = rng.standard_normal((B_FULL, 6, 12, 12, 64)).astype(np.float32)
+    params = orc.make_unet2_params(7, 7, base=32, seed=8)[:6]
+    net = CubeSphereNet(base_filter_number=32, output_channels=7)
+    inp = Input(shape=(6, 48, 48, 7), name='main_input')
+    model = Model(inputs=inp, outputs=net.encoder6(inp))
+    convs = [l for l in model.layers if l.__class__.__name__ == 'CubeSphereConv2D']
+    assert len(convs) == 6
+    model.compile(optimizer='adam', loss='mse')
+    model.use_graphs = False
+    _set_params(convs, params)
+    y = model.predict(x, batch_size=B_FULL)
+    pick = [2, 29]
+    yr = orc.encoder6_forward(torch.tensor(x[pick], dtype=torch.float64), params).numpy()
+    assert y.shape == (B_FULL, 6, 12, 12, 64) and rel_err(y[pick], yr) < RTOL
+    assert rel_err(model.predict(x[2:3], batch_size=1)[0], y[2]) < 1e-6
+
+    def grad_of(xs, ts):
+        _set_params(convs, params)
+        hist = model.fit(xs, ts, batch_size=len(xs), epochs=1, verbose=0, shuffle=False)
+        return _flat_grad(convs), hist.history['loss'][0]
+    g_full, l_full = grad_of(x, t)
+    parts = [grad_of(x[s:s + 8], t[s:s + 8]) for s in range(0, B_FULL, 8)]
+    assert abs(l_full - sum(p[1] for p in parts) / 4) < 1e-5 * abs(l_full)
+    assert rel_err(g_full, sum(p[0] for p in parts) / 4) < RTOL
+    # gradient of the first (7-channel) layer against the fp64 oracle on an 8-sample batch
+    _set_params(convs, params)
+    model.fit(x[:8], t[:8], batch_size=8, epochs=1, verbose=0, shuffle=False)
+    got = [w.grad.double().cpu().numpy() for w in convs[0].weights]
+    prm = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
+    orc.mse_loss(orc.encoder6_forward(torch.tensor(x[:8], dtype=torch.float64), prm), torch.tensor(t[:8], dtype=torch.float64)).backward()
+    for g, name in zip(got, ('equatorial_kernel', 'polar_kernel', 'equatorial_bias', 'polar_bias')):
+        assert rel_err(g, prm[0][name].grad.numpy()) < RTOL, name

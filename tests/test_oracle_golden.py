@@ -91,3 +91,17 @@ def test_flip_conv_flip_equals_row_reversed_kernel():
     a = torch.flip(orc.conv2d_tf(torch.flip(x, dims=(1,)), w), dims=(1,))
     b = orc.conv2d_tf(x, torch.flip(w, dims=(0,)))
     assert torch.allclose(a, b, atol=1e-12)
+
+
+def test_oracle_unet2_equals_the_reference_model_function(golden_dir):
+    """oracle.unet2_forward against the reference's own `unet2` function executed over its own layers
+    (/root/reference/Azure/train_cs.py:277-305, tests/golden/gen_golden_wirings.py)."""
+    import torch
+    g = np.load(os.path.join(golden_dir, 'g9_wirings.npz'))
+    order = ['conv_2d_1', 'conv_2d_1_2', 'conv_2d_2', 'conv_2d_2_2', 'conv_2d_5_2', 'conv_2d_5', 'conv_2d_6_2', 'conv_2d_6',
+             'conv_2d_7', 'conv_2d_7_2', 'conv_2d_8']
+    assert sorted(order) == sorted(str(n) for n in g['unet2/layers'])
+    params = [{k: torch.tensor(g['unet2/%s/%s' % (n, k)], dtype=torch.float64)
+               for k in ('equatorial_kernel', 'polar_kernel', 'equatorial_bias', 'polar_bias')} for n in order]
+    y = orc.unet2_forward(torch.tensor(g['unet2/x'], dtype=torch.float64), params).numpy()
+    assert np.abs(y - g['unet2/y']).max() <= 1e-12 * np.abs(g['unet2/y']).max()
