@@ -180,3 +180,41 @@ def test_estimator_device_rollout_matches_oracle_and_host_loop(dtype):
     fk = est.predict(steps, samples=samples, keep_time_dim=True)
     assert fk.dims[:3] == ('f_hour', 'time', 'time_step') and fk.values.shape == (6, 4, ITS, 6, N, N, V)
     assert np.array_equal(fk.values[0, :, 0], fc.values[0])
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
+# pinned to the reference: g10_estimator.npz holds outputs of the reference's OWN TimeSeriesEstimator.__init__ / .predict
+# (tests/golden/gen_golden_estimator.py) for the sequence-model + insolation + constants configuration
+# --------------------------------------------------------------------------------------------------------------------- #
+
+def test_estimator_matches_reference_estimator(golden_dir):
+    import os
+    from DLWP.keras import backend
+    backend.set_device('cpu')
+    from DLWP.model import DLWPFunctional, TimeSeriesEstimator
+    from DLWP.model.generators import ArrayDataGenerator
+    g = np.load(os.path.join(golden_dir, 'g10_estimator.npz'))
+    n_out = 2
+    dlwp = DLWPFunctional(is_convolutional=True, time_dim=ITS)
+    dlwp.build_model(_StubNet(n_out), loss='mse')
+    gen = ArrayDataGenerator(dlwp, g['array'], rank=3, batch_size=4, input_time_steps=ITS, output_time_steps=ITS,
+                             sequence=n_out, insolation_array=g['insolation'][:T], constants=g['constants'],
+                             channels_last=True)
+    times = g['times'].astype('datetime64[ns]')
+    est = TimeSeriesEstimator(dlwp, gen, sample_times=times[:T], lat=g['lat'], lon=g['lon'])
+    samples = g['samples']
+    for name in [str(n) for n in g['names']]:
+        steps, keep = int(name.split('_')[0][1:]), bool(int(name.split('_')[1][1:]))
+        fc = est.predict(steps, samples=list(samples), keep_time_dim=keep)
+        ref = g[name + '_values']
+        assert fc.dims == tuple(str(d) for d in g[name + '_dims']), name
+        assert fc.values.shape == ref.shape, name
+        # rows of the insolation past the end of the data come from DLWP.util.insolation (pinned to the reference's function
+        # at 2e-6, g6): everything else is exact bookkeeping
+        assert np.abs(fc.values - ref).max() <= 1e-5 * np.abs(ref).max(), name
+        assert np.array_equal(fc.coords['f_hour'], g[name + '_f_hour']), name
+        assert np.array_equal(np.asarray(fc.coords['time']).astype('datetime64[ns]').astype(np.int64), g[name + '_time']), name
+        assert np.array_equal(fc.coords['varlev'], g[name + '_varlev'])
+    # forecasts that stay inside the data use the generator's own insolation rows: bit-exact
+    fc = est.predict(3, samples=list(samples[:3]))
+    assert np.array_equal(fc.values, g['s3_k0_values'][:, :3])
