@@ -96,7 +96,7 @@ def _cpu_model():
     return platform.processor() or 'unknown'
 
 
-def cpu_baseline(workload, N, c_in, c_out, base, batch, warmup=3, timed=10, budget_s=45.0):
+def cpu_baseline(workload, N, c_in, c_out, base, batch, warmup=3, timed=10, budget_s=35.0):
     """Reference-structured CPU port (oracle/cs_oracle.py), torch-CPU fp32, host cores of this box: >= 3 warm-up + >= 10
     timed steps at the benchmark's own batch size (fewer only if the time budget runs out), MEDIAN step time."""
     from oracle import cs_oracle as orc
@@ -455,6 +455,18 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc):
                 live_err = src
                 recs, src = newest_committed_pmc(args.workload, dtype)
                 src = '%s [live collection unavailable: %s]' % (src, live_err)
+        if recs and getattr(args, 'pmc_out', None):
+            try:
+                doc = json.load(open(args.pmc_out)) if os.path.exists(args.pmc_out) else {}
+            except ValueError:
+                doc = {}
+            doc['%s/%s' % (args.workload, dtype)] = {k: v for k, v in recs.items()
+                                                     if any(x in k for x in ('conv_mfma', 'wgrad', 'pw_', 'pad_', 'src_pair',
+                                                                             'avgpool', 'mse_', 'adam', 'pack_batch',
+                                                                             'state_repack', 'batch_gather'))}
+            doc['_source'] = src
+            with open(args.pmc_out, 'w') as f:
+                json.dump(doc, f, indent=1, sort_keys=True)
         rec = (recs or {}).get(name)
         if rec is None and recs:
             rec = next((v for k, v in recs.items() if k.startswith(name[:84])), None)
@@ -519,6 +531,9 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='no rocprofv3 child passes (traffic / mfma_busy stay null)')
     ap.add_argument('--no-graphs', action='store_true')
+    ap.add_argument('--pmc-out', default=None,
+                    help='also write the per-kernel PMC records of this run to FILE (JSON; tools/make_profiles.py commits it as '
+                         'profiles/rNN_*_pmc.json, the fallback source when rocprofv3 cannot run)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.face is None:

@@ -112,6 +112,9 @@ PROTOTYPES = {
     'dlwpcs_pad_channels': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_slice_channels': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_state_repack': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_head_mse_scratch_bytes': (c_size_t, []),
+    'dlwpcs_head_mse_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_int, c_void_p, c_void_p]),
     'dlwpcs_adam_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int,
                                      c_void_p]),
     'dlwpcs_batch_gather': (c_int, [c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int, c_void_p, c_int,

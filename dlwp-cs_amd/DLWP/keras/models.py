@@ -58,6 +58,8 @@ class Model(object):
         self.wgrad_side_stream = os.environ.get('DLWPCS_SIDE_STREAM', '0') == '1'   # measured slower on MI355X: off
         # one reduction launch for all layers' weight-gradient partials (DLWPCS_CONV_DEFER_REDUCE)
         self.defer_wgrad_reduce = os.environ.get('DLWPCS_DEFER_REDUCE', '1') == '1'
+        # training step: output layer + loss + loss gradient + the layer's data gradient as one launch (ops.head_mse)
+        self.fuse_head_loss = os.environ.get('DLWPCS_FUSE_HEAD', '1') == '1'
         # True: the caller feeds every step through the SAME device tensors (e.g. a generator that assembles each batch in
         # place): the captured graphs read them directly instead of copying each batch into private static buffers
         self.static_batch_buffers = False
@@ -161,6 +163,9 @@ class Model(object):
                               isinstance(t.layer, Concatenate)))
         self._plan = steps
         self.n_fused = len(fused)
+        # model outputs that no other node consumes (candidates for the fused head + loss step) and appear once
+        uids = [o.uid for o in self.outputs]
+        self._sole_outputs = {u for u in uids if not consumers.get(u) and uids.count(u) == 1}
 
     def _pack_state(self, device):
         """Packed-weight buffers + the device item table of every matrix-core convolution layer (built once per
@@ -189,7 +194,7 @@ class Model(object):
         self._pack_cache = st
         return st
 
-    def _forward(self, inputs, repack=True):
+    def _forward(self, inputs, repack=True, fuse_targets=None):
         want = backend.torch_dtype(self.compute_dtype)
         inputs = [v if v.dtype == want else v.to(want) for v in inputs]
         if inputs and inputs[0].is_cuda and self.prepack_weights:
@@ -201,12 +206,17 @@ class Model(object):
                 st['packed'] = True
             ops.PREPACKED = st['table']
             try:
-                return self._run_plan(inputs)
+                return self._run_plan(inputs, fuse_targets)
             finally:
                 ops.PREPACKED = {}
-        return self._run_plan(inputs)
+        return self._run_plan(inputs, fuse_targets)
 
-    def _run_plan(self, inputs):
+    def _run_plan(self, inputs, fuse_targets=None):
+        """fuse_targets (training step only): {output tensor uid: (target, loss weight)} -- an output produced by a pointwise
+        CubeSphereConv2D that nothing else consumes is then computed together with its loss, its loss gradient and the layer's
+        data gradient by ONE launch (ops.head_mse); the entry of the returned list is the (2,) stats tensor instead of the
+        prediction."""
+        from ..custom import CubeSphereConv2D
         values = {t.uid: v for t, v in zip(self.inputs, inputs)}
         for st in self._plan:
             if st[0] == 'fused_conv':
@@ -219,6 +229,15 @@ class Model(object):
             else:
                 _, out_uid, lay, in_uids, takes_list = st
                 args = [values[u] for u in in_uids]
+                if (fuse_targets is not None and out_uid in fuse_targets and out_uid in self._sole_outputs
+                        and isinstance(lay, CubeSphereConv2D) and len(args) == 1 and lay._is_mfma_config()
+                        and lay.data_format == 'channels_last' and lay.activation is None and lay.north_pole_kernel is None
+                        and ops.head_mse_applicable(args[0], lay.equatorial_kernel, lay.kernel_size[0], ACT_NONE,
+                                                    fuse_targets[out_uid][0])):
+                    tgt, wgt = fuse_targets[out_uid]
+                    values[out_uid] = ops.head_mse(args[0], tgt, lay.equatorial_kernel, lay.polar_kernel, lay.equatorial_bias,
+                                                   lay.polar_bias, wgt, lay.flip_north_pole)
+                    continue
                 values[out_uid] = lay.call(args if (takes_list or len(args) > 1) else args[0])
         return [values[o.uid] for o in self.outputs]
 
@@ -356,11 +375,20 @@ class Model(object):
         return vals
 
     def _loss_and_backward(self, inputs, targets, train=True):
-        outs = self._forward(inputs)
-        if len(targets) != len(outs):
+        if len(targets) != len(self.outputs):
             raise ValueError('Error when checking model target: expected %d target arrays, got %d'
-                             % (len(outs), len(targets)))
-        stats = [ops.mse_mae(o, t, w) for o, t, w in zip(outs, targets, self.loss_weights)]
+                             % (len(self.outputs), len(targets)))
+        fuse = None
+        if train and self.fuse_head_loss:
+            fuse = {o.uid: (t, w) for o, t, w in zip(self.outputs, targets, self.loss_weights)}
+            ops.DIRECT_PARAM_GRADS = True       # (head_mse_applicable checks it: the fused step needs the flat gradient buffer)
+        try:
+            outs = self._forward(inputs, fuse_targets=fuse)
+        finally:
+            if fuse is not None:
+                ops.DIRECT_PARAM_GRADS = False
+        stats = [o if (o.dim() == 1 and o.numel() == 2 and fuse is not None) else ops.mse_mae(o, t, w)
+                 for o, t, w in zip(outs, targets, self.loss_weights)]
         if train:
             dev = stats[0].device
             ones = [ops.unit_seed(dev) for _ in stats]

@@ -212,6 +212,56 @@ def _f32_param(t, what):
         raise TypeError('%s: parameters must be float32 master copies, got %s' % (what, t.dtype))
 
 
+def _weight_gradients(d, src0, src1, dy, y, params, table, ws, nbytes, direct, defer, need, has_np, has_bias, has_bnp):
+    """Weight / bias gradients of one fused convolution (shared by _CSConv.backward and the fused head + loss step).
+    direct: accumulate straight into the parameters' preset .grad buffers (views of the model's flat gradient buffer, zeroed
+    once per step): no temporaries, no AccumulateGrad add kernels; shared layers simply accumulate twice.  Returns the six
+    gradient tensors (None in direct mode)."""
+    dev = dy.device
+    w_eq, w_pol, w_np = params[0], params[1], params[2]
+    dw_eq = dw_pol = dw_np = db_eq = db_pol = db_np = None
+    if direct:
+        pe, pp, pn, be, bp, bn = params
+        d2 = ConvDesc.from_buffer_copy(d)
+        d2.flags = d.flags | nat.CONV_ACCUMULATE_WGRAD | (nat.CONV_DEFER_REDUCE if defer else 0)
+        grads = (ptr(pe.grad), ptr(pp.grad), ptr(None if pn is None else pn.grad),
+                 ptr(None if be is None else be.grad), ptr(None if bp is None else bp.grad),
+                 ptr(None if bn is None else bn.grad))
+
+        def launch(wsx):
+            check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d2), ptr(src0), ptr(src1), ptr(dy), ptr(y), *grads,
+                                                ptr(table), ptr(wsx), wsx.numel(), stream_ptr()),
+                  'dlwpcs_conv_bwd_weights')
+            if defer:
+                item = nat.ReduceItem()
+                check(lib().dlwpcs_conv_wgrad_reduce_item(ctypes.byref(d2), *grads, ptr(wsx), wsx.numel(),
+                                                          ctypes.byref(item)), 'dlwpcs_conv_wgrad_reduce_item')
+                _deferred.append((item, wsx))
+        if WGRAD_SIDE_STREAM:
+            side = side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))      # dy and the saved activations are ready
+            ws2 = _workspace(nbytes, dev, 'side')                 # own workspace: the main stream keeps using `ws`
+            with torch.cuda.stream(side):
+                launch(ws2)
+            for t in (src0, src1, dy, y):                         # keep their memory until the side stream is done
+                if t is not None:
+                    t.record_stream(side)
+        else:
+            launch(ws)
+    elif any(need):
+        dw_eq, dw_pol = torch.empty_like(w_eq), torch.empty_like(w_pol)
+        dw_np = torch.empty_like(w_np) if has_np else None
+        if has_bias:
+            db_eq = torch.empty(d.Cout, dtype=torch.float32, device=dev)
+            db_pol = torch.empty(d.Cout, dtype=torch.float32, device=dev)
+            db_np = torch.empty(d.Cout, dtype=torch.float32, device=dev) if has_bnp else None
+        check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d), ptr(src0), ptr(src1), ptr(dy), ptr(y), ptr(dw_eq),
+                                            ptr(dw_pol), ptr(dw_np), ptr(db_eq), ptr(db_pol), ptr(db_np),
+                                            ptr(table), ptr(ws), ws.numel(), stream_ptr()),
+              'dlwpcs_conv_bwd_weights')
+    return dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np
+
+
 class _CSConv(torch.autograd.Function):
     """
     y = act(conv(halo_pad(concat(up?(src0), src1))) + bias); see dlwpcs_conv_fwd in include/dlwpcs.h.
@@ -308,48 +358,8 @@ class _CSConv(torch.autograd.Function):
                       'dlwpcs_conv_bwd_data')
         if not reuse_dz:
             run_bwd_data()
-        dw_eq = dw_pol = dw_np = db_eq = db_pol = db_np = None
-        if direct:
-            # Accumulate straight into the preset .grad buffers (views of the model's flat gradient buffer, zeroed once
-            # per step): no temporaries, no AccumulateGrad add kernels; shared layers simply accumulate twice.
-            pe, pp, pn, be, bp, bn = ctx.params
-            d2 = ConvDesc.from_buffer_copy(d)
-            d2.flags = d.flags | nat.CONV_ACCUMULATE_WGRAD | (nat.CONV_DEFER_REDUCE if defer else 0)
-            grads = (ptr(pe.grad), ptr(pp.grad), ptr(None if pn is None else pn.grad),
-                     ptr(None if be is None else be.grad), ptr(None if bp is None else bp.grad),
-                     ptr(None if bn is None else bn.grad))
-
-            def launch(wsx):
-                check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d2), ptr(src0), ptr(src1), ptr(dy), ptr(y), *grads,
-                                                    ptr(table), ptr(wsx), wsx.numel(), stream_ptr()),
-                      'dlwpcs_conv_bwd_weights')
-                if defer:
-                    item = nat.ReduceItem()
-                    check(lib().dlwpcs_conv_wgrad_reduce_item(ctypes.byref(d2), *grads, ptr(wsx), wsx.numel(),
-                                                              ctypes.byref(item)), 'dlwpcs_conv_wgrad_reduce_item')
-                    _deferred.append((item, wsx))
-            if WGRAD_SIDE_STREAM:
-                side = side_stream(dev)
-                side.wait_stream(torch.cuda.current_stream(dev))      # dy and the saved activations are ready
-                ws2 = _workspace(nbytes, dev, 'side')                 # own workspace: the main stream keeps using `ws`
-                with torch.cuda.stream(side):
-                    launch(ws2)
-                for t in (src0, src1, dy, y):                         # keep their memory until the side stream is done
-                    if t is not None:
-                        t.record_stream(side)
-            else:
-                launch(ws)
-        elif need[2] or need[3] or need[4] or need[5] or need[6] or need[7]:
-            dw_eq, dw_pol = torch.empty_like(w_eq), torch.empty_like(w_pol)
-            dw_np = torch.empty_like(w_np) if has_np else None
-            if has_bias:
-                db_eq = torch.empty(d.Cout, dtype=torch.float32, device=dev)
-                db_pol = torch.empty(d.Cout, dtype=torch.float32, device=dev)
-                db_np = torch.empty(d.Cout, dtype=torch.float32, device=dev) if has_bnp else None
-            check(lib().dlwpcs_conv_bwd_weights(ctypes.byref(d), ptr(src0), ptr(src1), ptr(dy), ptr(y), ptr(dw_eq),
-                                                ptr(dw_pol), ptr(dw_np), ptr(db_eq), ptr(db_pol), ptr(db_np),
-                                                ptr(table), ptr(ws), ws.numel(), stream_ptr()),
-                  'dlwpcs_conv_bwd_weights')
+        dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np = _weight_gradients(
+            d, src0, src1, dy, y, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp)
         if reuse_dz:
             run_bwd_data()
         return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 8
@@ -774,6 +784,75 @@ class _MSE(torch.autograd.Function):
 
 def mse_mae(y, t, weight=1.0):
     return _MSE.apply(y, t, float(weight))
+
+
+_head_scratch = {}
+
+
+def head_mse_applicable(x, w_eq, ksize, act, target):
+    """True when the fused training tail (dlwpcs_head_mse_step) serves this output layer + loss: bf16 activations, pointwise
+    kernel on 32 input channels, even C_out in 8..32, no activation, fp32 target, weights packed by the model's pack launch."""
+    if not (DIRECT_PARAM_GRADS and x.is_cuda and x.dtype == torch.bfloat16 and ksize == 1 and act == nat.ACT_NONE):
+        return False
+    packed = PREPACKED.get(id(w_eq))
+    cout = w_eq.shape[3]
+    return (packed is not None and packed[0] == nat.BF16 and x.dim() == 5 and x.shape[1] == 6 and x.shape[4] == 32
+            and w_eq.shape[2] == 32 and cout % 2 == 0 and 8 <= cout <= 32 and (x.shape[2] * x.shape[3]) % 16 == 0
+            and target.dtype == torch.float32 and tuple(target.shape) == tuple(x.shape[:4]) + (cout,)
+            and x.numel() < (1 << 31) and x.requires_grad)
+
+
+class _HeadMSE(torch.autograd.Function):
+    """stats = [weight * mse, mae] of the pointwise output layer applied to x, against `target`; the forward launch also
+    leaves dy and dx behind (dlwpcs_head_mse_step), the backward only runs the layer's weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, target, w_eq, w_pol, b_eq, b_pol, weight, flip):
+        x, target = _c(x), _c(target)
+        B, _, N, _, C0 = x.shape
+        Cout = w_eq.shape[3]
+        d = _make_desc(B, N, C0, 0, Cout, 1, False, False, flip, nat.ACT_NONE, 0.0, 0.0, nat.BF16)
+        packed = PREPACKED[id(w_eq)]
+        d.flags |= nat.CONV_PREPACKED
+        key = str(x.device)
+        scratch = _head_scratch.get(key)
+        if scratch is None:
+            scratch = torch.empty(lib().dlwpcs_head_mse_scratch_bytes(), dtype=torch.uint8, device=x.device)
+            _head_scratch[key] = scratch
+        out = torch.empty(2, dtype=torch.float32, device=x.device)
+        dy = torch.empty((B, 6, N, N, Cout), dtype=x.dtype, device=x.device)
+        dx = torch.empty_like(x)
+        check(lib().dlwpcs_head_mse_step(ctypes.byref(d), ptr(x), ptr(packed[1]), ptr(packed[2]) if b_eq is not None else 0,
+                                         ptr(packed[3]), ptr(target), float(weight), ptr(dy), ptr(dx), ptr(out), 1,
+                                         ptr(scratch), stream_ptr()), 'dlwpcs_head_mse_step')
+        ctx.desc = d
+        ctx.params = (w_eq, w_pol, None, b_eq, b_pol, None)
+        ctx.save_for_backward(x, dy, dx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, dy, dx = ctx.saved_tensors
+        seed = _unit_seeds.get(str(dout.device))
+        if seed is None or dout.data_ptr() != seed.data_ptr():
+            raise RuntimeError('the fused head + loss step is seeded by DLWP.keras.Model only (upstream gradient 1)')
+        d = ctx.desc
+        dev = dy.device
+        nbytes = lib().dlwpcs_conv_workspace_bytes(ctypes.byref(d))
+        need = ctx.needs_input_grad
+        direct = DIRECT_PARAM_GRADS and all(p is None or (p.is_leaf and p.grad is not None and p.grad.is_contiguous())
+                                            for p in ctx.params)
+        if not direct:
+            raise RuntimeError('the fused head + loss step accumulates straight into the model\'s flat gradient buffer')
+        defer = DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM
+        ws = _workspace(nbytes, dev, 'defer%d' % len(_deferred)) if defer else _workspace(nbytes, dev)
+        _weight_gradients(d, x, None, dy, None, ctx.params, None, ws, nbytes, True, defer, need[2:6],
+                          False, ctx.params[3] is not None, False)
+        return (dx if need[0] else None), None, None, None, None, None, None, None
+
+
+def head_mse(x, target, w_eq, w_pol, b_eq, b_pol, weight=1.0, flip_north_pole=True):
+    return _HeadMSE.apply(x, target, w_eq, w_pol, b_eq, b_pol, float(weight), bool(flip_north_pole))
 
 
 def adam_step(p, g, m, v, step_dev, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, zero_grads=False):

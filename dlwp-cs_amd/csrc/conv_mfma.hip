@@ -1104,6 +1104,10 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     constexpr int IT_DY = (CT == 2 ? 3 : 6) * (QD / 4);   // dZ vectors per producer thread per item: capacity 192 / 384 pixels
     constexpr int NPH = 4 / CT;             // consumer waves sharing the slabs of one ci tile
     static_assert(CT == 1 || (XV == 8 && QX == 4), "two ci tiles per worker need full 16-B X vectors");
+    // cross-wave reduction of the epilogue: tap t is summed by the wave of phase t % NPH; every other wave of the ci tile
+    // parks its accumulators of that tap in one of its RSLOTS 4-KB LDS slots
+    constexpr int RSLOTS = TAPS - TAPS / NPH;
+    constexpr int RED_FLOATS = 4 * RSLOTS * 1024;
     const ConvKParams &P = W.c;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pix_cap = (P.pix_per_block + 15) & ~15;
@@ -1294,12 +1298,12 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         }
         // ---- bias partial: thread (q = ptid % QD, 256/QD pixel phases) holds sums of channels DV*q.. -> fixed-order sum
         __syncthreads();                // consumers are done with the buffers (matches the consumers' final barrier)
-        float *red = reinterpret_cast<float *>(smem) + WG_SCRATCH_FLOATS;   // behind the consumers' reduction scratch
+        float *red = reinterpret_cast<float *>(smem) + RED_FLOATS;   // behind the consumers' reduction slots
         if (want_bias) {
 #pragma unroll
             for (int u = 0; u < DV; ++u) red[ptid * DV + u] = bsum[u];
         }
-        __syncthreads();
+        __syncthreads();                // (the consumers parked their accumulators between the two barriers)
         if (want_bias && ptid < 32) {
             float sum = 0.f;
             if (ptid < QD * DV) {
@@ -1308,9 +1312,6 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             }
             W.bpartial[(size_t)worker * W.CoutP + cot * 32 + ptid] = sum;
         }
-        // the consumers' reduction loop below executes 2 barriers per round: keep the barrier counts of both halves equal
-#pragma unroll
-        for (int t0 = 0; t0 < TAPS; t0 += (TAPS >= WG_TG ? WG_TG : 1)) { __syncthreads(); __syncthreads(); }
         return;
     }
 
@@ -1382,40 +1383,53 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     }
     TL_MARK();
     __syncthreads();                            // all consumers finished reading the last buffer
-    __syncthreads();                            // (producers stage their bias sums between these two)
-    TL_MARK();
-
-    // cross-wave reduction through LDS (fixed order over the slab phases of each ci tile), WG_TG taps per round (2 barriers
-    // per round, not per tap)
-    float *red = reinterpret_cast<float *>(smem);
+    // Cross-wave reduction, ONE LDS round for all taps: the NPH waves of a ci tile hold K-split partial sums of the same
+    // (taps, 32, 32) block.  Tap t belongs to the wave of phase t % NPH; the others park their 16 accumulator registers of
+    // that tap in LDS ([slot][r / 4][lane][4]: one ds_write_b128 per register quad), the owner adds them in phase order
+    // (fixed -> bitwise reproducible) and writes the rows straight from its registers: in the C/D layout register r of lanes
+    // 0-31 / 32-63 is row ci = (r & 3) + 8 (r >> 2) + 4 half of 32 consecutive output channels = two whole 128-B lines per
+    // store instruction.  (The previous version went through LDS in three rounds of 4-B accesses: 10 k cycles per worker.)
+    float4 *red4 = reinterpret_cast<float4 *>(smem);
     float *pout = W.partial + (size_t)worker * TAPS * W.CinP * W.CoutP;
-    constexpr int TG = TAPS >= WG_TG ? WG_TG : 1;
+    auto slot_of = [](int t, int p) { int c = 0; for (int u = 0; u < t; ++u) c += (u % NPH != p) ? 1 : 0; return c; };
 #pragma unroll
-    for (int t0 = 0; t0 < TAPS; t0 += TG) {
+    for (int t = 0; t < TAPS; ++t) {
+        if (ph != t % NPH) {
+            float4 *dst = red4 + (size_t)((ct * NPH + ph) * RSLOTS + slot_of(t, ph)) * 256 + lane;
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt)
+            for (int q = 0; q < 4; ++q)
+                dst[q * 64] = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+        }
+    }
+    __syncthreads();                            // (the producers staged their bias sums meanwhile)
+    TL_MARK();
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        if (ph == t % NPH) {
+            const int o = t % NPH;
+            f32x16 v[NPH];
+#pragma unroll
+            for (int p = 0; p < NPH; ++p) {
+                if (p == o) { v[p] = acc[t]; continue; }
+                const float4 *src = red4 + (size_t)((ct * NPH + p) * RSLOTS + slot_of(t, p)) * 256 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 f = src[q * 64];
+                    v[p][4 * q] = f.x; v[p][4 * q + 1] = f.y; v[p][4 * q + 2] = f.z; v[p][4 * q + 3] = f.w;
+                }
+            }
+            float *row0 = pout + ((size_t)t * W.CinP + (cit * CT + ct) * 32 + 4 * half) * W.CoutP + cot * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-                red[(tt * 4 + wave) * 1024 + ci * 32 + l31] = acc[t0 + tt][r];
-            }
-        __syncthreads();
-#pragma unroll
-        for (int tt = 0; tt < TG; ++tt)
-#pragma unroll
-            for (int i = 0; i < 4 * CT; ++i) {
-                const int e = tid + i * NCT;                    // (ci tile, ci, co) = (e / 1024, (e / 32) % 32, e % 32)
-                const int t2 = e >> 10, e10 = e & 1023;
-                const float *rt = red + tt * 4096;
                 float sum;
-                if (CT == 1) sum = (rt[e10] + rt[1024 + e10]) + (rt[2048 + e10] + rt[3072 + e10]);
-                else sum = rt[t2 * 1024 + e10] + rt[(t2 + 2) * 1024 + e10];     // waves t2 and t2 + 2 share ci tile t2
-                const int ci = e10 >> 5, co = e10 & 31;
-                pout[((size_t)(t0 + tt) * W.CinP + (cit * CT + t2) * 32 + ci) * W.CoutP + cot * 32 + co] = sum;
+                if (NPH == 4) sum = (v[0][r] + v[1][r]) + (v[2][r] + v[3][r]);
+                else if (NPH == 2) sum = v[0][r] + v[1][r];
+                else sum = v[0][r];
+                row0[(size_t)((r & 3) + 8 * (r >> 2)) * W.CoutP] = sum;
             }
-        __syncthreads();
-        TL_MARK();
+        }
     }
+    TL_MARK();
 #ifdef DLWPCS_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TL_MARK();
@@ -1732,6 +1746,152 @@ __global__ void __launch_bounds__(256) pw_dgrad_kernel(PwParams P) {
                 pw_next(r, gpf);
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused training tail of the network (bf16): pointwise head + 'mse' loss (+ 'mae') + its gradient + the head's data
+// gradient in ONE pass over the 32-channel input -- y = W x + b is rounded to bf16 exactly as pw_fwd_kernel stores it, the
+// loss terms and dy = gscale (y - t) are formed in fp32 against the fp32 target (mse_stage1_kernel's arithmetic), dy is
+// rounded to bf16 and goes through the wave's LDS patch twice: as aligned 16-B pieces to HBM (the head's weight gradient
+// reads it) and, re-read as this lane's K fragment, into the two MFMAs of pw_dgrad_kernel.  The prediction itself is never
+// written.  Replaces pw_fwd + mse_stage1 + pw_dgrad (3 launches, ~30 us) of the unfused step; same dy / dx bits.
+// Per-workgroup partial sums -> head_stage2_kernel (fixed order).
+// ------------------------------------------------------------------------------------------------------------------
+struct HeadParams {
+    PwParams f;              // in = x, wpk = wpk_fwd, bias, out = dy (pix, Cout)
+    const bf16_t *wpk_bwd;
+    const float *target;     // (pix, Cout) fp32
+    bf16_t *dx;              // (pix, 32)
+    float *partial;          // [gridDim.x][2]
+    float gscale;            // weight * 2 / n
+};
+
+template <int MT>
+__global__ void __launch_bounds__(256) pw_head_train_kernel(HeadParams H) {
+    const PwParams &P = H.f;
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+    const bf16_t *wlane = P.wpk + (q * 32 + n) * 8;
+    const float *blane = P.bias ? P.bias + q * 4 : nullptr;
+    const int Cout = P.Cout, gpf = P.groups_per_face;
+    const int kgroups = ((Cout + 15) / 16) * 2;
+    const bool kvalid = q < kgroups && q * 8 < Cout;
+    const bf16_t *wblane = H.wpk_bwd + (q * 32 + n) * 8;
+    PwRange r = pw_range(P);
+    const bf16_t *src = P.in + (unsigned)(n * 32 + q * 8);
+    __shared__ __attribute__((aligned(16))) uint32_t pw_stage[4][128 * MT + 4];
+    uint32_t *stage = pw_stage[threadIdx.x >> 6];
+    if (lane < 4) stage[128 * MT + lane] = 0u;              // the K fragment of the last pixel may read 4 B past the rows
+    const bool wr16 = lane < 2 * Cout;
+    bf16_t *dst = P.out + (unsigned)(lane * 8);
+    bf16_t *dxl = H.dx + (unsigned)(n * 32 + q * 4);
+    // this lane's K fragment of dy: channels 8q .. 8q+7 of pixel n = bytes n*2*Cout + 16q .. +15 of the patch (4-B aligned)
+    const int nch = Cout - q * 8;
+    const uint32_t *frag = stage + ((n * Cout + q * 8) >> 1);
+    const bool k1 = nch > 0, k2 = nch > 2, k3 = nch > 4, k4 = nch > 6;
+    int vcur = -1;
+    uint4 a[MT], a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    f32x4 b[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { a[t] = make_uint4(0, 0, 0, 0); b[t] = (f32x4)0.f; }
+    float sq = 0.f, ab = 0.f;
+    while (r.g < r.end) {
+        uint4 xv[PW_U];
+        float2 tv[PW_U][MT][2];
+#pragma unroll
+        for (int u = 0; u < PW_U; ++u) {
+            const int g = r.g + u < r.end ? r.g + u : r.end - 1;
+            xv[u] = *reinterpret_cast<const uint4 *>(src + (unsigned)g * 512u);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int co0 = t * 16 + q * 4;
+                const float *tp = H.target + ((size_t)g * 16 + n) * Cout + co0;
+                tv[u][t][0] = co0 + 2 <= Cout ? *reinterpret_cast<const float2 *>(tp) : make_float2(0.f, 0.f);
+                tv[u][t][1] = co0 + 4 <= Cout ? *reinterpret_cast<const float2 *>(tp + 2) : make_float2(0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PW_U; ++u) {
+            if (r.g < r.end) {
+                const int v = r.face < 4 ? 0 : r.face - 3;
+                if (v != vcur) {
+                    vcur = v;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        a[t] = *reinterpret_cast<const uint4 *>(wlane + v * 1024 + t * 128);
+                        if (blane) b[t] = *reinterpret_cast<const f32x4 *>(blane + v * 32 + t * 16);
+                    }
+                    if (kvalid) {
+                        a0 = *reinterpret_cast<const uint4 *>(wblane + v * kgroups * 256);
+                        a1 = *reinterpret_cast<const uint4 *>(wblane + v * kgroups * 256 + 128);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[t]), __builtin_bit_cast(bf16x8, xv[u]),
+                                                                            b[t], 0, 0, 0);
+                    const int co0 = t * 16 + q * 4, sidx = (n * Cout + co0) >> 1;
+                    // the prediction as the unfused path stores it (bf16), loss terms and gradient in fp32
+                    const uint32_t y01 = f2bf2(d[0], d[1]), y23 = f2bf2(d[2], d[3]);
+                    const float e0 = bf_lo(y01) - tv[u][t][0].x, e1 = bf_hi(y01) - tv[u][t][0].y;
+                    const float e2 = bf_lo(y23) - tv[u][t][1].x, e3 = bf_hi(y23) - tv[u][t][1].y;
+                    if (co0 + 2 <= Cout) {
+                        sq += e0 * e0; ab += fabsf(e0); sq += e1 * e1; ab += fabsf(e1);
+                        stage[sidx] = f2bf2(H.gscale * e0, H.gscale * e1);
+                    }
+                    if (co0 + 4 <= Cout) {
+                        sq += e2 * e2; ab += fabsf(e2); sq += e3 * e3; ab += fabsf(e3);
+                        stage[sidx + 1] = f2bf2(H.gscale * e2, H.gscale * e3);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (wr16) *reinterpret_cast<uint4 *>(dst + (unsigned)r.g * (unsigned)(16 * Cout)) = reinterpret_cast<const uint4 *>(stage)[lane];
+                uint4 bv = make_uint4(0, 0, 0, 0);
+                if (k1) bv.x = frag[0];
+                if (k2) bv.y = frag[1];
+                if (k3) bv.z = frag[2];
+                if (k4) bv.w = frag[3];
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bv),
+                                                                         (f32x4)0.f, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bv),
+                                                                         (f32x4)0.f, 0, 0, 0);
+                bf16_t *o_ptr = dxl + (unsigned)r.g * 512u;
+                uint2 o;
+                o.x = f2bf2(d0[0], d0[1]); o.y = f2bf2(d0[2], d0[3]);
+                *reinterpret_cast<uint2 *>(o_ptr) = o;
+                o.x = f2bf2(d1[0], d1[1]); o.y = f2bf2(d1[2], d1[3]);
+                *reinterpret_cast<uint2 *>(o_ptr + 16) = o;
+                pw_next(r, gpf);
+            }
+        }
+    }
+    // workgroup partial sums in a fixed order: lanes -> waves -> workgroup
+    __shared__ float s_sq[256], s_ab[256];
+    s_sq[threadIdx.x] = sq; s_ab[threadIdx.x] = ab;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { s_sq[threadIdx.x] += s_sq[threadIdx.x + st]; s_ab[threadIdx.x] += s_ab[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { H.partial[2 * blockIdx.x] = s_sq[0]; H.partial[2 * blockIdx.x + 1] = s_ab[0]; }
+}
+
+__global__ void __launch_bounds__(256) head_stage2_kernel(const float *__restrict__ partial, float *__restrict__ loss_out,
+                                                          int nblocks, float inv_n, float weight, int overwrite) {
+    __shared__ double s_sq[256], s_ab[256];
+    double sq = 0.0, ab = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { sq += partial[2 * i]; ab += partial[2 * i + 1]; }
+    s_sq[threadIdx.x] = sq; s_ab[threadIdx.x] = ab;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { s_sq[threadIdx.x] += s_sq[threadIdx.x + s]; s_ab[threadIdx.x] += s_ab[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float l0 = (float)(s_sq[0] * inv_n) * weight, l1 = (float)(s_ab[0] * inv_n);
+        loss_out[0] = overwrite ? l0 : loss_out[0] + l0;
+        loss_out[1] = overwrite ? l1 : loss_out[1] + l1;
     }
 }
 
@@ -2087,6 +2247,41 @@ extern "C" int dlwpcs_pack_batch(const dlwpcs_pack_item *items_dev, int n_items,
     return check_launch("pack_batch");
 }
 
+extern "C" size_t dlwpcs_head_mse_scratch_bytes(void) { return (size_t)2048 * 2 * sizeof(float); }
+
+extern "C" int dlwpcs_head_mse_step(const dlwpcs_conv_desc *d, const void *x, const void *wpk_fwd, const void *bias_pk,
+                                    const void *wpk_bwd, const float *target, float weight, void *dy, void *dx,
+                                    float *loss_out, int overwrite, void *scratch, dlwpcs_stream_t stream) {
+    int rc = validate(d, "head_mse_step");
+    if (rc) return rc;
+    if (!x || !wpk_fwd || !wpk_bwd || !target || !dy || !dx || !loss_out || !scratch)
+        return fail(DLWPCS_E_INVALID, "head_mse_step: null pointer");
+    if (!pw_applies(d) || d->act != DLWPCS_ACT_NONE || d->c0_valid != 0)
+        return fail(DLWPCS_E_UNSUPPORTED, "head_mse_step: serves the bf16 pointwise head (k = 1, 32 input channels, even C_out in "
+                                         "8..32, no activation)");
+    hipStream_t s = (hipStream_t)stream;
+    HeadParams H{};
+    H.f.in = (const bf16_t *)x; H.f.wpk = (const bf16_t *)wpk_fwd; H.f.bias = (const float *)bias_pk; H.f.out = (bf16_t *)dy;
+    H.f.ngroups = (long)d->B * 6 * d->N * d->N / 16; H.f.groups_per_face = d->N * d->N / 16; H.f.Cout = d->Cout;
+    H.wpk_bwd = (const bf16_t *)wpk_bwd; H.target = target; H.dx = (bf16_t *)dx; H.partial = (float *)scratch;
+    const double n = (double)d->B * 6 * d->N * d->N * d->Cout;
+    H.gscale = (float)(weight * 2.0 / n);
+    const unsigned grid = pw_grid(H.f.ngroups);
+    int pidx = -1;
+    if (prof_enabled()) {
+        Work wk = conv_work(d);
+        wk.flops *= 2.0;                                                        // forward + data gradient
+        wk.bytes = (double)d->B * 6 * d->N * d->N * (2.0 * 32 * 2 + d->Cout * (4.0 + 2.0));   // x, dx, target, dy
+        pidx = prof_begin("pw_head_train_kernel", wk.flops, wk.bytes, s);
+    }
+    if (d->Cout <= 16) hipLaunchKernelGGL((pw_head_train_kernel<1>), dim3(grid), dim3(256), 0, s, H);
+    else hipLaunchKernelGGL((pw_head_train_kernel<2>), dim3(grid), dim3(256), 0, s, H);
+    if (pidx >= 0) prof_end(pidx, s);
+    hipLaunchKernelGGL(head_stage2_kernel, dim3(1), dim3(256), 0, s, (const float *)scratch, loss_out, (int)grid,
+                       (float)(1.0 / n), weight, overwrite);
+    return check_launch("head_mse_step");
+}
+
 extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
                                const void *w_eq, const void *w_pol, const void *w_np,
                                const void *b_eq, const void *b_pol, const void *b_np,
@@ -2288,7 +2483,11 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
         const int pcap = (L.wg_pix + 15) & ~15;
         size_t lds = 2 * ((size_t)ct * P.tile_rows_max * P.W2 * 64 + (size_t)pcap * 64);
         grid.y = (unsigned)(CinP / (32 * ct));
-        if (lds < (WG_SCRATCH_FLOATS + 2048) * 4) lds = (WG_SCRATCH_FLOATS + 2048) * 4;   // reduction scratch + bias staging alias the buffers
+        {   // the epilogue's reduction slots + bias staging alias the buffers: 4 * (TAPS - TAPS / (4 / ct)) slots of 4 KB + 8 KB
+            const int nph = 4 / ct, rslots = TAPS - TAPS / nph;
+            const size_t need = ((size_t)4 * rslots * 1024 + 2048) * 4;
+            if (lds < need) lds = need;
+        }
         if (lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: LDS tile of %zu bytes exceeds 160 KiB", lds);
         if ((long)P.Nin * P.Nin >= (1l << 16))
             return fail(DLWPCS_E_UNSUPPORTED, "conv_bwd_weights: face size %d too large for the 16-bit index arithmetic", P.Nin);

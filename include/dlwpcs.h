@@ -278,6 +278,16 @@ int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float *loss_out, 
 /* TF2.1-keras Adam on flat fp32 buffers: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps).
  * `step_dev` points to a device int32 holding t-1 (incremented by the kernel), so the call is graph-capturable.
  * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+/* Fused training tail (bf16): pointwise output layer (k = 1, 32 -> even C_out in 8..32, Azure/train_cs.py:228) + 'mse' loss
+ * (+ 'mae') against the fp32 target + loss gradient dy (bf16, what the head's weight gradient reads) + the head's data
+ * gradient dx (bf16, (B,6,N,N,32)) in one pass: replaces dlwpcs_conv_fwd + dlwpcs_mse_fwd_bwd + dlwpcs_conv_bwd_data of the
+ * output layer; the prediction itself is not written.  wpk_fwd / bias_pk / wpk_bwd are dlwpcs_pack_batch outputs;
+ * loss_out[0] = weight * mse, loss_out[1] = mae (overwrite != 0: assigned, else added); scratch >= dlwpcs_head_mse_scratch_bytes(). */
+size_t dlwpcs_head_mse_scratch_bytes(void);
+int dlwpcs_head_mse_step(const dlwpcs_conv_desc *d, const void *x, const void *wpk_fwd, const void *bias_pk,
+                         const void *wpk_bwd, const float *target, float weight, void *dy, void *dx, float *loss_out,
+                         int overwrite, void *scratch, dlwpcs_stream_t stream);
+
 int dlwpcs_adam_step(float *p, const float *g, float *m, float *v, size_t n, int32_t *step_dev,
                      float lr, float beta1, float beta2, float eps, float grad_scale, dlwpcs_stream_t stream);
 /* Same update as one launch: `state_dev` points to TWO device int32 {t-1, 0}; the second is a ticket counter (must be 0

@@ -154,3 +154,41 @@ def test_mixed_precision_optimizer_switches_a_model_built_earlier():
     m2.compile(optimizer=Adam(), loss='mse')
     assert m2.compute_dtype == 'float32'
     assert orc is not None
+
+
+@pytest.mark.parametrize('cout,use_graphs', [(14, False), (14, True), (26, False), (8, False)])
+def test_fused_head_loss_step_equals_the_unfused_step(cout, use_graphs):
+    """dlwpcs_head_mse_step (output layer + mse/mae + dy + the layer's data gradient in one launch) against the three-launch
+    path: same dy / dx bits -> bitwise equal parameters after 3 Adam steps; loss and mae agree to fp32 summation order."""
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    backend.set_device('cuda:0')
+    rng = np.random.default_rng(17)
+    N, B = 8, 3
+    x = rng.standard_normal((B, 6, N, N, cout)).astype(np.float32)
+    t = rng.standard_normal((B, 6, N, N, cout)).astype(np.float32)
+    res = []
+    w0 = None
+    for fuse in (False, True):
+        backend.set_compute_dtype('bfloat16')
+        try:
+            np.random.seed(5)
+            model = build_cs_model((6, N, N, cout), cout, 'unet2', base_filter_number=32)
+        finally:
+            backend.set_compute_dtype('float32')
+        model.fuse_head_loss = fuse
+        model.use_graphs = use_graphs
+        model.compile(optimizer='adam', loss='mse', metrics=['mae'])
+        if w0 is None:
+            w0 = model.get_weights()
+        model.set_weights(w0)
+        dx = [to_dev(x).to(torch.bfloat16)]
+        dt = [to_dev(t)]
+        stats = None
+        for _ in range(3):
+            stats = model.train_on_device_batch(dx, dt)
+        torch.cuda.synchronize()
+        res.append((_flat(model), stats.cpu().numpy().copy()))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.allclose(res[0][1], res[1][1], rtol=1e-5)
+    assert res[1][1][0, 0] > 0 and res[1][1][0, 1] > 0
