@@ -96,7 +96,7 @@ def _cpu_model():
     return platform.processor() or 'unknown'
 
 
-def cpu_baseline(workload, N, c_in, c_out, base, batch, warmup=3, timed=10, budget_s=35.0):
+def cpu_baseline(workload, N, c_in, c_out, base, batch, warmup=3, timed=10, budget_s=25.0):
     """Reference-structured CPU port (oracle/cs_oracle.py), torch-CPU fp32, host cores of this box: >= 3 warm-up + >= 10
     timed steps at the benchmark's own batch size (fewer only if the time budget runs out), MEDIAN step time."""
     from oracle import cs_oracle as orc
@@ -143,6 +143,7 @@ def cpu_baseline(workload, N, c_in, c_out, base, batch, warmup=3, timed=10, budg
     for i in range(warmup):
         step(i + 2)
     times = []
+    t_start = time.perf_counter()          # the budget bounds the TIMED steps (tuning and warm-up above are a few steps)
     while len(times) < timed and (len(times) < 3 or time.perf_counter() - t_start < budget_s):
         t0 = time.perf_counter()
         step(len(times) + 2)
