@@ -13,6 +13,7 @@ Execution model (MI355X-first, replaces TF's graph executor):
   * a training step with static shapes is captured into a hipGraph (torch.cuda.CUDAGraph) after one eager warm-up step
     and replayed, so the ~150 kernel launches of a step cost one graph launch on the host.
 """
+import gc
 import json
 import os
 import time
@@ -465,14 +466,25 @@ class Model(object):
         # here for the first one: the step graph needs no fill launch
         self._flat_grads.zero_()
         self._grads_clean = True
-        with torch.cuda.graph(g1):
-            stats = self._loss_and_backward(static_in, static_tg, True)
-            if self._world == 1:        # no exchange step: the update rides in the same graph (no inter-graph gap)
-                self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
+        # No cyclic garbage collection while a stream is capturing: a collector pass that happens to run inside the capture
+        # would destroy whatever garbage it finds there (older models' graphs, pools, streams) through HIP calls that are
+        # not allowed during capture -- seen as a rare abort() of the process.  torch.cuda.graph collects once on entry.
+        gc_was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g1):
+                stats = self._loss_and_backward(static_in, static_tg, True)
+                if self._world == 1:    # no exchange step: the update rides in the same graph (no inter-graph gap)
+                    self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
+            if self._world == 1:
                 g2 = None
-        if g2 is not None:
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
+            else:
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
         entry = {'fwd_bwd': g1, 'update': g2, 'inputs': static_in, 'targets': static_tg, 'stats': stats,
                  'grad_scale': grad_scale}
         self._graphs[key] = entry

@@ -24,6 +24,7 @@
 //   - the MFMA runs as D[co][pixel] (weights = A operand), the epilogue (bias, activation, rounding) leaves through a
 //     wave-private LDS patch as whole-line stores; in data-gradient mode interior cells go straight to the sources.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace dlwpcs {
@@ -135,8 +136,7 @@ template <> struct MmaPerFrag<bf16_t> { static constexpr int N = 1; };
 //      half of the workgroup and the consumers wait for them at every barrier)
 //   2: forward / data-gradient kernel: the same for its producer waves
 //   4: forward / data-gradient kernel: weight fragments stay in LDS across tiles (see `wres` in the producer)
-//   8: bf16 forward / data-gradient kernel with TWO consumer teams (see conv_mfma_ws_kernel, TEAMS)
-enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_TEAMS = 8 };
+enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4 };
 static int tune_bits() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : TUNE_CONV_WEIGHTS_STAY; }
@@ -176,17 +176,18 @@ static int tune_bits() {
 // TAIL8 (bf16, VW = 8, one source): the source's channel count is even and >= 8 but not a multiple of 8 (14 = 7 variables
 // x 2 steps, 26 = 13 x 2).  Pixel rows are then only 4-B aligned; the vector that would run past the last channel is loaded
 // as the pixel's LAST 8 channels (in bounds) and shifted into place, instead of falling back to 4-B loads (7 / 13 per pixel).
-// TEAMS = 2: TWO teams of consumer waves (2 x WM*WN waves + WM*WN producer waves, three waves per SIMD) take the workgroup's
-// tiles alternately: while one team runs the MFMAs of its tile the other one runs the epilogue (bias, activation, rounding,
-// LDS patch, stores) of the tile it finished before, so the matrix cores no longer idle through every epilogue -- with one
-// team a 32 -> 32 channel tile cost the consumers 2.8 k cycles of MFMA phase + 3.0 k of epilogue + 0.8 k of set-up while
-// the producers needed ~4 k (s_memtime marks).  Every wave still executes ONE workgroup barrier per chunk: a team that does
-// not own the chunk's tile arrives at the tile's first barrier at once and spreads the remaining ones over its epilogue.
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false,
-          int TEAMS = 1>
-__global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P) {
+// Who sets the tile period (s_memtime marks, 32 -> 32 channels at N = 48, cycles per tile): the consumers used to, with 2.2 k
+// of MFMA phase + 3.1 k of epilogue + 0.8 k of set-up against ~4 k for the producers.  Two attempts to run the epilogue
+// BESIDE the next tile's MFMAs (a second team of consumer waves: three waves per SIMD = 168 VGPRs, spilled; the epilogue cut
+// into slices between the MFMAs of the same wave: hipcc hoists the slices' arithmetic into clumps, and the extra VALU work in
+// the MFMA phase slows the co-resident producer wave) both measured slower and are gone.  What worked was making the
+// epilogue itself cheap -- it is VALU-issue bound, sharing its SIMD with a producer wave: accumulators start at the bias,
+// the activation is one v_med3_f32, store addresses are per-(face, band) constants -- 1.75 k + 0.44 k cycles now -- and then
+// the producers' address arithmetic per load was cut to one multiply-add (see `sup`): the two sides are now balanced within
+// ~10 % (4.4 k consumer vs ~4.9 k producer cycles per tile).
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false>
+__global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P) {
     static_assert(!TAIL8 || (VW == 8 && sizeof(T) == 2 && !MASK), "TAIL8: bf16 16-B vectors, forward only");
-    static_assert(TEAMS == 1 || TEAMS == 2, "one or two consumer teams");
     constexpr int ES = sizeof(T);
     constexpr int CGW = 32 / ES;                    // channels per MFMA operand group (two 16-B half fragments)
     constexpr int TAPS = KS * KS;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
     constexpr int KCG = KC / CGW;
     constexpr int Q = KC / VW;
     constexpr int NTB = NT * WN;
-    constexpr int NCT = 64 * WM * WN;               // threads of one consumer team == producer threads
+    constexpr int NCT = 64 * WM * WN;               // consumer threads == producer threads
     constexpr int WF4 = NTB * KCG * TAPS * 64;      // 16-B entries per weight chunk
     constexpr int GF4 = TAPS * 64;
     constexpr int ITS = 3 * KC / VW;                // input vectors per producer thread per chunk (3*NCT pixels)
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
     const int buf_bytes = in_bytes + WF4 * 16;
 
     const int tid = threadIdx.x;
-    const bool is_producer = tid >= TEAMS * NCT;
+    const bool is_producer = tid >= NCT;
     const int nt0 = blockIdx.y * NTB;
     const int face_pix = P.No * P.No;
     const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
     const uint32_t lw = xcd_remap(blockIdx.x, (uint32_t)G);
     const int t_first = (int)(((long)P.ntiles * lw) / G), t_last = (int)(((long)P.ntiles * (lw + 1)) / G);
     struct Geo { int b, f, v, combo, m0, npix, y0, nitems; };
-    auto geo_of = [&](int t) {
+    auto geo_of = [&](int t) __attribute__((always_inline)) {
         Geo gq;
         gq.combo = P.magicB ? __umulhi((uint32_t)t, P.magicB) : t;                      // t / B   (magic 0 <=> divisor 1)
         gq.b = t - gq.combo * P.B;
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
 
     if (is_producer) {
         // =========================================== producers ===========================================
-        const int ptid = tid - TEAMS * NCT;
+        const int ptid = tid - NCT;
         const int qv = (ptid % Q) * VW;
         const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.wpk);
         if (t_first >= t_last) return;
@@ -266,8 +267,18 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
             const int xok = (vx >= 0) & (vx < P.Nin);
             slot_c[i] = (((ty - PADZ) * rstride + vx + OFF) << 6) | (xok << 5) | ty;
         }
-        // flat source index on the Nin grid (-1 = zero cell) of every item slot of a tile, all loads in flight at once
-        auto lookup = [&](const Geo &gq, int (&sidx)[ITS]) {
+        // flat source index on the Nin grid (-1 = zero cell) of every item slot of a tile, all loads in flight at once;
+        // full-vector kernels (SUP) also keep (as an offset) the pixel index on the nearest-upsampled source's own grid (row r = face*Nin + y
+        // of the Nin grid -> row r/2 = face*g0 + y/2 of the Nin/2 grid, Nin = 2*g0 even; column x -> x/2), so that issuing a
+        // chunk's loads costs one multiply-add per vector
+        constexpr bool SUP = VW * ES == 16 && !MASK;     // (the act' mask's second load stream leaves no registers)
+        int sidx[ITS];
+        int sup[SUP ? ITS : 1];
+        auto upmap = [&](int ii) __attribute__((always_inline)) {
+            const int r = __umulhi((uint32_t)ii, P.magicN);
+            return (r >> 1) * g0 + ((ii - r * P.Nin) >> 1);
+        };
+        auto lookup = [&](const Geo &gq) __attribute__((always_inline)) {
             const int base = (gq.f * rstride + gq.y0) * rstride - OFF;
 #pragma unroll
             for (int i = 0; i < ITS; ++i) {
@@ -285,8 +296,13 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
                 }
                 sidx[i] = live ? v0 : -1;
             }
+            if constexpr (SUP) {
+                // kept as the DIFFERENCE to sidx: `up ? sup[i] : sidx[i]` becomes a select of two stack addresses in LLVM and
+                // sends both arrays (and the kernel arguments with them) to scratch memory
+#pragma unroll
+                for (int i = 0; i < ITS; ++i) sup[i] = sidx[i] >= 0 ? upmap(sidx[i]) - sidx[i] : 0;
+            }
         };
-        int sidx[ITS];
         int g = 0;
         // Weight-stationary LDS: the weight fragments of (face variant, chunk) are the same for every tile, and consecutive
         // tiles of a workgroup are the same (face, band) in consecutive samples.  wres[b] = what buffer b's weight area holds;
@@ -296,30 +312,33 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
         // CU's load path, which is what bounds these kernels -- ~10 B/clk/CU -- not the matrix cores.)
         int wres[2] = {-1, -1};
 
-        // one chunk: weights + input tile -> LDS, straight-line
-        auto fill = [&](const Geo &gc, int ch) {
+        // per-thread constants of a chunk: source, channel offset inside it, TAIL8 shift
+        auto chunk_src = [&](const Geo &gc, int ch, const T *&sb, int &cstride, int &cs_ld, int &sh, bool &c_ok, bool &up)
+            __attribute__((always_inline)) {
+            const T *s0b = reinterpret_cast<const T *>(P.src0) + (size_t)gc.b * 6 * g0 * g0 * P.C0;
+            const T *s1b = P.C1 > 0 ? reinterpret_cast<const T *>(P.src1) + (size_t)gc.b * 6 * P.Nin * P.Nin * P.C1 : s0b;
+            const int c = ch * KC + qv;
+            c_ok = c < P.Cin;
+            const bool from0 = c < P.C0;
+            sb = from0 ? s0b : s1b;
+            const int cs = from0 ? c : c - P.C0;              // channel inside the chosen source
+            cstride = from0 ? P.C0 : P.C1;
+            up = from0 && P.up0;
+            cs_ld = cs; sh = 0;
+            if constexpr (TAIL8) {
+                if (c_ok && cs + 8 > cstride) { sh = (cs + 8 - cstride) >> 1; cs_ld = cstride - 8; }
+            }
+        };
+        // issue(): (rarely) the weight fragments -> LDS buffer g & 1, then every load of the chunk's input tile, back to back
+        auto issue = [&](const Geo &gc, int ch, V (&val)[ITS], V (&ymv)[MASK ? ITS : 1], uint32_t &okm) __attribute__((always_inline)) {
             char *buf = smem + (g & 1) * buf_bytes;
             const int wkey = gc.v * 1024 + ch;
             const bool need_w = !(P.tune & TUNE_CONV_WEIGHTS_STAY) || wres[g & 1] != wkey;
             wres[g & 1] = wkey;
-            const T *s0b = reinterpret_cast<const T *>(P.src0) + (size_t)gc.b * 6 * g0 * g0 * P.C0;
-            const T *s1b = P.C1 > 0 ? reinterpret_cast<const T *>(P.src1) + (size_t)gc.b * 6 * P.Nin * P.Nin * P.C1 : s0b;
-            const T *ymb = MASK ? reinterpret_cast<const T *>(P.ymask) + (size_t)gc.b * 6 * g0 * g0 * P.C0 : nullptr;
-            const int c = ch * KC + qv;
-            const bool c_ok = c < P.Cin;
-            const bool from0 = c < P.C0;
-            const T *sb = from0 ? s0b : s1b;
-            const int cs = from0 ? c : c - P.C0;              // channel inside the chosen source
-            const int cstride = from0 ? P.C0 : P.C1;
-            const bool up = from0 && P.up0;
-            int cs_ld = cs, sh = 0;                     // TAIL8: per-thread constants of this chunk
-            if constexpr (TAIL8) {
-                if (c_ok && cs + 8 > cstride) { sh = (cs + 8 - cstride) >> 1; cs_ld = cstride - 8; }
-            }
-            PL_MARK();
             if (need_w) {
-                // uniform and rare (weights stay): the fragments are fetched and written in a block of their own, so their
-                // registers are free again before the input vectors are loaded (the two-team build has 168 VGPRs per wave)
+                // uniform and rare (weights stay): the fragments are fetched and written in a block of their own, all loads in
+                // flight at once (fetching them four at a time cost 2-3 serial L2 round trips on each workgroup's first tiles:
+                // +5 % on the whole training step)
                 uint4 wv[ITW];
 #pragma unroll
                 for (int u = 0; u < ITW; ++u) {
@@ -336,27 +355,32 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
                     if (idx < WF4) reinterpret_cast<uint4 *>(buf + in_bytes)[idx] = wv[u];
                 }
             }
-            V val[ITS];
-            V ymv[MASK ? ITS : 1];
-            bool okv[ITS];
+            const T *sb; int cstride, cs_ld, sh; bool c_ok, up;
+            chunk_src(gc, ch, sb, cstride, cs_ld, sh, c_ok, up);
+            const T *ymb = MASK ? reinterpret_cast<const T *>(P.ymask) + (size_t)gc.b * 6 * g0 * g0 * P.C0 : nullptr;
+            PL_MARK();
+            okm = 0;
 #pragma unroll
             for (int i = 0; i < ITS; ++i) {
-                const int idx = sidx[i];
+                int idx = sidx[i];
+                if constexpr (SUP) idx += up ? sup[i] : 0;
                 const bool ok = c_ok && idx >= 0;
-                const int ii = ok ? idx : 0;
-                // nearest-upsampled source: row r = face*Nin + y of the Nin grid -> row r/2 = face*g0 + y/2 of the Nin/2 grid
-                // (Nin = 2*g0 is even), column x -> x/2
-                const int r = __umulhi((uint32_t)ii, P.magicN);
-                const int pix_up = (r >> 1) * g0 + ((ii - r * P.Nin) >> 1);
-                const int pix = up ? pix_up : ii;
+                int pix = ok ? idx : 0;
+                if constexpr (!SUP) pix = up ? upmap(pix) : pix;
                 const size_t oo = ok ? (size_t)pix * cstride + cs_ld : 0;
                 if constexpr (TAIL8) val[i] = *reinterpret_cast<const uint4_a4 *>(sb + oo);
                 else val[i] = *reinterpret_cast<const V *>(sb + oo);
                 if (MASK) ymv[i] = *reinterpret_cast<const V *>(ymb + oo);
-                okv[i] = ok;
+                okm |= (uint32_t)ok << i;
             }
             PL_MARK();
+        };
+        // commit(): the loaded vectors -> LDS buffer g & 1, barrier B_g
+        auto commit = [&](const Geo &gc, int ch, V (&val)[ITS], V (&ymv)[MASK ? ITS : 1], uint32_t okm) __attribute__((always_inline)) {
+            char *buf = smem + (g & 1) * buf_bytes;
             if constexpr (TAIL8) {
+                const T *sb; int cstride, cs_ld, sh; bool c_ok, up;
+                chunk_src(gc, ch, sb, cstride, cs_ld, sh, c_ok, up);
                 if (sh) {
 #pragma unroll
                     for (int i = 0; i < ITS; ++i) val[i] = vshl_dwords(val[i], sh);
@@ -370,31 +394,43 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
 #pragma unroll
             for (int i = 0; i < ITS; ++i) {
                 const int e = ptid + i * NCT;
-                if (e < gc.nitems) *reinterpret_cast<V *>(buf + (e / Q) * RB + qv * ES) = vsel(okv[i], val[i]);
+                if (e < gc.nitems) *reinterpret_cast<V *>(buf + (e / Q) * RB + qv * ES) = vsel(((okm >> i) & 1u) != 0, val[i]);
             }
             PL_MARK();
             __syncthreads();            // B_g: chunk g is in LDS
             ++g;
         };
 
+        // (Measured negative: issuing the loads of chunk g+1 BEFORE chunk g is written to LDS -- two register sets, one chunk
+        // ahead -- hides the 1.2-1.9 k cycles a producer waits for its loads, but its LDS writes then land in the consumers'
+        // MFMA phase, whose fragment reads slow down by more than was gained: 2.2 k -> 3.0 k cycles per tile at 32 -> 32
+        // channels, 0.936 -> 1.02 ms per training step.)
         int cur_combo = -1;
+        V val[ITS], ymv[MASK ? ITS : 1];
+        uint32_t okm = 0;
         for (int t = t_first; t < t_last; ++t) {
             const Geo gq = geo_of(t);
-            if (gq.combo != cur_combo) { lookup(gq, sidx); cur_combo = gq.combo; }      // uniform; a few times per workgroup
-            for (int ch = 0; ch < nchunks; ++ch) fill(gq, ch);
+            if (gq.combo != cur_combo) { lookup(gq); cur_combo = gq.combo; }        // uniform; a few times per workgroup
+            for (int ch = 0; ch < nchunks; ++ch) {
+                issue(gq, ch, val, ymv, okm);
+                commit(gq, ch, val, ymv, okm);
+            }
         }
         return;
     }
 
     // ============================================= consumers =============================================
-    const int team = tid / NCT, ctid = tid - team * NCT;            // consumer team of this wave; thread inside the team
-    const int lane = ctid & 63, wave = ctid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
     // NOTE: no s_setprio(1) here: a prioritised wave waiting for the busy matrix pipe still wins its SIMD's issue
     // arbitration and starves the co-resident producer wave's address arithmetic.
 
     f32x16 acc[MT][NT];
+    constexpr int LPP = 32 * ES / 16;           // epilogue: lanes per pixel on the way out (16 B each): 8 fp32 / 4 bf16
+    constexpr int PPP = 64 / LPP;               // pixels per store pass
+    constexpr int NPS = 32 / PPP;               // store passes per M tile
+    constexpr bool DIRECT = MODE == MODE_ZERO && KS == 3;   // data gradient: interior cells go straight to the sources
     int g = 0;
 #ifdef DLWPCS_TIMELINE
     int tli = 0;
@@ -402,12 +438,42 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
 #endif
     TL_MARK();
     int abase[MT];
-    int cur_combo = -1;
+    int cur_combo = -1, cur_v = -1;
     float4 bq[NT][4];
+    // store pass (nt, mt, ps) of this lane: element offset of its 16 B inside ONE sample of the destination (-1: nothing to
+    // store) and, data gradient in direct mode, which destination (2 bits each: 0 = out, 1 = d0, 2 = d1).  Like the LDS
+    // addresses they depend on the (face, band) only, not on the sample.
+    // (SOFF: kept in registers when there are at most 12 passes; the MT = 5 tilings recompute them per store)
+    constexpr bool SOFF = NT * MT * NPS <= 12;
+    int soff[SOFF ? NT : 1][SOFF ? MT : 1][SOFF ? NPS : 1];
+    uint32_t ssel = 0;
+    auto store_off = [&](const Geo &gq, int nt, int mt, int ps, uint32_t &sel) __attribute__((always_inline)) {
+        const int px = ps * PPP + lane / LPP, q = lane % LPP;
+        const int mm = (wm * MT + mt) * 32 + px;
+        const int c = (nt0 + wn * NT + nt) * 32 + q * (16 / ES);
+        const int gm = gq.m0 + mm;
+        int off = (gq.f * face_pix + gm) * P.Cout + c;
+        sel = 0;
+        if constexpr (DIRECT) {
+            // direct mode: an interior cell of the padded gradient IS cell (oy-1, ox-1) of the source
+            const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
+            const int Ns = P.No - 2;
+            const bool in0 = c < P.dsplit;
+            const bool have = (in0 ? P.d0 : P.d1) != nullptr;
+            const int cs = in0 ? c : c - P.dsplit, CS = in0 ? P.dsplit : P.Cout - P.dsplit;
+            const bool interior = ((uint32_t)(oy - 1) < (uint32_t)Ns) & ((uint32_t)(ox - 1) < (uint32_t)Ns);
+            if (interior && have) {
+                off = ((gq.f * Ns + (oy - 1)) * Ns + (ox - 1)) * CS + cs;
+                sel = in0 ? 1u : 2u;
+            }
+        }
+        return (mm < gq.npix && c < P.Cout) ? off : -1;
+    };
 
-    // ---- per-tile set-up: LDS addresses (rebuilt at (face, band) changes), zero accumulators, this tile's bias quads
+    // ---- per-tile set-up: LDS addresses and store offsets (rebuilt at (face, band) changes), bias quads (reloaded at face
+    // variant changes), accumulators = bias
     auto setup = [&](const Geo &gq) {
-        if (gq.combo != cur_combo) {            // LDS addresses of this lane's pixels: the same for every sample of a combo
+        if (gq.combo != cur_combo) {            // uniform; the same for every sample of a combo
             cur_combo = gq.combo;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -421,32 +487,171 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
                 }
                 abase[mt] = base + half * 16;
             }
+            if constexpr (SOFF) {
+                ssel = 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int ps = 0; ps < NPS; ++ps) {
+                            uint32_t sel;
+                            soff[nt][mt][ps] = store_off(gq, nt, mt, ps, sel);
+                            ssel |= sel << (2 * ((nt * MT + mt) * NPS + ps));
+                        }
+            }
         }
+        // the bias quads of the face variant (the packed bias vector is zero-padded to NTtot*32 floats, so every quad is
+        // readable; an N tile beyond C_out -- NTtot not a multiple of the workgroup's N tiles -- re-reads the last tile's)
+        if (gq.v != cur_v) {
+            cur_v = gq.v;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq)
+                    bq[nt][jq] = P.bias ? *reinterpret_cast<const float4 *>(P.bias + (size_t)gq.v * P.NTtot * 32 +
+                                                                             min(nt0 + wn * NT + nt, P.NTtot - 1) * 32 + 8 * jq + 4 * half)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // the accumulators start at the bias (row = output channel in the MFMA's D[co][pixel] layout): no add in the epilogue
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-        // this tile's bias quads (face variant gq.v): issued here so that the latency is covered by the chunk loop.
-        // (The packed bias vector is zero-padded to NTtot*32 floats, so every quad is readable.)
+                for (int jq = 0; jq < 4; ++jq) {
+                    acc[mt][nt][4 * jq] = bq[nt][jq].x; acc[mt][nt][4 * jq + 1] = bq[nt][jq].y;
+                    acc[mt][nt][4 * jq + 2] = bq[nt][jq].z; acc[mt][nt][4 * jq + 3] = bq[nt][jq].w;
+                }
+    };
+
+    // ---- tile epilogue: bias + activation + stores.  The MFMA ran as D[co][pixel] (weights as the A operand), so in
+    // the C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) a lane owns ONE pixel and, per r>>2, FOUR
+    // CONSECUTIVE output channels.  Storing those quads directly costs one L2 write request per lane and quad (8 per
+    // 64-B line; measured: ~1 request/clk/CU, 3 k of a 5 k-cycle epilogue), so each M tile goes through a wave-private
+    // LDS patch [32 pixels][32 channels + 16 B pad] instead: 4 quad writes per lane in, 16 B per lane out with the
+    // lanes of a pixel contiguous -> every store instruction writes whole lines.  No fence: the LDS executes one wave's
+    // instructions in order; wave_barrier only pins the compiler's schedule (a release fence here waits vmcnt(0),
+    // i.e. for the previous stores to land -- that was the cost of the first LDS epilogue).
+    //
+    // Per (n tile, m tile) pair: 4 x "one quad -> patch" then NPS x "one store pass out of the patch" (epi_slice, called
+    // with compile-time-constant i from a fully unrolled loop).
+    constexpr int PROW = 32 * ES + 16;          // patch row: one pixel's 32 channels + pad
+    constexpr int SPP = 4 + NPS;                // slices per (n tile, m tile) pair
+    constexpr int NSLICE = NT * MT * SPP;
+    char *const patch = smem + 2 * buf_bytes + wave * (32 * PROW);
+    // no activation == ReLU(alpha = 1, max = +inf): the epilogue applies the activation unconditionally and stays
+    // straight-line (a branch per quad chops it into 5-instruction blocks whose dependent chains cannot interleave).
+    // FAST (0 <= alpha <= 1, max > 0, i.e. every activation of the reference's models and "none"): the activation is
+    // med3(x, alpha*x, max) -- 1.5 VALU instructions per value instead of 3.5 (min, compare, select, half a packed multiply);
+    // the consumers' epilogue is VALU-issue bound.  (A NaN comes out as `max` on this path: v_med3_f32 returns min3 then.)
+    const float e_alpha = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.alpha : 1.f;
+    const float e_vmax = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.vmax : __builtin_inff();
+    const bool fast_act = e_alpha >= 0.f && e_alpha <= 1.f && e_vmax > 0.f;
+    auto quad = [&](auto fast_tag, const f32x16 &a, int jq) {
+        float4 v4 = make_float4(a[4 * jq], a[4 * jq + 1], a[4 * jq + 2], a[4 * jq + 3]);
+        if constexpr (decltype(fast_tag)::value) {
+            v4.x = __builtin_amdgcn_fmed3f(v4.x, e_alpha * v4.x, e_vmax); v4.y = __builtin_amdgcn_fmed3f(v4.y, e_alpha * v4.y, e_vmax);
+            v4.z = __builtin_amdgcn_fmed3f(v4.z, e_alpha * v4.z, e_vmax); v4.w = __builtin_amdgcn_fmed3f(v4.w, e_alpha * v4.w, e_vmax);
+        } else {
+            v4.x = act_leaky_clip(v4.x, e_alpha, e_vmax); v4.y = act_leaky_clip(v4.y, e_alpha, e_vmax);
+            v4.z = act_leaky_clip(v4.z, e_alpha, e_vmax); v4.w = act_leaky_clip(v4.w, e_alpha, e_vmax);
+        }
+        return v4;
+    };
+    // per-sample bases of the destinations (uniform; plain scalars -- a struct of pointers handed through the lambdas ended
+    // up in scratch memory)
+    auto out_of = [&](const Geo &gq) { return reinterpret_cast<T *>(P.out) + (size_t)gq.b * 6 * face_pix * P.Cout; };
+    auto d0_of = [&](const Geo &gq) {
+        return reinterpret_cast<T *>(P.d0) + (size_t)gq.b * 6 * (P.No - 2) * (P.No - 2) * P.dsplit;
+    };
+    auto d1_of = [&](const Geo &gq) {
+        return reinterpret_cast<T *>(P.d1) + (size_t)gq.b * 6 * (P.No - 2) * (P.No - 2) * (P.Cout - P.dsplit);
+    };
+    auto epi_slice = [&](auto fast_tag, int i, const Geo &gq, T *d_out, T *d_0, T *d_1, const auto &A) {
+        const int pr = i / SPP, k = i % SPP;
+        const int nt = pr / MT, mt = pr % MT;
+        if (k < 4) {
+            const float4 v4 = quad(fast_tag, A[mt][nt], k);
+            char *pp = patch + l31 * PROW + (8 * k + 4 * half) * ES;
+            if constexpr (ES == 4) *reinterpret_cast<float4 *>(pp) = v4;
+            else *reinterpret_cast<uint2 *>(pp) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
+            if (k == 3) __builtin_amdgcn_wave_barrier();
+        } else {
+            const int ps = k - 4;
+            const int px = ps * PPP + lane / LPP, q = lane % LPP;
+            const uint4 v = *reinterpret_cast<const uint4 *>(patch + px * PROW + q * 16);
+            int off;
+            uint32_t sel;
+            if constexpr (SOFF) { off = soff[nt][mt][ps]; sel = (ssel >> (2 * ((nt * MT + mt) * NPS + ps))) & 3u; }
+            else off = store_off(gq, nt, mt, ps, sel);
+            bool live = off >= 0;
+#ifdef DLWPCS_TIMELINE
+            if (P.abl & 1) live = false;            // ablation: no global stores
+#endif
+            T *base = d_out;
+            if constexpr (DIRECT) base = sel == 0 ? d_out : (sel == 1 ? d_0 : d_1);
+            if (live) *reinterpret_cast<uint4 *>(base + off) = v;
+            if (ps == NPS - 1) __builtin_amdgcn_wave_barrier();
+        }
+    };
+    auto epilogue_lines = [&](const Geo &gq, const auto &A) {
+        TL_MARK();
+        T *const d_out = out_of(gq);
+        T *const d_0 = DIRECT ? d0_of(gq) : nullptr, *const d_1 = DIRECT ? d1_of(gq) : nullptr;
+        if (fast_act) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int i = 0; i < NSLICE; ++i) epi_slice(std::true_type{}, i, gq, d_out, d_0, d_1, A);
+        } else {
 #pragma unroll
-            for (int jq = 0; jq < 4; ++jq)
-                // (an N tile beyond C_out -- NTtot not a multiple of the workgroup's N tiles -- re-reads the last tile's quads)
-                bq[nt][jq] = P.bias ? *reinterpret_cast<const float4 *>(P.bias + (size_t)gq.v * P.NTtot * 32 +
-                                                                         min(nt0 + wn * NT + nt, P.NTtot - 1) * 32 + 8 * jq + 4 * half)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < NSLICE; ++i) epi_slice(std::false_type{}, i, gq, d_out, d_0, d_1, A);
+        }
+        TL_MARK();
+    };
+    // fallback (odd channel counts, or no LDS room for the patches): quads / scalars straight from the accumulators
+    auto epilogue_plain = [&](const Geo &gq) {
+        TL_MARK();
+        T *outp = reinterpret_cast<T *>(P.out) + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
+        const bool wide = (P.Cout & 3) == 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cot = (nt0 + wn * NT + nt) * 32;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = (wm * MT + mt) * 32 + l31;
+                T *dst = outp + (size_t)(gq.m0 + m) * P.Cout + cot + 4 * half;
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq) {
+                    const int co = cot + 8 * jq + 4 * half;
+                    const float4 v4 = quad(std::false_type{}, acc[mt][nt], jq);
+                    if (m >= gq.npix) continue;
+                    if (wide) {
+                        if (co < P.Cout) {
+                            if constexpr (ES == 4) *reinterpret_cast<float4 *>(dst + 8 * jq) = v4;
+                            else *reinterpret_cast<uint2 *>(dst + 8 * jq) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
+                        }
+                    } else {
+                        const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (co + u < P.Cout) {
+                                if constexpr (ES == 4) dst[8 * jq + u] = vs[u];
+                                else dst[8 * jq + u] = f2bf(vs[u]);
+                            }
+                    }
+                }
+            }
+        }
+        TL_MARK();
     };
 
     // ---- one chunk of MFMAs out of LDS buffer g & 1 (between two barriers: fragment reads + MFMAs only)
+    // Explicit two-register-set pipeline over the (channel group, tap) steps: the fragments of step s+1 are read from LDS
+    // BEFORE the MFMAs of step s are issued (left alone, the compiler reuses one register set and stalls on lgkmcnt after
+    // every step).
+    constexpr int NSTEP = KCG * TAPS;
     auto mma_chunk = [&]() {
         const char *lds_in = smem + (g & 1) * buf_bytes, *lds_w = lds_in + in_bytes;
-        // Explicit two-register-set pipeline over the (channel group, tap) steps: the fragments of step s+1 are
-        // read from LDS BEFORE the MFMAs of step s are issued (left alone, the compiler reuses one register set
-        // and stalls on lgkmcnt after every step).
-        constexpr int NSTEP = KCG * TAPS;
         uint4 fa[2][MT], fb[2][NT];
         auto load_frag = [&](int step, uint4 (&a)[MT], uint4 (&bw)[NT]) {
             const int cgl = step / TAPS, tap = step % TAPS;
@@ -473,150 +678,19 @@ __global__ void __launch_bounds__((1 + TEAMS) * 64 * WM * WN) conv_mfma_ws_kerne
         }
     };
 
-    // ---- tile epilogue: bias + activation + stores.  The MFMA ran as D[co][pixel] (weights as the A operand), so in
-    // the C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) a lane owns ONE pixel and, per r>>2, FOUR
-    // CONSECUTIVE output channels.  Storing those quads directly costs one L2 write request per lane and quad (8 per
-    // 64-B line; measured: ~1 request/clk/CU, 3 k of a 5 k-cycle epilogue), so each M tile goes through a wave-private
-    // LDS patch [32 pixels][32 channels + 16 B pad] instead: 4 quad writes per lane in, 16 B per lane out with the
-    // lanes of a pixel contiguous -> every store instruction writes whole lines.  No fence: the LDS executes one wave's
-    // instructions in order; wave_barrier only pins the compiler's schedule (a release fence here waits vmcnt(0),
-    // i.e. for the previous stores to land -- that was the cost of the first LDS epilogue).
-    // `nbar` workgroup barriers are spread evenly over the (n tile, m tile) pairs: a team running this epilogue beside the other
-    // team's tile owes one barrier per chunk of that tile (TEAMS = 2); 0 for an epilogue inside the team's own interval.
-    auto epilogue = [&](const Geo &gq, int nbar) {
-        TL_MARK();
-        T *outp = reinterpret_cast<T *>(P.out) + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
-        constexpr int PROW = 32 * ES + 16;          // patch row: one pixel's 32 channels + pad
-        constexpr int LPP = 32 * ES / 16;           // lanes per pixel on the way out (16 B each): 8 fp32 / 4 bf16
-        constexpr int PPP = 64 / LPP;               // pixels per store pass
-        constexpr int NPAIR = NT * MT;
-        char *patch = smem + 2 * buf_bytes + (team * WM * WN + wave) * (32 * PROW);
-        const bool lines = P.patches && (P.Cout % (16 / ES)) == 0;
-        const bool wide = (P.Cout & 3) == 0;
-        // no activation == ReLU(alpha = 1, max = +inf): the epilogue applies the activation unconditionally and stays
-        // straight-line (a branch per quad chops it into 5-instruction blocks whose dependent chains cannot interleave)
-        const float e_alpha = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.alpha : 1.f;
-        const float e_vmax = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.vmax : __builtin_inff();
-        int placed = 0;
-        auto owe = [&](int pair_done) {             // barriers due after `pair_done` of the NPAIR pairs
-            if (TEAMS > 1) {
-                const int want = (pair_done * nbar) / NPAIR;
-                while (placed < want) { __syncthreads(); ++placed; }
-            }
-        };
-        auto quad = [&](int mt, int nt, int jq) {
-            float4 v4 = make_float4(acc[mt][nt][4 * jq] + bq[nt][jq].x, acc[mt][nt][4 * jq + 1] + bq[nt][jq].y,
-                                    acc[mt][nt][4 * jq + 2] + bq[nt][jq].z, acc[mt][nt][4 * jq + 3] + bq[nt][jq].w);
-            v4.x = act_leaky_clip(v4.x, e_alpha, e_vmax); v4.y = act_leaky_clip(v4.y, e_alpha, e_vmax);
-            v4.z = act_leaky_clip(v4.z, e_alpha, e_vmax); v4.w = act_leaky_clip(v4.w, e_alpha, e_vmax);
-            return v4;
-        };
-        if (lines) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int cot = (nt0 + wn * NT + nt) * 32;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                    for (int jq = 0; jq < 4; ++jq) {
-                        const float4 v4 = quad(mt, nt, jq);
-                        char *pp = patch + l31 * PROW + (8 * jq + 4 * half) * ES;
-                        if constexpr (ES == 4) *reinterpret_cast<float4 *>(pp) = v4;
-                        else *reinterpret_cast<uint2 *>(pp) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
-                    }
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int ps = 0; ps < 32 / PPP; ++ps) {
-                        const int px = ps * PPP + lane / LPP, q = lane % LPP;
-                        const uint4 v = *reinterpret_cast<const uint4 *>(patch + px * PROW + q * 16);
-                        const int mm = (wm * MT + mt) * 32 + px;
-                        const int c = cot + q * (16 / ES);
-#ifdef DLWPCS_TIMELINE
-                        if (P.abl & 1) continue;            // ablation: no global stores
-#endif
-                        if (mm < gq.npix && c < P.Cout) {
-                            T *dst = outp + (size_t)(gq.m0 + mm) * P.Cout + c;
-                            if constexpr (MODE == MODE_ZERO && KS == 3) {
-                                // direct mode: an interior cell of the padded gradient IS cell (oy-1, ox-1) of the source
-                                const int gm = gq.m0 + mm;
-                                const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
-                                const int Ns = P.No - 2;
-                                const bool in0 = c < P.dsplit;
-                                T *sbase = reinterpret_cast<T *>(in0 ? P.d0 : P.d1);
-                                const int cs = in0 ? c : c - P.dsplit, CS = in0 ? P.dsplit : P.Cout - P.dsplit;
-                                const bool interior = ((uint32_t)(oy - 1) < (uint32_t)Ns) & ((uint32_t)(ox - 1) < (uint32_t)Ns);
-                                T *direct = sbase + ((((size_t)gq.b * 6 + gq.f) * Ns + (oy - 1)) * Ns + (ox - 1)) * CS + cs;
-                                dst = (interior && sbase != nullptr) ? direct : dst;
-                            }
-                            *reinterpret_cast<uint4 *>(dst) = v;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    owe(nt * MT + mt + 1);
-                }
-            }
-        } else {
-            // fallback (odd channel counts, or no LDS room for the patches): quads / scalars straight from the accumulators
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int cot = (nt0 + wn * NT + nt) * 32;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int m = (wm * MT + mt) * 32 + l31;
-                    T *dst = outp + (size_t)(gq.m0 + m) * P.Cout + cot + 4 * half;
-#pragma unroll
-                    for (int jq = 0; jq < 4; ++jq) {
-                        const int co = cot + 8 * jq + 4 * half;
-                        const float4 v4 = quad(mt, nt, jq);
-                        if (m >= gq.npix) continue;
-                        if (wide) {
-                            if (co < P.Cout) {
-                                if constexpr (ES == 4) *reinterpret_cast<float4 *>(dst + 8 * jq) = v4;
-                                else *reinterpret_cast<uint2 *>(dst + 8 * jq) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
-                            }
-                        } else {
-                            const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (co + u < P.Cout) {
-                                    if constexpr (ES == 4) dst[8 * jq + u] = vs[u];
-                                    else dst[8 * jq + u] = f2bf(vs[u]);
-                                }
-                        }
-                    }
-                    owe(nt * MT + mt + 1);
-                }
-            }
-        }
-        owe(NPAIR);
-        TL_MARK();
-    };
-
-    Geo pend{};
-    bool pending = false;
+    const bool lines = P.patches && (P.Cout % (16 / ES)) == 0;
     for (int t = t_first; t < t_last; ++t) {
-        const bool own = TEAMS == 1 || ((t - t_first) & (TEAMS - 1)) == team;
-        if (own) {
-            const Geo gq = geo_of(t);
-            setup(gq);
-            for (int ch = 0; ch < nchunks; ++ch, ++g) {
-                TL_MARK();
-                __syncthreads();                // B_g: chunk g has been written by the producers
-                TL_MARK();
-                mma_chunk();
-            }
-            if (TEAMS == 1) epilogue(gq, 0);
-            else { pend = gq; pending = true; }
-        } else {
-            // the other team's tile: arrive at its first barrier at once (it releases that team's MFMAs), then finish the
-            // tile computed before while paying the remaining nchunks - 1 barriers
-            __syncthreads();
-            if (pending) { epilogue(pend, nchunks - 1); pending = false; }
-            else for (int ch = 1; ch < nchunks; ++ch) __syncthreads();
-            g += nchunks;
+        const Geo gq = geo_of(t);
+        setup(gq);
+        for (int ch = 0; ch < nchunks; ++ch, ++g) {
+            TL_MARK();
+            __syncthreads();                // B_g: chunk g has been written by the producers
+            TL_MARK();
+            mma_chunk();
         }
+        if (lines) epilogue_lines(gq, acc);
+        else epilogue_plain(gq);
     }
-    if (TEAMS > 1 && pending) epilogue(pend, 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1933,8 +2007,7 @@ template <typename T> struct TName;
 template <> struct TName<float> { static const char *str() { return "float"; } };
 template <> struct TName<bf16_t> { static const char *str() { return "unsigned short"; } };
 
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false,
-          int TEAMS = 1>
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false>
 static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     constexpr int ES = sizeof(T), CGW = 32 / ES;
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
@@ -1957,7 +2030,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     { const char *e = getenv("DLWPCS_ABL"); P.abl = e ? atoi(e) : 0; }
 #endif
     const size_t buf = (size_t)P.tile_rows_max * P.W2 * (KC * ES + 16) + (size_t)NTB * (KC / CGW) * KS * KS * 1024;
-    size_t lds = 2 * buf + (size_t)(TEAMS * WM * WN) * 32 * (32 * ES + 16);    // + wave-private epilogue patches
+    size_t lds = 2 * buf + (size_t)(WM * WN) * 32 * (32 * ES + 16);    // + wave-private epilogue patches
     P.patches = 1;
     if (lds > 160 * 1024) { lds = 2 * buf; P.patches = 0; }                     // large faces: direct quad stores instead
     if (MODE == MODE_ZERO && KS == 3 && P.patches && P.Cout % (16 / ES) == 0 && P.dsplit % (16 / ES) == 0) {
@@ -1971,9 +2044,12 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
         return fail(DLWPCS_E_UNSUPPORTED, "conv: %d tile rows exceed the producers' 5-bit row field", P.tile_rows_max);
     if ((size_t)P.tile_rows_max * P.W2 > (size_t)3 * NTHREADS)
         return fail(DLWPCS_E_UNSUPPORTED, "conv: tile of %d x %d pixels exceeds the producers' register capacity", P.tile_rows_max, P.W2);
+    if ((long)6 * face_pix * P.Cout >= (1l << 31))
+        return fail(DLWPCS_E_UNSUPPORTED, "conv: one sample of the output (%ld elements) exceeds the 32-bit store offsets",
+                    (long)6 * face_pix * P.Cout);
     if ((long)P.Nin * P.Nin * 6 >= (1l << 16) * 6 && (long)P.Nin * P.Nin >= (1l << 16))
         return fail(DLWPCS_E_UNSUPPORTED, "conv: face size %d too large for the 16-bit index arithmetic", P.Nin);
-    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8, TEAMS>;
+    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1984,11 +2060,11 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     int pidx = -1;
     if (prof_enabled()) {
         char tag[160];
-        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %d>", TName<T>::str(), KS, KC,
-                 MT, NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? "true" : "false", TEAMS);
+        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s>", TName<T>::str(), KS, KC,
+                 MT, NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? "true" : "false");
         pidx = prof_begin(tag, W.flops, W.bytes, s);
     }
-    hipLaunchKernelGGL(kern, grid, dim3((1 + TEAMS) * NTHREADS), lds, s, P);
+    hipLaunchKernelGGL(kern, grid, dim3(2 * NTHREADS), lds, s, P);
     if (pidx >= 0) prof_end(pidx, s);
     return check_launch("conv_mfma");
 }
@@ -2004,14 +2080,6 @@ static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
     else {
         // Measured (MI355X, batch 32): the smaller tiles (MT = 2 / MT = 1) that would even out the tile count per CU
         // lose more to halo re-staging (the producers become the bottleneck) than they gain -> fixed MT = 3 tilings.
-        // bf16: two consumer teams (epilogue of tile t beside the MFMAs of tile t+1) on the MT = 3 tilings
-        if constexpr (sizeof(T) == 2 && KS == 3) {
-            if (tune_bits() & TUNE_CONV_TEAMS) {
-                if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, 2>(P, W, s);
-                if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK, false, 2>(P, W, s);
-                if (face_pix > 320) return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK, false, 2>(P, W, s);
-            }
-        }
         if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
         if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
         if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK>(P, W, s);
