@@ -41,6 +41,39 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
     return base + idx;
 }
 
+// ---- output stores -------------------------------------------------------------------------------------------------
+// The big outputs (activations, gradients, weight-gradient partials) are stored WRITE-THROUGH (sc1) through a buffer
+// descriptor: a kernel that leaves B dirty bytes in the L2s pays ~B / 6 TB/s at its end before the next kernel of the stream
+// may start (MI355X_MICROARCH.md, "boundary"), and these kernels write 14-28 MB each, so plain stores put 2-4 us of
+// write-back behind every launch.  Lanes with nothing to store pass ST_SKIP: an offset beyond num_records is dropped by the
+// hardware's range check -- no branch around the store.  -DDLWPCS_WT_STORES=0 builds plain stores for A/B runs.
+#ifndef DLWPCS_WT_STORES
+#define DLWPCS_WT_STORES 1
+#endif
+constexpr int ST_AUX = DLWPCS_WT_STORES ? 16 : 0;           // aux bit 4 = sc1
+constexpr uint32_t ST_SKIP = 0xffffffffu;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// raw buffer (stride 0) over [base, base + bytes): byte offsets, range-checked
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, base ? bytes : 0u, 0x00020000);
+}
+__device__ __forceinline__ void bst128(const uint4 &v, rsrc_t r, uint32_t byte_off) {
+    const u32x4 q = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, byte_off, 0, ST_AUX);
+}
+__device__ __forceinline__ void bst64(const uint2 &v, rsrc_t r, uint32_t byte_off) {
+    const u32x2 q = {v.x, v.y};
+    __builtin_amdgcn_raw_buffer_store_b64(q, r, byte_off, 0, ST_AUX);
+}
+__device__ __forceinline__ void bst32(uint32_t v, rsrc_t r, uint32_t byte_off) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, byte_off, 0, ST_AUX);
+}
+__device__ __forceinline__ void bstv(const uint4 &v, rsrc_t r, uint32_t o) { bst128(v, r, o); }
+__device__ __forceinline__ void bstv(const uint2 &v, rsrc_t r, uint32_t o) { bst64(v, r, o); }
+__device__ __forceinline__ void bstv(uint32_t v, rsrc_t r, uint32_t o) { bst32(v, r, o); }
+
 // keras ReLU(negative_slope=alpha, max_value=vmax)  (Azure/train_cs.py:199)
 __device__ __forceinline__ float act_leaky_clip(float x, float alpha, float vmax) {
     return x >= 0.f ? fminf(x, vmax) : alpha * x;

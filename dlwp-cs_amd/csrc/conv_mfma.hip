@@ -440,12 +440,12 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     int abase[MT];
     int cur_combo = -1, cur_v = -1;
     float4 bq[NT][4];
-    // store pass (nt, mt, ps) of this lane: element offset of its 16 B inside ONE sample of the destination (-1: nothing to
+    // store pass (nt, mt, ps) of this lane: byte offset of its 16 B inside ONE sample of the destination (ST_SKIP: nothing to
     // store) and, data gradient in direct mode, which destination (2 bits each: 0 = out, 1 = d0, 2 = d1).  Like the LDS
     // addresses they depend on the (face, band) only, not on the sample.
     // (SOFF: kept in registers when there are at most 12 passes; the MT = 5 tilings recompute them per store)
     constexpr bool SOFF = NT * MT * NPS <= 12;
-    int soff[SOFF ? NT : 1][SOFF ? MT : 1][SOFF ? NPS : 1];
+    uint32_t soff[SOFF ? NT : 1][SOFF ? MT : 1][SOFF ? NPS : 1];      // BYTE offsets, ST_SKIP = nothing to store
     uint32_t ssel = 0;
     auto store_off = [&](const Geo &gq, int nt, int mt, int ps, uint32_t &sel) __attribute__((always_inline)) {
         const int px = ps * PPP + lane / LPP, q = lane % LPP;
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 sel = in0 ? 1u : 2u;
             }
         }
-        return (mm < gq.npix && c < P.Cout) ? off : -1;
+        return (mm < gq.npix && c < P.Cout) ? (uint32_t)off * ES : ST_SKIP;
     };
 
     // ---- per-tile set-up: LDS addresses and store offsets (rebuilt at (face, band) changes), bias quads (reloaded at face
@@ -559,16 +559,19 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         }
         return v4;
     };
-    // per-sample bases of the destinations (uniform; plain scalars -- a struct of pointers handed through the lambdas ended
-    // up in scratch memory)
-    auto out_of = [&](const Geo &gq) { return reinterpret_cast<T *>(P.out) + (size_t)gq.b * 6 * face_pix * P.Cout; };
+    // per-sample buffer descriptors of the destinations (uniform): write-through stores, see common.h
+    auto out_of = [&](const Geo &gq) {
+        return make_rsrc(reinterpret_cast<T *>(P.out) + (size_t)gq.b * 6 * face_pix * P.Cout, (uint32_t)(6 * face_pix * P.Cout * ES));
+    };
     auto d0_of = [&](const Geo &gq) {
-        return reinterpret_cast<T *>(P.d0) + (size_t)gq.b * 6 * (P.No - 2) * (P.No - 2) * P.dsplit;
+        const int spix = 6 * (P.No - 2) * (P.No - 2);
+        return make_rsrc(P.d0 ? reinterpret_cast<T *>(P.d0) + (size_t)gq.b * spix * P.dsplit : nullptr, (uint32_t)(spix * P.dsplit * ES));
     };
     auto d1_of = [&](const Geo &gq) {
-        return reinterpret_cast<T *>(P.d1) + (size_t)gq.b * 6 * (P.No - 2) * (P.No - 2) * (P.Cout - P.dsplit);
+        const int spix = 6 * (P.No - 2) * (P.No - 2), c1 = P.Cout - P.dsplit;
+        return make_rsrc(P.d1 ? reinterpret_cast<T *>(P.d1) + (size_t)gq.b * spix * c1 : nullptr, (uint32_t)(spix * c1 * ES));
     };
-    auto epi_slice = [&](auto fast_tag, int i, const Geo &gq, T *d_out, T *d_0, T *d_1, const auto &A) {
+    auto epi_slice = [&](auto fast_tag, int i, const Geo &gq, rsrc_t d_out, rsrc_t d_0, rsrc_t d_1, const auto &A) {
         const int pr = i / SPP, k = i % SPP;
         const int nt = pr / MT, mt = pr % MT;
         if (k < 4) {
@@ -581,24 +584,27 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             const int ps = k - 4;
             const int px = ps * PPP + lane / LPP, q = lane % LPP;
             const uint4 v = *reinterpret_cast<const uint4 *>(patch + px * PROW + q * 16);
-            int off;
-            uint32_t sel;
-            if constexpr (SOFF) { off = soff[nt][mt][ps]; sel = (ssel >> (2 * ((nt * MT + mt) * NPS + ps))) & 3u; }
-            else off = store_off(gq, nt, mt, ps, sel);
-            bool live = off >= 0;
+            uint32_t boff, sel;
+            if constexpr (SOFF) { boff = soff[nt][mt][ps]; sel = (ssel >> (2 * ((nt * MT + mt) * NPS + ps))) & 3u; }
+            else boff = store_off(gq, nt, mt, ps, sel);
 #ifdef DLWPCS_TIMELINE
-            if (P.abl & 1) live = false;            // ablation: no global stores
+            if (P.abl & 1) boff = ST_SKIP;          // ablation: no global stores
 #endif
-            T *base = d_out;
-            if constexpr (DIRECT) base = sel == 0 ? d_out : (sel == 1 ? d_0 : d_1);
-            if (live) *reinterpret_cast<uint4 *>(base + off) = v;
+            if constexpr (DIRECT) {
+                // three possible destinations: one store each, the lanes of the other two skip
+                bst128(v, d_out, sel == 0 ? boff : ST_SKIP);
+                bst128(v, d_0, sel == 1 ? boff : ST_SKIP);
+                bst128(v, d_1, sel == 2 ? boff : ST_SKIP);
+            } else {
+                bst128(v, d_out, boff);
+            }
             if (ps == NPS - 1) __builtin_amdgcn_wave_barrier();
         }
     };
     auto epilogue_lines = [&](const Geo &gq, const auto &A) {
         TL_MARK();
-        T *const d_out = out_of(gq);
-        T *const d_0 = DIRECT ? d0_of(gq) : nullptr, *const d_1 = DIRECT ? d1_of(gq) : nullptr;
+        const rsrc_t d_out = out_of(gq);
+        const rsrc_t d_0 = DIRECT ? d0_of(gq) : d_out, d_1 = DIRECT ? d1_of(gq) : d_out;
         if (fast_act) {
 #pragma unroll
             for (int i = 0; i < NSLICE; ++i) epi_slice(std::true_type{}, i, gq, d_out, d_0, d_1, A);
@@ -1279,8 +1285,20 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             DVec dv[IT_DY], yv[MASK ? IT_DY : 1];
             bool xok[IT_X], dok[IT_DY];
         };
+#ifdef DLWPCS_TIMELINE
+        int pli = 0;
+        long long *plp = (P.dbg && ptid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
+        PL_MARK();
+#endif
         auto issue = [&](const Item &it, Stage &st) {
+#ifdef DLWPCS_TIMELINE
+            const bool first = cur_combo < 0;
+            if (first) PL_MARK();
+#endif
             if (it.combo != cur_combo) rebuild(it);                 // uniform, <= 2-3 times per worker
+#ifdef DLWPCS_TIMELINE
+            if (first) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PL_MARK(); }
+#endif
             const bf16_t *sb = src_base + (size_t)it.b * sample_elems;
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
@@ -1302,10 +1320,6 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                 st.dok[i] = ok;
             }
         };
-#ifdef DLWPCS_TIMELINE
-        int pli = 0;
-        long long *plp = (P.dbg && ptid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
-#endif
         auto commit = [&](const Item &it, int k, Stage &st) {
             char *buf = smem + (k & 1) * buf_bytes;
             PL_MARK();
@@ -1319,9 +1333,9 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             // data-gradient kernel that follows (which then needs neither y nor the act' arithmetic)
             if (MASK && W.dz_out != nullptr && cit == 0) {
                 bf16_t *dzb = reinterpret_cast<bf16_t *>(W.dz_out) + (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * P.Cout;
+                const rsrc_t dzr = make_rsrc(dzb, (uint32_t)(it.npix * P.Cout * 2));
 #pragma unroll
-                for (int i = 0; i < IT_DY; ++i)
-                    if (st.dok[i]) *reinterpret_cast<DVec *>(dzb + (uint32_t)doff[i]) = st.dv[i];
+                for (int i = 0; i < IT_DY; ++i) bstv(st.dv[i], dzr, st.dok[i] ? (uint32_t)doff[i] * 2 : ST_SKIP);
             }
             PL_MARK();
 #pragma unroll
@@ -1464,7 +1478,7 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     // 0-31 / 32-63 is row ci = (r & 3) + 8 (r >> 2) + 4 half of 32 consecutive output channels = two whole 128-B lines per
     // store instruction.  (The previous version went through LDS in three rounds of 4-B accesses: 10 k cycles per worker.)
     float4 *red4 = reinterpret_cast<float4 *>(smem);
-    float *pout = W.partial + (size_t)worker * TAPS * W.CinP * W.CoutP;
+    const rsrc_t pr = make_rsrc(W.partial + (size_t)worker * TAPS * W.CinP * W.CoutP, (uint32_t)(TAPS * W.CinP * W.CoutP * 4));
     auto slot_of = [](int t, int p) { int c = 0; for (int u = 0; u < t; ++u) c += (u % NPH != p) ? 1 : 0; return c; };
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
@@ -1492,14 +1506,14 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                     v[p][4 * q] = f.x; v[p][4 * q + 1] = f.y; v[p][4 * q + 2] = f.z; v[p][4 * q + 3] = f.w;
                 }
             }
-            float *row0 = pout + ((size_t)t * W.CinP + (cit * CT + ct) * 32 + 4 * half) * W.CoutP + cot * 32 + l31;
+            const uint32_t row0 = (uint32_t)(((t * W.CinP + (cit * CT + ct) * 32 + 4 * half) * W.CoutP + cot * 32 + l31) * 4);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float sum;
                 if (NPH == 4) sum = (v[0][r] + v[1][r]) + (v[2][r] + v[3][r]);
                 else if (NPH == 2) sum = v[0][r] + v[1][r];
                 else sum = v[0][r];
-                row0[(size_t)((r & 3) + 8 * (r >> 2)) * W.CoutP] = sum;
+                bst32(__float_as_uint(sum), pr, row0 + (uint32_t)(((r & 3) + 8 * (r >> 2)) * W.CoutP * 4));
             }
         }
     }
@@ -2044,9 +2058,9 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
         return fail(DLWPCS_E_UNSUPPORTED, "conv: %d tile rows exceed the producers' 5-bit row field", P.tile_rows_max);
     if ((size_t)P.tile_rows_max * P.W2 > (size_t)3 * NTHREADS)
         return fail(DLWPCS_E_UNSUPPORTED, "conv: tile of %d x %d pixels exceeds the producers' register capacity", P.tile_rows_max, P.W2);
-    if ((long)6 * face_pix * P.Cout >= (1l << 31))
-        return fail(DLWPCS_E_UNSUPPORTED, "conv: one sample of the output (%ld elements) exceeds the 32-bit store offsets",
-                    (long)6 * face_pix * P.Cout);
+    if ((long)6 * face_pix * P.Cout * ES >= (1l << 31))
+        return fail(DLWPCS_E_UNSUPPORTED, "conv: one sample of the output (%ld bytes) exceeds the 32-bit store offsets",
+                    (long)6 * face_pix * P.Cout * ES);
     if ((long)P.Nin * P.Nin * 6 >= (1l << 16) * 6 && (long)P.Nin * P.Nin >= (1l << 16))
         return fail(DLWPCS_E_UNSUPPORTED, "conv: face size %d too large for the 16-bit index arithmetic", P.Nin);
     auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8>;
