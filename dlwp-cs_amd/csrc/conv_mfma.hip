@@ -329,9 +329,28 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 if (c_ok && cs + 8 > cstride) { sh = (cs + 8 - cstride) >> 1; cs_ld = cstride - 8; }
             }
         };
+        // weight fragments of (face variant v, chunk ch) -> registers -> the weight area of LDS buffer b
+        auto load_w = [&](int v, int ch, uint4 (&wv)[ITW]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < ITW; ++u) {
+                const int idx = min(ptid + u * NCT, WF4 - 1);
+                const int gg = idx / GF4, w = idx % GF4;
+                const int ntl = gg / KCG, cgl = gg % KCG;
+                const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
+                const bool ok = ntile < P.NTtot && cg < P.CG;
+                wv[u] = vsel(ok, wsrc[ok ? (((size_t)v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0]);
+            }
+        };
+        auto store_w = [&](int b, const uint4 (&wv)[ITW]) __attribute__((always_inline)) {
+            char *buf = smem + b * buf_bytes;
+#pragma unroll
+            for (int u = 0; u < ITW; ++u) {
+                const int idx = ptid + u * NCT;
+                if (idx < WF4) reinterpret_cast<uint4 *>(buf + in_bytes)[idx] = wv[u];
+            }
+        };
         // issue(): (rarely) the weight fragments -> LDS buffer g & 1, then every load of the chunk's input tile, back to back
         auto issue = [&](const Geo &gc, int ch, V (&val)[ITS], V (&ymv)[MASK ? ITS : 1], uint32_t &okm) __attribute__((always_inline)) {
-            char *buf = smem + (g & 1) * buf_bytes;
             const int wkey = gc.v * 1024 + ch;
             const bool need_w = !(P.tune & TUNE_CONV_WEIGHTS_STAY) || wres[g & 1] != wkey;
             wres[g & 1] = wkey;
@@ -340,20 +359,8 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 // flight at once (fetching them four at a time cost 2-3 serial L2 round trips on each workgroup's first tiles:
                 // +5 % on the whole training step)
                 uint4 wv[ITW];
-#pragma unroll
-                for (int u = 0; u < ITW; ++u) {
-                    const int idx = min(ptid + u * NCT, WF4 - 1);
-                    const int gg = idx / GF4, w = idx % GF4;
-                    const int ntl = gg / KCG, cgl = gg % KCG;
-                    const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
-                    const bool ok = ntile < P.NTtot && cg < P.CG;
-                    wv[u] = vsel(ok, wsrc[ok ? (((size_t)gc.v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0]);
-                }
-#pragma unroll
-                for (int u = 0; u < ITW; ++u) {
-                    const int idx = ptid + u * NCT;
-                    if (idx < WF4) reinterpret_cast<uint4 *>(buf + in_bytes)[idx] = wv[u];
-                }
+                load_w(gc.v, ch, wv);
+                store_w(g & 1, wv);
             }
             const T *sb; int cstride, cs_ld, sh; bool c_ok, up;
             chunk_src(gc, ch, sb, cstride, cs_ld, sh, c_ok, up);
@@ -408,6 +415,9 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         int cur_combo = -1;
         V val[ITS], ymv[MASK ? ITS : 1];
         uint32_t okm = 0;
+        // (Measured negative: requesting the first two chunks' weight fragments before the first tile's halo-table lookup and
+        // its input vectors before the weight stores -- two dependent round trips instead of three at the start of the kernel
+        // -- made the training step 3 % SLOWER: with 256 workgroups starting at once the start-up is bandwidth, not latency.)
         for (int t = t_first; t < t_last; ++t) {
             const Geo gq = geo_of(t);
             if (gq.combo != cur_combo) { lookup(gq); cur_combo = gq.combo; }        // uniform; a few times per workgroup
@@ -1306,7 +1316,8 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                 st.xv[i] = *reinterpret_cast<const XVec *>(sb + (uint32_t)max(o, 0));
                 st.xok[i] = o >= 0;
             }
-            // dZ tile [pix][32 output channels of tile cot] = dy * act'(y), zero beyond npix / Cout
+            // dZ tile [pix][32 output channels of tile cot] = dy * act'(y), zero beyond npix / Cout.  (Issuing these BEFORE the
+            // X gather -- they need no table -- measured 0.7 % slower on the training step.)
             const size_t rowbase = (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * P.Cout;
             const bf16_t *dyb = reinterpret_cast<const bf16_t *>(W.dy) + rowbase;
             const bf16_t *yb = MASK ? reinterpret_cast<const bf16_t *>(W.y) + rowbase : nullptr;
