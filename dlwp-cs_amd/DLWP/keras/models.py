@@ -472,15 +472,18 @@ class Model(object):
         gc_was_enabled = gc.isenabled()
         gc.collect()
         gc.disable()
+        # With a process group alive its watchdog thread issues HIP calls of its own: only THIS thread's calls are held to the
+        # capture rules then (a foreign call must not invalidate the capture).
+        mode = 'thread_local' if self._world > 1 else 'global'
         try:
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, capture_error_mode=mode):
                 stats = self._loss_and_backward(static_in, static_tg, True)
                 if self._world == 1:    # no exchange step: the update rides in the same graph (no inter-graph gap)
                     self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
             if self._world == 1:
                 g2 = None
             else:
-                with torch.cuda.graph(g2, pool=g1.pool()):
+                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
                     self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
         finally:
             if gc_was_enabled:

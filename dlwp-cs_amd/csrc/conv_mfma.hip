@@ -182,7 +182,7 @@ static int tune_bits() {
 // into slices between the MFMAs of the same wave: hipcc hoists the slices' arithmetic into clumps, and the extra VALU work in
 // the MFMA phase slows the co-resident producer wave) both measured slower and are gone.  What worked was making the
 // epilogue itself cheap -- it is VALU-issue bound, sharing its SIMD with a producer wave: accumulators start at the bias,
-// the activation is one v_med3_f32, store addresses are per-(face, band) constants -- 1.75 k + 0.44 k cycles now -- and then
+// the activation is max + min instead of compare + select, store addresses are per-(face, band) constants -- 1.75 k + 0.44 k cycles now -- and then
 // the producers' address arithmetic per load was cut to one multiply-add (see `sup`): the two sides are now balanced within
 // ~10 % (4.4 k consumer vs ~4.9 k producer cycles per tile).
 template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false>
@@ -552,17 +552,27 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     char *const patch = smem + 2 * buf_bytes + wave * (32 * PROW);
     // no activation == ReLU(alpha = 1, max = +inf): the epilogue applies the activation unconditionally and stays
     // straight-line (a branch per quad chops it into 5-instruction blocks whose dependent chains cannot interleave).
-    // FAST (0 <= alpha <= 1, max > 0, i.e. every activation of the reference's models and "none"): the activation is
-    // med3(x, alpha*x, max) -- 1.5 VALU instructions per value instead of 3.5 (min, compare, select, half a packed multiply);
-    // the consumers' epilogue is VALU-issue bound.  (A NaN comes out as `max` on this path: v_med3_f32 returns min3 then.)
+    // FAST (0 <= alpha <= 1, max >= 0, i.e. every activation of the reference's models and "none"): the activation is
+    // min(max(x, alpha*x), max) -- 2.5 VALU instructions per value (v_max_f32, v_min_f32, half a packed multiply) instead of 4.5
+    // (canonicalise, min, compare, select, half a multiply); the consumers' epilogue is VALU-issue bound.  (NOT med3(x, alpha*x, max): that is alpha*x,
+    // not max, once alpha*x itself exceeds max.  A NaN comes out as `max` on this path: v_min_f32 is IEEE minNum.)
     const float e_alpha = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.alpha : 1.f;
     const float e_vmax = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.vmax : __builtin_inff();
-    const bool fast_act = e_alpha >= 0.f && e_alpha <= 1.f && e_vmax > 0.f;
+    const bool fast_act = e_alpha >= 0.f && e_alpha <= 1.f && e_vmax >= 0.f;
     auto quad = [&](auto fast_tag, const f32x16 &a, int jq) {
         float4 v4 = make_float4(a[4 * jq], a[4 * jq + 1], a[4 * jq + 2], a[4 * jq + 3]);
         if constexpr (decltype(fast_tag)::value) {
-            v4.x = __builtin_amdgcn_fmed3f(v4.x, e_alpha * v4.x, e_vmax); v4.y = __builtin_amdgcn_fmed3f(v4.y, e_alpha * v4.y, e_vmax);
-            v4.z = __builtin_amdgcn_fmed3f(v4.z, e_alpha * v4.z, e_vmax); v4.w = __builtin_amdgcn_fmed3f(v4.w, e_alpha * v4.w, e_vmax);
+            // v_max_f32 / v_min_f32 as (pure) asm: fmaxf / fminf -- and v_med3_f32 with an infinite operand, which LLVM folds
+            // back into them -- put a canonicalising `v_max x, x` in front of every value that comes out of an accumulator
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            auto lc = [&](float x, float ax) {
+                float t, y;
+                asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(ax));
+                asm("v_min_f32 %0, %1, %2" : "=v"(y) : "v"(t), "v"(e_vmax));
+                return y;
+            };
+            const f32x2 a01 = f32x2{v4.x, v4.y} * e_alpha, a23 = f32x2{v4.z, v4.w} * e_alpha;     // v_pk_mul_f32
+            v4.x = lc(v4.x, a01.x); v4.y = lc(v4.y, a01.y); v4.z = lc(v4.z, a23.x); v4.w = lc(v4.w, a23.y);
         } else {
             v4.x = act_leaky_clip(v4.x, e_alpha, e_vmax); v4.y = act_leaky_clip(v4.y, e_alpha, e_vmax);
             v4.z = act_leaky_clip(v4.z, e_alpha, e_vmax); v4.w = act_leaky_clip(v4.w, e_alpha, e_vmax);
@@ -2173,6 +2183,9 @@ static int validate(const dlwpcs_conv_desc *d, const char *who) {
     if (d->halo && d->ksize == 1) return fail(DLWPCS_E_INVALID, "%s: halo with a 1x1 kernel", who);
     if (!d->halo && d->N < d->ksize) return fail(DLWPCS_E_INVALID, "%s: N < kernel size", who);
     if (d->act != DLWPCS_ACT_NONE && d->act != DLWPCS_ACT_LEAKY_CLIP) return fail(DLWPCS_E_INVALID, "%s: unknown activation %d", who, d->act);
+    // keras ReLU: negative_slope >= 0, max_value >= 0 (the backward kernels read act' off the saved OUTPUT: y < 0 <=> x < 0)
+    if (d->act == DLWPCS_ACT_LEAKY_CLIP && (!(d->alpha >= 0.f) || !(d->vmax >= 0.f)))
+        return fail(DLWPCS_E_INVALID, "%s: activation needs negative_slope >= 0 and max_value >= 0, got %g / %g", who, d->alpha, d->vmax);
     if (d->N > 1024) return fail(DLWPCS_E_UNSUPPORTED, "%s: N > 1024", who);
     if (d->c0_valid != 0) {
         if (d->c0_valid < 1 || d->c0_valid > d->C0) return fail(DLWPCS_E_INVALID, "%s: c0_valid %d outside [1, C0 = %d]", who, d->c0_valid, d->C0);

@@ -182,6 +182,51 @@ def test_conv_forward_and_backward(case):
             assert rel_err(db[n].grad.cpu().numpy(), tb[n].grad.numpy()) < RTOL, 'db ' + n
 
 
+@pytest.mark.parametrize('alpha,vmax', [(0.1, 10.0), (1.0, 4.0), (0.0, 2.5), (1.5, 6.0), (4.0, 3.0)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_activation_parameter_forms(alpha, vmax, dtype):
+    """keras ReLU(negative_slope=alpha, max_value=vmax) in the fused epilogue: 0 <= alpha <= 1 takes the one-instruction
+    med3(x, alpha*x, vmax) form, alpha > 1 the compare / select form; both must be the oracle's function, forward and
+    through act'(y) in both gradient kernels.  A negative slope is rejected like in Keras."""
+    from DLWP import ops
+    from DLWP._native import ACT_LEAKY_CLIP
+    B, N, C0, Cout = 2, 12, 16, 32
+    rng = np.random.default_rng(int(1000 * abs(alpha) + 10 * vmax))
+    bf = dtype == torch.bfloat16
+    rnd = (lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()) if bf else (lambda a: a)
+    x0 = rnd(3.0 * rng.standard_normal((B, 6, N, N, C0)))
+    gy = rnd(rng.standard_normal((B, 6, N, N, Cout)))
+    w, b = _rand_conv_params(rng, 3, C0, Cout, False)
+    wr = {n: (None if v is None else rnd(v)) for n, v in w.items()}       # the matrix cores see bf16-rounded kernels
+    t0 = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
+    tw = {n: (None if v is None else torch.tensor(v, dtype=torch.float64, requires_grad=True)) for n, v in wr.items()}
+    tb = {n: (None if v is None else torch.tensor(v, dtype=torch.float64, requires_grad=True)) for n, v in b.items()}
+    yref = orc.cs_conv2d(orc.cs_pad(t0, 1, 'channels_last'), tw['eq'], tw['pol'], None, tb['eq'], tb['pol'], None,
+                         data_format='channels_last', flip_north_pole=True, independent_north_pole=False)
+    yref = orc.relu_leaky_clip(yref, alpha, vmax)
+    yref.backward(torch.tensor(gy, dtype=torch.float64))
+    d0 = to_dev(x0).to(dtype).requires_grad_(True)
+    dw = {n: (None if v is None else to_dev(v).requires_grad_(True)) for n, v in w.items()}
+    db = {n: (None if v is None else to_dev(v).requires_grad_(True)) for n, v in b.items()}
+    y = ops.cs_conv(d0, dw['eq'], dw['pol'], None, db['eq'], db['pol'], None, ksize=3, halo=True, flip_north_pole=True,
+                    act=ACT_LEAKY_CLIP, alpha=alpha, vmax=vmax)
+    eps = 2.0 ** -8
+    assert rel_err(y.detach().float().cpu().numpy(), yref.detach().numpy()) < (eps if bf else RTOL)
+    # both regions of the activation must occur in the data, or the test says nothing
+    yn = yref.detach().numpy()
+    assert (yn >= vmax).any() and ((yn < 0).any() or alpha <= 0.0)
+    with pytest.raises(ValueError):
+        ops.cs_conv(d0.detach(), dw['eq'].detach(), dw['pol'].detach(), None, None, None, None, ksize=3, halo=True,
+                    act=ACT_LEAKY_CLIP, alpha=-0.25, vmax=vmax)
+    if bf:
+        return          # act'(y) is evaluated on the bf16-rounded y: elements at a kink flip; fp32 checks the gradients
+    y.backward(to_dev(gy).to(dtype))
+    assert rel_err(d0.grad.float().cpu().numpy(), t0.grad.numpy()) < RTOL
+    for n in ('eq', 'pol'):
+        assert rel_err(dw[n].grad.cpu().numpy(), tw[n].grad.numpy()) < RTOL, 'dW ' + n
+        assert rel_err(db[n].grad.cpu().numpy(), tb[n].grad.numpy()) < RTOL, 'db ' + n
+
+
 def test_conv_cfg1_golden(golden_dir):
     """BASELINE config 1 against the vector produced by the reference layers."""
     from DLWP import ops
