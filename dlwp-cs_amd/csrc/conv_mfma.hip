@@ -417,7 +417,8 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         uint32_t okm = 0;
         // (Measured negative: requesting the first two chunks' weight fragments before the first tile's halo-table lookup and
         // its input vectors before the weight stores -- two dependent round trips instead of three at the start of the kernel
-        // -- made the training step 3 % SLOWER: with 256 workgroups starting at once the start-up is bandwidth, not latency.)
+        // -- made the training step 3 % SLOWER; the first chunk's fragments alone before the lookup: 1 % slower.  The loads of a
+        // wave return in order: whatever is requested ahead of the table entries delays them.)
         for (int t = t_first; t < t_last; ++t) {
             const Geo gq = geo_of(t);
             if (gq.combo != cur_combo) { lookup(gq); cur_combo = gq.combo; }        // uniform; a few times per workgroup
