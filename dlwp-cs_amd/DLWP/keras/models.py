@@ -23,7 +23,7 @@ import torch
 
 from .. import ops, parallel
 from .._native import ACT_LEAKY_CLIP, ACT_NONE
-from . import backend, callbacks as cbks, optimizers
+from . import backend, callbacks as cbks, optimizers, staging
 from .engine import KTensor, Layer
 from .layers import AveragePooling3D, Concatenate, InputLayer, ReLU, UpSampling3D
 
@@ -59,6 +59,7 @@ class Model(object):
         self.wgrad_side_stream = os.environ.get('DLWPCS_SIDE_STREAM', '0') == '1'   # measured slower on MI355X: off
         # one reduction launch for all layers' weight-gradient partials (DLWPCS_CONV_DEFER_REDUCE)
         self.defer_wgrad_reduce = os.environ.get('DLWPCS_DEFER_REDUCE', '1') == '1'
+        self._stager = None                 # pinned-memory / copy-stream feed of fit() on host arrays (keras/staging.py)
         # training step: output layer + loss + loss gradient + the layer's data gradient as one launch (ops.head_mse)
         self.fuse_head_loss = os.environ.get('DLWPCS_FUSE_HEAD', '1') == '1'
         # True: the caller feeds every step through the SAME device tensors (e.g. a generator that assembles each batch in
@@ -501,9 +502,30 @@ class Model(object):
         dt = torch.float32 if target else backend.torch_dtype(self.compute_dtype)
         if isinstance(arr, torch.Tensor):
             return arr.to(backend.device(), dtype=dt)
+        if isinstance(arr, staging.LazyTake):
+            arr = arr.materialise()
         a = np.ascontiguousarray(arr, dtype=np.float32)
         t = torch.from_numpy(a).to(backend.device(), non_blocking=False)
         return t if dt == torch.float32 else t.to(dt)
+
+    def _feed(self, x, y, batch_size, shuffle):
+        """(device inputs, device targets) per batch.  On a HIP device host arrays go through pinned staging buffers and a copy
+        stream (keras/staging.py): the upload of a batch overlaps the training of the one before."""
+        if backend.device().type != 'cuda' or os.environ.get('DLWPCS_HOST_STAGING', '1') != '1':
+            for bx, by in self._batches_from(x, y, batch_size, shuffle):
+                yield [self._to_device(a) for a in bx], [self._to_device(a, target=True) for a in by]
+            return
+        dev = backend.device()
+        if self._stager is None or self._stager.device != dev:
+            self._stager = staging.Stager(dev)
+        cdt = backend.torch_dtype(self.compute_dtype)
+        for bx, by in self._batches_from(x, y, batch_size, shuffle, lazy=True):
+            ts, ev = self._stager.upload(list(bx) + list(by), [cdt] * len(bx) + [torch.float32] * len(by))
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ev)
+            for t in ts:
+                t.record_stream(cur)
+            yield ts[:len(bx)], ts[len(bx):]
 
     def _standardize_inputs(self, x):
         if isinstance(x, dict):
@@ -530,7 +552,7 @@ class Model(object):
                 raise ValueError('Error when checking %s: expected %s to have shape %s but got array with shape %s'
                                  % (what, t.name, t.shape, tuple(a.shape)))
 
-    def _batches_from(self, x, y, batch_size, shuffle):
+    def _batches_from(self, x, y, batch_size, shuffle, lazy=False):
         """yield (inputs, targets) lists of host arrays / tensors, one batch at a time."""
         if y is None and hasattr(x, '__getitem__') and hasattr(x, '__len__') and not isinstance(
                 x, (np.ndarray, list, tuple, dict, torch.Tensor)):
@@ -550,12 +572,13 @@ class Model(object):
         idx = np.arange(n)
         if shuffle:
             np.random.shuffle(idx)
+        def pick(a, sel, sl):
+            if lazy and isinstance(a, np.ndarray):
+                return staging.LazyTake(a, sel if shuffle else sl)      # gathered straight into pinned memory later
+            return a[sel] if shuffle else a[sl]
         for s in range(0, n, bs):
-            sel = idx[s:s + bs]
-            if shuffle:
-                yield [a[sel] for a in xs], [a[sel] for a in ys]
-            else:
-                yield [a[s:s + bs] for a in xs], [a[s:s + bs] for a in ys]
+            sel, sl = idx[s:s + bs], slice(s, min(s + bs, n))
+            yield [pick(a, sel, sl) for a in xs], [pick(a, sel, sl) for a in ys]
 
     def _n_batches(self, x, y, batch_size):
         if y is None and hasattr(x, '__len__') and not isinstance(x, (np.ndarray, list, tuple, dict, torch.Tensor)):
@@ -585,22 +608,24 @@ class Model(object):
             cbl.call('on_epoch_begin', epoch, None)
             sums = torch.zeros((len(self.outputs), 2), dtype=torch.float32, device=dev)
             count = 0
-            for bi, (bx, by) in enumerate(self._batches_from(x, y, batch_size, shuffle)):
-                if steps_per_epoch is not None and bi >= steps_per_epoch:
-                    break
-                if cbl.wants_batch_logs:
-                    cbl.call('on_train_batch_begin', bi, None)
-                dx = [self._to_device(a) for a in bx]
-                dt = [self._to_device(a, target=True) for a in by]
-                if count == 0 and epoch == initial_epoch:
-                    self._check_shapes(dx, self.inputs, 'input')
-                    self._check_shapes(dt, self.outputs, 'target')
-                stats = self.train_on_device_batch(dx, dt)
-                sums += stats
-                count += 1
-                if cbl.wants_batch_logs:
-                    vals = self._assemble_logs(stats, 1)
-                    cbl.call('on_train_batch_end', bi, dict(zip(names, vals), batch=bi, size=int(dx[0].shape[0])))
+            feed = self._feed(x, y, batch_size, shuffle)
+            try:
+                for bi, (dx, dt) in enumerate(feed):
+                    if steps_per_epoch is not None and bi >= steps_per_epoch:
+                        break
+                    if cbl.wants_batch_logs:
+                        cbl.call('on_train_batch_begin', bi, None)
+                    if count == 0 and epoch == initial_epoch:
+                        self._check_shapes(dx, self.inputs, 'input')
+                        self._check_shapes(dt, self.outputs, 'target')
+                    stats = self.train_on_device_batch(dx, dt)
+                    sums += stats
+                    count += 1
+                    if cbl.wants_batch_logs:
+                        vals = self._assemble_logs(stats, 1)
+                        cbl.call('on_train_batch_end', bi, dict(zip(names, vals), batch=bi, size=int(dx[0].shape[0])))
+            finally:
+                feed.close()
             logs = dict(zip(names, self._assemble_logs(sums, count)))
             if validation_data is not None:
                 vals = self._evaluate_impl(validation_data, None, batch_size, validation_steps)

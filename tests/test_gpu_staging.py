@@ -1,0 +1,95 @@
+"""
+GPU tests (`-m gpu`) of the host -> HBM feed of Model.fit (DLWP/keras/staging.py): batches staged ahead of the training step
+through pinned memory and a copy stream must train EXACTLY like batches uploaded one by one -- shuffled and unshuffled epochs, float64 sources,
+epochs cut short by steps_per_epoch, several inputs of one shape, and sources that are not arrays (generator objects).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    return torch.device('cuda', 0)
+
+
+def _model(C=3):
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    backend.set_device('cuda:0')
+    np.random.seed(7)
+    m = build_cs_model((6, 8, 8, C), C, 'unet2', base_filter_number=4)
+    m.compile(optimizer='adam', loss='mse', metrics=['mae'])
+    return m
+
+
+def _flat(model):
+    return np.concatenate([w.ravel() for w in model.get_weights()])
+
+
+def _fit(staged, x, y, C=3, **kw):
+    _dev()
+    os.environ['DLWPCS_HOST_STAGING'] = '1' if staged else '0'
+    try:
+        m = _model(C)
+        np.random.seed(11)                       # the epoch shuffles
+        h = m.fit(x, y, verbose=0, **kw)
+        torch.cuda.synchronize()
+        return _flat(m), h.history
+    finally:
+        os.environ.pop('DLWPCS_HOST_STAGING', None)
+
+
+@pytest.mark.parametrize('shuffle', [False, True])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_staged_fit_equals_plain_fit(shuffle, dtype):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((22, 6, 8, 8, 3)).astype(dtype)      # 22 = 5 batches of 4 + a ragged one of 2
+    y = rng.standard_normal((22, 6, 8, 8, 3)).astype(dtype)
+    a, ha = _fit(True, x, y, batch_size=4, epochs=3, shuffle=shuffle)
+    b, hb = _fit(False, x, y, batch_size=4, epochs=3, shuffle=shuffle)
+    assert np.array_equal(a, b)
+    assert ha == hb
+
+
+def test_staged_fit_with_an_epoch_cut_short_and_a_strided_source():
+    rng = np.random.default_rng(4)
+    big = rng.standard_normal((40, 6, 8, 8, 6)).astype(np.float32)
+    x, y = big[..., :3], big[..., 3:]                              # non-contiguous views of one array
+    a, _ = _fit(True, x, y, batch_size=4, epochs=4, shuffle=True, steps_per_epoch=3)
+    b, _ = _fit(False, x, y, batch_size=4, epochs=4, shuffle=True, steps_per_epoch=3)
+    assert np.array_equal(a, b)
+
+
+def test_staged_fit_from_a_sequence_of_batches():
+    """keras.utils.Sequence-like source (what DLWP's generators are): items are (inputs, targets) of host arrays"""
+    rng = np.random.default_rng(5)
+    xs = [rng.standard_normal((4, 6, 8, 8, 3)).astype(np.float32) for _ in range(6)]
+    ys = [rng.standard_normal((4, 6, 8, 8, 3)).astype(np.float32) for _ in range(6)]
+
+    class Seq(object):
+        def __len__(self):
+            return len(xs)
+
+        def __getitem__(self, i):
+            return xs[i], ys[i]
+    a, _ = _fit(True, Seq(), None, epochs=2)
+    b, _ = _fit(False, Seq(), None, epochs=2)
+    assert np.array_equal(a, b)
+
+
+def test_stager_reuses_its_pinned_buffers():
+    from DLWP.keras.staging import LazyTake, Stager
+    st = Stager(_dev())
+    rng = np.random.default_rng(6)
+    src = rng.standard_normal((64, 5, 7)).astype(np.float64)
+    for k in range(40):
+        sel = rng.permutation(64)[:8]
+        (d,), ev = st.upload([LazyTake(src, sel)], [torch.float32])
+        torch.cuda.current_stream().wait_event(ev)
+        assert np.array_equal(d.cpu().numpy(), src[sel].astype(np.float32))
+    assert len(st._rings[(8, 5, 7)]) <= 4
