@@ -671,16 +671,38 @@ class Model(object):
         n = xs[0].shape[0]
         bs = 32 if batch_size is None else int(batch_size)
         outs = None
+        dev = backend.device()
+        staged = dev.type == 'cuda' and os.environ.get('DLWPCS_HOST_STAGING', '1') == '1'
+        if staged:
+            # inputs through pinned memory + the copy stream, results back through a second copy stream: upload, forward pass and
+            # download of neighbouring batches overlap (keras/staging.py)
+            if self._stager is None or self._stager.device != dev:
+                self._stager = staging.Stager(dev)
+            down = staging.Downloader(dev)
+            cdt = backend.torch_dtype(self.compute_dtype)
         with torch.no_grad():
             for s in range(0, n, bs):
-                dx = [self._to_device(a[s:s + bs]) for a in xs]
+                if staged:
+                    dx, ev = self._stager.upload([staging.LazyTake(a, slice(s, min(s + bs, n))) if isinstance(a, np.ndarray)
+                                                  else a[s:s + bs] for a in xs], [cdt] * len(xs))
+                    cur = torch.cuda.current_stream(dev)
+                    cur.wait_event(ev)
+                    for t in dx:
+                        t.record_stream(cur)
+                else:
+                    dx = [self._to_device(a[s:s + bs]) for a in xs]
                 if s == 0:
                     self._check_shapes(dx, self.inputs, 'input')
                 res = self._forward(dx, repack=(s == 0))
                 if outs is None:
                     outs = [np.empty((n,) + tuple(r.shape[1:]), dtype=np.float32) for r in res]
                 for o, r in zip(outs, res):
-                    o[s:s + bs] = r.float().cpu().numpy()
+                    if staged:
+                        down.push(o[s:s + bs], r)
+                    else:
+                        o[s:s + bs] = r.float().cpu().numpy()
+            if staged:
+                down.flush()
         if outs is None:
             outs = [np.empty((0,) + tuple(o.shape[1:]), dtype=np.float32) for o in self.outputs]
         return outs[0] if self._single_output else outs

@@ -115,3 +115,47 @@ class Stager(object):
                 if slot is not None:
                     slot[1] = ev
         return out, ev
+
+
+class Downloader(object):
+    """Device -> host for predict(): results leave on a copy stream into pinned buffers; the host copies batch k-1 into the
+    caller's array while batch k computes."""
+
+    def __init__(self, device, depth=3):
+        self.device = device
+        self.depth = int(depth)
+        self.stream = torch.cuda.Stream(device=device)
+        self._rings = {}
+        self._pending = []          # [(destination numpy view, pinned tensor, event)]
+
+    def _pinned(self, shape):
+        ring = self._rings.setdefault(shape, {'bufs': [], 'next': 0})
+        if len(ring['bufs']) < self.depth:
+            ring['bufs'].append(torch.empty(shape, dtype=torch.float32).pin_memory())
+            return ring['bufs'][-1]
+        buf = ring['bufs'][ring['next'] % self.depth]
+        ring['next'] += 1
+        return buf
+
+    def push(self, dst, t):
+        """queue `dst[...] = t` (t: device tensor, any float dtype)"""
+        while len(self._pending) >= self.depth - 1:
+            self._retire()
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        buf = self._pinned(tuple(t.shape))
+        with torch.cuda.stream(self.stream):
+            buf.copy_(t if t.dtype == torch.float32 else t.float(), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        t.record_stream(self.stream)
+        self._pending.append((dst, buf, ev))
+
+    def _retire(self):
+        dst, buf, ev = self._pending.pop(0)
+        ev.synchronize()
+        np.copyto(dst, buf.numpy())
+
+    def flush(self):
+        while self._pending:
+            self._retire()

@@ -93,3 +93,28 @@ def test_stager_reuses_its_pinned_buffers():
         torch.cuda.current_stream().wait_event(ev)
         assert np.array_equal(d.cpu().numpy(), src[sel].astype(np.float32))
     assert len(st._rings[(8, 5, 7)]) <= 4
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_staged_predict_equals_plain_predict(dtype):
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    _dev()
+    backend.set_device('cuda:0')
+    backend.set_compute_dtype(dtype)
+    try:
+        np.random.seed(9)
+        m = build_cs_model((6, 8, 8, 3), 3, 'unet2', base_filter_number=4)
+    finally:
+        backend.set_compute_dtype('float32')
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((23, 6, 8, 8, 3))           # float64, ragged last batch
+    res = []
+    for staged in ('1', '0'):
+        os.environ['DLWPCS_HOST_STAGING'] = staged
+        try:
+            res.append(m.predict(x, batch_size=4))
+        finally:
+            os.environ.pop('DLWPCS_HOST_STAGING', None)
+    assert res[0].shape == (23, 6, 8, 8, 3) and res[0].dtype == np.float32
+    assert np.array_equal(res[0], res[1])
