@@ -648,16 +648,18 @@ class Model(object):
         dev = backend.device()
         sums = torch.zeros((len(self.outputs), 2), dtype=torch.float64, device=dev)
         total = 0
-        with torch.no_grad():
-            for bi, (bx, by) in enumerate(self._batches_from(x, y, batch_size, False)):
-                if steps is not None and bi >= steps:
-                    break
-                dx = [self._to_device(a) for a in bx]
-                dt = [self._to_device(a, target=True) for a in by]
-                n = dx[0].shape[0]
-                stats = self._loss_and_backward(dx, dt, train=False)
-                sums += stats.double() * n            # keras weights batches by their size
-                total += n
+        feed = self._feed(x, y, batch_size, False)
+        try:
+            with torch.no_grad():
+                for bi, (dx, dt) in enumerate(feed):
+                    if steps is not None and bi >= steps:
+                        break
+                    n = dx[0].shape[0]
+                    stats = self._loss_and_backward(dx, dt, train=False)
+                    sums += stats.double() * n            # keras weights batches by their size
+                    total += n
+        finally:
+            feed.close()
         return self._assemble_logs((sums / max(total, 1)).float(), 1)
 
     def evaluate(self, x=None, y=None, batch_size=None, verbose=1, steps=None, **kwargs):

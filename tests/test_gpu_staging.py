@@ -118,3 +118,19 @@ def test_staged_predict_equals_plain_predict(dtype):
             os.environ.pop('DLWPCS_HOST_STAGING', None)
     assert res[0].shape == (23, 6, 8, 8, 3) and res[0].dtype == np.float32
     assert np.array_equal(res[0], res[1])
+
+
+def test_staged_evaluate_equals_plain_evaluate():
+    rng = np.random.default_rng(10)
+    x = rng.standard_normal((14, 6, 8, 8, 3)).astype(np.float32)
+    y = rng.standard_normal((14, 6, 8, 8, 3)).astype(np.float32)
+    _dev()
+    m = _model(3)
+    res = []
+    for staged in ('1', '0'):
+        os.environ['DLWPCS_HOST_STAGING'] = staged
+        try:
+            res.append(m.evaluate(x, y, batch_size=4, verbose=0))
+        finally:
+            os.environ.pop('DLWPCS_HOST_STAGING', None)
+    assert res[0] == res[1]
