@@ -73,7 +73,9 @@ class Stager(object):
         if isinstance(src, LazyTake):
             arr, sel, n = src.array, src.sel, src.shape[0]
         else:
-            arr, sel, n = (src.numpy() if isinstance(src, torch.Tensor) else np.asarray(src)), slice(None), dst.shape[0]
+            if isinstance(src, torch.Tensor):       # host tensor; numpy has no bfloat16 / float16-on-some-builds view
+                src = (src if src.dtype in (torch.float32, torch.float64) else src.float()).detach().numpy()
+            arr, sel, n = np.asarray(src), slice(None), dst.shape[0]
 
         def part(i0, i1):
             np.copyto(dst[i0:i1], arr[_rows(sel, i0, i1)], casting='unsafe')
