@@ -136,10 +136,12 @@ template <> struct MmaPerFrag<bf16_t> { static constexpr int N = 1; };
 //      half of the workgroup and the consumers wait for them at every barrier)
 //   2: forward / data-gradient kernel: the same for its producer waves
 //   4: forward / data-gradient kernel: weight fragments stay in LDS across tiles (see `wres` in the producer)
-enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4 };
+//  16: forward / data-gradient kernel, more than 64 output channels: 64 per workgroup and the workgroups split over the
+//      output-channel groups (see launch_conv), instead of 128 per workgroup in 16-channel chunks
+enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_SPLIT_N = 16 };
 static int tune_bits() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : TUNE_CONV_WEIGHTS_STAY; }
+    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N); }
     return v;
 }
 
@@ -2090,9 +2092,11 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    int gx = 256;                                   // one workgroup (consumers + producers) per CU
+    const int gy = ceil_div(P.NTtot, NTB);
+    int gx = 256 / gy;                              // one workgroup (consumers + producers) per CU, all groups resident at once
+    if (gx < 1) gx = 1;
     if (gx > P.ntiles) gx = P.ntiles;
-    dim3 grid((unsigned)gx, (unsigned)ceil_div(P.NTtot, NTB));
+    dim3 grid((unsigned)gx, (unsigned)gy);
     int pidx = -1;
     if (prof_enabled()) {
         char tag[160];
@@ -2118,6 +2122,11 @@ static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
         // lose more to halo re-staging (the producers become the bottleneck) than they gain -> fixed MT = 3 tilings.
         if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
         if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
+        // bf16, more than 64 output channels: 64 per workgroup (two 32-channel chunks whose weight fragments STAY in the two LDS
+        // buffers) and the 256 workgroups split over the output-channel groups, instead of 128 channels per workgroup in four
+        // 16-channel chunks whose 37 KB of fragments had to be re-fetched every chunk (the 128-channel data gradient at N = 24:
+        // 43.9 us, producers weight-fetch-bound; whole step -1.9 %)
+        if (sizeof(T) == 2 && (tune_bits() & TUNE_CONV_SPLIT_N)) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
         if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK>(P, W, s);
         return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK>(P, W, s);
     }
