@@ -138,10 +138,12 @@ template <> struct MmaPerFrag<bf16_t> { static constexpr int N = 1; };
 //   4: forward / data-gradient kernel: weight fragments stay in LDS across tiles (see `wres` in the producer)
 //  16: forward / data-gradient kernel, more than 64 output channels: 64 per workgroup and the workgroups split over the
 //      output-channel groups (see launch_conv), instead of 128 per workgroup in 16-channel chunks
-enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_SPLIT_N = 16 };
+//  32: data gradient with 64 output channels (= the layer's input channels): two groups of 32 with the 384-pixel tiling
+enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_SPLIT_N = 16,
+       TUNE_CONV_SPLIT2_BWD = 32 };
 static int tune_bits() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N); }
+    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD); }
     return v;
 }
 
@@ -2121,6 +2123,11 @@ static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
         // Measured (MI355X, batch 32): the smaller tiles (MT = 2 / MT = 1) that would even out the tile count per CU
         // lose more to halo re-staging (the producers become the bottleneck) than they gain -> fixed MT = 3 tilings.
         if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
+        // bf16 data gradient with 64 output channels: the padded grid (N + 2 columns) leaves a 192-pixel tile 3 rows at N = 48
+        // (5 fetched per 3 computed, 150 of 192 pixels used); two 32-channel groups with 384-pixel tiles get 7 rows (9 per 7,
+        // 350 of 384) and read the smaller operand (dz) twice.  Step -0.7 %; the same split for the forward pass measured +-0.
+        if (P.NTtot == 2 && sizeof(T) == 2 && MODE == MODE_ZERO && (tune_bits() & TUNE_CONV_SPLIT2_BWD))
+            return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
         if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
         // bf16, more than 64 output channels: 64 per workgroup (two 32-channel chunks whose weight fragments STAY in the two LDS
         // buffers) and the 256 workgroups split over the output-channel groups, instead of 128 channels per workgroup in four
