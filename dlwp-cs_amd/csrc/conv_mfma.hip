@@ -53,6 +53,7 @@ struct ConvKParams {
     uint32_t magicW2, magicNo, magicN;
     uint32_t magicB, magicNblk; // exact-division magics of B and nblk_face (0 when the divisor is 1)
     int patches;                // LDS holds the wave-private epilogue patches (0: no room -> direct quad stores)
+    int wstat;                  // > 0: one resident LDS weight area per channel chunk (= the chunk count), see the kernel
     // Data-gradient direct mode (MODE_ZERO, k = 3, halo): output channels [0, dsplit) belong to source 0, the rest to source
     // 1; where d0 / d1 is non-null the INTERIOR cells of the padded gradient go straight to that source's gradient tensor
     // (B,6,No-2,No-2,channels of the source) and only the halo ring is written to `out`
@@ -139,11 +140,12 @@ template <> struct MmaPerFrag<bf16_t> { static constexpr int N = 1; };
 //  16: forward / data-gradient kernel, more than 64 output channels: 64 per workgroup and the workgroups split over the
 //      output-channel groups (see launch_conv), instead of 128 per workgroup in 16-channel chunks
 //  32: data gradient with 64 output channels (= the layer's input channels): two groups of 32 with the 384-pixel tiling
+//  64: 3-4 channel chunks per tile: one resident LDS weight area per chunk (P.wstat), with the tiling that makes them fit
 enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_SPLIT_N = 16,
-       TUNE_CONV_SPLIT2_BWD = 32 };
+       TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64 };
 static int tune_bits() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD); }
+    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT); }
     return v;
 }
 
@@ -209,7 +211,13 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     typedef typename VecT<T, VW>::type V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int in_bytes = P.tile_rows_max * P.W2 * RB;
-    const int buf_bytes = in_bytes + WF4 * 16;
+    // LDS: two chunk buffers [input tile | weight fragments], then the epilogue patches.  With 3-4 chunks per tile (P.wstat) the
+    // fragments get one RESIDENT area per chunk behind two input-only buffers instead: two buffers alternate between two
+    // different chunks' fragments and would re-fetch 18-37 KB every chunk (the 128 -> 64 forward layers ran weight-fetch-bound).
+    const int in_step = P.wstat ? in_bytes : in_bytes + WF4 * 16;     // distance between the two input buffers
+    const int w_base = P.wstat ? 2 * in_bytes : in_bytes;             // first weight area
+    const int w_step = P.wstat ? WF4 * 16 : in_bytes + WF4 * 16;      // distance between weight areas (per chunk / per buffer)
+    const int patch_base = P.wstat ? 2 * in_bytes + P.wstat * WF4 * 16 : 2 * (in_bytes + WF4 * 16);
 
     const int tid = threadIdx.x;
     const bool is_producer = tid >= NCT;
@@ -314,7 +322,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         // converge after two tiles, with an even chunk count chunk ch always lands in buffer ch & 1; other counts simply
         // never match.  (Measured need: at 64 -> 64 channels the fragments were 74 of the 107 KB a tile pulled through the
         // CU's load path, which is what bounds these kernels -- ~10 B/clk/CU -- not the matrix cores.)
-        int wres[2] = {-1, -1};
+        int wres[4] = {-1, -1, -1, -1};     // by buffer (g & 1), or by chunk with resident areas (P.wstat)
 
         // per-thread constants of a chunk: source, channel offset inside it, TAIL8 shift
         auto chunk_src = [&](const Geo &gc, int ch, const T *&sb, int &cstride, int &cs_ld, int &sh, bool &c_ok, bool &up)
@@ -345,26 +353,27 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 wv[u] = vsel(ok, wsrc[ok ? (((size_t)v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0]);
             }
         };
-        auto store_w = [&](int b, const uint4 (&wv)[ITW]) __attribute__((always_inline)) {
-            char *buf = smem + b * buf_bytes;
+        auto store_w = [&](int area, const uint4 (&wv)[ITW]) __attribute__((always_inline)) {
+            char *wa = smem + w_base + area * w_step;
 #pragma unroll
             for (int u = 0; u < ITW; ++u) {
                 const int idx = ptid + u * NCT;
-                if (idx < WF4) reinterpret_cast<uint4 *>(buf + in_bytes)[idx] = wv[u];
+                if (idx < WF4) reinterpret_cast<uint4 *>(wa)[idx] = wv[u];
             }
         };
         // issue(): (rarely) the weight fragments -> LDS buffer g & 1, then every load of the chunk's input tile, back to back
         auto issue = [&](const Geo &gc, int ch, V (&val)[ITS], V (&ymv)[MASK ? ITS : 1], uint32_t &okm) __attribute__((always_inline)) {
             const int wkey = gc.v * 1024 + ch;
-            const bool need_w = !(P.tune & TUNE_CONV_WEIGHTS_STAY) || wres[g & 1] != wkey;
-            wres[g & 1] = wkey;
+            const int area = P.wstat ? ch : (g & 1);
+            const bool need_w = !(P.tune & TUNE_CONV_WEIGHTS_STAY) || wres[area] != wkey;
+            wres[area] = wkey;
             if (need_w) {
                 // uniform and rare (weights stay): the fragments are fetched and written in a block of their own, all loads in
                 // flight at once (fetching them four at a time cost 2-3 serial L2 round trips on each workgroup's first tiles:
                 // +5 % on the whole training step)
                 uint4 wv[ITW];
                 load_w(gc.v, ch, wv);
-                store_w(g & 1, wv);
+                store_w(area, wv);
             }
             const T *sb; int cstride, cs_ld, sh; bool c_ok, up;
             chunk_src(gc, ch, sb, cstride, cs_ld, sh, c_ok, up);
@@ -388,7 +397,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         };
         // commit(): the loaded vectors -> LDS buffer g & 1, barrier B_g
         auto commit = [&](const Geo &gc, int ch, V (&val)[ITS], V (&ymv)[MASK ? ITS : 1], uint32_t okm) __attribute__((always_inline)) {
-            char *buf = smem + (g & 1) * buf_bytes;
+            char *buf = smem + (g & 1) * in_step;
             if constexpr (TAIL8) {
                 const T *sb; int cstride, cs_ld, sh; bool c_ok, up;
                 chunk_src(gc, ch, sb, cstride, cs_ld, sh, c_ok, up);
@@ -554,7 +563,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     constexpr int PROW = 32 * ES + 16;          // patch row: one pixel's 32 channels + pad
     constexpr int SPP = 4 + NPS;                // slices per (n tile, m tile) pair
     constexpr int NSLICE = NT * MT * SPP;
-    char *const patch = smem + 2 * buf_bytes + wave * (32 * PROW);
+    char *const patch = smem + patch_base + wave * (32 * PROW);
     // no activation == ReLU(alpha = 1, max = +inf): the epilogue applies the activation unconditionally and stays
     // straight-line (a branch per quad chops it into 5-instruction blocks whose dependent chains cannot interleave).
     // FAST (0 <= alpha <= 1, max >= 0, i.e. every activation of the reference's models and "none"): the activation is
@@ -681,8 +690,8 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     // BEFORE the MFMAs of step s are issued (left alone, the compiler reuses one register set and stalls on lgkmcnt after
     // every step).
     constexpr int NSTEP = KCG * TAPS;
-    auto mma_chunk = [&]() {
-        const char *lds_in = smem + (g & 1) * buf_bytes, *lds_w = lds_in + in_bytes;
+    auto mma_chunk = [&](int ch) {
+        const char *lds_in = smem + (g & 1) * in_step, *lds_w = smem + w_base + (P.wstat ? ch : (g & 1)) * w_step;
         uint4 fa[2][MT], fb[2][NT];
         auto load_frag = [&](int step, uint4 (&a)[MT], uint4 (&bw)[NT]) {
             const int cgl = step / TAPS, tap = step % TAPS;
@@ -717,7 +726,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             TL_MARK();
             __syncthreads();                // B_g: chunk g has been written by the producers
             TL_MARK();
-            mma_chunk();
+            mma_chunk(ch);
         }
         if (lines) epilogue_lines(gq, acc);
         else epilogue_plain(gq);
@@ -2069,10 +2078,16 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
     { const char *e = getenv("DLWPCS_ABL"); P.abl = e ? atoi(e) : 0; }
 #endif
-    const size_t buf = (size_t)P.tile_rows_max * P.W2 * (KC * ES + 16) + (size_t)NTB * (KC / CGW) * KS * KS * 1024;
-    size_t lds = 2 * buf + (size_t)(WM * WN) * 32 * (32 * ES + 16);    // + wave-private epilogue patches
+    const size_t in_b = (size_t)P.tile_rows_max * P.W2 * (KC * ES + 16), w_b = (size_t)NTB * (KC / CGW) * KS * KS * 1024;
+    const size_t buf = in_b + w_b, patch_b = (size_t)(WM * WN) * 32 * (32 * ES + 16);
+    size_t lds = 2 * buf + patch_b;                                              // + wave-private epilogue patches
     P.patches = 1;
-    if (lds > 160 * 1024) { lds = 2 * buf; P.patches = 0; }                     // large faces: direct quad stores instead
+    P.wstat = 0;
+    const int nchunks = ceil_div(P.CG, KC / CGW);
+    if (nchunks > 2 && nchunks <= 4 && (tune_bits() & TUNE_CONV_WSTAT) && 2 * in_b + nchunks * w_b + patch_b <= 160 * 1024) {
+        P.wstat = nchunks;                                                       // one resident weight area per chunk
+        lds = 2 * in_b + nchunks * w_b + patch_b;
+    } else if (lds > 160 * 1024) { lds = 2 * buf; P.patches = 0; }               // large faces: direct quad stores instead
     if (MODE == MODE_ZERO && KS == 3 && P.patches && P.Cout % (16 / ES) == 0 && P.dsplit % (16 / ES) == 0) {
         if (P.direct_done) *P.direct_done = (P.d0 || P.d1) ? 1 : 0;             // the line-store epilogue honours d0 / d1
     } else {
@@ -2127,6 +2142,13 @@ static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
         // (5 fetched per 3 computed, 150 of 192 pixels used); two 32-channel groups with 384-pixel tiles get 7 rows (9 per 7,
         // 350 of 384) and read the smaller operand (dz) twice.  Step -0.7 %; the same split for the forward pass measured +-0.
         if (P.NTtot == 2 && sizeof(T) == 2 && MODE == MODE_ZERO && (tune_bits() & TUNE_CONV_SPLIT2_BWD))
+            return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
+        // bf16, 64 output channels from 65-128 input channels (3-4 chunks): 32 output channels per workgroup, whose 4 x 18 KB of
+        // fragments fit as resident areas beside two 384-pixel input buffers (64 per workgroup would need 4 x 37 KB)
+        // (faces of more than 320 pixels: at N = 12 a 384-pixel tile is 37 % full and the layer came out 6 us slower; the
+        // 128 -> 64 forward at N = 24: 33.3 -> 28.5 us)
+        if (P.NTtot == 2 && sizeof(T) == 2 && P.CG > 2 * (K2 / (32 / (int)sizeof(T))) && P.CG <= 4 * (K2 / (32 / (int)sizeof(T))) &&
+            face_pix > 320 && (tune_bits() & TUNE_CONV_WSTAT))
             return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
         if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
         // bf16, more than 64 output channels: 64 per workgroup (two 32-channel chunks whose weight fragments STAY in the two LDS
