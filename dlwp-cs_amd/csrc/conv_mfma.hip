@@ -2155,7 +2155,9 @@ static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
         // buffers) and the 256 workgroups split over the output-channel groups, instead of 128 channels per workgroup in four
         // 16-channel chunks whose 37 KB of fragments had to be re-fetched every chunk (the 128-channel data gradient at N = 24:
         // 43.9 us, producers weight-fetch-bound; whole step -1.9 %)
-        if (sizeof(T) == 2 && (tune_bits() & TUNE_CONV_SPLIT_N)) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
+        // (not the forward pass on faces of <= 320 pixels: 64 -> 128 at N = 12 measured 13.4 us with the 160-pixel tiling, 14.9 split)
+        if (sizeof(T) == 2 && (tune_bits() & TUNE_CONV_SPLIT_N) && (face_pix > 320 || MODE == MODE_ZERO))
+            return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
         if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK>(P, W, s);
         return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK>(P, W, s);
     }
