@@ -2138,10 +2138,11 @@ static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
         // Measured (MI355X, batch 32): the smaller tiles (MT = 2 / MT = 1) that would even out the tile count per CU
         // lose more to halo re-staging (the producers become the bottleneck) than they gain -> fixed MT = 3 tilings.
         if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
-        // bf16 data gradient with 64 output channels: the padded grid (N + 2 columns) leaves a 192-pixel tile 3 rows at N = 48
+        // data gradient with 64 output channels: the padded grid (N + 2 columns) leaves a 192-pixel tile 3 rows at N = 48
         // (5 fetched per 3 computed, 150 of 192 pixels used); two 32-channel groups with 384-pixel tiles get 7 rows (9 per 7,
-        // 350 of 384) and read the smaller operand (dz) twice.  Step -0.7 %; the same split for the forward pass measured +-0.
-        if (P.NTtot == 2 && sizeof(T) == 2 && MODE == MODE_ZERO && (tune_bits() & TUNE_CONV_SPLIT2_BWD))
+        // 350 of 384) and read the smaller operand (dz) twice.  bf16 step -0.7 % (fp32 -0.3 %); the same split for the forward pass
+        // measured +-0.
+        if (P.NTtot == 2 && MODE == MODE_ZERO && (tune_bits() & TUNE_CONV_SPLIT2_BWD))
             return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
         // bf16, 64 output channels from 65-128 input channels (3-4 chunks): 32 output channels per workgroup, whose 4 x 18 KB of
         // fragments fit as resident areas beside two 384-pixel input buffers (64 per workgroup would need 4 x 37 KB)
@@ -2151,12 +2152,12 @@ static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
             face_pix > 320 && (tune_bits() & TUNE_CONV_WSTAT))
             return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
         if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
-        // bf16, more than 64 output channels: 64 per workgroup (two 32-channel chunks whose weight fragments STAY in the two LDS
+        // more than 64 output channels: 64 per workgroup (two 32-channel chunks whose weight fragments STAY in the two LDS
         // buffers) and the 256 workgroups split over the output-channel groups, instead of 128 channels per workgroup in four
         // 16-channel chunks whose 37 KB of fragments had to be re-fetched every chunk (the 128-channel data gradient at N = 24:
-        // 43.9 us, producers weight-fetch-bound; whole step -1.9 %)
+        // 43.9 us, producers weight-fetch-bound; whole bf16 step -1.9 %, fp32 -0.9 %)
         // (not the forward pass on faces of <= 320 pixels: 64 -> 128 at N = 12 measured 13.4 us with the 160-pixel tiling, 14.9 split)
-        if (sizeof(T) == 2 && (tune_bits() & TUNE_CONV_SPLIT_N) && (face_pix > 320 || MODE == MODE_ZERO))
+        if ((tune_bits() & TUNE_CONV_SPLIT_N) && (face_pix > 320 || MODE == MODE_ZERO))
             return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
         if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK>(P, W, s);
         return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK>(P, W, s);
