@@ -30,6 +30,7 @@ CONV_PREPACKED = 2
 CONV_REUSE_DZ = 4
 CONV_DEFER_REDUCE = 8
 PACK_FWD, PACK_BWD, PACK_BIAS = 0, 1, 2
+WGRAD_BATCH_MAX = 24
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -60,6 +61,12 @@ class ReduceItem(ctypes.Structure):
                [('reserved', ctypes.c_int32 * 4)]
 
 
+class WgradItem(ctypes.Structure):
+    """struct dlwpcs_wgrad_item (include/dlwpcs.h)"""
+    _fields_ = [('d', ConvDesc)] + [(n, ctypes.c_void_p) for n in ('src0', 'src1', 'dz', 'table_dev', 'dw_eq', 'dw_pol',
+                                                                    'dw_np', 'db_eq', 'db_pol', 'db_np')]
+
+
 class GConvDesc(ctypes.Structure):
     """struct dlwpcs_gconv_desc (include/dlwpcs.h)"""
     _fields_ = [(n, ctypes.c_int32) for n in
@@ -87,6 +94,10 @@ PROTOTYPES = {
     'dlwpcs_conv_wgrad_reduce_item': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 6 +
                                       [c_void_p, c_size_t, ctypes.POINTER(ReduceItem)]),
     'dlwpcs_wgrad_reduce_batch': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'dlwpcs_wgrad_batch_supported': (c_int, [ctypes.POINTER(ConvDesc)]),
+    'dlwpcs_wgrad_batch_sizes': (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
+    'dlwpcs_wgrad_batch_plan': (c_int, [c_void_p, c_int, c_void_p, c_size_t]),
+    'dlwpcs_wgrad_batch': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'dlwpcs_gconv_fwd': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),
     'dlwpcs_gconv_bwd_data': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 6),
     'dlwpcs_gconv_bwd_weights': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),

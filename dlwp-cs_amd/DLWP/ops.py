@@ -104,6 +104,57 @@ def flush_deferred_reduce(device):
               'dlwpcs_wgrad_reduce_batch')
 
 
+# ------------------------------------------------------------------------------------------------------------------ #
+# Batched weight gradients (dlwpcs_wgrad_batch): ONE persistent launch + one reduction for all layers of a backward pass
+# ------------------------------------------------------------------------------------------------------------------ #
+_wb_plans = {}              # geometry key -> (host plan buffer, device plan tensor, workspace bytes)
+
+
+def wgrad_batch_supported(d):
+    return bool(lib().dlwpcs_wgrad_batch_supported(ctypes.byref(d)))
+
+
+def _wb_items(entries):
+    arr = (nat.WgradItem * len(entries))()
+    key = []
+    for it, (d, src0, src1, dz, table, grads) in zip(arr, entries):
+        it.d = d
+        it.src0, it.src1, it.dz, it.table_dev = ptr(src0), ptr(src1), ptr(dz), ptr(table)
+        it.dw_eq, it.dw_pol, it.dw_np, it.db_eq, it.db_pol, it.db_np = [ptr(g) for g in grads]
+        key.append((d.B, d.N, d.C0, d.C1, d.Cout, d.ksize, d.halo, d.up0, d.flip_north_pole, d.dtype, d.c0_valid,
+                    tuple(g is not None for g in grads)))
+    return arr, tuple(key)
+
+
+def wgrad_batch(entries):
+    """entries: [(ConvDesc, src0, src1 | None, dz, halo table | None, (dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np))] with
+    fp32 gradient tensors that are ACCUMULATED into (None where the layer has no such parameter).  dz is the gradient
+    w.r.t. the layer's pre-activation output (already masked).  The plan of a layer list is built once and cached."""
+    if not entries:
+        return
+    dev = entries[0][3].device
+    for lo in range(0, len(entries), nat.WGRAD_BATCH_MAX):
+        chunk = entries[lo:lo + nat.WGRAD_BATCH_MAX]
+        arr, key = _wb_items(chunk)
+        key = (str(dev), key)
+        hit = _wb_plans.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise nat.NativeError('the weight-gradient plan would have to be uploaded during graph capture; run one eager '
+                                      'step first')
+            pb, wb = ctypes.c_size_t(), ctypes.c_size_t()
+            check(lib().dlwpcs_wgrad_batch_sizes(arr, len(chunk), ctypes.byref(pb), ctypes.byref(wb)), 'dlwpcs_wgrad_batch_sizes')
+            host = (ctypes.c_char * pb.value)()
+            check(lib().dlwpcs_wgrad_batch_plan(arr, len(chunk), host, pb.value), 'dlwpcs_wgrad_batch_plan')
+            plan_dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev)
+            hit = (host, plan_dev, wb.value)
+            _wb_plans[key] = hit
+        host, plan_dev, ws_bytes = hit
+        ws = _workspace(ws_bytes, dev, 'wgrad_batch')
+        check(lib().dlwpcs_wgrad_batch(arr, len(chunk), host, ptr(plan_dev), ptr(ws), ws.numel(), stream_ptr()),
+              'dlwpcs_wgrad_batch')
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 

@@ -17,7 +17,7 @@ TAG = os.environ.get('DLWPCS_LIB_TAG', '')          # development only: instrume
 OBJ = os.path.join(HERE, 'build' + ('_' + TAG if TAG else ''))
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdlwpcs%s.so' % ('_' + TAG if TAG else ''))
-SOURCES = ['halo_table.cpp', 'prof.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_generic.hip']
+SOURCES = ['halo_table.cpp', 'prof.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_generic.hip', 'wgrad_batch.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 CFLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-x', 'hip', '-Wall', '-Wno-unused-function'] + \

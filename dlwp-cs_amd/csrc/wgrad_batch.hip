@@ -1,0 +1,885 @@
+// Batched weight gradients of a whole backward pass (gfx950, bf16 mode): ONE persistent launch for every layer.
+//
+// Per layer the weight gradient is  dW[tap][ci][co] = sum over (sample, face of the weight group, pixel)
+//     Xpad[pixel + tap][ci] * dZ[pixel][co]                                   (DLWP/custom.py:921-1002, transposed)
+// and it depends on nothing but the layer's saved input and the gradient dZ w.r.t. its pre-activation output: it is off
+// the critical path of the backward pass.  Launched layer by layer (conv_mfma.hip, wgrad_bf16_kernel) each of the 11
+// launches of the DLWP-CS U-Net splits ~4.5 work items per CU, i.e. spends more time filling and draining than streaming
+// (measured on MI355X, batch 32: 339 us for the 11 launches of which 146 us do not scale with the batch), and leaves 256
+// full-size fp32 partial sums per layer behind (153 MB per step for a 2.7 MB gradient).  Here all layers form ONE work list:
+//   * a SEGMENT = (layer, ci-tile group, co-tile group, face class, contiguous range of work items); the host plan
+//     (dlwpcs_wgrad_batch_plan) cuts the list into one chain of segments per CU with equal estimated cost, so a layer gets
+//     CUs in proportion to its work (a dozen instead of 256 per layer: ~20x fewer partial sums) and every CU streams ~45
+//     items instead of 4.5;
+//   * the kernel walks its chain: per segment the main loop of wgrad_bf16_kernel (4 producer waves: global -> registers ->
+//     LDS with the halo gather / upsample / concat resolved in the address; 4 consumer waves: ds_read_b64_tr_b16 + bf16 MFMA,
+//     K = 16 pixels), then one partial sum per segment;
+//   * a worker covers up to 64 input x 64 output channels (CT x NT tiles of 32 x 32, one consumer wave each): X and dZ are
+//     then read once per layer where the per-layer kernel re-read X per 32-wide output tile;
+//   * dZ arrives PRE-MASKED (the producer of the gradient applied act'(y)): no second load stream, no mask arithmetic;
+//   * wb_reduce_kernel adds the few partial sums per (layer, group, class) in a fixed order (no atomics: bitwise
+//     reproducible), applies the weight-group map / north-pole row reversal and accumulates into the fp32 gradients.
+// Tensor addresses travel BY VALUE in the kernel arguments (a captured hipGraph keeps them); the plan holds geometry only.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "common.h"
+#include "mfma_common.h"
+
+namespace dlwpcs {
+
+constexpr int WB_MAX_LAYERS = DLWPCS_WGRAD_BATCH_MAX;
+constexpr uint32_t WB_MAGIC = 0x57424c31u;       // 'WBL1'
+
+// instantiations of the segment body: (KS, XV, QX, CT, NT, DV)
+enum {
+    WB_V_3_8_22 = 0,    // 3x3, 16-B X vectors, 64 ci x 64 co per worker
+    WB_V_3_8_21,        // 64 ci x 32 co
+    WB_V_3_8_12,        // 32 ci x 64 co
+    WB_V_3_8_11,        // 32 ci x 32 co
+    WB_V_3_2_8,         // 4-B X vectors, <= 16 input channels (the 14-channel network input)
+    WB_V_3_2_16,        // 4-B X vectors, <= 32 input channels (26 = 13 x 2)
+    WB_V_1_8_11,        // 1x1, C_out % 8 == 0
+    WB_V_1_8_D2,        // 1x1, even C_out <= 16 (the 14-channel head): 4-B dZ vectors
+    WB_NVARIANTS
+};
+
+struct WbLayer {                    // 32 ints
+    int32_t B, Nin, No, C0, C1, Cin, Cout, up0;
+    int32_t halo, KS, W2, tile_rows_max, pix, nbands, pix_cap, variant;
+    uint32_t magicW2, magicNo, magicN, magicB, magicNb;
+    int32_t CT, NT, ncit, ncot, cin_logical, flip, want_bias, group_base, has_np, slot_floats, pad0;
+};
+static_assert(sizeof(WbLayer) == 128, "WbLayer layout");
+
+struct WbSeg {                      // 8 ints
+    int32_t layer, cls, cit, cot, t_first, t_last;
+    uint32_t slot_off;              // floats from the workspace base
+    int32_t bias;                   // this segment also sums dZ columns (bias gradient)
+};
+
+struct WbGroup { uint32_t off, stride; int32_t count, pad; };      // partial slots of one (layer, cit, cot, class)
+
+struct WbHeader {
+    uint32_t magic, n_layers, n_segments, n_workers, n_groups, lds_bytes;
+    uint32_t off_layers, off_segs, off_groups, total_bytes;
+    uint64_t ws_floats;
+    uint32_t red_first[WB_MAX_LAYERS + 1];      // first reduction workgroup of every layer
+    uint32_t seg_start[257];                     // worker w runs segments [seg_start[w], seg_start[w + 1])
+};
+
+struct WbPtrs {
+    const void *src0[WB_MAX_LAYERS], *src1[WB_MAX_LAYERS], *dz[WB_MAX_LAYERS];
+    const int32_t *table[WB_MAX_LAYERS];
+};
+struct WbRedPtrs {
+    float *dw_eq[WB_MAX_LAYERS], *dw_pol[WB_MAX_LAYERS], *dw_np[WB_MAX_LAYERS];
+    float *db_eq[WB_MAX_LAYERS], *db_pol[WB_MAX_LAYERS], *db_np[WB_MAX_LAYERS];
+    uint32_t first[WB_MAX_LAYERS + 1];
+    uint32_t live;                               // bit l: layer l is reduced by this launch
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// One segment.  Called by all 512 threads of the workgroup; threads 256.. are the producers.  Both halves execute
+// n_items + 3 workgroup barriers.
+// ------------------------------------------------------------------------------------------------------------------
+// development only (-DDLWPCS_WB_TIMING): s_memtime accounting of one producer and one consumer thread per workgroup,
+// dbg[worker][role][8] (cycles): producer {issue, wait + LDS writes, barrier, epilogue, items}, consumer {barrier, mma, epilogue}
+#ifdef DLWPCS_WB_TIMING
+#define WB_T(var) const long long var = __builtin_amdgcn_s_memtime()
+#define WB_ACC(slot, a, b) do { tacc[slot] += (b) - (a); } while (0)
+#else
+#define WB_T(var) do { } while (0)
+#define WB_ACC(slot, a, b) do { } while (0)
+#endif
+
+// a plan record -> scalar registers (the plan is the same for every lane; read through a reference the fields would be
+// re-fetched with vector loads inside the loops, behind vmcnt(0) waits)
+template <typename T> __device__ __forceinline__ T load_uniform(const T &g) {
+    T out;
+    const int *s = reinterpret_cast<const int *>(&g);
+    int *d = reinterpret_cast<int *>(&out);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) d[i] = __builtin_amdgcn_readfirstlane(s[i]);
+    return out;
+}
+
+template <int KS, int XV, int QX, int CT, int NT, int DV>
+__device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const WbSeg &sgg, const void *src0, const void *src1,
+                                           const void *dzp, const int32_t *table, float *ws, char *smem, long long *dbg) {
+    const WbLayer L = load_uniform(Lg);
+    const WbSeg sg = load_uniform(sgg);
+    constexpr int QD = DV == 8 ? 4 : 8;     // dZ vectors per pixel and 32-channel plane
+    constexpr int QDT = QD * NT;            // dZ vectors staged per pixel
+    typedef typename VecT<bf16_t, DV>::type DVec;
+    typedef typename VecT<bf16_t, XV>::type XVec;
+    constexpr int TAPS = KS * KS;
+    constexpr int PB = 64;                  // LDS bytes per pixel and plane: 32 channels bf16
+    constexpr int NCT = 256;                // consumer threads == producer threads
+    constexpr int QXT = QX * CT;            // X vectors staged per tile pixel
+    constexpr int IT_X = XV == 8 ? (CT == 2 ? 10 : 8) : 16;      // tile-pixel capacity IT_X * 256 / QXT: 320 | 512 | 512 / 256
+    constexpr int CAP_PIX = (CT == 2 || NT == 2) ? 192 : 384;    // item pixels the producers' dZ registers hold
+    constexpr int IT_DY = CAP_PIX * QDT / NCT;
+    constexpr int NPH = 4 / (CT * NT);      // consumer waves sharing the K slabs of one (ci tile, co tile)
+    constexpr int RSLOTS = TAPS - TAPS / NPH;
+    constexpr int RED_FLOATS = 4 * RSLOTS * 1024;
+    static_assert(CT * NT * NPH == 4, "four consumer waves");
+    static_assert(CT == 1 || (XV == 8 && QX == 4), "two ci tiles per worker need full 16-B X vectors");
+    static_assert(NCT % QXT == 0 && NCT % QDT == 0, "thread -> channel-vector maps must not depend on the item");
+
+    const int pix_cap = L.pix_cap;
+    const int plane_bytes = L.tile_rows_max * L.W2 * PB;
+    const int x_bytes = CT * plane_bytes;
+    const int dzplane_bytes = pix_cap * PB;
+    const int buf_bytes = x_bytes + NT * dzplane_bytes;
+
+    const int nfaces = sg.cls == 0 ? 4 : 1, fbase = sg.cls == 0 ? 0 : (sg.cls == 1 ? 4 : 5);
+    const int n_my = sg.t_last - sg.t_first;
+    const int face_pix = L.No * L.No;
+    const int tid = threadIdx.x;
+    (void)nfaces;
+
+    struct Item { int b, f, combo, m0, npix, y0, nitems; };
+    auto item_of = [&](int k) {
+        Item it;
+        const int t = sg.t_first + max(min(k, n_my - 1), 0);
+        it.combo = L.magicB ? __umulhi((uint32_t)t, L.magicB) : t;                       // t / B  (magic 0 <=> divisor 1)
+        it.b = t - it.combo * L.B;
+        const int fl = L.magicNb ? __umulhi((uint32_t)it.combo, L.magicNb) : it.combo;   // combo / nbands
+        const int band = it.combo - fl * L.nbands;
+        it.f = fbase + fl;
+        it.m0 = band * L.pix;
+        it.npix = min(L.pix, face_pix - it.m0);
+        it.y0 = __umulhi((uint32_t)it.m0, L.magicNo);
+        const int ylast = __umulhi((uint32_t)(it.m0 + it.npix - 1), L.magicNo);
+        it.nitems = (ylast - it.y0 + KS) * L.W2 * QXT;
+        return it;
+    };
+    float *slot = ws + sg.slot_off;
+
+    if (tid >= NCT) {
+        // =========================================== producers ===========================================
+        const int ptid = tid - NCT;
+        const int qd = ptid % QDT;                              // this thread's dZ vector inside a pixel: fixed
+        const int cx = sg.cit * 32 * CT + (ptid % QXT) * XV;    // this thread's X channels: fixed as well
+        const bool cx_ok = cx < L.Cin;
+        const bool from0 = cx < L.C0;
+        const int g0 = L.up0 ? (L.Nin >> 1) : L.Nin;
+        const int cs = from0 ? cx : cx - L.C0;
+        const int cstride = from0 ? L.C0 : L.C1;
+        const bool up = from0 && L.up0;
+        const int M = L.Nin + KS - 1;
+        const int co = sg.cot * 32 * NT + (qd / QD) * 32 + (qd % QD) * DV;
+        const bool co_ok = co < L.Cout;
+        const bool want_bias = sg.bias != 0;
+        float bsum[DV];
+#pragma unroll
+        for (int u = 0; u < DV; ++u) bsum[u] = 0.f;
+#ifdef DLWPCS_WB_TIMING
+        long long *tdbg = (dbg && ptid == 0) ? dbg + ((size_t)blockIdx.x * 2 + 0) * 8 : nullptr;
+        long long tacc[4] = {0, 0, 0, 0};
+#endif
+        int xoff[IT_X];
+        int cur_combo = -1;
+        auto rebuild = [&](const Item &it) {
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int e = min(ptid + i * NCT, it.nitems - 1);
+                const int pix = e / QXT;
+                const int ty = __umulhi((uint32_t)pix, L.magicW2);
+                const int tx = pix - ty * L.W2;
+                const int iy = it.y0 + ty;
+                int ii;                                              // flat cell on the Nin grid
+                if (L.halo) ii = table[(it.f * M + iy) * M + tx];
+                else ii = (it.f * L.Nin + iy) * L.Nin + tx;
+                const int r = __umulhi((uint32_t)ii, L.magicN);      // row face*Nin + y of the Nin grid -> row r/2 of Nin/2
+                const int pix_up = (r >> 1) * g0 + ((ii - r * L.Nin) >> 1);
+                const int spix = up ? pix_up : ii;
+                xoff[i] = (cx_ok && ptid + i * NCT < it.nitems) ? spix * cstride + cs : -1;
+            }
+            cur_combo = it.combo;
+        };
+        int doff[IT_DY];
+#pragma unroll
+        for (int i = 0; i < IT_DY; ++i) doff[i] = ((ptid + i * NCT) / QDT) * L.Cout + co;
+        const size_t sample_elems = from0 ? (size_t)6 * g0 * g0 * L.C0 : (size_t)6 * L.Nin * L.Nin * L.C1;
+        const bf16_t *src_base = reinterpret_cast<const bf16_t *>(from0 ? src0 : src1);
+        // two register sets, prefetch distance 2 (see wgrad_bf16_kernel)
+        struct Stage {
+            XVec xv[IT_X];
+            DVec dv[IT_DY];
+            bool xok[IT_X], dok[IT_DY];
+        };
+        auto issue = [&](const Item &it, Stage &st) {
+            if (it.combo != cur_combo) rebuild(it);                 // uniform, a few times per segment
+            const bf16_t *sb = src_base + (size_t)it.b * sample_elems;
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int o = xoff[i];
+                st.xv[i] = *reinterpret_cast<const XVec *>(sb + (uint32_t)max(o, 0));
+                st.xok[i] = o >= 0;
+            }
+            const size_t rowbase = (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * L.Cout;
+            const bf16_t *dzb = reinterpret_cast<const bf16_t *>(dzp) + rowbase;
+            const int dlim = it.npix * L.Cout;                      // slot valid <=> its pixel < npix
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) {
+                const bool ok = co_ok && doff[i] < dlim;
+                const uint32_t o = ok ? (uint32_t)doff[i] : 0u;
+                st.dv[i] = *reinterpret_cast<const DVec *>(dzb + o);
+                st.dok[i] = ok;
+            }
+        };
+        auto commit = [&](const Item &it, int k, Stage &st) {
+            char *buf = smem + (k & 1) * buf_bytes;
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int e = ptid + i * NCT;
+                if (e < it.nitems)
+                    *reinterpret_cast<XVec *>(buf + ((ptid % QXT) / QX) * plane_bytes + (size_t)(e / QXT) * PB +
+                                              ((ptid % QXT) % QX) * (XV * 2)) = vsel(st.xok[i], st.xv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) {
+                const int e = ptid + i * NCT;
+                const DVec v = vsel(st.dok[i], st.dv[i]);
+                if (e < pix_cap * QDT)
+                    *reinterpret_cast<DVec *>(buf + x_bytes + (qd / QD) * dzplane_bytes + (size_t)(e / QDT) * PB +
+                                              (qd % QD) * (DV * 2)) = v;
+                if (want_bias) {
+                    if constexpr (DV == 8) {
+                        bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
+                        bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
+                    } else {
+                        bsum[0] += bf_lo(v); bsum[1] += bf_hi(v);
+                    }
+                }
+            }
+            // B_k: item k is in LDS.  RAW barrier behind an explicit LDS wait (a __syncthreads() would drain vmcnt(0), i.e. wait
+            // for the loads of item k + 1 that were issued a moment ago)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WB_T(tq0);
+            __builtin_amdgcn_s_barrier();
+            WB_T(tq1);
+            WB_ACC(2, tq0, tq1);
+#ifdef DLWPCS_WB_TIMING
+            tacc[1] -= tq1 - tq0;
+#endif
+        };
+#ifdef DLWPCS_WB_TIMING
+        if (tdbg) tdbg[4] += n_my;
+#endif
+        {
+            Stage A, B;
+            Item i0 = item_of(0), i1 = item_of(1);          // item_of clamps: prefetches past the end re-read the last item
+            WB_T(ta);
+            issue(i0, A);
+            WB_T(tb);
+            WB_ACC(0, ta, tb);
+            for (int k = 0; k < n_my; k += 2) {
+                const Item i2 = item_of(k + 2);
+                WB_T(t0);
+                issue(i1, B);
+                WB_T(t1);
+                commit(i0, k, A);
+                WB_T(t2);
+                WB_ACC(0, t0, t1); WB_ACC(1, t1, t2);
+                if (k + 1 >= n_my) break;
+                const Item i3 = item_of(k + 3);
+                issue(i2, A);
+                WB_T(t3);
+                commit(i1, k + 1, B);
+                WB_T(t4);
+                WB_ACC(0, t2, t3); WB_ACC(1, t3, t4);
+                i0 = i2; i1 = i3;
+            }
+        }
+        WB_T(te0);
+        // ---- bias partial: thread (vector qd, 256 / QDT pixel phases) holds sums of DV channels -> fixed-order sum
+        __syncthreads();                // E1: consumers are done with the buffers
+        float *red = reinterpret_cast<float *>(smem) + RED_FLOATS;   // behind the consumers' reduction slots
+        if (want_bias) {
+#pragma unroll
+            for (int u = 0; u < DV; ++u) red[ptid * DV + u] = bsum[u];
+        }
+        __syncthreads();                // E2: (the consumers parked their accumulators between the two barriers)
+        if (want_bias && ptid < 32 * NT) {
+            // channel c = ptid of the 32 * NT staged columns: vector qd = (c / 32) * QD + (c % 32) / DV, element (c % 32) % DV
+            float sum = 0.f;
+            const int cc = ptid & 31, pl = ptid >> 5;
+            if (cc < QD * DV) {
+                const int q = pl * QD + cc / DV;
+#pragma unroll 4
+                for (int ph = 0; ph < NCT / QDT; ++ph) sum += red[(ph * QDT + q) * DV + (cc % DV)];
+            }
+            slot[TAPS * (32 * CT) * (32 * NT) + ptid] = sum;
+        }
+        __syncthreads();                // E3: the next segment may overwrite the buffers
+        WB_T(te1);
+        WB_ACC(3, te0, te1);
+#ifdef DLWPCS_WB_TIMING
+        if (tdbg) { for (int u = 0; u < 4; ++u) tdbg[u] += tacc[u]; }
+#endif
+        return;
+    }
+
+    // ============================================= consumers =============================================
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int li = lane & 15;
+    const int choff = ((((lane >> 4) & 1) * 16) + (li & 3) * 4) * 2;   // byte offset of this lane's 4 contiguous channels
+    const int prow = li >> 2;                                            // which of the 4 pixels of a transpose block
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int tapoff[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) tapoff[t] = ((t / KS) * L.W2 + (t % KS)) * PB;
+
+    const int nslab = pix_cap / 16;             // K slabs (16 pixels) per item
+    const int S = (((nslab + NPH - 1) / NPH) + 1) & ~1;   // slabs per consumer wave, rounded up to even (extras add zero)
+    const int ct = wave % CT, nt = (wave / CT) % NT, ph = wave / (CT * NT);
+#ifdef DLWPCS_WB_TIMING
+    long long *tdbg = (dbg && tid == 0) ? dbg + ((size_t)blockIdx.x * 2 + 1) * 8 : nullptr;
+    long long tacc[3] = {0, 0, 0};
+    long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+    for (int k = 0; k < n_my; ++k) {
+        __syncthreads();                        // B_k
+#ifdef DLWPCS_WB_TIMING
+        { const long long tn = __builtin_amdgcn_s_memtime(); WB_ACC(0, tprev, tn); tprev = tn; }
+#endif
+        const char *lds_x0 = smem + (k & 1) * buf_bytes, *lds_dy = lds_x0 + x_bytes + nt * dzplane_bytes;
+        const char *lds_x = lds_x0 + ct * plane_bytes;
+        const Item it = item_of(k);
+        auto frag = [&](int si, uint4 (&a)[TAPS], uint4 &bq) {
+            const int s = ph + NPH * si;
+            const int sc = min(s, nslab - 1);
+            const bool live = s < nslab;
+            int xaddr[2], daddr[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int m = 16 * sc + 8 * half + 4 * jj + prow;
+                const int gm = it.m0 + min(m, it.npix - 1);
+                const int oy = __umulhi((uint32_t)gm, L.magicNo);
+                xaddr[jj] = ((oy - it.y0) * L.W2 + (gm - oy * L.No)) * PB + choff;
+                daddr[jj] = m * PB + choff;
+            }
+            const uint2 b0 = lds_tr16(lds_dy + daddr[0]), b1 = lds_tr16(lds_dy + daddr[1]);
+            bq = vsel(live, make_uint4(b0.x, b0.y, b1.x, b1.y));
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const uint2 a0 = lds_tr16(lds_x + xaddr[0] + tapoff[tap]), a1 = lds_tr16(lds_x + xaddr[1] + tapoff[tap]);
+                a[tap] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            }
+        };
+        uint4 fa[2][TAPS], fb[2];
+        frag(0, fa[0], fb[0]);
+        for (int si = 0; si < S; si += 2) {
+            frag(si + 1, fa[1], fb[1]);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fa[0][tap], fb[0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TAPS + 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);
+            frag(si + 2, fa[0], fb[0]);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fa[1][tap], fb[1]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TAPS + 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);
+        }
+#ifdef DLWPCS_WB_TIMING
+        { const long long tn = __builtin_amdgcn_s_memtime(); WB_ACC(1, tprev, tn); tprev = tn; }
+#endif
+    }
+    __syncthreads();                            // E1: all consumers finished reading the last buffer
+    // Cross-wave reduction, one LDS round (see wgrad_bf16_kernel): the NPH waves of a (ci tile, co tile) hold K-split sums
+    // of the same (taps, 32, 32) block; tap t belongs to the wave of phase t % NPH, the others park theirs in LDS.
+    float4 *red4 = reinterpret_cast<float4 *>(smem);
+    const int wgrp = ct * NT + nt;
+    auto slot_of = [](int t, int p) { int c = 0; for (int u = 0; u < t; ++u) c += (u % NPH != p) ? 1 : 0; return c; };
+    if constexpr (NPH > 1) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            if (ph != t % NPH) {
+                float4 *dst = red4 + (size_t)((wgrp * NPH + ph) * RSLOTS + slot_of(t, ph)) * 256 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    dst[q * 64] = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+            }
+        }
+    }
+    __syncthreads();                            // E2
+    const rsrc_t pr = make_rsrc(slot, (uint32_t)(TAPS * (32 * CT) * (32 * NT) * 4));
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        if (ph == t % NPH) {
+            f32x16 v[NPH];
+#pragma unroll
+            for (int p = 0; p < NPH; ++p) {
+                if (p == t % NPH) { v[p] = acc[t]; continue; }
+                if constexpr (NPH > 1) {
+                    const float4 *src = red4 + (size_t)((wgrp * NPH + p) * RSLOTS + slot_of(t, p)) * 256 + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 f = src[q * 64];
+                        v[p][4 * q] = f.x; v[p][4 * q + 1] = f.y; v[p][4 * q + 2] = f.z; v[p][4 * q + 3] = f.w;
+                    }
+                }
+            }
+            const uint32_t row0 = (uint32_t)(((t * (32 * CT) + ct * 32 + 4 * half) * (32 * NT) + nt * 32 + l31) * 4);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sum;
+                if (NPH == 4) sum = (v[0][r] + v[1][r]) + (v[2][r] + v[3][r]);
+                else if (NPH == 2) sum = v[0][r] + v[1][r];
+                else sum = v[0][r];
+                bst32(__float_as_uint(sum), pr, row0 + (uint32_t)(((r & 3) + 8 * (r >> 2)) * (32 * NT) * 4));
+            }
+        }
+    }
+    __syncthreads();                            // E3
+#ifdef DLWPCS_WB_TIMING
+    { const long long tn = __builtin_amdgcn_s_memtime(); WB_ACC(2, tprev, tn); }
+    if (tdbg) { for (int u = 0; u < 3; ++u) tdbg[u] += tacc[u]; }
+#endif
+}
+
+__global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict__ plan, const WbPtrs ptrs, float *__restrict__ ws,
+                                                          long long *dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WbHeader *H = reinterpret_cast<const WbHeader *>(plan);
+    const WbLayer *layers = reinterpret_cast<const WbLayer *>(plan + H->off_layers);
+    const WbSeg *segs = reinterpret_cast<const WbSeg *>(plan + H->off_segs);
+    const int w = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int s0 = (int)H->seg_start[w], s1 = (int)H->seg_start[w + 1];
+    for (int s = s0; s < s1; ++s) {
+        const WbSeg &sg = segs[s];
+        const WbLayer &L = layers[sg.layer];
+        const void *a0 = ptrs.src0[sg.layer], *a1 = ptrs.src1[sg.layer], *dz = ptrs.dz[sg.layer];
+        const int32_t *tb = ptrs.table[sg.layer];
+        switch (L.variant) {
+            case WB_V_3_8_22: wb_segment<3, 8, 4, 2, 2, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
+            case WB_V_3_8_21: wb_segment<3, 8, 4, 2, 1, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
+            case WB_V_3_8_12: wb_segment<3, 8, 4, 1, 2, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
+            case WB_V_3_8_11: wb_segment<3, 8, 4, 1, 1, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
+            case WB_V_3_2_8:  wb_segment<3, 2, 8, 1, 1, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
+            case WB_V_3_2_16: wb_segment<3, 2, 16, 1, 1, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
+            case WB_V_1_8_11: wb_segment<1, 8, 4, 1, 1, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
+            default:          wb_segment<1, 8, 4, 1, 1, 2>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Reduction: one thread per VEC consecutive output channels of one (layer, tap, ci) row (or of the bias vector); the
+// partial sums of its (ci group, co group) are added class by class, slot by slot -- a fixed order.
+// ------------------------------------------------------------------------------------------------------------------
+template <int VEC>
+__device__ __forceinline__ void wb_reduce_body(const WbLayer &L, const WbGroup *__restrict__ groups, const float *__restrict__ ws,
+                                               float *dw_eq, float *dw_pol, float *dw_np, float *db_eq, float *db_pol,
+                                               float *db_np, int block) {
+    typedef float VT __attribute__((ext_vector_type(VEC)));
+    const int KS = L.KS, TAPS = KS * KS, Cin = L.cin_logical, Cout = L.Cout;
+    const int nW = TAPS * Cin * Cout;
+    const int e = (block * 256 + (int)threadIdx.x) * VEC;
+    const bool is_w = e < nW, is_b = !is_w && L.want_bias && e < nW + Cout;
+    if (!is_w && !is_b) return;
+    const int TC = 32 * L.CT, TN = 32 * L.NT;
+    VT s[3];
+    s[0] = 0.f; s[1] = 0.f; s[2] = 0.f;
+    if (is_w) {
+        const int co = e % Cout, ci = (e / Cout) % Cin, tap = e / (Cout * Cin);
+        const int cit = ci / TC, cot = co / TN, lci = ci - cit * TC, lco = co - cot * TN;
+        const int ty = tap / KS, tx = tap - ty * KS;
+        const int tap5 = L.flip ? (KS - 1 - ty) * KS + tx : tap;    // face 5 ran with the row-reversed kernel
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const WbGroup g = groups[L.group_base + (cit * L.ncot + cot) * 3 + c];
+            const float *p = ws + g.off + (size_t)(((c == 2 ? tap5 : tap) * TC + lci) * TN + lco);
+#pragma unroll 8
+            for (int j = 0; j < g.count; ++j) s[c] += *reinterpret_cast<const VT *>(p + (size_t)j * g.stride);
+        }
+        auto add = [&](float *dst, VT v) { VT *q = reinterpret_cast<VT *>(dst + e); *q = *q + v; };
+        add(dw_eq, s[0]);
+        if (dw_np) { add(dw_pol, s[1]); add(dw_np, s[2]); } else add(dw_pol, s[1] + s[2]);
+    } else {
+        const int co = e - nW;
+        const int cot = co / TN, lco = co - cot * TN;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const WbGroup g = groups[L.group_base + cot * 3 + c];         // ci group 0 carries the bias sums
+            const float *p = ws + g.off + (size_t)TAPS * TC * TN + lco;
+            for (int j = 0; j < g.count; ++j) s[c] += *reinterpret_cast<const VT *>(p + (size_t)j * g.stride);
+        }
+        auto add = [&](float *dst, VT v) { if (dst) { VT *q = reinterpret_cast<VT *>(dst + co); *q = *q + v; } };
+        add(db_eq, s[0]);
+        if (db_np) { add(db_pol, s[1]); add(db_np, s[2]); } else add(db_pol, s[1] + s[2]);
+    }
+}
+
+__global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__ plan, const WbRedPtrs R, const float *__restrict__ ws) {
+    const WbHeader *H = reinterpret_cast<const WbHeader *>(plan);
+    const WbLayer *layers = reinterpret_cast<const WbLayer *>(plan + H->off_layers);
+    const WbGroup *groups = reinterpret_cast<const WbGroup *>(plan + H->off_groups);
+    const uint32_t b = blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < WB_MAX_LAYERS; ++k) l += (k < (int)H->n_layers && b >= R.first[k]) ? 1 : 0;
+    if (!((R.live >> l) & 1u)) return;
+    const WbLayer L = layers[l];
+    const int blk = (int)(b - R.first[l]);
+    const bool al = ((((uintptr_t)R.dw_eq[l] | (uintptr_t)R.dw_pol[l] | (uintptr_t)R.dw_np[l] | (uintptr_t)R.db_eq[l] |
+                       (uintptr_t)R.db_pol[l] | (uintptr_t)R.db_np[l]) & 15) == 0);
+    if (L.Cout % 4 == 0 && al)
+        wb_reduce_body<4>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk);
+    else
+        wb_reduce_body<1>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Host: variant choice, item geometry, cost model, plan
+// ------------------------------------------------------------------------------------------------------------------
+static inline int wb_out_size(const dlwpcs_conv_desc *d) { return d->halo ? d->N : d->N - d->ksize + 1; }
+
+// -1: the layer cannot be an item of the batch
+static int wb_variant(const dlwpcs_conv_desc *d, int &CT, int &NT, int &cap_tile_px, int &cap_pix) {
+    CT = NT = 1;
+    if (d->dtype != DLWPCS_BF16 || d->B < 1 || (d->ksize != 1 && d->ksize != 3)) return -1;
+    if (d->halo && d->ksize != 3) return -1;
+    if (d->up0 && (d->N % 2)) return -1;
+    if (!d->halo && d->N < d->ksize) return -1;
+    if ((long)d->N * d->N >= (1l << 16)) return -1;                 // 16-bit index arithmetic (magic divisions)
+    if ((long)6 * d->N * d->N * (d->C0 > d->C1 ? d->C0 : d->C1) >= (1l << 31) || (long)6 * d->N * d->N * d->Cout >= (1l << 31))
+        return -1;                                                  // 32-bit element offsets inside a sample
+    const int Cin = d->C0 + d->C1;
+    const bool xv8 = d->C0 % 8 == 0 && d->C1 % 8 == 0;
+    if (d->ksize == 3) {
+        if (d->Cout % 8 != 0) return -1;
+        if (xv8) {
+            CT = Cin % 64 == 0 ? 2 : 1;
+            NT = d->Cout % 64 == 0 ? 2 : 1;
+            cap_tile_px = CT == 2 ? 320 : 512;
+            cap_pix = (CT == 2 || NT == 2) ? 192 : 384;
+            return CT == 2 ? (NT == 2 ? WB_V_3_8_22 : WB_V_3_8_21) : (NT == 2 ? WB_V_3_8_12 : WB_V_3_8_11);
+        }
+        if (d->C0 % 2 || d->C1 % 2 || Cin > 32) return -1;
+        cap_pix = 384;
+        if (Cin <= 16) { cap_tile_px = 512; return WB_V_3_2_8; }
+        cap_tile_px = 256;
+        return WB_V_3_2_16;
+    }
+    if (!xv8 || d->c0_valid != 0) return -1;
+    if (Cin > 32) return -1;                                        // (1x1 layers wider than one ci tile: per-layer path)
+    cap_tile_px = 512; cap_pix = 384;
+    if (d->Cout % 8 == 0) return d->Cout <= 32 ? WB_V_1_8_11 : -1;
+    if (d->Cout % 2 == 0 && d->Cout <= 16) return WB_V_1_8_D2;
+    return -1;
+}
+
+struct WbGeom {
+    WbLayer L;
+    size_t lds;
+    double cost_item[2];      // estimated cycles per item of a full / the last (possibly narrower) ci group
+};
+
+static inline int wb_cin_logical(const dlwpcs_conv_desc *d) { return (d->c0_valid > 0 ? d->c0_valid : d->C0) + d->C1; }
+
+static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, WbGeom &G) {
+    int CT, NT, cap_tile_px, cap_pix;
+    const int variant = wb_variant(d, CT, NT, cap_tile_px, cap_pix);
+    if (variant < 0) return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: layer (N=%d C0=%d C1=%d Cout=%d k=%d dtype=%d) has no batched kernel",
+                                 d->N, d->C0, d->C1, d->Cout, d->ksize, d->dtype);
+    const int KS = d->ksize, No = wb_out_size(d), face_pix = No * No, W2 = No + KS - 1;
+    int CAP = cap_pix;
+    auto pix_of = [&](int cap) { int p = cap; if (No <= cap) p = (cap / No) * No; if (p > face_pix) p = face_pix; return p; };
+    while (CAP > 16 && (long)(tile_rows_for(pix_of(CAP), No) + KS - 1) * W2 > cap_tile_px) CAP -= (CAP > 96 ? 96 : 16);
+    const int pix = pix_of(CAP);
+    const int rows = tile_rows_for(pix, No) + KS - 1;
+    if ((long)rows * W2 > cap_tile_px || pix < 1)
+        return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: a row of face size %d exceeds the producers' register capacity", No);
+    WbLayer &L = G.L;
+    memset(&L, 0, sizeof(L));
+    L.B = d->B; L.Nin = d->N; L.No = No; L.C0 = d->C0; L.C1 = d->C1; L.Cin = d->C0 + d->C1; L.Cout = d->Cout; L.up0 = d->up0;
+    L.halo = d->halo; L.KS = KS; L.W2 = W2; L.tile_rows_max = rows; L.pix = pix; L.nbands = ceil_div(face_pix, pix);
+    L.pix_cap = (pix + 15) & ~15; L.variant = variant;
+    if ((long)d->B * 4 * L.nbands >= (1l << 16))
+        return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: %ld work items per face class exceed the 16-bit item arithmetic", (long)d->B * 4 * L.nbands);
+    L.magicW2 = div_magic(W2); L.magicNo = div_magic(No); L.magicN = div_magic(d->N);
+    L.magicB = d->B > 1 ? div_magic(d->B) : 0; L.magicNb = L.nbands > 1 ? div_magic(L.nbands) : 0;
+    L.CT = CT; L.NT = NT;
+    L.ncit = ceil_div(L.Cin, 32 * CT); L.ncot = ceil_div(d->Cout, 32 * NT);
+    L.cin_logical = wb_cin_logical(d); L.flip = d->flip_north_pole ? 1 : 0; L.want_bias = want_bias ? 1 : 0;
+    L.has_np = has_np ? 1 : 0;
+    const int TAPS = KS * KS;
+    L.slot_floats = (int)align_up((size_t)TAPS * 32 * CT * 32 * NT + 32 * NT, 64);
+    const size_t buf = (size_t)CT * rows * W2 * 64 + (size_t)NT * L.pix_cap * 64;
+    const int nph = 4 / (CT * NT), rslots = TAPS - TAPS / nph;
+    const size_t need = ((size_t)4 * rslots * 1024 + 2048) * 4;
+    G.lds = 2 * buf > need ? 2 * buf : need;
+    if (G.lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: LDS tile of %zu bytes exceeds 160 KiB", G.lds);
+    // Cost model (cycles per item and CU), fitted to the s_memtime accounting of tools/wb_timing.py on MI355X (eleven layer
+    // shapes of the U-Net, +-7 %): when the producers set the period an item costs ~3300 cycles plus its bytes at 23 B/clk
+    // (plus ~45 per 4-B load instruction of a thread); when the consumers do, ~615 cycles per 16-pixel slab of 9 taps (260
+    // for a 1x1 kernel; the slab count per wave is rounded up to even) plus ~1200.
+    static double fix = -1, bpc = -1, slab3 = -1, slab1 = -1, ld4 = -1, cfix = -1;
+    if (fix < 0) {
+        const char *e = getenv("DLWPCS_WB_COST");
+        fix = 3300.0; bpc = 23.0; slab3 = 615.0; slab1 = 260.0; ld4 = 45.0; cfix = 1200.0;
+        if (e) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &fix, &bpc, &slab3, &slab1, &ld4, &cfix);
+    }
+    const int nslab = L.pix_cap / 16;
+    const int S = ((ceil_div(nslab, nph)) + 1) & ~1;
+    const double mma = (double)S * (KS == 3 ? slab3 : slab1) + cfix;
+    const bool x4 = variant == WB_V_3_2_8 || variant == WB_V_3_2_16, d4 = variant == WB_V_1_8_D2;
+    for (int last = 0; last < 2; ++last) {
+        int cin_grp = 32 * CT;
+        if (last) { cin_grp = L.Cin - (L.ncit - 1) * 32 * CT; }
+        const double xbytes = (double)rows * W2 * cin_grp * 2.0, dbytes = (double)pix * (d->Cout < 32 * NT ? d->Cout : 32 * NT) * 2.0;
+        double ld = fix + (xbytes + dbytes) / bpc;
+        if (x4) ld += ld4 * ((double)rows * W2 * (variant == WB_V_3_2_8 ? 8 : 16) / 256.0);
+        if (d4) ld += ld4 * ((double)pix * 8 / 256.0);
+        G.cost_item[last] = ld > mma ? ld : mma;
+    }
+    return DLWPCS_OK;
+}
+
+static double wb_seg_overhead() {
+    static double v = -1;
+    if (v < 0) { const char *e = getenv("DLWPCS_WB_SEG"); v = e ? atof(e) : 20000.0; }
+    return v;
+}
+
+struct WbPlanOut {
+    WbHeader H;
+    std::vector<WbLayer> layers;
+    std::vector<WbSeg> segs;
+    std::vector<WbGroup> groups;
+};
+
+static int wb_build(const dlwpcs_wgrad_item *items, int n, int n_workers, WbPlanOut &P) {
+    if (n < 1 || n > WB_MAX_LAYERS) return fail(DLWPCS_E_INVALID, "wgrad_batch: %d items (1..%d)", n, WB_MAX_LAYERS);
+    if (n_workers < 1 || n_workers > 256) return fail(DLWPCS_E_INVALID, "wgrad_batch: %d workers", n_workers);
+    std::vector<WbGeom> G(n);
+    size_t lds = 0;
+    struct Grp { int layer, cit, cot, cls; long items; double cost_item; };
+    std::vector<Grp> grps;
+    double total = 0;
+    int group_base = 0;
+    uint32_t red_blocks = 0;
+    memset(&P.H, 0, sizeof(P.H));
+    for (int l = 0; l < n; ++l) {
+        const dlwpcs_wgrad_item &it = items[l];
+        const bool want_bias = it.db_eq || it.db_pol || it.db_np;
+        int rc = wb_geometry(&it.d, want_bias, it.dw_np != nullptr, G[l]);
+        if (rc) return rc;
+        if ((it.db_np != nullptr) != (it.dw_np != nullptr) && it.db_eq)
+            return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d: dw_np / db_np must match", l);
+        WbLayer &L = G[l].L;
+        L.group_base = group_base;
+        group_base += L.ncit * L.ncot * 3;
+        if (G[l].lds > lds) lds = G[l].lds;
+        for (int cit = 0; cit < L.ncit; ++cit)
+            for (int cot = 0; cot < L.ncot; ++cot)
+                for (int cls = 0; cls < 3; ++cls) {
+                    Grp g{l, cit, cot, cls, (long)L.B * (cls == 0 ? 4 : 1) * L.nbands, G[l].cost_item[cit == L.ncit - 1 ? 1 : 0]};
+                    grps.push_back(g);
+                    total += g.items * g.cost_item;
+                }
+        const int nout = L.KS * L.KS * L.cin_logical * L.Cout + (want_bias ? L.Cout : 0);
+        P.H.red_first[l] = red_blocks;
+        red_blocks += (uint32_t)ceil_div(L.Cout % 4 == 0 ? nout / 4 : nout, 256);
+    }
+    for (int l = n; l <= WB_MAX_LAYERS; ++l) P.H.red_first[l] = red_blocks;
+    // Equal-cost chains: walk the groups in order and cut at worker boundaries; every piece of a group costs its items plus a
+    // fixed per-segment overhead (first loads, epilogue).  The smallest per-worker budget that fits n_workers chains is found
+    // by bisection (the greedy walk is monotone in the budget).
+    const double seg_ovh = wb_seg_overhead();
+    std::vector<uint32_t> seg_start(257, 0);
+    auto pack = [&](double target, bool emit) -> bool {
+        if (emit) P.segs.clear();
+        int w = 0;
+        double acc = 0;
+        uint32_t nseg = 0;
+        if (emit) seg_start[0] = 0;
+        for (size_t gi = 0; gi < grps.size(); ++gi) {
+            const Grp &g = grps[gi];
+            long done = 0;
+            while (done < g.items) {
+                long take = (long)((target - acc - seg_ovh) / g.cost_item);
+                if (take < 1) {
+                    if (acc > 0) {                                  // this worker is full: open the next chain
+                        if (++w >= n_workers) return false;
+                        if (emit) seg_start[w] = nseg;
+                        acc = 0;
+                        continue;
+                    }
+                    take = 1;                                       // (a single item above the budget)
+                }
+                if (take > g.items - done) take = g.items - done;
+                if (emit) {
+                    WbSeg s{};
+                    s.layer = g.layer; s.cls = g.cls; s.cit = g.cit; s.cot = g.cot;
+                    s.t_first = (int)done; s.t_last = (int)(done + take);
+                    s.bias = (G[g.layer].L.want_bias && g.cit == 0) ? 1 : 0;
+                    P.segs.push_back(s);
+                }
+                ++nseg;
+                acc += seg_ovh + take * g.cost_item;
+                done += take;
+            }
+        }
+        if (emit) for (int k = w + 1; k <= 256; ++k) seg_start[k] = nseg;
+        return true;
+    };
+    double lo = total / n_workers, hi = total + (double)grps.size() * seg_ovh + 1.0;
+    for (int it = 0; it < 40 && hi - lo > 1.0; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (pack(mid, false)) hi = mid; else lo = mid;
+    }
+    if (!pack(hi, true)) return fail(DLWPCS_E_INVALID, "wgrad_batch: internal: the work list does not fit %d workers", n_workers);
+    // slots: the segments of a group are consecutive -> one (offset, stride, count) triple per group
+    P.groups.assign((size_t)group_base, WbGroup{0, 0, 0, 0});
+    uint64_t off = 0;
+    for (size_t si = 0; si < P.segs.size(); ++si) {
+        WbSeg &s = P.segs[si];
+        const WbLayer &L = G[s.layer].L;
+        WbGroup &g = P.groups[(size_t)L.group_base + (s.cit * L.ncot + s.cot) * 3 + s.cls];
+        if (g.count == 0) { g.off = (uint32_t)off; g.stride = (uint32_t)L.slot_floats; }
+        s.slot_off = (uint32_t)off;
+        g.count += 1;
+        off += (uint64_t)L.slot_floats;
+        if (off >= (1ull << 32)) return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: partial sums exceed 16 GiB");
+    }
+    P.layers.resize(n);
+    for (int l = 0; l < n; ++l) P.layers[l] = G[l].L;
+    WbHeader &H = P.H;
+    H.magic = WB_MAGIC; H.n_layers = (uint32_t)n; H.n_segments = (uint32_t)P.segs.size(); H.n_workers = (uint32_t)n_workers;
+    H.n_groups = (uint32_t)group_base; H.lds_bytes = (uint32_t)lds;
+    H.off_layers = (uint32_t)align_up(sizeof(WbHeader), 256);
+    H.off_segs = (uint32_t)align_up(H.off_layers + sizeof(WbLayer) * n, 256);
+    H.off_groups = (uint32_t)align_up(H.off_segs + sizeof(WbSeg) * P.segs.size(), 256);
+    H.total_bytes = (uint32_t)align_up(H.off_groups + sizeof(WbGroup) * P.groups.size(), 256);
+    H.ws_floats = off;
+    memcpy(H.seg_start, seg_start.data(), sizeof(H.seg_start));
+    return DLWPCS_OK;
+}
+
+static int wb_workers() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLWPCS_WB_WORKERS"); v = e ? atoi(e) : 256; if (v < 1 || v > 256) v = 256; }
+    return v;
+}
+
+// upper bound of the plan size that does not depend on where the cuts fall: every group is cut at most once per worker
+static size_t wb_plan_bound(int n_groups, int n_layers, int n_workers) {
+    return align_up(sizeof(WbHeader), 256) + align_up(sizeof(WbLayer) * n_layers, 256) +
+           align_up(sizeof(WbSeg) * (size_t)(n_groups + n_workers + 8), 256) + align_up(sizeof(WbGroup) * (size_t)n_groups, 256) + 256;
+}
+
+}  // namespace dlwpcs
+
+using namespace dlwpcs;
+
+extern "C" int dlwpcs_wgrad_batch_supported(const dlwpcs_conv_desc *d) {
+    if (!d) return 0;
+    int CT, NT, a, b;
+    if (wb_variant(d, CT, NT, a, b) < 0) return 0;
+    WbGeom G;
+    const int rc = wb_geometry(d, true, false, G);
+    return rc == DLWPCS_OK ? 1 : 0;
+}
+
+extern "C" int dlwpcs_wgrad_batch_sizes(const dlwpcs_wgrad_item *items, int n_items, size_t *plan_bytes, size_t *workspace_bytes) {
+    if (!items || !plan_bytes || !workspace_bytes) return fail(DLWPCS_E_INVALID, "wgrad_batch_sizes: null pointer");
+    WbPlanOut P;
+    const int rc = wb_build(items, n_items, wb_workers(), P);
+    if (rc) return rc;
+    *plan_bytes = wb_plan_bound((int)P.H.n_groups, n_items, wb_workers());
+    *workspace_bytes = align_up((size_t)P.H.ws_floats * 4, 256);
+    return DLWPCS_OK;
+}
+
+extern "C" int dlwpcs_wgrad_batch_plan(const dlwpcs_wgrad_item *items, int n_items, void *plan_host, size_t plan_bytes) {
+    if (!items || !plan_host) return fail(DLWPCS_E_INVALID, "wgrad_batch_plan: null pointer");
+    WbPlanOut P;
+    const int rc = wb_build(items, n_items, wb_workers(), P);
+    if (rc) return rc;
+    if (plan_bytes < P.H.total_bytes) return fail(DLWPCS_E_WORKSPACE, "wgrad_batch_plan: plan buffer %zu < %u bytes", plan_bytes, P.H.total_bytes);
+    char *out = (char *)plan_host;
+    memset(out, 0, plan_bytes);
+    memcpy(out, &P.H, sizeof(WbHeader));
+    memcpy(out + P.H.off_layers, P.layers.data(), sizeof(WbLayer) * P.layers.size());
+    memcpy(out + P.H.off_segs, P.segs.data(), sizeof(WbSeg) * P.segs.size());
+    memcpy(out + P.H.off_groups, P.groups.data(), sizeof(WbGroup) * P.groups.size());
+    return DLWPCS_OK;
+}
+
+extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                                  void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
+    if (!items || !plan_host || !plan_dev || !workspace) return fail(DLWPCS_E_INVALID, "wgrad_batch: null pointer");
+    const WbHeader *H = (const WbHeader *)plan_host;
+    if (H->magic != WB_MAGIC || (int)H->n_layers != n_items) return fail(DLWPCS_E_INVALID, "wgrad_batch: plan does not match the items");
+    if (workspace_bytes < H->ws_floats * 4) return fail(DLWPCS_E_WORKSPACE, "wgrad_batch: workspace %zu < %llu bytes", workspace_bytes,
+                                                        (unsigned long long)H->ws_floats * 4);
+    const WbLayer *layers = (const WbLayer *)((const char *)plan_host + H->off_layers);
+    WbPtrs ptrs{};
+    WbRedPtrs R{};
+    double flops = 0, bytes = 0;
+    for (int l = 0; l < n_items; ++l) {
+        const dlwpcs_wgrad_item &it = items[l];
+        const WbLayer &L = layers[l];
+        if (L.B != it.d.B || L.Nin != it.d.N || L.C0 != it.d.C0 || L.C1 != it.d.C1 || L.Cout != it.d.Cout || L.KS != it.d.ksize ||
+            L.halo != it.d.halo || L.up0 != it.d.up0)
+            return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d differs from the plan", l);
+        if (!it.src0 || !it.dz || !it.dw_eq || !it.dw_pol || (it.d.C1 > 0 && !it.src1) || (it.d.halo && !it.table_dev))
+            return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d: null pointer", l);
+        if ((L.want_bias != 0) != (it.db_eq || it.db_pol || it.db_np) || (L.has_np != 0) != (it.dw_np != nullptr))
+            return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d: bias / north-pole pointers differ from the plan", l);
+        ptrs.src0[l] = it.src0; ptrs.src1[l] = it.d.C1 > 0 ? it.src1 : it.src0; ptrs.dz[l] = it.dz; ptrs.table[l] = it.table_dev;
+        R.dw_eq[l] = (float *)it.dw_eq; R.dw_pol[l] = (float *)it.dw_pol; R.dw_np[l] = (float *)it.dw_np;
+        R.db_eq[l] = (float *)it.db_eq; R.db_pol[l] = (float *)it.db_pol; R.db_np[l] = (float *)it.db_np;
+        const double n0 = L.up0 ? L.Nin / 2 : L.Nin;
+        flops += 2.0 * L.B * 6 * (double)L.No * L.No * L.KS * L.KS * L.cin_logical * L.Cout;
+        bytes += 2.0 * L.B * 6.0 * (n0 * n0 * L.C0 + (double)L.Nin * L.Nin * L.C1 + (double)L.No * L.No * L.Cout) +
+                 4.0 * L.KS * L.KS * L.cin_logical * L.Cout;
+    }
+    memcpy(R.first, H->red_first, sizeof(R.first));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = H->lds_bytes;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)wgrad_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "wgrad_batch: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    int pidx = -1;
+    if (prof_enabled()) pidx = prof_begin("wgrad_batch_kernel", flops, bytes, s);
+    long long *dbg = nullptr;
+#ifdef DLWPCS_WB_TIMING
+    { const char *e = getenv("DLWPCS_DBG_PTR"); dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
+#endif
+    hipLaunchKernelGGL(wgrad_batch_kernel, dim3(H->n_workers), dim3(512), lds, s, (const char *)plan_dev, ptrs, (float *)workspace, dbg);
+    if (pidx >= 0) prof_end(pidx, s);
+    int rc = check_launch("wgrad_batch");
+    if (rc) return rc;
+    // reduction rounds: items that share their destination (a layer applied twice) go into successive launches
+    uint32_t pending = n_items >= 32 ? 0xffffffffu : ((1u << n_items) - 1u);
+    while (pending) {
+        uint32_t live = 0;
+        for (int l = 0; l < n_items; ++l) {
+            if (!((pending >> l) & 1u)) continue;
+            bool clash = false;
+            for (int k = 0; k < l; ++k)
+                if (((live >> k) & 1u) && items[k].dw_eq == items[l].dw_eq) clash = true;
+            if (!clash) live |= 1u << l;
+        }
+        R.live = live;
+        pidx = -1;
+        if (prof_enabled()) pidx = prof_begin("wb_reduce_kernel", 0.0, (double)H->ws_floats * 4.0, s);
+        hipLaunchKernelGGL(wb_reduce_kernel, dim3(H->red_first[WB_MAX_LAYERS]), dim3(256), 0, s, (const char *)plan_dev, R,
+                           (const float *)workspace);
+        if (pidx >= 0) prof_end(pidx, s);
+        pending &= ~live;
+    }
+    return check_launch("wgrad_batch_reduce");
+}

@@ -206,6 +206,39 @@ int dlwpcs_wgrad_reduce_batch(const dlwpcs_reduce_item *items_dev, const dlwpcs_
                               dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
+ * Batched weight gradients: ONE persistent launch for every layer of a backward pass (DLWPCS_BF16 hot-path shapes).
+ * The weight gradient of a layer needs only the layer's saved inputs and dz, the gradient w.r.t. its PRE-activation
+ * output, so nothing in the backward chain waits for it: a training step queues one item per layer and runs them
+ * together after the last data gradient.  The host plan cuts the joint work list of all layers into one equal-cost
+ * chain per compute unit (a layer gets workers in proportion to its work, few partial sums), the reduction adds the
+ * partial sums in a fixed order (bitwise reproducible) and ACCUMULATES into dw_* / db_* (shared layers add up;
+ * the caller zeroes the gradient buffer once per step).  Replaces n_items calls of dlwpcs_conv_bwd_weights.
+ *
+ *   dz          (B,6,No,No,Cout) bf16: dy * act'(y) already applied by whoever produced the gradient
+ *               (dlwpcs_conv_bwd_data_masked, dlwpcs_avgpool2_bwd_add_masked, ...); act / alpha / vmax / flags of d are
+ *               ignored
+ *   plan        built on the HOST from the descriptors (and from which of the bias / north-pole pointers are non-NULL);
+ *               holds geometry only -- every tensor address travels by value in the kernel arguments, so one plan (and
+ *               its device copy, which the caller makes once) serves every step and a captured hipGraph keeps replaying
+ *               the addresses it was captured with.
+ * dlwpcs_wgrad_batch_supported: 1 if the layer described by d can be an item (others use dlwpcs_conv_bwd_weights).
+ * ------------------------------------------------------------------------------------------------------------- */
+#define DLWPCS_WGRAD_BATCH_MAX 24
+typedef struct dlwpcs_wgrad_item {
+    dlwpcs_conv_desc d;
+    const void *src0, *src1;              /* the layer's saved inputs (src1 NULL when C1 == 0) */
+    const void *dz;
+    const int32_t *table_dev;             /* halo table (halo == 1) */
+    void *dw_eq, *dw_pol, *dw_np;         /* fp32 HWIO, accumulated into; dw_np NULL unless independent north pole */
+    void *db_eq, *db_pol, *db_np;         /* fp32 (Cout,) or NULL */
+} dlwpcs_wgrad_item;
+int dlwpcs_wgrad_batch_supported(const dlwpcs_conv_desc *d);
+int dlwpcs_wgrad_batch_sizes(const dlwpcs_wgrad_item *items, int n_items, size_t *plan_bytes, size_t *workspace_bytes);
+int dlwpcs_wgrad_batch_plan(const dlwpcs_wgrad_item *items, int n_items, void *plan_host, size_t plan_bytes);
+int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                       void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------- *
  * Generic (any kernel size / stride / dilation / 'same') per-face convolution on an ALREADY PADDED channels_last
  * tensor: the off-hot-path options of CubeSphereConv2D (DLWP/custom.py:824-842).  Direct VALU kernels.
  * x: (B,6,H,W,Cin) -> y: (B,6,Ho,Wo,Cout);  pad_{t,l}: zero padding already resolved by the caller ('same').
