@@ -89,6 +89,8 @@ PROTOTYPES = {
                                                                                  c_void_p]),
     'dlwpcs_conv_bwd_data': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 5 + [c_void_p, c_void_p, c_void_p,
                                                                                       c_void_p, c_size_t, c_void_p]),
+    'dlwpcs_conv_bwd_data_masked': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_void_p] * 4 + [c_float, c_float] +
+                                    [c_void_p, c_void_p, c_size_t, c_void_p]),
     'dlwpcs_conv_bwd_weights': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_void_p] * 6 +
                                 [c_void_p, c_void_p, c_size_t, c_void_p]),
     'dlwpcs_conv_wgrad_reduce_item': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 6 +
@@ -106,6 +108,8 @@ PROTOTYPES = {
     'dlwpcs_avgpool2_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_avgpool2_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_avgpool2_bwd_add': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_avgpool2_bwd_masked': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
+                                           c_void_p]),
     'dlwpcs_upsample2_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_upsample2_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_concat2': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
@@ -126,6 +130,8 @@ PROTOTYPES = {
     'dlwpcs_head_mse_scratch_bytes': (c_size_t, []),
     'dlwpcs_head_mse_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p]),
+    'dlwpcs_head_mse_step_masked': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                            c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_void_p]),
     'dlwpcs_adam_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int,
                                      c_void_p]),
     'dlwpcs_batch_gather': (c_int, [c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int, c_void_p, c_int,

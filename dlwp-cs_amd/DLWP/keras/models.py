@@ -59,6 +59,8 @@ class Model(object):
         self.wgrad_side_stream = os.environ.get('DLWPCS_SIDE_STREAM', '0') == '1'   # measured slower on MI355X: off
         # one reduction launch for all layers' weight-gradient partials (DLWPCS_CONV_DEFER_REDUCE)
         self.defer_wgrad_reduce = os.environ.get('DLWPCS_DEFER_REDUCE', '1') == '1'
+        # one persistent launch for the weight gradients of all layers of a step (ops.wgrad_batch)
+        self.batch_wgrad = os.environ.get('DLWPCS_WGRAD_BATCH', '1') == '1'
         self._stager = None                 # pinned-memory / copy-stream feed of fit() on host arrays (keras/staging.py)
         # training step: output layer + loss + loss gradient + the layer's data gradient as one launch (ops.head_mse)
         self.fuse_head_loss = os.environ.get('DLWPCS_FUSE_HEAD', '1') == '1'
@@ -165,9 +167,51 @@ class Model(object):
                               isinstance(t.layer, Concatenate)))
         self._plan = steps
         self.n_fused = len(fused)
+        self._plan_premask(steps, out_uids)
         # model outputs that no other node consumes (candidates for the fused head + loss step) and appear once
         uids = [o.uid for o in self.outputs]
         self._sole_outputs = {u for u in uids if not consumers.get(u) and uids.count(u) == 1}
+
+    def _plan_premask(self, steps, out_uids):
+        """Pre-masked gradient convention (include/dlwpcs.h, dlwpcs_conv_bwd_data_masked): the output y of a fused
+        convolution + ReLU receives its gradient already multiplied by act'(y) when EVERY consumer of y is an op of this engine
+        that can apply the mask where it produces the gradient -- another fused convolution (data-gradient epilogue / routing
+        kernels), the pooling node of a skip connection, the pointwise output layer.  Decided statically, per step:
+        self._premask[uid] = (negative_slope, max_value) of the tensors that carry the convention, and per consuming step
+        which of its sources it must mask (a consumer that runs after the tensor's 'pool_skip' step sees the ALIAS, which
+        hands plain gradients back to the pooling node)."""
+        from ..custom import CubeSphereConv2D
+        produced = {}                  # uid -> (alpha, vmax) of fused conv + activation outputs
+        for st in steps:
+            if st[0] == 'fused_conv' and st[6] == ACT_LEAKY_CLIP:
+                produced[st[1]] = (float(st[7]), float(st[8]))
+        capable = {u: (u not in out_uids) for u in produced}
+        aliased = set()
+        src_mask = {}                  # step index -> (mask source 0?, mask source 1?) | bool for pool / head steps
+        for i, st in enumerate(steps):
+            if st[0] == 'fused_conv':
+                s0, s1 = st[3], st[4]
+                src_mask[i] = (s0 in produced and s0 not in aliased, s1 is not None and s1 in produced and s1 not in aliased)
+                if s0 == s1 and s0 in produced:
+                    capable[s0] = False            # (both sources the same tensor: keep the plain path)
+            elif st[0] == 'pool_skip':
+                u = st[3]
+                src_mask[i] = u in produced and u not in aliased
+                aliased.add(u)
+            else:
+                _, out_uid, lay, in_uids, _ = st
+                head = (isinstance(lay, CubeSphereConv2D) and len(in_uids) == 1 and lay._is_mfma_config()
+                        and lay.data_format == 'channels_last' and lay.activation is None)
+                src_mask[i] = bool(head and in_uids[0] in produced and in_uids[0] not in aliased)
+                for u in in_uids:
+                    if u in produced and u not in aliased and not head:
+                        capable[u] = False         # a consumer that cannot mask: the tensor keeps plain gradients
+        self._premask = {u: produced[u] for u in produced if capable[u]}
+        self._src_mask = src_mask
+
+    def _premask_on(self):
+        return (self.compute_dtype == 'bfloat16' and torch.is_grad_enabled()
+                and os.environ.get('DLWPCS_PREMASK', '1') == '1')
 
     def _pack_state(self, device):
         """Packed-weight buffers + the device item table of every matrix-core convolution layer (built once per
@@ -220,17 +264,23 @@ class Model(object):
         prediction."""
         from ..custom import CubeSphereConv2D
         values = {t.uid: v for t, v in zip(self.inputs, inputs)}
-        for st in self._plan:
+        pm = self._premask if self._premask_on() else {}
+        for i, st in enumerate(self._plan):
             if st[0] == 'fused_conv':
                 _, out_uid, lay, s0, s1, up0, act, alpha, vmax = st
+                m0, m1 = self._src_mask[i]
                 values[out_uid] = lay.fused_call(values[s0], None if s1 is None else values[s1], up0=up0, halo=True,
-                                                 act=act, alpha=alpha, vmax=vmax)
+                                                 act=act, alpha=alpha, vmax=vmax,
+                                                 premask0=pm.get(s0) if m0 else None, premask1=pm.get(s1) if m1 else None,
+                                                 dy_premasked=out_uid in pm)
             elif st[0] == 'pool_skip':
                 _, out_uid, lay, in_uid = st
-                values[out_uid], values[in_uid] = ops.avgpool2_skip(values[in_uid])
+                values[out_uid], values[in_uid] = ops.avgpool2_skip(values[in_uid],
+                                                                     pm.get(in_uid) if self._src_mask[i] else None)
             else:
                 _, out_uid, lay, in_uids, takes_list = st
                 args = [values[u] for u in in_uids]
+                head_pm = pm.get(in_uids[0]) if (self._src_mask[i] and in_uids) else None
                 if (fuse_targets is not None and out_uid in fuse_targets and out_uid in self._sole_outputs
                         and isinstance(lay, CubeSphereConv2D) and len(args) == 1 and lay._is_mfma_config()
                         and lay.data_format == 'channels_last' and lay.activation is None and lay.north_pole_kernel is None
@@ -238,7 +288,11 @@ class Model(object):
                                                     fuse_targets[out_uid][0])):
                     tgt, wgt = fuse_targets[out_uid]
                     values[out_uid] = ops.head_mse(args[0], tgt, lay.equatorial_kernel, lay.polar_kernel, lay.equatorial_bias,
-                                                   lay.polar_bias, wgt, lay.flip_north_pole)
+                                                   lay.polar_bias, wgt, lay.flip_north_pole, premask=head_pm)
+                    continue
+                if head_pm is not None:
+                    # pointwise / 'valid' convolution on a pre-masked source: the layer's own call with the mask handed down
+                    values[out_uid] = lay.fused_call(args[0], halo=False, premask0=head_pm)
                     continue
                 values[out_uid] = lay.call(args if (takes_list or len(args) > 1) else args[0])
         return [values[o.uid] for o in self.outputs]
@@ -397,15 +451,22 @@ class Model(object):
             ops.DIRECT_PARAM_GRADS = True       # weight gradients accumulate straight into the flat gradient buffer
             ops.WGRAD_SIDE_STREAM = self.wgrad_side_stream
             ops.DEFER_WGRAD_REDUCE = self.defer_wgrad_reduce    # ... through ONE reduction launch for all layers
+            # ... and where the batched kernel applies (bf16, pre-masked or activation-free layers) the weight gradients of all
+            # layers are ONE launch after the last data gradient
+            ops.WGRAD_BATCH = self.batch_wgrad and not self.wgrad_side_stream
             ops.drop_deferred_reduce()
+            ops.drop_wgrad_batch()
             try:
                 torch.autograd.backward(stats, ones)
+                ops.flush_wgrad_batch()
                 ops.flush_deferred_reduce(dev)
             finally:
                 ops.DIRECT_PARAM_GRADS = False
                 ops.WGRAD_SIDE_STREAM = False
                 ops.DEFER_WGRAD_REDUCE = False
+                ops.WGRAD_BATCH = False
                 ops.drop_deferred_reduce()
+                ops.drop_wgrad_batch()
                 ops.join_side_stream(stats[0].device)
         if len(stats) == 1:
             return stats[0].detach().view(1, 2)                 # no copy launch for the single-output case

@@ -110,8 +110,27 @@ def flush_deferred_reduce(device):
 _wb_plans = {}              # geometry key -> (host plan buffer, device plan tensor, workspace bytes)
 
 
+# When True (DLWP.keras.Model training step) a convolution's backward node does not launch its weight gradient: it queues
+# (descriptor, inputs, dz, gradient buffers) and flush_wgrad_batch() runs ALL queued layers with one launch after the last
+# data gradient (the weight gradients are off the critical path of the backward pass).  Needs DIRECT_PARAM_GRADS (the
+# gradients are accumulated into the parameters' preset .grad buffers); whoever sets the flag must flush.
+WGRAD_BATCH = False
+_wb_pending = []
+
+
 def wgrad_batch_supported(d):
     return bool(lib().dlwpcs_wgrad_batch_supported(ctypes.byref(d)))
+
+
+def drop_wgrad_batch():
+    del _wb_pending[:]
+
+
+def flush_wgrad_batch():
+    if _wb_pending:
+        pending = list(_wb_pending)
+        del _wb_pending[:]
+        wgrad_batch(pending)
 
 
 def _wb_items(entries):
@@ -271,6 +290,14 @@ def _weight_gradients(d, src0, src1, dy, y, params, table, ws, nbytes, direct, d
     dev = dy.device
     w_eq, w_pol, w_np = params[0], params[1], params[2]
     dw_eq = dw_pol = dw_np = db_eq = db_pol = db_np = None
+    if direct and WGRAD_BATCH and d.act == nat.ACT_NONE and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(d):
+        # dy IS dz (no activation, or the gradient arrived pre-masked): queue the layer for the batched launch
+        pe, pp, pn, be, bp, bn = params
+        d2 = ConvDesc.from_buffer_copy(d)
+        _wb_pending.append((d2, src0, src1, dy, table,
+                            (pe.grad, pp.grad, None if pn is None else pn.grad, None if be is None else be.grad,
+                             None if bp is None else bp.grad, None if bn is None else bn.grad)))
+        return dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np
     if direct:
         pe, pp, pn, be, bp, bn = params
         d2 = ConvDesc.from_buffer_copy(d)
@@ -321,7 +348,10 @@ class _CSConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, ksize, halo, up0, flip, act, alpha, vmax,
-                c0_valid=0):
+                c0_valid=0, premask0=None, premask1=None, dy_premasked=False):
+        """premask0 / premask1 = (negative_slope, max_value) | None: src0 / src1 is the output of an activated layer that expects
+        its gradient PRE-MASKED (multiplied by act'(src)): the backward applies it to dsrc0 / dsrc1.  dy_premasked: the gradient
+        THIS node receives is already dz = dy * act'(y) (every consumer of y honours premask).  See dlwpcs_conv_bwd_data_masked."""
         require_device(src0, 'cs_conv')
         src0 = _c(src0)
         B = src0.shape[0]
@@ -366,6 +396,10 @@ class _CSConv(torch.autograd.Function):
             check(lib().dlwpcs_conv_fwd(ctypes.byref(d), ptr(src0), ptr(src1), ptr(w_eq), ptr(w_pol), ptr(w_np),
                                         ptr(b_eq), ptr(b_pol), ptr(b_np), ptr(y), ptr(table), ptr(ws), ws.numel(),
                                         stream_ptr()), 'dlwpcs_conv_fwd')
+        if premask0 is not None and premask1 is not None and tuple(premask0) != tuple(premask1):
+            raise ValueError('cs_conv: both sources must share the activation parameters of their masks')
+        ctx.premask = (premask0, premask1)
+        ctx.dy_premasked = bool(dy_premasked) and act != nat.ACT_NONE
         ctx.packed = packed
         ctx.desc = d
         ctx.tables = (table, inv)
@@ -390,7 +424,41 @@ class _CSConv(torch.autograd.Function):
         want_w = any(need[2:8])
         direct = DIRECT_PARAM_GRADS and (need[2] or need[3]) and all(
             p is None or (p.is_leaf and p.grad is not None and p.grad.is_contiguous()) for p in ctx.params)
-        defer = direct and DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM and d.B > 0
+        pm0, pm1 = ctx.premask
+        if dsrc0 is None:
+            pm0 = None
+        if dsrc1 is None:
+            pm1 = None
+        masked_io = ctx.dy_premasked or pm0 is not None or pm1 is not None
+        if masked_io:
+            # Pre-masked gradient convention.  dy_premasked: dy is dz already -> both gradient kernels run as for a layer
+            # without activation and never read y.  Otherwise (only the sources want masks) dz is formed once, elementwise.
+            if ctx.dy_premasked or d.act == nat.ACT_NONE:
+                dz = dy
+            else:
+                dz = torch.empty_like(dy)
+                check(lib().dlwpcs_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), nat.ACT_LEAKY_CLIP, d.alpha, d.vmax,
+                                           nat.dtype_tag(dy), stream_ptr()), 'dlwpcs_act_bwd')
+            dn = ConvDesc.from_buffer_copy(d)
+            dn.act = nat.ACT_NONE
+            dn.flags = d.flags & nat.CONV_PREPACKED
+            batching = (direct and WGRAD_BATCH and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(dn))
+            defer = direct and DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM and d.B > 0 and not batching
+            ws = _workspace(nbytes, dev, 'defer%d' % len(_deferred)) if defer else _workspace(nbytes, dev)
+            if dsrc0 is not None or dsrc1 is not None:
+                wq = ctx.packed[3] if ctx.packed is not None else w_eq
+                pm = pm0 if pm0 is not None else pm1
+                ma, mv = (float(pm[0]), float(pm[1])) if pm is not None else (0.0, 0.0)
+                check(lib().dlwpcs_conv_bwd_data_masked(ctypes.byref(dn), ptr(dz), ptr(wq), ptr(w_pol), ptr(w_np), ptr(dsrc0),
+                                                        ptr(dsrc1), ptr(src0 if pm0 is not None else None),
+                                                        ptr(src1 if pm1 is not None else None), ma, mv, ptr(inv), ptr(ws),
+                                                        ws.numel(), stream_ptr()), 'dlwpcs_conv_bwd_data_masked')
+            dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np = _weight_gradients(
+                dn, src0, src1, dz, None, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp)
+            return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 11
+        batching = (direct and WGRAD_BATCH and d.act == nat.ACT_NONE and d.B > 0 and not WGRAD_SIDE_STREAM
+                    and wgrad_batch_supported(d))
+        defer = direct and DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM and d.B > 0 and not batching
         # deferred reduction: the partials (and the dz hand-over next to them) live in this node's own workspace
         ws = _workspace(nbytes, dev, 'defer%d' % len(_deferred)) if defer else _workspace(nbytes, dev)
         reuse_dz = ((dsrc0 is not None or dsrc1 is not None) and want_w and d.act != nat.ACT_NONE
@@ -413,7 +481,7 @@ class _CSConv(torch.autograd.Function):
             d, src0, src1, dy, y, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp)
         if reuse_dz:
             run_bwd_data()
-        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 8
+        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 11
 
 
 def conv_packed_buffers(ksize, cin, cout, dtype_tag, device, bias=True):
@@ -452,7 +520,7 @@ def pack_batch(items_dev, n_items):
 
 
 def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1=None, ksize=3, halo=True, up0=False,
-            flip_north_pole=True, act=nat.ACT_NONE, alpha=0.0, vmax=0.0):
+            flip_north_pole=True, act=nat.ACT_NONE, alpha=0.0, vmax=0.0, premask0=None, premask1=None, dy_premasked=False):
     if (w_np is None) != (b_np is None) and b_eq is not None:
         raise ValueError('cs_conv: north-pole kernel and bias must be given together')
     # Network inputs with a channel count that is not a multiple of the 16-B vector (7 variables; optionally 14 = 7 x 2):
@@ -471,7 +539,8 @@ def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1
         elif cin_w < c_phys <= (cin_w + channel_vector(src0.dtype) - 1) // channel_vector(src0.dtype) * channel_vector(src0.dtype):
             c0_valid = cin_w
     return _CSConv.apply(src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, int(ksize), bool(halo), bool(up0),
-                         bool(flip_north_pole), int(act), float(alpha), float(vmax), int(c0_valid))
+                         bool(flip_north_pole), int(act), float(alpha), float(vmax), int(c0_valid), premask0, premask1,
+                         bool(dy_premasked))
 
 
 # ------------------------------------------------------------------------------------------------------------------ #
@@ -590,7 +659,7 @@ def _bnc(x, what):
 
 class _AvgPool2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, premask=None):
         B, N, C = _bnc(x, 'avgpool2')
         if N % 2:
             raise ValueError('avgpool2: odd face size %d' % N)
@@ -598,6 +667,9 @@ class _AvgPool2(torch.autograd.Function):
         y = torch.empty((B, 6, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
         check(lib().dlwpcs_avgpool2_fwd(ptr(x), ptr(y), B, N, C, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_avgpool2_fwd')
         ctx.shape = (B, N, C)
+        ctx.premask = premask
+        if premask is not None:
+            ctx.save_for_backward(x)
         return y
 
     @staticmethod
@@ -605,9 +677,15 @@ class _AvgPool2(torch.autograd.Function):
         B, N, C = ctx.shape
         dy = _c(dy)
         dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
+        if ctx.premask is not None:
+            (x,) = ctx.saved_tensors
+            check(lib().dlwpcs_avgpool2_bwd_masked(ptr(dy), 0, ptr(x), ptr(dx), B, N, C, float(ctx.premask[0]),
+                                                   float(ctx.premask[1]), nat.dtype_tag(dy), stream_ptr()),
+                  'dlwpcs_avgpool2_bwd_masked')
+            return dx, None
         check(lib().dlwpcs_avgpool2_bwd(ptr(dy), ptr(dx), B, N, C, nat.dtype_tag(dy), stream_ptr()),
               'dlwpcs_avgpool2_bwd')
-        return dx
+        return dx, None
 
 
 class _AvgPool2Skip(torch.autograd.Function):
@@ -616,7 +694,10 @@ class _AvgPool2Skip(torch.autograd.Function):
     dx = d_alias + avgpool2_bwd(d_pooled) instead of avgpool2_bwd + autograd's elementwise add."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, premask=None):
+        """premask = (negative_slope, max_value) | None: x is the output of an activated layer that expects its gradient
+        pre-masked; the backward then writes act'(x) * (d_alias + avgpool2_bwd(d_pooled)) (the alias itself is NOT premask: its
+        consumers hand back plain gradients)."""
         B, N, C = _bnc(x, 'avgpool2')
         if N % 2:
             raise ValueError('avgpool2: odd face size %d' % N)
@@ -625,13 +706,30 @@ class _AvgPool2Skip(torch.autograd.Function):
         check(lib().dlwpcs_avgpool2_fwd(ptr(x), ptr(y), B, N, C, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_avgpool2_fwd')
         ctx.shape = (B, N, C)
         ctx.dtype = x.dtype
+        ctx.premask = premask
+        if premask is not None:
+            ctx.save_for_backward(x)
         return y, x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, dskip):
         B, N, C = ctx.shape
+        if ctx.premask is not None:
+            (x,) = ctx.saved_tensors
+            if dy is None:
+                dx = _c(dskip).clone()
+                check(lib().dlwpcs_act_bwd(ptr(dx), ptr(x), ptr(dx), dx.numel(), nat.ACT_LEAKY_CLIP, float(ctx.premask[0]),
+                                           float(ctx.premask[1]), nat.dtype_tag(dx), stream_ptr()), 'dlwpcs_act_bwd')
+                return dx, None
+            dy = _c(dy)
+            dskip = _c(dskip) if dskip is not None else None
+            dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
+            check(lib().dlwpcs_avgpool2_bwd_masked(ptr(dy), ptr(dskip), ptr(x), ptr(dx), B, N, C, float(ctx.premask[0]),
+                                                   float(ctx.premask[1]), nat.dtype_tag(dy), stream_ptr()),
+                  'dlwpcs_avgpool2_bwd_masked')
+            return dx, None
         if dy is None:
-            return dskip
+            return dskip, None
         dy = _c(dy)
         dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
         if dskip is None:
@@ -641,12 +739,12 @@ class _AvgPool2Skip(torch.autograd.Function):
             dskip = _c(dskip)
             check(lib().dlwpcs_avgpool2_bwd_add(ptr(dy), ptr(dskip), ptr(dx), B, N, C, nat.dtype_tag(dy), stream_ptr()),
                   'dlwpcs_avgpool2_bwd_add')
-        return dx
+        return dx, None
 
 
-def avgpool2_skip(x):
+def avgpool2_skip(x, premask=None):
     """-> (avgpool2(x), x') where x' aliases x and must be used by x's remaining consumers."""
-    return _AvgPool2Skip.apply(x)
+    return _AvgPool2Skip.apply(x, premask)
 
 
 class _Upsample2(torch.autograd.Function):
@@ -670,8 +768,8 @@ class _Upsample2(torch.autograd.Function):
         return dx
 
 
-def avgpool2(x):
-    return _AvgPool2.apply(x)
+def avgpool2(x, premask=None):
+    return _AvgPool2.apply(x, premask)
 
 
 def upsample2(x):
@@ -858,7 +956,7 @@ class _HeadMSE(torch.autograd.Function):
     leaves dy and dx behind (dlwpcs_head_mse_step), the backward only runs the layer's weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, target, w_eq, w_pol, b_eq, b_pol, weight, flip):
+    def forward(ctx, x, target, w_eq, w_pol, b_eq, b_pol, weight, flip, premask=None):
         x, target = _c(x), _c(target)
         B, _, N, _, C0 = x.shape
         Cout = w_eq.shape[3]
@@ -873,9 +971,16 @@ class _HeadMSE(torch.autograd.Function):
         out = torch.empty(2, dtype=torch.float32, device=x.device)
         dy = torch.empty((B, 6, N, N, Cout), dtype=x.dtype, device=x.device)
         dx = torch.empty_like(x)
-        check(lib().dlwpcs_head_mse_step(ctypes.byref(d), ptr(x), ptr(packed[1]), ptr(packed[2]) if b_eq is not None else 0,
-                                         ptr(packed[3]), ptr(target), float(weight), ptr(dy), ptr(dx), ptr(out), 1,
-                                         ptr(scratch), stream_ptr()), 'dlwpcs_head_mse_step')
+        if premask is not None:
+            check(lib().dlwpcs_head_mse_step_masked(ctypes.byref(d), ptr(x), ptr(packed[1]),
+                                                    ptr(packed[2]) if b_eq is not None else 0, ptr(packed[3]), ptr(target),
+                                                    float(weight), ptr(dy), ptr(dx), ptr(out), 1, ptr(scratch),
+                                                    float(premask[0]), float(premask[1]), stream_ptr()),
+                  'dlwpcs_head_mse_step_masked')
+        else:
+            check(lib().dlwpcs_head_mse_step(ctypes.byref(d), ptr(x), ptr(packed[1]), ptr(packed[2]) if b_eq is not None else 0,
+                                             ptr(packed[3]), ptr(target), float(weight), ptr(dy), ptr(dx), ptr(out), 1,
+                                             ptr(scratch), stream_ptr()), 'dlwpcs_head_mse_step')
         ctx.desc = d
         ctx.params = (w_eq, w_pol, None, b_eq, b_pol, None)
         ctx.save_for_backward(x, dy, dx)
@@ -895,15 +1000,16 @@ class _HeadMSE(torch.autograd.Function):
                                             for p in ctx.params)
         if not direct:
             raise RuntimeError('the fused head + loss step accumulates straight into the model\'s flat gradient buffer')
-        defer = DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM
+        batching = WGRAD_BATCH and not WGRAD_SIDE_STREAM and wgrad_batch_supported(d)
+        defer = DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM and not batching
         ws = _workspace(nbytes, dev, 'defer%d' % len(_deferred)) if defer else _workspace(nbytes, dev)
         _weight_gradients(d, x, None, dy, None, ctx.params, None, ws, nbytes, True, defer, need[2:6],
                           False, ctx.params[3] is not None, False)
-        return (dx if need[0] else None), None, None, None, None, None, None, None
+        return (dx if need[0] else None), None, None, None, None, None, None, None, None
 
 
-def head_mse(x, target, w_eq, w_pol, b_eq, b_pol, weight=1.0, flip_north_pole=True):
-    return _HeadMSE.apply(x, target, w_eq, w_pol, b_eq, b_pol, float(weight), bool(flip_north_pole))
+def head_mse(x, target, w_eq, w_pol, b_eq, b_pol, weight=1.0, flip_north_pole=True, premask=None):
+    return _HeadMSE.apply(x, target, w_eq, w_pol, b_eq, b_pol, float(weight), bool(flip_north_pole), premask)
 
 
 def adam_step(p, g, m, v, step_dev, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, zero_grads=False):

@@ -58,7 +58,13 @@ struct ConvKParams {
     // (B,6,No-2,No-2,channels of the source) and only the halo ring is written to `out`
     void *d0, *d1;
     int dsplit;
+    // Pre-masked gradients (data gradient, direct mode, bf16, MOUT instantiations): where m0 / m1 is non-null the cells that go
+    // straight to d0 / d1 are multiplied by act'(m) first -- m0 / m1 are the SOURCES themselves (outputs of the activated layers
+    // that produced them, same shape as d0 / d1), so that the gradient arrives at those layers as dz = dy * act'(y) already
+    const void *m0, *m1;
+    float m_alpha, m_vmax;
     int *direct_done;           // HOST pointer: set to 1 by launch_conv_cfg when the kernel it launched honours d0 / d1
+    int *mask_done;             // HOST pointer: bit 0 / 1 set when the launched kernel masks what it stores to d0 / d1
     int abl;                    // development only (-DDLWPCS_TIMELINE): epilogue ablation bits
     int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
     int tile_rows_max;          // rows reserved in LDS
@@ -125,9 +131,10 @@ static int tune_bits() {
 // the activation is max + min instead of compare + select, store addresses are per-(face, band) constants -- 1.75 k + 0.44 k cycles now -- and then
 // the producers' address arithmetic per load was cut to one multiply-add (see `sup`): the two sides are now balanced within
 // ~10 % (4.4 k consumer vs ~4.9 k producer cycles per tile).
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false>
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false, bool MOUT = false>
 __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P) {
     static_assert(!TAIL8 || (VW == 8 && sizeof(T) == 2 && !MASK), "TAIL8: bf16 16-B vectors, forward only");
+    static_assert(!MOUT || (MODE == MODE_ZERO && KS == 3 && sizeof(T) == 2 && !MASK), "MOUT: bf16 data gradient, direct mode");
     constexpr int ES = sizeof(T);
     constexpr int CGW = 32 / ES;                    // channels per MFMA operand group (two 16-B half fragments)
     constexpr int TAPS = KS * KS;
@@ -539,6 +546,30 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         const int spix = 6 * (P.No - 2) * (P.No - 2), c1 = P.Cout - P.dsplit;
         return make_rsrc(P.d1 ? reinterpret_cast<T *>(P.d1) + (size_t)gq.b * spix * c1 : nullptr, (uint32_t)(spix * c1 * ES));
     };
+    // MOUT: the sources' own values at the cells this lane will store to d0 / d1, requested at the start of the tile (they land
+    // during its matrix phase) with the store offsets of the (face, band)
+    static_assert(!MOUT || SOFF, "MOUT needs the per-band store offsets in registers");
+    uint4 ymq[MOUT ? NT : 1][MOUT ? MT : 1][MOUT ? NPS : 1];
+    auto mask_load = [&](const Geo &gq) {
+        if constexpr (MOUT) {
+            const int spix = 6 * (P.No - 2) * (P.No - 2), c1 = P.Cout - P.dsplit;
+            const rsrc_t r0 = make_rsrc(P.m0 ? reinterpret_cast<const T *>(P.m0) + (size_t)gq.b * spix * P.dsplit : nullptr,
+                                        (uint32_t)(spix * P.dsplit * ES));
+            const rsrc_t r1 = make_rsrc(P.m1 ? reinterpret_cast<const T *>(P.m1) + (size_t)gq.b * spix * c1 : nullptr,
+                                        (uint32_t)(spix * c1 * ES));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int ps = 0; ps < NPS; ++ps) {
+                        const uint32_t boff = soff[nt][mt][ps], sel = (ssel >> (2 * ((nt * MT + mt) * NPS + ps))) & 3u;
+                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r0, sel == 1 ? boff : ST_SKIP, 0, 0);
+                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r1, sel == 2 ? boff : ST_SKIP, 0, 0);
+                        ymq[nt][mt][ps] = make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w);
+                    }
+        }
+    };
     auto epi_slice = [&](auto fast_tag, int i, const Geo &gq, rsrc_t d_out, rsrc_t d_0, rsrc_t d_1, const auto &A) {
         const int pr = i / SPP, k = i % SPP;
         const int nt = pr / MT, mt = pr % MT;
@@ -551,10 +582,16 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         } else {
             const int ps = k - 4;
             const int px = ps * PPP + lane / LPP, q = lane % LPP;
-            const uint4 v = *reinterpret_cast<const uint4 *>(patch + px * PROW + q * 16);
+            uint4 v = *reinterpret_cast<const uint4 *>(patch + px * PROW + q * 16);
             uint32_t boff, sel;
             if constexpr (SOFF) { boff = soff[nt][mt][ps]; sel = (ssel >> (2 * ((nt * MT + mt) * NPS + ps))) & 3u; }
             else boff = store_off(gq, nt, mt, ps, sel);
+            if constexpr (MOUT) {
+                uint4 vm = v;
+                vmask(vm, ymq[nt][mt][ps], P.m_alpha, P.m_vmax);
+                const bool on = (sel == 1 && P.m0 != nullptr) || (sel == 2 && P.m1 != nullptr);
+                v = on ? vm : v;
+            }
 #ifdef DLWPCS_TIMELINE
             if (P.abl & 1) boff = ST_SKIP;          // ablation: no global stores
 #endif
@@ -656,6 +693,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     for (int t = t_first; t < t_last; ++t) {
         const Geo gq = geo_of(t);
         setup(gq);
+        mask_load(gq);
         for (int ch = 0; ch < nchunks; ++ch, ++g) {
             TL_MARK();
             __syncthreads();                // B_g: chunk g has been written by the producers
@@ -1628,11 +1666,12 @@ static void launch_wgrad_reduce(hipStream_t s, const float *partial, const float
 // Host side: configuration choice and launches
 // ------------------------------------------------------------------------------------------------------------------
 int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int up,
-                    int halo, int dtype, hipStream_t s);
+                    int halo, int dtype, hipStream_t s, const void *msrc, float m_alpha, float m_vmax, int *masked);
 int launch_src_pair(const void *dxv, void *dsrc0, void *dsrc1, const int32_t *inv, int B, int N, int C0, int C1, int up0,
-                    int dtype, hipStream_t s);
+                    int dtype, hipStream_t s, const void *m0, const void *m1, float m_alpha, float m_vmax);
 int launch_ring_fix(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int dtype,
-                    hipStream_t s);
+                    hipStream_t s, const void *msrc, float m_alpha, float m_vmax);
+int launch_mask_inplace(void *dx, const void *m, size_t n, float alpha, float vmax, int dtype, hipStream_t s);
 
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1816,6 +1855,8 @@ struct HeadParams {
     bf16_t *dx;              // (pix, 32)
     float *partial;          // [gridDim.x][2]
     float gscale;            // weight * 2 / n
+    int mask_dx;             // pre-masked gradients: dx *= act'(x; m_alpha, m_vmax), x being the output of an activated layer
+    float m_alpha, m_vmax;
 };
 
 template <int MT>
@@ -1848,11 +1889,18 @@ __global__ void __launch_bounds__(256) pw_head_train_kernel(HeadParams H) {
     float sq = 0.f, ab = 0.f;
     while (r.g < r.end) {
         uint4 xv[PW_U];
+        uint2 xm[PW_U][2];
         float2 tv[PW_U][MT][2];
 #pragma unroll
         for (int u = 0; u < PW_U; ++u) {
             const int g = r.g + u < r.end ? r.g + u : r.end - 1;
             xv[u] = *reinterpret_cast<const uint4 *>(src + (unsigned)g * 512u);
+            if (H.mask_dx) {
+                // x at the channels this lane's dx quads cover (4q.. and 16 + 4q.. of pixel n): same lines as xv, L1 hits
+                const bf16_t *xp = P.in + (unsigned)g * 512u + (unsigned)(n * 32 + q * 4);
+                xm[u][0] = *reinterpret_cast<const uint2 *>(xp);
+                xm[u][1] = *reinterpret_cast<const uint2 *>(xp + 16);
+            }
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 const int co0 = t * 16 + q * 4;
@@ -1910,8 +1958,11 @@ __global__ void __launch_bounds__(256) pw_head_train_kernel(HeadParams H) {
                 bf16_t *o_ptr = dxl + (unsigned)r.g * 512u;
                 uint2 o;
                 o.x = f2bf2(d0[0], d0[1]); o.y = f2bf2(d0[2], d0[3]);
+                // (the mask multiplies the ROUNDED gradient, like the unfused sequence data gradient -> elementwise mask: same bits)
+                if (H.mask_dx) { o.x = bmask2(o.x, xm[u][0].x, H.m_alpha, H.m_vmax); o.y = bmask2(o.y, xm[u][0].y, H.m_alpha, H.m_vmax); }
                 *reinterpret_cast<uint2 *>(o_ptr) = o;
                 o.x = f2bf2(d1[0], d1[1]); o.y = f2bf2(d1[2], d1[3]);
+                if (H.mask_dx) { o.x = bmask2(o.x, xm[u][1].x, H.m_alpha, H.m_vmax); o.y = bmask2(o.y, xm[u][1].y, H.m_alpha, H.m_vmax); }
                 *reinterpret_cast<uint2 *>(o_ptr + 16) = o;
                 pw_next(r, gpf);
             }
@@ -1977,7 +2028,7 @@ template <typename T> struct TName;
 template <> struct TName<float> { static const char *str() { return "float"; } };
 template <> struct TName<bf16_t> { static const char *str() { return "unsigned short"; } };
 
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false>
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false, bool MOUT = false>
 static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     constexpr int ES = sizeof(T), CGW = 32 / ES;
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
@@ -2025,7 +2076,14 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
                     (long)6 * face_pix * P.Cout * ES);
     if ((long)P.Nin * P.Nin * 6 >= (1l << 16) * 6 && (long)P.Nin * P.Nin >= (1l << 16))
         return fail(DLWPCS_E_UNSUPPORTED, "conv: face size %d too large for the 16-bit index arithmetic", P.Nin);
-    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8>;
+    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8, MOUT>;
+    if (!MOUT || !(P.d0 || P.d1)) {
+        // the epilogue masks only what it stores directly: whoever routes the rest (ring fix-up, inverse gather) applies the rest
+        if (!(P.d0)) P.m0 = nullptr;
+        if (!(P.d1)) P.m1 = nullptr;
+        if (!MOUT) P.m0 = P.m1 = nullptr;
+    }
+    if (P.mask_done) *P.mask_done = (MOUT && (P.m0 || P.m1)) ? ((P.m0 ? 1 : 0) | (P.m1 ? 2 : 0)) : 0;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -2038,8 +2096,8 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     int pidx = -1;
     if (prof_enabled()) {
         char tag[160];
-        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s>", TName<T>::str(), KS, KC,
-                 MT, NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? "true" : "false");
+        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s%s>", TName<T>::str(), KS, KC,
+                 MT, NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? "true" : "false", MOUT ? ", true" : "");
         pidx = prof_begin(tag, W.flops, W.bytes, s);
     }
     hipLaunchKernelGGL(kern, grid, dim3(2 * NTHREADS), lds, s, P);
@@ -2047,41 +2105,41 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     return check_launch("conv_mfma");
 }
 
-template <typename T, int KS, int VW, int MODE, bool MASK>
+template <typename T, int KS, int VW, int MODE, bool MASK, bool MOUT = false>
 static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
     const int face_pix = P.No * P.No;
     constexpr int VWF = 16 / (int)sizeof(T);        // full 16-B vectors
     constexpr int K2 = 64 / (int)sizeof(T);         // channels in a 64-B chunk row (16 fp32 / 32 bf16)
     constexpr int K1 = K2 / 2;
-    if constexpr (KS == 1) return launch_conv_cfg<T, KS, K1, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
-    else if constexpr (VW != VWF) return launch_conv_cfg<T, KS, K1, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);   // odd channel counts
+    if constexpr (KS == 1) return launch_conv_cfg<T, KS, K1, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT>(P, W, s);
+    else if constexpr (VW != VWF) return launch_conv_cfg<T, KS, K1, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT>(P, W, s);   // odd channel counts
     else {
         // Measured (MI355X, batch 32): the smaller tiles (MT = 2 / MT = 1) that would even out the tile count per CU
         // lose more to halo re-staging (the producers become the bottleneck) than they gain -> fixed MT = 3 tilings.
-        if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
+        if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT>(P, W, s);
         // data gradient with 64 output channels: the padded grid (N + 2 columns) leaves a 192-pixel tile 3 rows at N = 48
         // (5 fetched per 3 computed, 150 of 192 pixels used); two 32-channel groups with 384-pixel tiles get 7 rows (9 per 7,
         // 350 of 384) and read the smaller operand (dz) twice.  bf16 step -0.7 % (fp32 -0.3 %); the same split for the forward pass
         // measured +-0.
         if (P.NTtot == 2 && MODE == MODE_ZERO && (tune_bits() & TUNE_CONV_SPLIT2_BWD))
-            return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
+            return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT>(P, W, s);
         // bf16, 64 output channels from 65-128 input channels (3-4 chunks): 32 output channels per workgroup, whose 4 x 18 KB of
         // fragments fit as resident areas beside two 384-pixel input buffers (64 per workgroup would need 4 x 37 KB)
         // (faces of more than 320 pixels: at N = 12 a 384-pixel tile is 37 % full and the layer came out 6 us slower; the
         // 128 -> 64 forward at N = 24: 33.3 -> 28.5 us)
         if (P.NTtot == 2 && sizeof(T) == 2 && P.CG > 2 * (K2 / (32 / (int)sizeof(T))) && P.CG <= 4 * (K2 / (32 / (int)sizeof(T))) &&
             face_pix > 320 && (tune_bits() & TUNE_CONV_WSTAT))
-            return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK>(P, W, s);
-        if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
+            return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT>(P, W, s);
+        if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK, false, MOUT>(P, W, s);
         // more than 64 output channels: 64 per workgroup (two 32-channel chunks whose weight fragments STAY in the two LDS
         // buffers) and the 256 workgroups split over the output-channel groups, instead of 128 channels per workgroup in four
         // 16-channel chunks whose 37 KB of fragments had to be re-fetched every chunk (the 128-channel data gradient at N = 24:
         // 43.9 us, producers weight-fetch-bound; whole bf16 step -1.9 %, fp32 -0.9 %)
         // (not the forward pass on faces of <= 320 pixels: 64 -> 128 at N = 12 measured 13.4 us with the 160-pixel tiling, 14.9 split)
         if ((tune_bits() & TUNE_CONV_SPLIT_N) && (face_pix > 320 || MODE == MODE_ZERO))
-            return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK>(P, W, s);
-        if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK>(P, W, s);
-        return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK>(P, W, s);
+            return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK, false, MOUT>(P, W, s);
+        if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK, false, MOUT>(P, W, s);
+        return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK, false, MOUT>(P, W, s);
     }
 }
 
@@ -2103,6 +2161,11 @@ static int dispatch_conv_t(int KS, int vw, const ConvKParams &P, const Work &W, 
     if (KS == 3) {
         if (P.mode == MODE_HALO) return dispatch_vw<T, 3, MODE_HALO, false>(vw, P, W, s);
         if (P.mode == MODE_DIRECT) return dispatch_vw<T, 3, MODE_DIRECT, false>(vw, P, W, s);
+        if constexpr (sizeof(T) == 2) {
+            // pre-masked gradients: the direct-store epilogue multiplies by act'(source) (full 16-B vectors only; other shapes
+            // leave the masks to the routing kernels / the caller, see mask_done)
+            if (!mask && vw == 8 && (P.m0 || P.m1)) return launch_conv<T, 3, 8, MODE_ZERO, false, true>(P, W, s);
+        }
         return mask ? dispatch_vw<T, 3, MODE_ZERO, true>(vw, P, W, s) : dispatch_vw<T, 3, MODE_ZERO, false>(vw, P, W, s);
     }
     return mask ? dispatch_vw<T, 1, MODE_DIRECT, true>(vw, P, W, s) : dispatch_vw<T, 1, MODE_DIRECT, false>(vw, P, W, s);
@@ -2318,9 +2381,30 @@ extern "C" int dlwpcs_pack_batch(const dlwpcs_pack_item *items_dev, int n_items,
 
 extern "C" size_t dlwpcs_head_mse_scratch_bytes(void) { return (size_t)2048 * 2 * sizeof(float); }
 
+static int head_mse_impl(const dlwpcs_conv_desc *d, const void *x, const void *wpk_fwd, const void *bias_pk,
+                         const void *wpk_bwd, const float *target, float weight, void *dy, void *dx,
+                         float *loss_out, int overwrite, void *scratch, int mask_dx, float m_alpha, float m_vmax,
+                         dlwpcs_stream_t stream);
+
 extern "C" int dlwpcs_head_mse_step(const dlwpcs_conv_desc *d, const void *x, const void *wpk_fwd, const void *bias_pk,
                                     const void *wpk_bwd, const float *target, float weight, void *dy, void *dx,
                                     float *loss_out, int overwrite, void *scratch, dlwpcs_stream_t stream) {
+    return head_mse_impl(d, x, wpk_fwd, bias_pk, wpk_bwd, target, weight, dy, dx, loss_out, overwrite, scratch, 0, 0.f, 0.f, stream);
+}
+
+extern "C" int dlwpcs_head_mse_step_masked(const dlwpcs_conv_desc *d, const void *x, const void *wpk_fwd, const void *bias_pk,
+                                           const void *wpk_bwd, const float *target, float weight, void *dy, void *dx,
+                                           float *loss_out, int overwrite, void *scratch, float m_alpha, float m_vmax,
+                                           dlwpcs_stream_t stream) {
+    if (!(m_alpha >= 0.f) || !(m_vmax >= 0.f))
+        return fail(DLWPCS_E_INVALID, "head_mse_step_masked: activation needs negative_slope >= 0 and max_value >= 0");
+    return head_mse_impl(d, x, wpk_fwd, bias_pk, wpk_bwd, target, weight, dy, dx, loss_out, overwrite, scratch, 1, m_alpha, m_vmax, stream);
+}
+
+static int head_mse_impl(const dlwpcs_conv_desc *d, const void *x, const void *wpk_fwd, const void *bias_pk,
+                         const void *wpk_bwd, const float *target, float weight, void *dy, void *dx,
+                         float *loss_out, int overwrite, void *scratch, int mask_dx, float m_alpha, float m_vmax,
+                         dlwpcs_stream_t stream) {
     int rc = validate(d, "head_mse_step");
     if (rc) return rc;
     if (!x || !wpk_fwd || !wpk_bwd || !target || !dy || !dx || !loss_out || !scratch)
@@ -2335,6 +2419,7 @@ extern "C" int dlwpcs_head_mse_step(const dlwpcs_conv_desc *d, const void *x, co
     H.wpk_bwd = (const bf16_t *)wpk_bwd; H.target = target; H.dx = (bf16_t *)dx; H.partial = (float *)scratch;
     const double n = (double)d->B * 6 * d->N * d->N * d->Cout;
     H.gscale = (float)(weight * 2.0 / n);
+    H.mask_dx = mask_dx; H.m_alpha = m_alpha; H.m_vmax = m_vmax;
     const unsigned grid = pw_grid(H.f.ngroups);
     int pidx = -1;
     if (prof_enabled()) {
@@ -2419,19 +2504,29 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
     return dispatch_conv(d->dtype, d->ksize, vec_width(d->C0, d->C1, d->dtype), P, conv_work(d), s);
 }
 
-extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, const void *y,
-                                    const void *w_eq, const void *w_pol, const void *w_np,
-                                    void *dsrc0, void *dsrc1, const int32_t *inv_table_dev,
-                                    void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
-    int rc = validate(d, "conv_bwd_data");
+// dz_given: `dy` is already dz = dy * act'(y) (pre-masked gradient convention): no mask on load, y unused.
+// m0 / m1 (nullable): the sources themselves; dsrc0 / dsrc1 come out multiplied by act'(m; m_alpha, m_vmax).  The multiply is
+// fused wherever a kernel of this call writes the final value (direct-store epilogue + ring fix-up, inverse gather); what is
+// left (in-place 1x1 / 'valid' gradients, odd vector widths) gets one elementwise launch.
+static int conv_bwd_data_impl(const dlwpcs_conv_desc *d, const void *dy, const void *y, bool dz_given,
+                              const void *w_eq, const void *w_pol, const void *w_np,
+                              void *dsrc0, void *dsrc1, const void *m0, const void *m1, float m_alpha, float m_vmax,
+                              const int32_t *inv_table_dev, void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream,
+                              const char *who) {
+    int rc = validate(d, who);
     if (rc) return rc;
     const bool prepacked = (d->flags & DLWPCS_CONV_PREPACKED) != 0;
-    if (!dy || !w_eq || (!w_pol && !prepacked) || !workspace) return fail(DLWPCS_E_INVALID, "conv_bwd_data: null pointer");
-    if (d->act != DLWPCS_ACT_NONE && !y) return fail(DLWPCS_E_INVALID, "conv_bwd_data: activation needs the saved output y");
-    if (d->halo && !inv_table_dev) return fail(DLWPCS_E_INVALID, "conv_bwd_data: halo requested without inverse table");
+    if (!dy || !w_eq || (!w_pol && !prepacked) || !workspace) return fail(DLWPCS_E_INVALID, "%s: null pointer", who);
+    const bool has_act = d->act != DLWPCS_ACT_NONE && !dz_given;
+    if (has_act && !y) return fail(DLWPCS_E_INVALID, "%s: activation needs the saved output y", who);
+    if (d->halo && !inv_table_dev) return fail(DLWPCS_E_INVALID, "%s: halo requested without inverse table", who);
+    if ((m0 || m1) && (!(m_alpha >= 0.f) || !(m_vmax >= 0.f)))
+        return fail(DLWPCS_E_INVALID, "%s: mask activation needs negative_slope >= 0 and max_value >= 0, got %g / %g", who, m_alpha, m_vmax);
     if (!dsrc0 && !dsrc1) return DLWPCS_OK;
+    if (!dsrc0) m0 = nullptr;
+    if (!dsrc1 || d->C1 == 0) m1 = nullptr;
     const WsLayout L = ws_layout(d);
-    if (workspace_bytes < L.total) return fail(DLWPCS_E_WORKSPACE, "conv_bwd_data: workspace %zu < %zu bytes", workspace_bytes, L.total);
+    if (workspace_bytes < L.total) return fail(DLWPCS_E_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, L.total);
     if (d->B == 0) return DLWPCS_OK;
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)workspace;
@@ -2440,7 +2535,16 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     void *dxv = ws + L.dxv;
     if (!prepacked) launch_pack(w_eq, w_pol, w_np, ws + L.wpk_b, d->ksize, cin_logical(d), d->Cout, 1, d->flip_north_pole, d->dtype, s);
     const int No = out_size(d);
-    if (pw_applies(d) && d->act == DLWPCS_ACT_NONE && dsrc0) {
+    const int n0 = d->up0 ? d->N / 2 : d->N;
+    const size_t n_src0 = (size_t)d->B * 6 * n0 * n0 * d->C0, n_src1 = (size_t)d->B * 6 * d->N * d->N * d->C1;
+    // what is still to be multiplied by act'(m) when the kernels of this call are done
+    auto finish_masks = [&](bool todo0, bool todo1) -> int {
+        int r = DLWPCS_OK;
+        if (todo0 && m0) r = launch_mask_inplace(dsrc0, m0, n_src0, m_alpha, m_vmax, d->dtype, s);
+        if (!r && todo1 && m1) r = launch_mask_inplace(dsrc1, m1, n_src1, m_alpha, m_vmax, d->dtype, s);
+        return r;
+    };
+    if (pw_applies(d) && !has_act && dsrc0) {
         PwParams Q{};
         Q.in = (const bf16_t *)dy; Q.wpk = (const bf16_t *)wpk; Q.bias = nullptr; Q.out = (bf16_t *)dsrc0;
         Q.ngroups = (long)d->B * 6 * d->N * d->N / 16; Q.groups_per_face = d->N * d->N / 16; Q.Cout = d->Cout;
@@ -2448,13 +2552,14 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
         if (prof_enabled()) { const Work wk = conv_work(d); pidx = prof_begin("pw_dgrad_kernel", wk.flops, wk.bytes, s); }
         hipLaunchKernelGGL(pw_dgrad_kernel, dim3(pw_grid(Q.ngroups)), dim3(256), 0, s, Q);
         if (pidx >= 0) prof_end(pidx, s);
-        return check_launch("pw_dgrad");
+        rc = check_launch("pw_dgrad");
+        return rc ? rc : finish_masks(true, false);
     }
     ConvKParams P{};
     // DLWPCS_CONV_REUSE_DZ: the weight-gradient call that ran just before left dz = dy * act'(y) in the workspace
-    const bool dz_ready = dz_handover(d);
+    const bool dz_ready = !dz_given && dz_handover(d);
     P.src0 = dz_ready ? (const void *)(ws + L.dz) : dy; P.src1 = nullptr;
-    P.ymask = (d->act != DLWPCS_ACT_NONE && !dz_ready) ? y : nullptr;
+    P.ymask = (has_act && !dz_ready) ? y : nullptr;
     P.wpk = wpk; P.bias = nullptr; P.out = dxv; P.table = nullptr;
     P.B = d->B; P.Nin = No; P.No = No + d->ksize - 1;     // full correlation: output = input + k - 1
     P.C0 = d->Cout; P.C1 = 0; P.Cin = d->Cout; P.Cout = Cin;
@@ -2463,32 +2568,74 @@ extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, c
     P.act = DLWPCS_ACT_NONE; P.alpha = d->alpha; P.vmax = d->vmax;
     // direct mode: interior cells of the padded gradient go straight to the (non-upsampled) sources' gradient tensors, only
     // the halo ring is materialised in dxv and a border fix-up replaces the full inverse-gather pass
-    int direct_done = 0;
+    int direct_done = 0, mask_done = 0;
     const bool can_direct = d->halo && d->ksize == 3;
     P.d0 = (can_direct && dsrc0 && !d->up0) ? dsrc0 : nullptr;
     P.d1 = (can_direct && dsrc1 && d->C1 > 0) ? dsrc1 : nullptr;
     P.dsplit = d->C0;
     P.direct_done = &direct_done;
+    P.m0 = P.d0 ? m0 : nullptr; P.m1 = P.d1 ? m1 : nullptr;
+    P.m_alpha = m_alpha; P.m_vmax = m_vmax;
+    P.mask_done = &mask_done;
     // no halo, no upsample, one source: the virtual input IS the source -> write its gradient in place (no routing pass)
     const bool whole = !d->halo && !d->up0 && d->C1 == 0 && dsrc0;
     if (whole) P.out = dsrc0;
     rc = dispatch_conv(d->dtype, d->ksize, vec_width(d->Cout, 0, d->dtype), P, conv_work(d), s);
-    if (rc || whole) return rc;
+    if (rc) return rc;
+    if (whole) return finish_masks(true, false);
     // dxv is the gradient of the (halo-padded, if halo) virtual input: (B,6,Nv,Nv,Cin), Nv = No + k - 1
     // halo: Nv = N + 2; plain: Nv = N.  Route to the sources (inverse halo gather, upsample adjoint, channel split).
-    if (dsrc0 && dsrc1 && d->C1 > 0 && d->halo && direct_done && !P.d0 && P.d1)       // decoder layer: both in one launch
-        return launch_src_pair(dxv, dsrc0, dsrc1, inv_table_dev, d->B, d->N, d->C0, d->C1, d->up0, d->dtype, s);
+    // A source the epilogue wrote directly: its ring fix-up masks iff the epilogue did (mask_done); otherwise both stay
+    // unmasked and the elementwise pass finishes.
+    bool todo0 = m0 != nullptr, todo1 = m1 != nullptr;
+    const bool direct0 = direct_done && P.d0, direct1 = direct_done && P.d1;
+    const void *rm0 = (direct0 && !(mask_done & 1)) ? nullptr : m0;      // mask handed to the kernel that finishes source 0
+    const void *rm1 = (direct1 && !(mask_done & 2)) ? nullptr : m1;
+    if (dsrc0 && dsrc1 && d->C1 > 0 && d->halo && direct_done && !P.d0 && P.d1) {     // decoder layer: both in one launch
+        rc = launch_src_pair(dxv, dsrc0, dsrc1, inv_table_dev, d->B, d->N, d->C0, d->C1, d->up0, d->dtype, s, m0, rm1, m_alpha, m_vmax);
+        if (rc) return rc;
+        return finish_masks(false, todo1 && !rm1);
+    }
     if (dsrc0) {
-        if (direct_done && P.d0) rc = launch_ring_fix(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->dtype, s);
-        else rc = launch_src_grad(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->up0, d->halo, d->dtype, s);
+        if (direct0) {
+            rc = launch_ring_fix(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->dtype, s, rm0, m_alpha, m_vmax);
+            if (rm0) todo0 = false;
+        } else {
+            int masked = 0;
+            rc = launch_src_grad(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->up0, d->halo, d->dtype, s, m0, m_alpha, m_vmax, &masked);
+            if (masked) todo0 = false;
+        }
         if (rc) return rc;
     }
     if (dsrc1 && d->C1 > 0) {
-        if (direct_done && P.d1) rc = launch_ring_fix(dxv, dsrc1, inv_table_dev, d->B, d->N, Cin, d->C0, d->C1, d->dtype, s);
-        else rc = launch_src_grad(dxv, dsrc1, inv_table_dev, d->B, d->N, Cin, d->C0, d->C1, 0, d->halo, d->dtype, s);
+        if (direct1) {
+            rc = launch_ring_fix(dxv, dsrc1, inv_table_dev, d->B, d->N, Cin, d->C0, d->C1, d->dtype, s, rm1, m_alpha, m_vmax);
+            if (rm1) todo1 = false;
+        } else {
+            int masked = 0;
+            rc = launch_src_grad(dxv, dsrc1, inv_table_dev, d->B, d->N, Cin, d->C0, d->C1, 0, d->halo, d->dtype, s, m1, m_alpha, m_vmax, &masked);
+            if (masked) todo1 = false;
+        }
         if (rc) return rc;
     }
-    return DLWPCS_OK;
+    return finish_masks(todo0, todo1);
+}
+
+extern "C" int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d, const void *dy, const void *y,
+                                    const void *w_eq, const void *w_pol, const void *w_np,
+                                    void *dsrc0, void *dsrc1, const int32_t *inv_table_dev,
+                                    void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
+    return conv_bwd_data_impl(d, dy, y, false, w_eq, w_pol, w_np, dsrc0, dsrc1, nullptr, nullptr, 0.f, 0.f, inv_table_dev, workspace,
+                              workspace_bytes, stream, "conv_bwd_data");
+}
+
+extern "C" int dlwpcs_conv_bwd_data_masked(const dlwpcs_conv_desc *d, const void *dz,
+                                           const void *w_eq, const void *w_pol, const void *w_np,
+                                           void *dsrc0, void *dsrc1, const void *m0, const void *m1, float m_alpha, float m_vmax,
+                                           const int32_t *inv_table_dev,
+                                           void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
+    return conv_bwd_data_impl(d, dz, nullptr, true, w_eq, w_pol, w_np, dsrc0, dsrc1, m0, m1, m_alpha, m_vmax, inv_table_dev, workspace,
+                              workspace_bytes, stream, "conv_bwd_data_masked");
 }
 
 extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *src0, const void *src1, const void *dy,

@@ -31,6 +31,12 @@ template <int N> __device__ __forceinline__ Acc<N> vscale(Acc<N> a, float s) {
     for (int i = 0; i < N; ++i) a.v[i] *= s;
     return a;
 }
+// a[i] *= act'(y[i]) of keras ReLU(negative_slope = alpha, max_value = vmax), evaluated from the activation's OUTPUT y
+template <int N> __device__ __forceinline__ Acc<N> vmaskacc(Acc<N> a, const Acc<N> &y, float alpha, float vmax) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) a.v[i] *= act_leaky_clip_grad_from_y(y.v[i], alpha, vmax);
+    return a;
+}
 template <int N> __device__ __forceinline__ Acc<N> vzero() {
     Acc<N> a;
 #pragma unroll
@@ -143,10 +149,12 @@ __global__ void __launch_bounds__(256) pad_bwd_kernel(const V *__restrict__ dy, 
 
 // Adjoint of the fused conv loader: dxpad (B,6,M,M,CT) -> gradient of ONE source (channel window [choff, choff+CS))
 // on the N grid, or on the N/2 grid with the 2x2 block sum of the nearest-upsample adjoint (up != 0).  p = 1.
+// msrc != nullptr (pre-masked gradients): the result is multiplied by act'(msrc), msrc = the source itself (same shape as dsrc)
 template <typename V>
 __device__ __forceinline__ void pad_bwd_src_body(const V *__restrict__ dxpad, V *__restrict__ dsrc,
                                                  const int32_t *__restrict__ inv, size_t total, int CSV, int CTV,
-                                                 int choffV, int N, int up, unsigned block, unsigned nblocks) {
+                                                 int choffV, int N, int up, unsigned block, unsigned nblocks,
+                                                 const V *__restrict__ msrc = nullptr, float m_alpha = 0.f, float m_vmax = 0.f) {
     const int p = 1;
     const int M = N + 2 * p;
     const int No = up ? N / 2 : N;
@@ -174,6 +182,7 @@ __device__ __forceinline__ void pad_bwd_src_body(const V *__restrict__ dxpad, V 
                     if (t.w >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.w * CTV));
                 }
             }
+        if (msrc) acc = vmaskacc(acc, VT<V>::ld(msrc + e), m_alpha, m_vmax);
         VT<V>::st(dsrc + e, acc);
     }
 }
@@ -181,17 +190,21 @@ __device__ __forceinline__ void pad_bwd_src_body(const V *__restrict__ dxpad, V 
 template <typename V>
 __global__ void __launch_bounds__(256) pad_bwd_src_kernel(const V *__restrict__ dxpad, V *__restrict__ dsrc,
                                                           const int32_t *__restrict__ inv, size_t total, int CSV,
-                                                          int CTV, int choffV, int N, int up) {
-    pad_bwd_src_body<V>(dxpad, dsrc, inv, total, CSV, CTV, choffV, N, up, blockIdx.x, gridDim.x);
+                                                          int CTV, int choffV, int N, int up, const V *__restrict__ msrc,
+                                                          float m_alpha, float m_vmax) {
+    pad_bwd_src_body<V>(dxpad, dsrc, inv, total, CSV, CTV, choffV, N, up, blockIdx.x, gridDim.x, msrc, m_alpha, m_vmax);
 }
 
 // Border fix-up after a data-gradient kernel that wrote the INTERIOR cells of dxpad straight into dsrc (conv_mfma.hip,
 // direct mode): only the halo ring of dxpad was materialised; every border cell of the source (row/column 0 or N-1) still
 // lacks the <= 4 ring cells that gathered from it.  One thread per (sample, border cell, channel vector); p = 1.
+// msrc != nullptr (pre-masked gradients): the data-gradient kernel stored act'(msrc) * interior already; the ring cells are
+// summed first and multiplied by act'(msrc) before they are added.
 template <typename V>
 __device__ __forceinline__ void pad_ring_fix_body(const V *__restrict__ dxpad, V *__restrict__ dsrc,
                                                   const int32_t *__restrict__ inv, size_t total, int CSV, int CTV,
-                                                  int choffV, int N, unsigned block, unsigned nblocks) {
+                                                  int choffV, int N, unsigned block, unsigned nblocks,
+                                                  const V *__restrict__ msrc = nullptr, float m_alpha = 0.f, float m_vmax = 0.f) {
     const int M = N + 2;
     const int nb = N > 1 ? 4 * N - 4 : 1;              // border cells per face
     const int dst_cells = 6 * M * M;
@@ -208,9 +221,19 @@ __device__ __forceinline__ void pad_ring_fix_body(const V *__restrict__ dxpad, V
         else { yy = k - (3 * N - 2) + 1; xx = N - 1; }
         const int src = (f * N + yy) * N + xx;
         const V *base = dxpad + b * dst_cells * (size_t)CTV + choffV + cv;
-        V *dst = dsrc + (b * 6 * N * N + src) * (size_t)CSV + cv;
-        auto acc = VT<V>::ld(dst);
+        const size_t didx = (b * 6 * N * N + src) * (size_t)CSV + cv;
+        V *dst = dsrc + didx;
         const int4 t = *reinterpret_cast<const int4 *>(inv + (size_t)src * 4);
+        if (msrc) {
+            auto ring = vzero<VT<V>::N>();
+            if (t.x >= 0) ring = vadd(ring, VT<V>::ld(base + (size_t)t.x * CTV));
+            if (t.y >= 0) ring = vadd(ring, VT<V>::ld(base + (size_t)t.y * CTV));
+            if (t.z >= 0) ring = vadd(ring, VT<V>::ld(base + (size_t)t.z * CTV));
+            if (t.w >= 0) ring = vadd(ring, VT<V>::ld(base + (size_t)t.w * CTV));
+            VT<V>::st(dst, vadd(VT<V>::ld(dst), vmaskacc(ring, VT<V>::ld(msrc + didx), m_alpha, m_vmax)));
+            continue;
+        }
+        auto acc = VT<V>::ld(dst);
         if (t.x >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.x * CTV));
         if (t.y >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.y * CTV));
         if (t.z >= 0) acc = vadd(acc, VT<V>::ld(base + (size_t)t.z * CTV));
@@ -222,8 +245,9 @@ __device__ __forceinline__ void pad_ring_fix_body(const V *__restrict__ dxpad, V
 template <typename V>
 __global__ void __launch_bounds__(256) pad_ring_fix_kernel(const V *__restrict__ dxpad, V *__restrict__ dsrc,
                                                            const int32_t *__restrict__ inv, size_t total, int CSV,
-                                                           int CTV, int choffV, int N) {
-    pad_ring_fix_body<V>(dxpad, dsrc, inv, total, CSV, CTV, choffV, N, blockIdx.x, gridDim.x);
+                                                           int CTV, int choffV, int N, const V *__restrict__ msrc,
+                                                           float m_alpha, float m_vmax) {
+    pad_ring_fix_body<V>(dxpad, dsrc, inv, total, CSV, CTV, choffV, N, blockIdx.x, gridDim.x, msrc, m_alpha, m_vmax);
 }
 
 // Both sources of a fused decoder convolution in ONE launch (each launch costs ~4-5 us of floor): workgroups [0, nb0) route
@@ -232,9 +256,11 @@ __global__ void __launch_bounds__(256) pad_ring_fix_kernel(const V *__restrict__
 template <typename V>
 __global__ void __launch_bounds__(256) src_pair_kernel(const V *__restrict__ dxpad, V *__restrict__ dsrc0, V *__restrict__ dsrc1,
                                                        const int32_t *__restrict__ inv, size_t total0, size_t total1,
-                                                       int CS0V, int CS1V, int CTV, int N, int up0, unsigned nb0) {
-    if (blockIdx.x < nb0) pad_bwd_src_body<V>(dxpad, dsrc0, inv, total0, CS0V, CTV, 0, N, up0, blockIdx.x, nb0);
-    else pad_ring_fix_body<V>(dxpad, dsrc1, inv, total1, CS1V, CTV, CS0V, N, blockIdx.x - nb0, gridDim.x - nb0);
+                                                       int CS0V, int CS1V, int CTV, int N, int up0, unsigned nb0,
+                                                       const V *__restrict__ m0, const V *__restrict__ m1, float m_alpha,
+                                                       float m_vmax) {
+    if (blockIdx.x < nb0) pad_bwd_src_body<V>(dxpad, dsrc0, inv, total0, CS0V, CTV, 0, N, up0, blockIdx.x, nb0, m0, m_alpha, m_vmax);
+    else pad_ring_fix_body<V>(dxpad, dsrc1, inv, total1, CS1V, CTV, CS0V, N, blockIdx.x - nb0, gridDim.x - nb0, m1, m_alpha, m_vmax);
 }
 
 // gradient of one source of a halo==0 convolution input (no padding): channel window copy, optional 2x2 sum
@@ -285,8 +311,8 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(const S *__restrict__ x, S
 }
 
 template <typename V, typename S>
-__global__ void __launch_bounds__(256) act_bwd_kernel(const S *__restrict__ dy, const S *__restrict__ y,
-                                                      S *__restrict__ dx, size_t n, float alpha, float vmax) {
+__global__ void __launch_bounds__(256) act_bwd_kernel(const S *dy, const S *__restrict__ y, S *dx, size_t n, float alpha,
+                                                      float vmax) {
     constexpr int W = VT<V>::N;
     const size_t nv = n / W;
     const V *gv = reinterpret_cast<const V *>(dy);
@@ -355,6 +381,25 @@ __global__ void __launch_bounds__(256) avgpool2_bwd_add_kernel(const V *__restri
         const size_t plane = pix / N;
         VT<V>::st(dx + e, vadd(VT<V>::ld(dskip + e),
                                vscale(VT<V>::ld(dy + ((plane * No + yy / 2) * No + xx / 2) * CV + cv), 0.25f)));
+    }
+}
+
+// pre-masked gradients: dx = act'(m) * (dskip + 0.25 * dy spread), m = the pooled tensor itself (output of the activated layer
+// that produced it); dskip may be null (no skip connection)
+template <typename V>
+__global__ void __launch_bounds__(256) avgpool2_bwd_masked_kernel(const V *__restrict__ dy, const V *__restrict__ dskip,
+                                                                  const V *__restrict__ m, V *__restrict__ dx, size_t total,
+                                                                  int CV, int N, float m_alpha, float m_vmax) {
+    const int No = N / 2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(e % CV);
+        size_t pix = e / CV;
+        const int xx = (int)(pix % N); pix /= N;
+        const int yy = (int)(pix % N);
+        const size_t plane = pix / N;
+        auto g = vscale(VT<V>::ld(dy + ((plane * No + yy / 2) * No + xx / 2) * CV + cv), 0.25f);
+        if (dskip) g = vadd(VT<V>::ld(dskip + e), g);
+        VT<V>::st(dx + e, vmaskacc(g, VT<V>::ld(m + e), m_alpha, m_vmax));
     }
 }
 
@@ -730,8 +775,12 @@ extern "C" int dlwpcs_pad_bwd(const void *dy, void *dx, int B, int N, int C, int
 
 namespace dlwpcs {
 // used by conv_bwd_data: gradient of one virtual-input source out of the (padded or plain) virtual-input gradient
+int launch_mask_inplace(void *dx, const void *m, size_t n, float alpha, float vmax, int dtype, hipStream_t s);
+
+// msrc (halo only): the source itself, the gradient is multiplied by act'(msrc); returns through *masked whether it was
 int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int up,
-                    int halo, int dtype, hipStream_t s) {
+                    int halo, int dtype, hipStream_t s, const void *msrc, float m_alpha, float m_vmax, int *masked) {
+    if (masked) *masked = (halo && msrc) ? 1 : 0;
     const int No = up ? N / 2 : N;
     // common divisor of the three channel counts decides the vector width
     int g = 8;
@@ -741,7 +790,7 @@ int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int 
         const size_t total = (size_t)B * 6 * No * No * (CS / w);
         if (halo)
             hipLaunchKernelGGL(pad_bwd_src_kernel<V>, stream_grid(total), dim3(256), 0, s, (const V *)dxv, (V *)dsrc, inv,
-                               total, CS / w, CT / w, choff / w, N, up);
+                               total, CS / w, CT / w, choff / w, N, up, (const V *)msrc, m_alpha, m_vmax);
         else
             hipLaunchKernelGGL(window_src_kernel<V>, stream_grid(total), dim3(256), 0, s, (const V *)dxv, (V *)dsrc, total,
                                CS / w, CT / w, choff / w, N, up);
@@ -751,7 +800,7 @@ int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int 
 
 // source 0 through the full inverse gather (upsampled source), source 1 through the ring fix-up, one launch
 int launch_src_pair(const void *dxv, void *dsrc0, void *dsrc1, const int32_t *inv, int B, int N, int C0, int C1, int up0,
-                    int dtype, hipStream_t s) {
+                    int dtype, hipStream_t s, const void *m0, const void *m1, float m_alpha, float m_vmax) {
     const int CT = C0 + C1;
     int g = 8;
     while (g > 1 && (C0 % g || C1 % g)) g >>= 1;
@@ -762,7 +811,7 @@ int launch_src_pair(const void *dxv, void *dsrc0, void *dsrc1, const int32_t *in
         const size_t total0 = (size_t)B * 6 * No * No * (C0 / w), total1 = (size_t)B * 6 * nb * (C1 / w);
         const unsigned nb0 = stream_grid(total0).x, nb1 = stream_grid(total1).x;
         hipLaunchKernelGGL(src_pair_kernel<V>, dim3(nb0 + nb1), dim3(256), 0, s, (const V *)dxv, (V *)dsrc0, (V *)dsrc1, inv,
-                           total0, total1, C0 / w, C1 / w, CT / w, N, up0, nb0);
+                           total0, total1, C0 / w, C1 / w, CT / w, N, up0, nb0, (const V *)m0, (const V *)m1, m_alpha, m_vmax);
     });
     return check_launch("src_pair");
 }
@@ -770,7 +819,7 @@ int launch_src_pair(const void *dxv, void *dsrc0, void *dsrc1, const int32_t *in
 // border fix-up of a source whose interior gradient was written directly by the data-gradient kernel (halo, p = 1, no
 // upsampling): adds the halo-ring cells of dxv that gathered from each border cell
 int launch_ring_fix(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int dtype,
-                    hipStream_t s) {
+                    hipStream_t s, const void *msrc, float m_alpha, float m_vmax) {
     int g = 8;
     while (g > 1 && (CT % g || choff % g || CS % g)) g >>= 1;
     const int nb = N > 1 ? 4 * N - 4 : 1;
@@ -778,9 +827,21 @@ int launch_ring_fix(const void *dxv, void *dsrc, const int32_t *inv, int B, int 
         using V = decltype(tag);
         const size_t total = (size_t)B * 6 * nb * (CS / w);
         hipLaunchKernelGGL(pad_ring_fix_kernel<V>, stream_grid(total), dim3(256), 0, s, (const V *)dxv, (V *)dsrc, inv, total,
-                           CS / w, CT / w, choff / w, N);
+                           CS / w, CT / w, choff / w, N, (const V *)msrc, m_alpha, m_vmax);
     });
     return check_launch("ring_fix");
+}
+
+// dx *= act'(m), in place (the fallback of the pre-masked gradient convention where no kernel fuses the multiply)
+int launch_mask_inplace(void *dx, const void *m, size_t n, float alpha, float vmax, int dtype, hipStream_t s) {
+    if (n == 0) return DLWPCS_OK;
+    if (dtype == DLWPCS_BF16)
+        hipLaunchKernelGGL((act_bwd_kernel<H8, bf16_t>), stream_grid(n / 8 + 1), dim3(256), 0, s, (const bf16_t *)dx,
+                           (const bf16_t *)m, (bf16_t *)dx, n, alpha, vmax);
+    else
+        hipLaunchKernelGGL((act_bwd_kernel<float4, float>), stream_grid(n / 4 + 1), dim3(256), 0, s, (const float *)dx,
+                           (const float *)m, (float *)dx, n, alpha, vmax);
+    return check_launch("mask_inplace");
 }
 }  // namespace dlwpcs
 
@@ -851,6 +912,21 @@ extern "C" int dlwpcs_avgpool2_bwd_add(const void *dy, const void *dskip, void *
                            (const V *)dskip, (V *)dx, total, C / w, N);
     });
     return check_launch("avgpool2_bwd_add");
+}
+extern "C" int dlwpcs_avgpool2_bwd_masked(const void *dy, const void *dskip, const void *m, void *dx, int B, int N, int C,
+                                          float m_alpha, float m_vmax, int dtype, dlwpcs_stream_t stream) {
+    REQUIRE_DTYPE(dtype, "avgpool2_bwd_masked");
+    REQUIRE(dy && m && dx, "avgpool2_bwd_masked: null pointer");
+    REQUIRE(B >= 0 && N >= 2 && N % 2 == 0 && C >= 1, "avgpool2_bwd_masked: bad shape B=%d N=%d C=%d", B, N, C);
+    REQUIRE(m_alpha >= 0.f && m_vmax >= 0.f, "avgpool2_bwd_masked: activation needs negative_slope >= 0 and max_value >= 0");
+    if (B == 0) return DLWPCS_OK;
+    dispatch_vec(dtype, C, [&](auto tag, int w) {
+        using V = decltype(tag);
+        const size_t total = (size_t)B * 6 * N * N * (C / w);
+        hipLaunchKernelGGL(avgpool2_bwd_masked_kernel<V>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, (const V *)dy,
+                           (const V *)dskip, (const V *)m, (V *)dx, total, C / w, N, m_alpha, m_vmax);
+    });
+    return check_launch("avgpool2_bwd_masked");
 }
 extern "C" int dlwpcs_upsample2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream) {
     REQUIRE_DTYPE(dtype, "upsample2_fwd");

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DLWPCS_VERSION 101            /* 0.1.1: dlwpcs_conv_desc.c0_valid, dlwpcs_adam_step_dev, dlwpcs_state_repack */
+#define DLWPCS_VERSION 102            /* 0.1.2: dlwpcs_wgrad_batch*, pre-masked gradients (dlwpcs_*_masked) */
 
 /* error codes */
 #define DLWPCS_OK             0
@@ -173,6 +173,21 @@ int dlwpcs_conv_bwd_data(const dlwpcs_conv_desc *d,
                          void *dsrc0, void *dsrc1, const int32_t *inv_table_dev,
                          void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
 
+/* Pre-masked gradient convention (training steps of a network whose activations are fused into the convolutions): the
+ * gradient w.r.t. the OUTPUT y of an activated layer is multiplied by act'(y) where it is PRODUCED -- by the data-gradient
+ * call of the layer that consumes y, by the pooling / loss kernels -- so that the layer itself receives dz = dy * act'(y):
+ * neither its data gradient nor its weight gradient reads y again, and no dz hand-over is written.
+ *   dz       gradient w.r.t. this layer's PRE-activation output (act / alpha / vmax of d are ignored)
+ *   m0, m1   NULL, or the source tensors themselves (src0 / src1 of the forward call: outputs of activated layers with
+ *            ReLU(negative_slope = m_alpha, max_value = m_vmax)): dsrc0 / dsrc1 come out multiplied by act'(m0) / act'(m1).
+ * The multiply happens in the direct-store epilogue of the matrix-core kernel and in the ring fix-up / inverse-gather
+ * kernels; shapes those do not serve get one elementwise launch inside the call.  Otherwise like dlwpcs_conv_bwd_data. */
+int dlwpcs_conv_bwd_data_masked(const dlwpcs_conv_desc *d, const void *dz,
+                                const void *w_eq, const void *w_pol, const void *w_np,
+                                void *dsrc0, void *dsrc1, const void *m0, const void *m1, float m_alpha, float m_vmax,
+                                const int32_t *inv_table_dev,
+                                void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
+
 /* Gradients w.r.t. kernels and biases (deterministic: fixed-order partial sums, no atomics).
  * dw_*: HWIO like the kernels; db_*: (Cout,) or NULL.  dw_np/db_np NULL unless independent north pole. */
 int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d,
@@ -276,6 +291,10 @@ int dlwpcs_avgpool2_bwd(const void *dy, void *dx, int B, int N, int C, int dtype
  * one pass instead of avgpool2_bwd + add.  dx may alias dskip. */
 int dlwpcs_avgpool2_bwd_add(const void *dy, const void *dskip, void *dx, int B, int N, int C, int dtype,
                             dlwpcs_stream_t stream);
+/* Pre-masked gradients: dx = act'(m) * (dskip + avgpool2_bwd(dy)); m = the pooled tensor itself (output of an activated layer,
+ * ReLU(m_alpha, m_vmax)), dskip may be NULL (no skip connection).  dx may alias dskip. */
+int dlwpcs_avgpool2_bwd_masked(const void *dy, const void *dskip, const void *m, void *dx, int B, int N, int C,
+                               float m_alpha, float m_vmax, int dtype, dlwpcs_stream_t stream);
 /* x: (B,6,N,N,C) -> y: (B,6,2N,2N,C), nearest;  backward sums 2x2 blocks */
 int dlwpcs_upsample2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
 int dlwpcs_upsample2_bwd(const void *dy, void *dx, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
@@ -323,6 +342,12 @@ size_t dlwpcs_head_mse_scratch_bytes(void);
 int dlwpcs_head_mse_step(const dlwpcs_conv_desc *d, const void *x, const void *wpk_fwd, const void *bias_pk,
                          const void *wpk_bwd, const float *target, float weight, void *dy, void *dx, float *loss_out,
                          int overwrite, void *scratch, dlwpcs_stream_t stream);
+
+/* The same with dx multiplied by act'(x; m_alpha, m_vmax): x is the output of an activated layer that expects its gradient
+ * pre-masked (see dlwpcs_conv_bwd_data_masked). */
+int dlwpcs_head_mse_step_masked(const dlwpcs_conv_desc *d, const void *x, const void *wpk_fwd, const void *bias_pk,
+                                const void *wpk_bwd, const float *target, float weight, void *dy, void *dx, float *loss_out,
+                                int overwrite, void *scratch, float m_alpha, float m_vmax, dlwpcs_stream_t stream);
 
 int dlwpcs_adam_step(float *p, const float *g, float *m, float *v, size_t n, int32_t *step_dev,
                      float lr, float beta1, float beta2, float eps, float grad_scale, dlwpcs_stream_t stream);
