@@ -63,7 +63,7 @@ class ReduceItem(ctypes.Structure):
 
 class WgradItem(ctypes.Structure):
     """struct dlwpcs_wgrad_item (include/dlwpcs.h)"""
-    _fields_ = [('d', ConvDesc)] + [(n, ctypes.c_void_p) for n in ('src0', 'src1', 'dz', 'table_dev', 'dw_eq', 'dw_pol',
+    _fields_ = [('d', ConvDesc)] + [(n, ctypes.c_void_p) for n in ('src0', 'src1', 'dz', 'y', 'table_dev', 'dw_eq', 'dw_pol',
                                                                     'dw_np', 'db_eq', 'db_pol', 'db_np')]
 
 

@@ -186,6 +186,12 @@ class Model(object):
             if st[0] == 'fused_conv' and st[6] == ACT_LEAKY_CLIP:
                 produced[st[1]] = (float(st[7]), float(st[8]))
         capable = {u: (u not in out_uids) for u in produced}
+        # a layer that computes no data gradient (its sources are model inputs) is the only reader of its dz: the batched
+        # weight-gradient kernel applies act' on load there, cheaper than a masking epilogue in the consumer's data gradient
+        in_uids_model = {t.uid for t in self.inputs}
+        for st in steps:
+            if st[0] == 'fused_conv' and st[1] in capable and st[3] in in_uids_model and (st[4] is None or st[4] in in_uids_model):
+                capable[st[1]] = False
         aliased = set()
         src_mask = {}                  # step index -> (mask source 0?, mask source 1?) | bool for pool / head steps
         for i, st in enumerate(steps):

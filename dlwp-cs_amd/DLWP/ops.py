@@ -136,19 +136,23 @@ def flush_wgrad_batch():
 def _wb_items(entries):
     arr = (nat.WgradItem * len(entries))()
     key = []
-    for it, (d, src0, src1, dz, table, grads) in zip(arr, entries):
+    for it, ent in zip(arr, entries):
+        d, src0, src1, dz, table, grads = ent[:6]
+        y = ent[6] if len(ent) > 6 else None
         it.d = d
-        it.src0, it.src1, it.dz, it.table_dev = ptr(src0), ptr(src1), ptr(dz), ptr(table)
+        it.src0, it.src1, it.dz, it.y, it.table_dev = ptr(src0), ptr(src1), ptr(dz), ptr(y), ptr(table)
         it.dw_eq, it.dw_pol, it.dw_np, it.db_eq, it.db_pol, it.db_np = [ptr(g) for g in grads]
         key.append((d.B, d.N, d.C0, d.C1, d.Cout, d.ksize, d.halo, d.up0, d.flip_north_pole, d.dtype, d.c0_valid,
-                    tuple(g is not None for g in grads)))
+                    tuple(g is not None for g in grads), None if y is None else (d.act, d.alpha, d.vmax)))
     return arr, tuple(key)
 
 
 def wgrad_batch(entries):
-    """entries: [(ConvDesc, src0, src1 | None, dz, halo table | None, (dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np))] with
+    """entries: [(ConvDesc, src0, src1 | None, dz, halo table | None, (dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np)[, y])] with
     fp32 gradient tensors that are ACCUMULATED into (None where the layer has no such parameter).  dz is the gradient
-    w.r.t. the layer's pre-activation output (already masked).  The plan of a layer list is built once and cached."""
+    w.r.t. the layer's pre-activation output (already masked) -- or, with the optional 7th element y (the layer's saved
+    output, desc.act = LEAKY_CLIP), the plain gradient dy, masked by the kernel on load.  The plan of a layer list is built
+    once and cached."""
     if not entries:
         return
     dev = entries[0][3].device
@@ -282,7 +286,8 @@ def _f32_param(t, what):
         raise TypeError('%s: parameters must be float32 master copies, got %s' % (what, t.dtype))
 
 
-def _weight_gradients(d, src0, src1, dy, y, params, table, ws, nbytes, direct, defer, need, has_np, has_bias, has_bnp):
+def _weight_gradients(d, src0, src1, dy, y, params, table, ws, nbytes, direct, defer, need, has_np, has_bias, has_bnp,
+                      batch_mask_ok=False):
     """Weight / bias gradients of one fused convolution (shared by _CSConv.backward and the fused head + loss step).
     direct: accumulate straight into the parameters' preset .grad buffers (views of the model's flat gradient buffer, zeroed
     once per step): no temporaries, no AccumulateGrad add kernels; shared layers simply accumulate twice.  Returns the six
@@ -290,13 +295,16 @@ def _weight_gradients(d, src0, src1, dy, y, params, table, ws, nbytes, direct, d
     dev = dy.device
     w_eq, w_pol, w_np = params[0], params[1], params[2]
     dw_eq = dw_pol = dw_np = db_eq = db_pol = db_np = None
-    if direct and WGRAD_BATCH and d.act == nat.ACT_NONE and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(d):
-        # dy IS dz (no activation, or the gradient arrived pre-masked): queue the layer for the batched launch
+    if (direct and WGRAD_BATCH and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(d)
+            and (d.act == nat.ACT_NONE or (batch_mask_ok and d.ksize == 3 and y is not None))):
+        # dy IS dz (no activation, or the gradient arrived pre-masked) -- or the batched kernel masks on load (a layer whose
+        # inputs need no gradient: nobody else wants dz): queue the layer for the batched launch
         pe, pp, pn, be, bp, bn = params
         d2 = ConvDesc.from_buffer_copy(d)
         _wb_pending.append((d2, src0, src1, dy, table,
                             (pe.grad, pp.grad, None if pn is None else pn.grad, None if be is None else be.grad,
-                             None if bp is None else bp.grad, None if bn is None else bn.grad)))
+                             None if bp is None else bp.grad, None if bn is None else bn.grad),
+                            None if d.act == nat.ACT_NONE else y))
         return dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np
     if direct:
         pe, pp, pn, be, bp, bn = params
@@ -456,8 +464,9 @@ class _CSConv(torch.autograd.Function):
             dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np = _weight_gradients(
                 dn, src0, src1, dz, None, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp)
             return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 11
-        batching = (direct and WGRAD_BATCH and d.act == nat.ACT_NONE and d.B > 0 and not WGRAD_SIDE_STREAM
-                    and wgrad_batch_supported(d))
+        no_dgrad = dsrc0 is None and dsrc1 is None        # (first layer: the batched kernel applies act' itself)
+        batching = (direct and WGRAD_BATCH and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(d)
+                    and (d.act == nat.ACT_NONE or (no_dgrad and d.ksize == 3)))
         defer = direct and DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM and d.B > 0 and not batching
         # deferred reduction: the partials (and the dz hand-over next to them) live in this node's own workspace
         ws = _workspace(nbytes, dev, 'defer%d' % len(_deferred)) if defer else _workspace(nbytes, dev)
@@ -478,7 +487,8 @@ class _CSConv(torch.autograd.Function):
         if not reuse_dz:
             run_bwd_data()
         dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np = _weight_gradients(
-            d, src0, src1, dy, y, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp)
+            d, src0, src1, dy, y, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp,
+            batch_mask_ok=no_dgrad)
         if reuse_dz:
             run_bwd_data()
         return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 11

@@ -63,6 +63,7 @@ struct ConvKParams {
     // that produced them, same shape as d0 / d1), so that the gradient arrives at those layers as dz = dy * act'(y) already
     const void *m0, *m1;
     float m_alpha, m_vmax;
+    uint32_t m_thr1;            // bf16_mask_threshold(m_vmax)
     int *direct_done;           // HOST pointer: set to 1 by launch_conv_cfg when the kernel it launched honours d0 / d1
     int *mask_done;             // HOST pointer: bit 0 / 1 set when the launched kernel masks what it stores to d0 / d1
     int abl;                    // development only (-DDLWPCS_TIMELINE): epilogue ablation bits
@@ -516,6 +517,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     const bool fast_act = e_alpha >= 0.f && e_alpha <= 1.f && e_vmax >= 0.f;
     auto quad = [&](auto fast_tag, const f32x16 &a, int jq) {
         float4 v4 = make_float4(a[4 * jq], a[4 * jq + 1], a[4 * jq + 2], a[4 * jq + 3]);
+        if constexpr (MODE == MODE_ZERO) return v4;         // data gradient: never an activation (2.5 instructions per value)
         if constexpr (decltype(fast_tag)::value) {
             // v_max_f32 / v_min_f32 as (pure) asm: fmaxf / fminf -- and v_med3_f32 with an infinite operand, which LLVM folds
             // back into them -- put a canonicalising `v_max x, x` in front of every value that comes out of an accumulator
@@ -564,9 +566,12 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 #pragma unroll
                     for (int ps = 0; ps < NPS; ++ps) {
                         const uint32_t boff = soff[nt][mt][ps], sel = (ssel >> (2 * ((nt * MT + mt) * NPS + ps))) & 3u;
-                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r0, sel == 1 ? boff : ST_SKIP, 0, 0);
-                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r1, sel == 2 ? boff : ST_SKIP, 0, 0);
-                        ymq[nt][mt][ps] = make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w);
+                        u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r0, sel == 1 ? boff : ST_SKIP, 0, 0);
+                        if (P.m1 != nullptr) {      // (uniform; a skip connection that is masked directly -- not in the U-Nets)
+                            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r1, sel == 2 ? boff : ST_SKIP, 0, 0);
+                            a = a | b;
+                        }
+                        ymq[nt][mt][ps] = make_uint4(a.x, a.y, a.z, a.w);
                     }
         }
     };
@@ -588,7 +593,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             else boff = store_off(gq, nt, mt, ps, sel);
             if constexpr (MOUT) {
                 uint4 vm = v;
-                vmask(vm, ymq[nt][mt][ps], P.m_alpha, P.m_vmax);
+                vmask_pk(vm, ymq[nt][mt][ps], P.m_alpha, P.m_thr1);
                 const bool on = (sel == 1 && P.m0 != nullptr) || (sel == 2 && P.m1 != nullptr);
                 v = on ? vm : v;
             }
@@ -2575,7 +2580,7 @@ static int conv_bwd_data_impl(const dlwpcs_conv_desc *d, const void *dy, const v
     P.dsplit = d->C0;
     P.direct_done = &direct_done;
     P.m0 = P.d0 ? m0 : nullptr; P.m1 = P.d1 ? m1 : nullptr;
-    P.m_alpha = m_alpha; P.m_vmax = m_vmax;
+    P.m_alpha = m_alpha; P.m_vmax = m_vmax; P.m_thr1 = bf16_mask_threshold(m_vmax);
     P.mask_done = &mask_done;
     // no halo, no upsample, one source: the virtual input IS the source -> write its gradient in place (no routing pass)
     const bool whole = !d->halo && !d->up0 && d->C1 == 0 && dsrc0;

@@ -1,6 +1,7 @@
 // Device / host helpers shared by the matrix-core convolution kernels (conv_mfma.hip) and the batched weight-gradient
 // kernel (wgrad_batch.hip): register vectors of VW channels, zero-selects, the MFMA fragment update, the LDS transpose read.
 #pragma once
+#include <string.h>
 #include "common.h"
 
 namespace dlwpcs {
@@ -36,6 +37,37 @@ __device__ __forceinline__ void vmask(uint2 &v, const uint2 &y, float a, float m
 __device__ __forceinline__ void vmask(uint4 &v, const uint4 &y, float a, float m) {
     v.x = bmask2(v.x, y.x, a, m); v.y = bmask2(v.y, y.y, a, m); v.z = bmask2(v.z, y.z, a, m); v.w = bmask2(v.w, y.w, a, m);
 }
+// The same product on packed bf16 pairs with 16-bit SIMD-in-register integer ops (11 VALU instructions per pair instead of ~17):
+// thr1 = (bits of the smallest bf16 >= vmax) - 1 in both halves (0 when vmax == 0), see bf16_mask_threshold().
+//   y < 0            -> alpha * v     (sign bit; y = -0.0 counts as negative here)
+//   0 < y < vmax     -> v             (1 <= bits(y) < thr, as an unsigned saturating subtraction)
+//   otherwise        -> 0
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bmask2_pk(uint32_t v, uint32_t y, float alpha, uint32_t thr1) {
+    const uint32_t m_neg = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, y) >> 15);
+    const u16x2 one = {1, 1}, zero = {0, 0};
+    const u16x2 t = __builtin_bit_cast(u16x2, y) - one;
+    const u16x2 c = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, thr1), t);
+    const uint32_t m_pos = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, zero - c) >> 15);
+    const uint32_t za = f2bf2(bf_lo(v) * alpha, bf_hi(v) * alpha);
+    return (v & m_pos) | (za & m_neg);
+}
+__device__ __forceinline__ void vmask_pk(uint4 &v, const uint4 &y, float a, uint32_t thr1) {
+    v.x = bmask2_pk(v.x, y.x, a, thr1); v.y = bmask2_pk(v.y, y.y, a, thr1);
+    v.z = bmask2_pk(v.z, y.z, a, thr1); v.w = bmask2_pk(v.w, y.w, a, thr1);
+}
+// host: thr1 of bmask2_pk for a max_value >= 0 (+inf: every finite positive value passes)
+static inline uint32_t bf16_mask_threshold(float vmax) {
+    uint32_t u;
+    memcpy(&u, &vmax, 4);
+    uint32_t thr = u >> 16;
+    if (u & 0xffffu) thr += 1;                      // not representable: the next bf16 above
+    if (vmax != vmax || thr > 0x7f80u) thr = 0x7f80u;
+    const uint32_t t1 = thr ? thr - 1 : 0;
+    return t1 | (t1 << 16);
+}
+
 __device__ __forceinline__ float vsel(bool c, float v) { return c ? v : 0.f; }
 __device__ __forceinline__ float2 vsel(bool c, float2 v) { return c ? v : make_float2(0.f, 0.f); }
 __device__ __forceinline__ float4 vsel(bool c, float4 v) { return c ? v : make_float4(0.f, 0.f, 0.f, 0.f); }

@@ -44,13 +44,15 @@ enum {
     WB_NVARIANTS
 };
 
-struct WbLayer {                    // 32 ints
+struct WbLayer {                    // 36 ints
     int32_t B, Nin, No, C0, C1, Cin, Cout, up0;
     int32_t halo, KS, W2, tile_rows_max, pix, nbands, pix_cap, variant;
     uint32_t magicW2, magicNo, magicN, magicB, magicNb;
-    int32_t CT, NT, ncit, ncot, cin_logical, flip, want_bias, group_base, has_np, slot_floats, pad0;
+    int32_t CT, NT, ncit, ncot, cin_logical, flip, want_bias, group_base, has_np, slot_floats, mask;
+    float alpha, vmax;              // mask != 0: dz = dy * act'(y) is formed by the producers (ReLU(alpha, vmax))
+    int32_t pad0, pad1;
 };
-static_assert(sizeof(WbLayer) == 128, "WbLayer layout");
+static_assert(sizeof(WbLayer) == 144, "WbLayer layout");
 
 struct WbSeg {                      // 8 ints
     int32_t layer, cls, cit, cot, t_first, t_last;
@@ -69,7 +71,7 @@ struct WbHeader {
 };
 
 struct WbPtrs {
-    const void *src0[WB_MAX_LAYERS], *src1[WB_MAX_LAYERS], *dz[WB_MAX_LAYERS];
+    const void *src0[WB_MAX_LAYERS], *src1[WB_MAX_LAYERS], *dz[WB_MAX_LAYERS], *y[WB_MAX_LAYERS];
     const int32_t *table[WB_MAX_LAYERS];
 };
 struct WbRedPtrs {
@@ -104,9 +106,10 @@ template <typename T> __device__ __forceinline__ T load_uniform(const T &g) {
     return out;
 }
 
-template <int KS, int XV, int QX, int CT, int NT, int DV>
+template <int KS, int XV, int QX, int CT, int NT, int DV, bool MASK = false>
 __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const WbSeg &sgg, const void *src0, const void *src1,
-                                           const void *dzp, const int32_t *table, float *ws, char *smem, long long *dbg) {
+                                           const void *dzp, const void *yp, const int32_t *table, float *ws, char *smem,
+                                           long long *dbg) {
     const WbLayer L = load_uniform(Lg);
     const WbSeg sg = load_uniform(sgg);
     constexpr int QD = DV == 8 ? 4 : 8;     // dZ vectors per pixel and 32-channel plane
@@ -172,6 +175,7 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
         const int co = sg.cot * 32 * NT + (qd / QD) * 32 + (qd % QD) * DV;
         const bool co_ok = co < L.Cout;
         const bool want_bias = sg.bias != 0;
+        const uint32_t mthr1 = (uint32_t)L.pad0;                // bf16_mask_threshold(vmax) (MASK)
         float bsum[DV];
 #pragma unroll
         for (int u = 0; u < DV; ++u) bsum[u] = 0.f;
@@ -207,7 +211,7 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
         // two register sets, prefetch distance 2 (see wgrad_bf16_kernel)
         struct Stage {
             XVec xv[IT_X];
-            DVec dv[IT_DY];
+            DVec dv[IT_DY], yv[MASK ? IT_DY : 1];
             bool xok[IT_X], dok[IT_DY];
         };
         auto issue = [&](const Item &it, Stage &st) {
@@ -221,12 +225,14 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
             }
             const size_t rowbase = (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * L.Cout;
             const bf16_t *dzb = reinterpret_cast<const bf16_t *>(dzp) + rowbase;
+            const bf16_t *yb = MASK ? reinterpret_cast<const bf16_t *>(yp) + rowbase : nullptr;
             const int dlim = it.npix * L.Cout;                      // slot valid <=> its pixel < npix
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
                 const bool ok = co_ok && doff[i] < dlim;
                 const uint32_t o = ok ? (uint32_t)doff[i] : 0u;
                 st.dv[i] = *reinterpret_cast<const DVec *>(dzb + o);
+                if (MASK) st.yv[i] = *reinterpret_cast<const DVec *>(yb + o);
                 st.dok[i] = ok;
             }
         };
@@ -242,6 +248,10 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
                 const int e = ptid + i * NCT;
+                if constexpr (MASK) {                                       // dz = dy * act'(y), rounded to bf16 like a stored dz
+                    if constexpr (DV == 8) vmask_pk(st.dv[i], st.yv[i], L.alpha, mthr1);
+                    else vmask(st.dv[i], st.yv[i], L.alpha, L.vmax);
+                }
                 const DVec v = vsel(st.dok[i], st.dv[i]);
                 if (e < pix_cap * QDT)
                     *reinterpret_cast<DVec *>(buf + x_bytes + (qd / QD) * dzplane_bytes + (size_t)(e / QDT) * PB +
@@ -457,17 +467,28 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
     for (int s = s0; s < s1; ++s) {
         const WbSeg &sg = segs[s];
         const WbLayer &L = layers[sg.layer];
-        const void *a0 = ptrs.src0[sg.layer], *a1 = ptrs.src1[sg.layer], *dz = ptrs.dz[sg.layer];
+        const void *a0 = ptrs.src0[sg.layer], *a1 = ptrs.src1[sg.layer], *dz = ptrs.dz[sg.layer], *yy = ptrs.y[sg.layer];
         const int32_t *tb = ptrs.table[sg.layer];
+        if (L.mask) {
+            switch (L.variant) {
+                case WB_V_3_8_22: wb_segment<3, 8, 4, 2, 2, 8, true>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+                case WB_V_3_8_21: wb_segment<3, 8, 4, 2, 1, 8, true>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+                case WB_V_3_8_12: wb_segment<3, 8, 4, 1, 2, 8, true>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+                case WB_V_3_8_11: wb_segment<3, 8, 4, 1, 1, 8, true>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+                case WB_V_3_2_8:  wb_segment<3, 2, 8, 1, 1, 8, true>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+                default:          wb_segment<3, 2, 16, 1, 1, 8, true>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+            }
+            continue;
+        }
         switch (L.variant) {
-            case WB_V_3_8_22: wb_segment<3, 8, 4, 2, 2, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
-            case WB_V_3_8_21: wb_segment<3, 8, 4, 2, 1, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
-            case WB_V_3_8_12: wb_segment<3, 8, 4, 1, 2, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
-            case WB_V_3_8_11: wb_segment<3, 8, 4, 1, 1, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
-            case WB_V_3_2_8:  wb_segment<3, 2, 8, 1, 1, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
-            case WB_V_3_2_16: wb_segment<3, 2, 16, 1, 1, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
-            case WB_V_1_8_11: wb_segment<1, 8, 4, 1, 1, 8>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
-            default:          wb_segment<1, 8, 4, 1, 1, 2>(L, sg, a0, a1, dz, tb, ws, smem, dbg); break;
+            case WB_V_3_8_22: wb_segment<3, 8, 4, 2, 2, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+            case WB_V_3_8_21: wb_segment<3, 8, 4, 2, 1, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+            case WB_V_3_8_12: wb_segment<3, 8, 4, 1, 2, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+            case WB_V_3_8_11: wb_segment<3, 8, 4, 1, 1, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+            case WB_V_3_2_8:  wb_segment<3, 2, 8, 1, 1, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+            case WB_V_3_2_16: wb_segment<3, 2, 16, 1, 1, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+            case WB_V_1_8_11: wb_segment<1, 8, 4, 1, 1, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
+            default:          wb_segment<1, 8, 4, 1, 1, 2>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
         }
     }
 }
@@ -586,7 +607,7 @@ struct WbGeom {
 
 static inline int wb_cin_logical(const dlwpcs_conv_desc *d) { return (d->c0_valid > 0 ? d->c0_valid : d->C0) + d->C1; }
 
-static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, WbGeom &G) {
+static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, bool mask, WbGeom &G) {
     int CT, NT, cap_tile_px, cap_pix;
     const int variant = wb_variant(d, CT, NT, cap_tile_px, cap_pix);
     if (variant < 0) return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: layer (N=%d C0=%d C1=%d Cout=%d k=%d dtype=%d) has no batched kernel",
@@ -612,6 +633,12 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, W
     L.ncit = ceil_div(L.Cin, 32 * CT); L.ncot = ceil_div(d->Cout, 32 * NT);
     L.cin_logical = wb_cin_logical(d); L.flip = d->flip_north_pole ? 1 : 0; L.want_bias = want_bias ? 1 : 0;
     L.has_np = has_np ? 1 : 0;
+    if (mask) {
+        if (KS != 3) return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: act' on load is built for the 3x3 kernels (pass a pre-masked dz)");
+        if (d->act != DLWPCS_ACT_LEAKY_CLIP || !(d->alpha >= 0.f) || !(d->vmax >= 0.f))
+            return fail(DLWPCS_E_INVALID, "wgrad_batch: item with y needs act = LEAKY_CLIP with negative_slope >= 0 and max_value >= 0");
+        L.mask = 1; L.alpha = d->alpha; L.vmax = d->vmax; L.pad0 = (int32_t)bf16_mask_threshold(d->vmax);
+    }
     const int TAPS = KS * KS;
     L.slot_floats = (int)align_up((size_t)TAPS * 32 * CT * 32 * NT + 32 * NT, 64);
     const size_t buf = (size_t)CT * rows * W2 * 64 + (size_t)NT * L.pix_cap * 64;
@@ -636,10 +663,12 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, W
     for (int last = 0; last < 2; ++last) {
         int cin_grp = 32 * CT;
         if (last) { cin_grp = L.Cin - (L.ncit - 1) * 32 * CT; }
-        const double xbytes = (double)rows * W2 * cin_grp * 2.0, dbytes = (double)pix * (d->Cout < 32 * NT ? d->Cout : 32 * NT) * 2.0;
+        const double xbytes = (double)rows * W2 * cin_grp * 2.0;
+        const double dbytes = (double)pix * (d->Cout < 32 * NT ? d->Cout : 32 * NT) * 2.0 * (mask ? 2.0 : 1.0);
         double ld = fix + (xbytes + dbytes) / bpc;
         if (x4) ld += ld4 * ((double)rows * W2 * (variant == WB_V_3_2_8 ? 8 : 16) / 256.0);
         if (d4) ld += ld4 * ((double)pix * 8 / 256.0);
+        if (mask) ld += 190.0 * ((double)pix * 4 * NT / 256.0);     // act' arithmetic + the second load stream (measured: 5.85 k -> 7.9 k)
         G.cost_item[last] = ld > mma ? ld : mma;
     }
     return DLWPCS_OK;
@@ -672,7 +701,7 @@ static int wb_build(const dlwpcs_wgrad_item *items, int n, int n_workers, WbPlan
     for (int l = 0; l < n; ++l) {
         const dlwpcs_wgrad_item &it = items[l];
         const bool want_bias = it.db_eq || it.db_pol || it.db_np;
-        int rc = wb_geometry(&it.d, want_bias, it.dw_np != nullptr, G[l]);
+        int rc = wb_geometry(&it.d, want_bias, it.dw_np != nullptr, it.y != nullptr, G[l]);
         if (rc) return rc;
         if ((it.db_np != nullptr) != (it.dw_np != nullptr) && it.db_eq)
             return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d: dw_np / db_np must match", l);
@@ -787,7 +816,7 @@ extern "C" int dlwpcs_wgrad_batch_supported(const dlwpcs_conv_desc *d) {
     int CT, NT, a, b;
     if (wb_variant(d, CT, NT, a, b) < 0) return 0;
     WbGeom G;
-    const int rc = wb_geometry(d, true, false, G);
+    const int rc = wb_geometry(d, true, false, false, G);
     return rc == DLWPCS_OK ? 1 : 0;
 }
 
@@ -835,8 +864,10 @@ extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, c
             return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d differs from the plan", l);
         if (!it.src0 || !it.dz || !it.dw_eq || !it.dw_pol || (it.d.C1 > 0 && !it.src1) || (it.d.halo && !it.table_dev))
             return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d: null pointer", l);
-        if ((L.want_bias != 0) != (it.db_eq || it.db_pol || it.db_np) || (L.has_np != 0) != (it.dw_np != nullptr))
-            return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d: bias / north-pole pointers differ from the plan", l);
+        if ((L.want_bias != 0) != (it.db_eq || it.db_pol || it.db_np) || (L.has_np != 0) != (it.dw_np != nullptr) ||
+            (L.mask != 0) != (it.y != nullptr))
+            return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d: bias / north-pole / y pointers differ from the plan", l);
+        ptrs.y[l] = it.y;
         ptrs.src0[l] = it.src0; ptrs.src1[l] = it.d.C1 > 0 ? it.src1 : it.src0; ptrs.dz[l] = it.dz; ptrs.table[l] = it.table_dev;
         R.dw_eq[l] = (float *)it.dw_eq; R.dw_pol[l] = (float *)it.dw_pol; R.dw_np[l] = (float *)it.dw_np;
         R.db_eq[l] = (float *)it.db_eq; R.db_pol[l] = (float *)it.db_pol; R.db_np[l] = (float *)it.db_np;

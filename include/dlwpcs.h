@@ -243,6 +243,8 @@ typedef struct dlwpcs_wgrad_item {
     dlwpcs_conv_desc d;
     const void *src0, *src1;              /* the layer's saved inputs (src1 NULL when C1 == 0) */
     const void *dz;
+    const void *y;                        /* NULL: dz is pre-masked.  Else (3x3 kernels, d.act = LEAKY_CLIP): `dz` holds the plain
+                                           * gradient dy and y the layer's saved output; the kernel forms dy * act'(y) on load */
     const int32_t *table_dev;             /* halo table (halo == 1) */
     void *dw_eq, *dw_pol, *dw_np;         /* fp32 HWIO, accumulated into; dw_np NULL unless independent north pole */
     void *db_eq, *db_pol, *db_np;         /* fp32 (Cout,) or NULL */

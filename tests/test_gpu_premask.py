@@ -1,0 +1,231 @@
+"""
+GPU tests of the pre-masked gradient convention (include/dlwpcs.h: dlwpcs_conv_bwd_data_masked, dlwpcs_avgpool2_bwd_masked,
+dlwpcs_head_mse_step_masked; DLWP.keras.Model._plan_premask): the gradient w.r.t. the output y of an activated layer is
+multiplied by act'(y) where it is produced, so that the layer receives dz = dy * act'(y) (keras ReLU(negative_slope,
+max_value), Azure/train_cs.py:199; act' evaluated from y like the reference's backward: slope for y < 0, 1 for 0 < y < max,
+0 otherwise).
+
+Checker: the same gradient computed WITHOUT the convention by the kernels that are pinned to the fp64 oracle elsewhere
+(tests/test_gpu_bf16.py), multiplied by act'(m) in fp32 and rounded to bf16 -- the masked kernels round in a different place
+(interior cells before the multiply, ring cells after), so the comparison allows 3 bf16 ulp of max|ref|; where the order is
+the same (interior cells of the direct-store epilogue) it is bit-exact.  The whole-model tests compare training steps with
+the convention switched on and off against each other and against the fp64 oracle network.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+EPS = 2.0 ** -8
+ALPHA, VMAX = 0.1, 10.0
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    return torch.device('cuda', 0)
+
+
+def _bf(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float32).to(torch.bfloat16).to(_dev())
+
+
+def _f32(t):
+    return t.detach().float().cpu().numpy()
+
+
+def slope(y, alpha=ALPHA, vmax=VMAX):
+    y = np.asarray(y, dtype=np.float32)
+    return np.where(y < 0, np.float32(alpha), np.where((y > 0) & (y < vmax), np.float32(1.0), np.float32(0.0)))
+
+
+def masked_ref(g, m, alpha=ALPHA, vmax=VMAX):
+    """bf16(g * act'(m)) with g, m bf16 tensors"""
+    r = torch.tensor(_f32(g) * slope(_f32(m), alpha, vmax)).to(torch.bfloat16)
+    return r.float().numpy()
+
+
+def close(a, ref, ulps):
+    d = np.abs(ref).max()
+    return np.abs(a - ref).max() <= ulps * EPS * (d if d > 0 else 1.0)
+
+
+def _conv_grads(B, N, C0, C1, up0, Cout, k, halo, mask0, mask1, seed):
+    """(masked dsrc0, dsrc1) and (plain dsrc0, dsrc1), (src0, src1)"""
+    from DLWP import _native as nat
+    rng = np.random.default_rng(seed)
+    dev = _dev()
+    n0 = N // 2 if up0 else N
+    # sources with values on both sides of 0 and beyond max_value so that all three branches of act' occur
+    src0 = _bf(rng.standard_normal((B, 6, n0, n0, C0)) * 6.0)
+    src1 = _bf(rng.standard_normal((B, 6, N, N, C1)) * 6.0) if C1 else None
+    No = N if halo else N - k + 1
+    dz = _bf(rng.standard_normal((B, 6, No, No, Cout)))
+    w = [torch.tensor(rng.standard_normal((k, k, C0 + C1, Cout)) / np.sqrt(k * k * (C0 + C1)), dtype=torch.float32, device=dev)
+         for _ in range(2)]
+    d = nat.ConvDesc(B=B, N=N, C0=C0, C1=C1, Cout=Cout, ksize=k, halo=int(halo), up0=int(up0), flip_north_pole=1, act=0,
+                     alpha=0., vmax=0., dtype=nat.BF16, flags=0, c0_valid=0)
+    nbytes = nat.lib().dlwpcs_conv_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    inv = nat.halo_tables(N, 1, dev)[1] if halo else None
+    out = []
+    for masked in (True, False):
+        g0 = torch.empty_like(src0)
+        g1 = torch.empty_like(src1) if C1 else None
+        if masked:
+            nat.check(nat.lib().dlwpcs_conv_bwd_data_masked(ctypes.byref(d), nat.ptr(dz), nat.ptr(w[0]), nat.ptr(w[1]), 0,
+                                                            nat.ptr(g0), nat.ptr(g1), nat.ptr(src0 if mask0 else None),
+                                                            nat.ptr(src1 if mask1 else None), ALPHA, VMAX, nat.ptr(inv),
+                                                            nat.ptr(ws), nbytes, nat.stream_ptr()), 'conv_bwd_data_masked')
+        else:
+            nat.check(nat.lib().dlwpcs_conv_bwd_data(ctypes.byref(d), nat.ptr(dz), 0, nat.ptr(w[0]), nat.ptr(w[1]), 0,
+                                                     nat.ptr(g0), nat.ptr(g1), nat.ptr(inv), nat.ptr(ws), nbytes,
+                                                     nat.stream_ptr()), 'conv_bwd_data')
+        torch.cuda.synchronize()
+        out.append((g0, g1))
+    return out[0], out[1], (src0, src1)
+
+
+# (B, N, C0, C1, up0, Cout, k, halo, mask0, mask1)
+CONV_CASES = [
+    (2, 48, 32, 0, 0, 32, 3, 1, True, False),      # direct-store epilogue + ring fix-up, 384-pixel tiles
+    (2, 24, 64, 0, 0, 64, 3, 1, True, False),      # ... 64 -> 64 (two 32-channel groups)
+    (2, 12, 128, 0, 0, 64, 3, 1, True, False),     # ... 128 gradient channels (64 per workgroup)
+    (2, 24, 64, 0, 0, 32, 3, 1, True, False),
+    (2, 24, 64, 64, 1, 64, 3, 1, True, False),     # decoder: upsampled source masked by the inverse-gather kernel
+    (2, 24, 64, 64, 1, 64, 3, 1, True, True),      # ... and the skip source by epilogue + ring fix-up
+    (2, 16, 32, 32, 0, 32, 3, 1, True, True),      # two directly written sources
+    (2, 16, 32, 32, 0, 32, 3, 1, False, True),
+    (3, 10, 12, 0, 0, 8, 3, 1, True, False),       # 4-channel vectors: routing kernels / elementwise finish
+    (2, 12, 7, 0, 0, 5, 3, 1, True, False),        # odd channel counts
+    (2, 16, 32, 0, 0, 14, 1, 0, True, False),      # pointwise head kernel, gradient written in place
+    (2, 14, 16, 0, 0, 16, 3, 0, True, False),      # 'valid' 3x3 on a padded tensor, written in place
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_masked_data_gradient(case):
+    B, N, C0, C1, up0, Cout, k, halo, mask0, mask1 = case
+    (m0, m1), (p0, p1), (s0, s1) = _conv_grads(*case, seed=abs(hash(case)) % (2 ** 31))
+    ulps = 5 if up0 else 3
+    for g_m, g_p, src, on in ((m0, p0, s0, mask0), (m1, p1, s1, mask1)):
+        if g_m is None:
+            continue
+        if on:
+            assert close(_f32(g_m), masked_ref(g_p, src), ulps), case
+        else:
+            assert torch.equal(g_m, g_p), case
+
+
+def test_masked_epilogue_is_exact_on_interior_cells():
+    """interior cells take one path in both runs: round(acc) -> * act' -> round"""
+    case = (2, 48, 32, 0, 0, 32, 3, 1, True, False)
+    (m0, _), (p0, _), (s0, _) = _conv_grads(*case, seed=3)
+    a, ref = _f32(m0)[:, :, 1:-1, 1:-1], masked_ref(p0, s0)[:, :, 1:-1, 1:-1]
+    assert np.array_equal(a, ref)
+    sl = slope(_f32(s0))
+    assert (sl == 0).any() and (sl == 1).any() and (sl == np.float32(ALPHA)).any()
+
+
+@pytest.mark.parametrize('B,N,C,skip', [(2, 24, 32, True), (2, 8, 64, True), (3, 12, 6, True), (2, 16, 32, False)])
+def test_masked_pool_backward(B, N, C, skip):
+    from DLWP import _native as nat
+    rng = np.random.default_rng(N + C)
+    x = _bf(rng.standard_normal((B, 6, N, N, C)) * 6.0)
+    dy = _bf(rng.standard_normal((B, 6, N // 2, N // 2, C)))
+    dskip = _bf(rng.standard_normal((B, 6, N, N, C))) if skip else None
+    dx = torch.empty_like(x)
+    nat.check(nat.lib().dlwpcs_avgpool2_bwd_masked(nat.ptr(dy), nat.ptr(dskip), nat.ptr(x), nat.ptr(dx), B, N, C, ALPHA, VMAX,
+                                                   nat.BF16, nat.stream_ptr()), 'avgpool2_bwd_masked')
+    g = 0.25 * np.repeat(np.repeat(_f32(dy), 2, axis=2), 2, axis=3)
+    if skip:
+        g = _f32(dskip) + g
+    ref = torch.tensor(g * slope(_f32(x))).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(_f32(dx), ref)            # one fp32 expression, one rounding
+
+
+def test_ops_level_chain_matches_the_plain_path():
+    """conv+ReLU -> pool (skip) -> conv+ReLU -> decoder conv on [up, skip]: gradients of all parameters and of the input with
+    the convention on (consumers mask, producers take dz) and off"""
+    from DLWP import ops
+    from DLWP._native import ACT_LEAKY_CLIP
+    rng = np.random.default_rng(2)
+    dev = _dev()
+    B, N = 2, 16
+    x = _bf(rng.standard_normal((B, 6, N, N, 8)) * 2)
+
+    def params(cin, cout):
+        return [torch.tensor(rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin), dtype=torch.float32, device=dev)
+                for _ in range(2)] + [torch.tensor(rng.standard_normal(cout) * 0.1, dtype=torch.float32, device=dev)
+                                      for _ in range(2)]
+    P1, P2, P3 = params(8, 32), params(32, 32), params(64, 16)
+    gy = _bf(rng.standard_normal((B, 6, N, N, 16)))
+    res = []
+    for on in (False, True):
+        pm = (ALPHA, VMAX) if on else None
+        xx = x.clone().requires_grad_(True)
+        ps = [[p.clone().requires_grad_(True) for p in P] for P in (P1, P2, P3)]
+
+        def conv(src0, p, src1=None, up0=False, premask0=None, premask1=None, dyp=False):
+            return ops.cs_conv(src0, p[0], p[1], None, p[2], p[3], None, src1=src1, ksize=3, halo=True, up0=up0,
+                               act=ACT_LEAKY_CLIP, alpha=ALPHA, vmax=VMAX, premask0=premask0, premask1=premask1,
+                               dy_premasked=dyp)
+        a = conv(xx, ps[0], dyp=on)                              # consumers: pooling node (masks), decoder via the alias
+        pooled, alias = ops.avgpool2_skip(a, pm)
+        b = conv(pooled, ps[1], dyp=on)                          # consumer: decoder conv as upsampled source 0 (masks)
+        y = conv(b, ps[2], src1=alias, up0=True, premask0=pm)    # the alias hands plain gradients back to the pooling node
+        y.backward(gy)
+        res.append([xx.grad] + [p.grad for P in ps for p in P])
+    for g_off, g_on in zip(*res):
+        a, b = _f32(g_off), _f32(g_on)
+        assert np.abs(a - b).max() <= 4 * EPS * np.abs(a).max()
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_unet2_training_with_and_without_the_convention(graphs):
+    """three Adam steps of a bf16 `unet2`: pre-masked gradients + batched weight gradients against the plain per-layer path"""
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    dev = _dev()
+    backend.set_device('cuda:0')
+    N, C, B = 16, 14, 4
+    rng = np.random.default_rng(0)
+    x = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    t = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
+    w0, out = None, []
+    for on in ('0', '1'):
+        os.environ['DLWPCS_PREMASK'] = on
+        os.environ['DLWPCS_WGRAD_BATCH'] = on
+        try:
+            backend.set_compute_dtype('bfloat16')
+            try:
+                np.random.seed(5)
+                model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=32)
+            finally:
+                backend.set_compute_dtype('float32')
+            model.use_graphs = graphs
+            model.compile(optimizer='adam', loss='mse', metrics=['mae'])
+            if w0 is None:
+                w0 = model.get_weights()
+            model.set_weights(w0)
+            if on == '1':
+                assert len(model._premask) == 9         # every activated layer but the first (no data gradient there)
+            stats = None
+            for _ in range(3):
+                stats = model.train_on_device_batch([x], [t])
+            torch.cuda.synchronize()
+            out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
+        finally:
+            os.environ.pop('DLWPCS_PREMASK', None)
+            os.environ.pop('DLWPCS_WGRAD_BATCH', None)
+    (p_off, s_off), (p_on, s_on) = out
+    # Adam's first steps move every weight by ~lr regardless of the gradient's size: compare the UPDATES
+    d_off, d_on = p_off - np.concatenate([w.ravel() for w in w0]), p_on - np.concatenate([w.ravel() for w in w0])
+    cos = float(np.dot(d_off, d_on) / (np.linalg.norm(d_off) * np.linalg.norm(d_on)))
+    assert cos > 0.995, cos
+    assert abs(s_on[0, 0] - s_off[0, 0]) <= 2e-3 * abs(s_off[0, 0])

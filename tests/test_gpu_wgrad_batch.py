@@ -143,6 +143,26 @@ def test_layer_options():
         l.check()
 
 
+@pytest.mark.parametrize('case', [(2, 48, 14, 0, 0, 32, 3, 1), (3, 16, 8, 0, 0, 32, 3, 1), (2, 24, 64, 0, 0, 64, 3, 1),
+                                  (2, 12, 32, 0, 0, 64, 3, 1)])
+def test_mask_on_load(case):
+    """item with y: `dz` is the plain gradient, the producers form dy * act'(y) (rounded to bf16 like a stored dz)"""
+    from DLWP import _native as nat
+    from DLWP import ops
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    lay = Layer(rng, *case)
+    y = _bf(rng.standard_normal(tuple(lay.dz.shape)) * 6.0)
+    dy = lay.dz
+    yf, gf = y.float().cpu().numpy(), dy.float().cpu().numpy()
+    sl = np.where(yf < 0, np.float32(0.1), np.where((yf > 0) & (yf < 10.0), np.float32(1.0), np.float32(0.0)))
+    lay.dz = torch.tensor(gf * sl).to(torch.bfloat16).to(_dev())        # what the reference sees
+    d = nat.ConvDesc.from_buffer_copy(lay.d)
+    d.act, d.alpha, d.vmax = nat.ACT_LEAKY_CLIP, 0.1, 10.0
+    e = lay.entry()
+    ops.wgrad_batch([(d, e[1], e[2], dy, e[4], e[5], y)])
+    lay.check()
+
+
 def test_unet2_layer_list_accumulates_and_is_reproducible():
     """the eleven convolutions of `unet2` as ONE batch; a second run adds to the gradients (x 2), bit for bit the same sum"""
     from DLWP import ops

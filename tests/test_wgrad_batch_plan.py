@@ -46,7 +46,7 @@ def _plan(arr):
     ws_floats, = struct.unpack_from('<Q', raw, 40)
     red_first = struct.unpack_from('<%dI' % (WB_MAX + 1), raw, 48)
     seg_start = struct.unpack_from('<257I', raw, 48 + 4 * (WB_MAX + 1))
-    layers = np.frombuffer(raw, dtype=np.int32, count=32 * n_layers, offset=off_l).reshape(n_layers, 32)
+    layers = np.frombuffer(raw, dtype=np.int32, count=36 * n_layers, offset=off_l).reshape(n_layers, 36)
     segs = np.frombuffer(raw, dtype=np.int32, count=8 * n_segs, offset=off_s).reshape(n_segs, 8)
     groups = np.frombuffer(raw, dtype=np.int32, count=4 * n_groups, offset=off_g).reshape(n_groups, 4)
     return dict(magic=magic, n_layers=n_layers, n_segs=n_segs, n_workers=n_workers, lds=lds, total=total, ws_floats=ws_floats,

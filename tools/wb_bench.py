@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--layers', default='')
+    ap.add_argument('--mask', default='', help='layers (of the full list) whose item carries y: act\' applied on load')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     lib = nat.lib()
@@ -46,7 +47,11 @@ def main():
         d = nat.ConvDesc(B=B, N=N, C0=C0, C1=C1, Cout=Cout, ksize=k, halo=halo, up0=up0, flip_north_pole=1, act=0, alpha=0.,
                          vmax=0., dtype=nat.BF16, flags=0, c0_valid=0)
         table = nat.halo_tables(N, 1, dev)[0] if halo else None
-        entries.append((d, x0, x1, dz, table, tuple(g)))
+        e = (d, x0, x1, dz, table, tuple(g))
+        if str(i) in args.mask.split(','):
+            d.act, d.alpha, d.vmax = nat.ACT_LEAKY_CLIP, 0.1, 10.0
+            e = e + (torch.randn_like(dz.float()).mul_(3).to(torch.bfloat16),)
+        entries.append(e)
         keep.append((x0, x1, dz, g))
     ops.wgrad_batch(entries)
     torch.cuda.synchronize()

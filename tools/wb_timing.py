@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--layers', default='')
+    ap.add_argument('--mask', default='', help='layers (of the full list) whose item carries y: act\' applied on load')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     B = args.batch
@@ -42,7 +43,11 @@ def main():
              torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev), None)
         d = nat.ConvDesc(B=B, N=N, C0=C0, C1=C1, Cout=Cout, ksize=k, halo=halo, up0=up0, flip_north_pole=1, act=0, alpha=0.,
                          vmax=0., dtype=nat.BF16, flags=0, c0_valid=0)
-        entries.append((d, x0, x1, dz, nat.halo_tables(N, 1, dev)[0] if halo else None, g))
+        e = (d, x0, x1, dz, nat.halo_tables(N, 1, dev)[0] if halo else None, g)
+        if str(i) in args.mask.split(','):
+            d.act, d.alpha, d.vmax = nat.ACT_LEAKY_CLIP, 0.1, 10.0
+            e = e + (torch.randn_like(dz.float()).mul_(3).to(torch.bfloat16),)
+        entries.append(e)
     for _ in range(2):
         ops.wgrad_batch(entries)
     torch.cuda.synchronize()
