@@ -53,12 +53,16 @@ import torch         # noqa: E402
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense (measured 2495)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-BF16_MFMA_KERNELS = ('conv_mfma_ws_kernel<unsigned short', 'wgrad_bf16_kernel', 'pw_')
+BF16_MFMA_KERNELS = ('conv_mfma_ws_kernel<unsigned short', 'wgrad_bf16_kernel', 'wgrad_batch_kernel', 'pw_')
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
 N_SIMD = 1024                      # 256 CUs x 4 SIMDs
 N_XCC = 8
 PEAK_CLOCK_MHZ = 2400.0
 PMC_GROUPS = (('FETCH_SIZE',), ('WRITE_SIZE',), ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'))
+# peaks MEASURED on an MI355X box with tools/peaks.hip (profiles/r01_peaks.txt): register-resident MFMA chains, streaming
+# read / write / copy kernels -- what a perfect kernel reaches on this hardware, next to the datasheet numbers above
+MEASURED_PEAKS = {'bf16_mfma_tflops': 2460.0, 'fp32_mfma_tflops': 156.0, 'hbm_read_gbs': 6400.0, 'hbm_write_gbs': 5200.0,
+                  'hbm_copy_gbs': 4800.0, 'source': 'tools/peaks.hip, profiles/r01_peaks.txt'}
 
 
 def conv_plan(workload, c_in, c_out, base):
@@ -186,6 +190,8 @@ def pmc_record(counters):
     f, w = counters.get('FETCH_SIZE'), counters.get('WRITE_SIZE')
     if f and w and f[0] and w[0]:
         rec['fetch_kb_x2'] = round(2.0 * f[1] / f[0], 1)
+        rec['fetch_kb_raw'] = round(f[1] / f[0], 1)             # as the counter reports it (the x 2 is the guide's gfx950 calibration
+        rec['traffic_raw'] = int((f[1] / f[0] + w[1] / w[0]) * 1024)   # for wide streaming reads: an estimate, not a measurement)
         rec['write_kb'] = round(w[1] / w[0], 1)
         rec['traffic'] = int((2.0 * f[1] / f[0] + w[1] / w[0]) * 1024)
         rec['launches'] = f[0]
@@ -203,7 +209,7 @@ def pmc_record(counters):
     return rec
 
 
-def collect_pmc_live(args, dtype, timeout_s=240):
+def collect_pmc_live(args, dtype, timeout_s=240, groups=None):
     """Run this same workload under rocprofv3, one counter group per pass (eager steps, no graphs).  Returns
     ({kernel: record}, source string) or (None, reason)."""
     exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
@@ -215,7 +221,8 @@ def collect_pmc_live(args, dtype, timeout_s=240):
     tmp = tempfile.mkdtemp(prefix='dlwpcs_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
     try:
-        for i, group in enumerate(PMC_GROUPS):
+        groups = groups or PMC_GROUPS
+        for i, group in enumerate(groups):
             d = os.path.join(tmp, 'pass%d' % i)
             cmd = [exe, '--kernel-trace', '--pmc'] + list(group) + ['-d', d, '-o', 'p', '--output-format', 'csv', '--',
                    sys.executable, os.path.abspath(__file__), '--pmc-child', '--workload', args.workload, '--dtype', dtype,
@@ -233,7 +240,7 @@ def collect_pmc_live(args, dtype, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
     recs = {k: pmc_record(v) for k, v in merged.items()}
     return {k: v for k, v in recs.items() if v}, 'live rocprofv3 --kernel-trace --pmc passes (%s), 3 eager steps each' % (
-        ' | '.join(' '.join(g) for g in PMC_GROUPS))
+        ' | '.join(' '.join(g) for g in groups))
 
 
 def newest_committed_pmc(workload, dtype):
@@ -355,7 +362,7 @@ def allreduce_probe(model, world, reps=20):
     return float(el.item()) * 1e6
 
 
-def measure(args, dtype, rank, world, with_roofline, with_pmc):
+def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
     """Build the workload in `dtype`, warm up, time the contract's K steps and then >= 5 blocks of >= 0.5 s (each bracketed
     by barrier + synchronize, MAX over ranks); optionally the per-launch roofline pass and the PMC passes.  Returns the
     result dict on rank 0, None elsewhere."""
@@ -392,6 +399,26 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc):
         per_block = int(pb.item())
     blocks = [timed(per_block) / per_block for _ in range(args.blocks)]
     step_s = float(np.median(blocks))
+    # self-check that the timed work ran on the device: the same steps between two HIP events on the compute stream (device
+    # clock) against the host clock, and the device the process is bound to
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(per_block):
+        run_step(st)
+    e1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    self_check = {'device': torch.cuda.get_device_name(dev), 'arch': getattr(torch.cuda.get_device_properties(dev), 'gcnArchName', ''),
+                  'steps': per_block, 'hip_event_ms_per_step': round(e0.elapsed_time(e1) / per_block, 4),
+                  'host_wall_ms_per_step': round(1e3 * wall / per_block, 4),
+                  'device_busy_fraction': round(min(1.0, e0.elapsed_time(e1) * 1e-3 / wall), 4)}
+    try:
+        self_check['smi_utilization_percent'] = int(torch.cuda.utilization(dev))
+    except Exception as exc:                  # amdsmi not importable on the box: say so instead of reporting 0
+        self_check['smi_utilization_percent'] = None
+        self_check['smi_note'] = 'torch.cuda.utilization unavailable: %s' % type(exc).__name__
     ar_us = allreduce_probe(model, world) if st['train'] else None
     # the roofline pass runs eager optimisation steps (gradient all-reduce included): EVERY rank takes part
     agg = roofline_pass(st) if with_roofline else None
@@ -422,6 +449,7 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc):
                    'block_ms_per_step': [round(1e3 * b, 4) for b in blocks],
                    'k_step_window_ms_per_step': round(1e3 * k_elapsed / args.steps, 4)},
         'model_tflops': round(flops_step * world / step_s / 1e12, 3),
+        'device_self_check': self_check,
     }
     if not st['train']:
         result['model_steps_per_s'] = round(B * world * st['n_fwd'] / step_s, 1)
@@ -446,12 +474,16 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc):
                     'frac': round(t_b / t, 4)}
         name, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
         rf = bound_of(name, cnt, ms, fl, by)
+        mp = (MEASURED_PEAKS['bf16_mfma_tflops'] if name.startswith(BF16_MFMA_KERNELS) else MEASURED_PEAKS['fp32_mfma_tflops']) \
+            if rf['bound'] == 'mfma' else MEASURED_PEAKS['hbm_read_gbs']
+        rf['measured_peaks'] = MEASURED_PEAKS
+        rf['frac_vs_measured_peak'] = round(rf['achieved'] / mp, 4)
         rf.update({'kernel': name, 'launches': cnt, 'avg_launch_us': round(1e3 * ms / cnt, 2),
                    'algorithmic_gflop_per_launch': round(fl / cnt / 1e9, 3),
                    'algorithmic_mbytes_per_launch': round(by / cnt / 1e6, 3)})
         recs, src = (None, 'PMC passes disabled (--no-pmc)')
         if with_pmc:
-            recs, src = collect_pmc_live(args, dtype)
+            recs, src = collect_pmc_live(args, dtype, groups=pmc_groups)
             if recs is None:
                 live_err = src
                 recs, src = newest_committed_pmc(args.workload, dtype)
@@ -463,7 +495,7 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc):
                 doc = {}
             doc['%s/%s' % (args.workload, dtype)] = {k: v for k, v in recs.items()
                                                      if any(x in k for x in ('conv_mfma', 'wgrad', 'pw_', 'pad_', 'src_pair',
-                                                                             'avgpool', 'mse_', 'adam', 'pack_batch',
+                                                                             'avgpool', 'mse_', 'adam', 'pack_batch', 'wb_',
                                                                              'state_repack', 'batch_gather'))}
             doc['_source'] = src
             with open(args.pmc_out, 'w') as f:
@@ -477,6 +509,9 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc):
             sys.stderr.write('bench.py: ERROR: %s\n' % rf['pmc_error'])
         else:
             rf['traffic'] = rec.get('traffic')
+            rf['traffic_raw_counters'] = rec.get('traffic_raw')
+            rf['traffic_note'] = 'traffic = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md: rocprofv3 on gfx950 reports half of the ' \
+                                 'bytes of wide streaming reads); traffic_raw_counters = FETCH_SIZE + WRITE_SIZE as reported' 
             rf['traffic_vs_algorithmic'] = (round(rec['traffic'] / (by / cnt), 3) if rec.get('traffic') and by else None)
             rf['hbm_gbs'] = round(rec['traffic'] / (ms / cnt * 1e-3) / 1e9, 1) if rec.get('traffic') else None
             rf['hbm_frac_of_peak'] = round(rf['hbm_gbs'] / PEAK_HBM_GBS, 4) if rf['hbm_gbs'] else None
@@ -529,6 +564,8 @@ def main():
     ap.add_argument('--no-companion', action='store_true',
                     help='skip the second measurement in the other dtype (N = 1 only) reported under "f32" / "bf16"')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true',
+                    help='N = 1, unet2: skip the extra measurements of BASELINE configs 2 (encoder6, fp32) and 5 (rollout, bf16)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='no rocprofv3 child passes (traffic / mfma_busy stay null)')
     ap.add_argument('--no-graphs', action='store_true')
@@ -547,11 +584,21 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if os.environ.get('DLWPCS_BENCH_SHARE_GPU') == '1':
         local_rank = 0
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # invoked plainly (`python bench.py --gpus N ...`): start the N ranks ourselves, one process per GPU, exactly as
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would; rank 0 of the
+        # children prints the JSON line on our stdout
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
     if world != args.gpus:
-        if rank == 0 and world == 1 and args.gpus > 1:
-            sys.stderr.write('bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`\n'
-                             % (args.gpus, args.gpus))
-            sys.exit(2)
+        if rank == 0:
+            sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
+        sys.exit(2)
     if not torch.cuda.is_available():
         sys.stderr.write('bench.py: no HIP device visible; the engine has no CPU path\n')
         sys.exit(2)
@@ -582,6 +629,27 @@ def main():
         comp = measure(args, other, rank, world, with_roofline=not args.no_roofline, with_pmc=not args.no_pmc)
         keep = ('value', 'unit', 'ms_per_step', 'dtype', 'model_tflops', 'timing', 'roofline')
         result[other] = {k: comp[k] for k in keep if k in comp}
+    if single and not args.no_configs and args.workload == 'unet2':
+        # BASELINE configs 2 and 5, timed by the same clock in the same run (their own lines: --workload encoder6 / rollout)
+        import copy
+        result['configs'] = {}
+        for key, wl, ch, face, dt in (('cfg2_encoder6_f32', 'encoder6', 7, 48, 'f32'), ('cfg5_rollout_bf16', 'rollout', 26, 96, 'bf16')):
+            a2 = copy.copy(args)
+            a2.workload, a2.channels, a2.face, a2.dtype = wl, ch, face, dt
+            a2.blocks, a2.min_block_s, a2.steps, a2.warmup, a2.pmc_out = 3, 0.3, (20 if wl == 'rollout' else 100), 5, None
+            r2 = measure(a2, dt, rank, world, with_roofline=not args.no_roofline, with_pmc=not args.no_pmc, pmc_groups=PMC_GROUPS[:2])
+            ent = {k: r2[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'model_tflops', 'config') if k in r2}
+            for k in ('ms_per_forward', 'model_steps_per_s'):
+                if k in r2:
+                    ent[k] = r2[k]
+            rf2 = r2.get('roofline')
+            if rf2:
+                ent['roofline'] = {k: rf2.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_vs_measured_peak',
+                                                           'avg_launch_us', 'launches', 'algorithmic_gflop_per_launch',
+                                                           'algorithmic_mbytes_per_launch', 'traffic', 'traffic_raw_counters',
+                                                           'traffic_vs_algorithmic', 'hbm_gbs', 'pmc_source', 'pmc_error')
+                                   if k in rf2}
+            result['configs'][key] = ent
     if rank == 0 and single and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args.workload, args.face, args.channels, args.channels, args.base, args.batch)
     if rank == 0:

@@ -586,13 +586,23 @@ class Model(object):
         if self._stager is None or self._stager.device != dev:
             self._stager = staging.Stager(dev)
         cdt = backend.torch_dtype(self.compute_dtype)
+        consumed = []                   # events behind the steps that read the last batches: bounds the run-ahead of the host
         for bx, by in self._batches_from(x, y, batch_size, shuffle, lazy=True):
-            ts, ev = self._stager.upload(list(bx) + list(by), [cdt] * len(bx) + [torch.float32] * len(by))
+            if len(consumed) >= 3:
+                consumed.pop(0).synchronize()
+            items = list(bx) + list(by)
+            ts, ev = self._stager.upload(items, [cdt] * len(bx) + [torch.float32] * len(by))
             cur = torch.cuda.current_stream(dev)
             cur.wait_event(ev)
-            for t in ts:
-                t.record_stream(cur)
+            for t, src in zip(ts, items):
+                if t is not src:                    # (device-resident items were passed through untouched)
+                    t.record_stream(cur)
+            # targets the caller already holds on the device in another dtype: converted here, on the compute stream
+            ts = ts[:len(bx)] + [t if t.dtype == torch.float32 else t.float() for t in ts[len(bx):]]
             yield ts[:len(bx)], ts[len(bx):]
+            ev2 = torch.cuda.Event()
+            ev2.record(torch.cuda.current_stream(dev))          # (the consumer has enqueued its step by now)
+            consumed.append(ev2)
 
     def _standardize_inputs(self, x):
         if isinstance(x, dict):
@@ -747,17 +757,21 @@ class Model(object):
             # download of neighbouring batches overlap (keras/staging.py)
             if self._stager is None or self._stager.device != dev:
                 self._stager = staging.Stager(dev)
-            down = staging.Downloader(dev)
+            if getattr(self, '_downloader', None) is None or self._downloader.device != dev:
+                self._downloader = staging.Downloader(dev)       # (its pinned buffers are reused by every predict() call)
+            down = self._downloader
             cdt = backend.torch_dtype(self.compute_dtype)
         with torch.no_grad():
             for s in range(0, n, bs):
                 if staged:
-                    dx, ev = self._stager.upload([staging.LazyTake(a, slice(s, min(s + bs, n))) if isinstance(a, np.ndarray)
-                                                  else a[s:s + bs] for a in xs], [cdt] * len(xs))
+                    srcs = [staging.LazyTake(a, slice(s, min(s + bs, n))) if isinstance(a, np.ndarray) else a[s:s + bs]
+                            for a in xs]
+                    dx, ev = self._stager.upload(srcs, [cdt] * len(xs))
                     cur = torch.cuda.current_stream(dev)
                     cur.wait_event(ev)
-                    for t in dx:
-                        t.record_stream(cur)
+                    for t, src in zip(dx, srcs):
+                        if t is not src:
+                            t.record_stream(cur)
                 else:
                     dx = [self._to_device(a[s:s + bs]) for a in xs]
                 if s == 0:

@@ -44,6 +44,10 @@ def _rows(sel, i0, i1):
 
 class Stager(object):
     MAX_SLOTS = 32
+    # pinned buffers of one shape with an upload still in flight before the host waits for the oldest: a step is only
+    # ENQUEUED by fit(), so without a bound the feed would stage up to MAX_SLOTS buffers ahead (1.6 GB of pinned memory at the
+    # headline configuration).  (Model._feed bounds the run-ahead against the COMPUTE stream the same way.)
+    MAX_AHEAD = 6
 
     def __init__(self, device, workers=4):
         self.device = device
@@ -53,20 +57,27 @@ class Stager(object):
         self._pool = None
 
     # ---- pinned buffers ------------------------------------------------------------------------------------------
-    def _slot(self, shape):
+    def _slot(self, shape, in_use):
+        """a pinned buffer of `shape` that no upload still reads; `in_use`: slots handed out earlier in the same upload()"""
         ring = self._rings.setdefault(shape, [])
+        busy = [s for s in ring if s[1] is not None and not s[1].query() and not any(s is u for u in in_use)]
+        if len(busy) >= self.MAX_AHEAD:
+            busy[0][1].synchronize()            # back-pressure: wait for the oldest upload of this shape
         for slot in ring:
-            if slot[1] is not None and slot[1].query():
+            if any(slot is u for u in in_use):
+                continue
+            if slot[1] is None or slot[1].query():
                 slot[1] = None
                 return slot
         if len(ring) < self.MAX_SLOTS:
-            ring.append([torch.empty(shape, dtype=torch.float32).pin_memory(), None])
+            ring.append([torch.empty(shape, dtype=torch.float32, pin_memory=True), None])
             return ring[-1]
-        slot = ring[0]
-        ring.append(ring.pop(0))
-        slot[1].synchronize()
-        slot[1] = None
-        return slot
+        for slot in ring:                       # every slot busy: wait for the first that is not part of this batch
+            if not any(slot is u for u in in_use) and slot[1] is not None:
+                slot[1].synchronize()
+                slot[1] = None
+                return slot
+        raise RuntimeError('Stager: a batch needs more than %d staging buffers of shape %s' % (self.MAX_SLOTS, shape))
 
     def _fill(self, dst, src):
         """one pass: gather / convert `src` (array, host tensor or LazyTake) into the pinned buffer `dst` (numpy view)"""
@@ -94,7 +105,7 @@ class Stager(object):
         """items: host arrays / LazyTake / tensors; dtypes: the torch dtype each one is wanted in.  Returns the device tensors
         and the event (on the copy stream) the consumer's stream has to wait for; the tensors are allocated on the copy
         stream, so the consumer also has to `record_stream` them."""
-        staged = []
+        staged, in_use = [], []
         for item in items:
             if isinstance(item, torch.Tensor) and item.is_cuda:
                 staged.append((item, None))
@@ -103,14 +114,23 @@ class Stager(object):
             if int(np.prod(shape)) == 0:
                 staged.append((torch.zeros(shape, dtype=torch.float32), None))
                 continue
-            slot = self._slot(shape)
+            slot = self._slot(shape, in_use)
+            in_use.append(slot)
             self._fill(slot[0].numpy(), item)
             staged.append((slot[0], slot))
-        out = []
+        out = [None] * len(staged)
+        # Device-resident items pass through UNTOUCHED: whoever produced them did so on the compute stream, and the copy
+        # stream does not wait for that stream -- converting them here would race with their producer.  Model._forward casts
+        # on the compute stream.
+        for i, (t, slot) in enumerate(staged):
+            if slot is None and t.is_cuda:
+                out[i] = t
         with torch.cuda.stream(self.copy_stream):
-            for (t, slot), dt in zip(staged, dtypes):
+            for i, ((t, slot), dt) in enumerate(zip(staged, dtypes)):
+                if out[i] is not None:
+                    continue
                 d = t.to(self.device, non_blocking=True)
-                out.append(d if d.dtype == dt else d.to(dt))
+                out[i] = d if d.dtype == dt else d.to(dt)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
             for t, slot in staged:

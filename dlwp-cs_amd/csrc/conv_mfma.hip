@@ -2101,8 +2101,8 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     int pidx = -1;
     if (prof_enabled()) {
         char tag[160];
-        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s%s>", TName<T>::str(), KS, KC,
-                 MT, NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? "true" : "false", MOUT ? ", true" : "");
+        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s>", TName<T>::str(), KS, KC,
+                 MT, NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? "true" : "false", MOUT ? "true" : "false");
         pidx = prof_begin(tag, W.flops, W.bytes, s);
     }
     hipLaunchKernelGGL(kern, grid, dim3(2 * NTHREADS), lds, s, P);

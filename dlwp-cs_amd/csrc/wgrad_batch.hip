@@ -494,19 +494,30 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Reduction: one thread per VEC consecutive output channels of one (layer, tap, ci) row (or of the bias vector); the
-// partial sums of its (ci group, co group) are added class by class, slot by slot -- a fixed order.
+// Reduction: a workgroup owns 64 groups of VEC consecutive output channels of one (layer, tap, ci) row (or of the bias
+// vector) x 4 slot phases: thread (o, ph) adds the partial sums ph, ph + 4, ... of its (ci group, co group) and face class in
+// slot order, the four phases are combined through LDS in phase order -- a fixed order, no atomics.
 // ------------------------------------------------------------------------------------------------------------------
-template <int VEC>
+constexpr int WB_RED_OUT = 64, WB_RED_PH = 4;
+
+template <int VEC, bool ALIGNED>
 __device__ __forceinline__ void wb_reduce_body(const WbLayer &L, const WbGroup *__restrict__ groups, const float *__restrict__ ws,
                                                float *dw_eq, float *dw_pol, float *dw_np, float *db_eq, float *db_pol,
                                                float *db_np, int block) {
     typedef float VT __attribute__((ext_vector_type(VEC)));
+    // destination update: one 16-B access when the caller's gradient tensors are 16-B aligned, else element by element
+    auto accum = [](float *dst, VT v) {
+        if constexpr (ALIGNED || VEC == 1) { VT *q = reinterpret_cast<VT *>(dst); *q = *q + v; }
+        else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dst[k] += v[k];
+        }
+    };
     const int KS = L.KS, TAPS = KS * KS, Cin = L.cin_logical, Cout = L.Cout;
     const int nW = TAPS * Cin * Cout;
-    const int e = (block * 256 + (int)threadIdx.x) * VEC;
+    const int o = (int)threadIdx.x % WB_RED_OUT, ph = (int)threadIdx.x / WB_RED_OUT;
+    const int e = (block * WB_RED_OUT + o) * VEC;
     const bool is_w = e < nW, is_b = !is_w && L.want_bias && e < nW + Cout;
-    if (!is_w && !is_b) return;
     const int TC = 32 * L.CT, TN = 32 * L.NT;
     VT s[3];
     s[0] = 0.f; s[1] = 0.f; s[2] = 0.f;
@@ -519,22 +530,33 @@ __device__ __forceinline__ void wb_reduce_body(const WbLayer &L, const WbGroup *
         for (int c = 0; c < 3; ++c) {
             const WbGroup g = groups[L.group_base + (cit * L.ncot + cot) * 3 + c];
             const float *p = ws + g.off + (size_t)(((c == 2 ? tap5 : tap) * TC + lci) * TN + lco);
-#pragma unroll 8
-            for (int j = 0; j < g.count; ++j) s[c] += *reinterpret_cast<const VT *>(p + (size_t)j * g.stride);
+#pragma unroll 4
+            for (int j = ph; j < g.count; j += WB_RED_PH) s[c] += *reinterpret_cast<const VT *>(p + (size_t)j * g.stride);
         }
-        auto add = [&](float *dst, VT v) { VT *q = reinterpret_cast<VT *>(dst + e); *q = *q + v; };
-        add(dw_eq, s[0]);
-        if (dw_np) { add(dw_pol, s[1]); add(dw_np, s[2]); } else add(dw_pol, s[1] + s[2]);
-    } else {
+    } else if (is_b) {
         const int co = e - nW;
         const int cot = co / TN, lco = co - cot * TN;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const WbGroup g = groups[L.group_base + cot * 3 + c];         // ci group 0 carries the bias sums
             const float *p = ws + g.off + (size_t)TAPS * TC * TN + lco;
-            for (int j = 0; j < g.count; ++j) s[c] += *reinterpret_cast<const VT *>(p + (size_t)j * g.stride);
+#pragma unroll 4
+            for (int j = ph; j < g.count; j += WB_RED_PH) s[c] += *reinterpret_cast<const VT *>(p + (size_t)j * g.stride);
         }
-        auto add = [&](float *dst, VT v) { if (dst) { VT *q = reinterpret_cast<VT *>(dst + co); *q = *q + v; } };
+    }
+    __shared__ VT red[3][WB_RED_PH][WB_RED_OUT];
+    red[0][ph][o] = s[0]; red[1][ph][o] = s[1]; red[2][ph][o] = s[2];
+    __syncthreads();
+    if (ph != 0 || (!is_w && !is_b)) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s[c] = ((red[c][0][o] + red[c][1][o]) + red[c][2][o]) + red[c][3][o];
+    if (is_w) {
+        auto add = [&](float *dst, VT v) { accum(dst + e, v); };
+        add(dw_eq, s[0]);
+        if (dw_np) { add(dw_pol, s[1]); add(dw_np, s[2]); } else add(dw_pol, s[1] + s[2]);
+    } else {
+        const int co = e - nW;
+        auto add = [&](float *dst, VT v) { if (dst) accum(dst + co, v); };
         add(db_eq, s[0]);
         if (db_np) { add(db_pol, s[1]); add(db_np, s[2]); } else add(db_pol, s[1] + s[2]);
     }
@@ -549,14 +571,16 @@ __global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__
 #pragma unroll
     for (int k = 1; k < WB_MAX_LAYERS; ++k) l += (k < (int)H->n_layers && b >= R.first[k]) ? 1 : 0;
     if (!((R.live >> l) & 1u)) return;
-    const WbLayer L = layers[l];
+    const WbLayer L = load_uniform(layers[l]);
     const int blk = (int)(b - R.first[l]);
     const bool al = ((((uintptr_t)R.dw_eq[l] | (uintptr_t)R.dw_pol[l] | (uintptr_t)R.dw_np[l] | (uintptr_t)R.db_eq[l] |
                        (uintptr_t)R.db_pol[l] | (uintptr_t)R.db_np[l]) & 15) == 0);
     if (L.Cout % 4 == 0 && al)
-        wb_reduce_body<4>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk);
+        wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk);
+    else if (L.Cout % 4 == 0)       // (the plan sized this layer's workgroups for 4 outputs per thread)
+        wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk);
     else
-        wb_reduce_body<1>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk);
+        wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -718,7 +742,7 @@ static int wb_build(const dlwpcs_wgrad_item *items, int n, int n_workers, WbPlan
                 }
         const int nout = L.KS * L.KS * L.cin_logical * L.Cout + (want_bias ? L.Cout : 0);
         P.H.red_first[l] = red_blocks;
-        red_blocks += (uint32_t)ceil_div(L.Cout % 4 == 0 ? nout / 4 : nout, 256);
+        red_blocks += (uint32_t)ceil_div(L.Cout % 4 == 0 ? nout / 4 : nout, WB_RED_OUT);
     }
     for (int l = n; l <= WB_MAX_LAYERS; ++l) P.H.red_first[l] = red_blocks;
     // Equal-cost chains: walk the groups in order and cut at worker boundaries; every piece of a group costs its items plus a

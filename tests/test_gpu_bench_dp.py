@@ -30,3 +30,52 @@ def test_bench_two_ranks_share_one_gpu():
     ex = r['exchange']
     assert ex['rccl_ranks'] == 2 and ex['backend'] == 'gloo' and ex['allreduce_us'] > 0 and ex['bytes'] > 0
     assert len(r['timing']['block_ms_per_step']) == 3 and r['ms_per_step'] > 0
+
+
+def test_bench_plain_invocation_spawns_its_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT a torchrun wrapper (how the driver calls it): bench.py starts the ranks itself"""
+    env = dict(os.environ, DLWPCS_BENCH_BACKEND='gloo', DLWPCS_BENCH_SHARE_GPU='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '3', '--batch', '4',
+           '--face', '16', '--base', '8', '--channels', '6', '--min-block-s', '0.05', '--blocks', '3', '--no-roofline']
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['config']['global_batch'] == 8 and r['value'] > 0
+    assert r['exchange']['rccl_ranks'] == 2
+    assert r['device_self_check']['device_busy_fraction'] > 0
+
+
+def test_rccl_executes_on_one_gpu():
+    """RCCL itself (backend 'nccl'), world size 1: the flat gradient buffer goes through parallel.allreduce_gradients and
+    the broadcast of the initial parameters -- the collectives of the data-parallel step -- in a process of their own."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%r, 'dlwp-cs_amd'))
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+import torch, torch.distributed as dist
+from DLWP import parallel
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+assert dist.get_backend() == 'nccl'
+g = torch.arange(673628, dtype=torch.float32, device='cuda')
+ref = g.clone()
+scale = parallel.allreduce_gradients(g)
+parallel.broadcast_parameters(g)
+torch.cuda.synchronize()
+assert scale == 1.0 and torch.equal(g, ref)
+# the captured form of the step: all-reduce between two graph replays
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    for _ in range(3):
+        dist.all_reduce(g)
+torch.cuda.synchronize()
+assert torch.equal(g, ref)
+dist.destroy_process_group()
+print('RCCL_OK')
+''' % ROOT
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'RCCL_OK' in out.stdout, (out.stdout[-500:], out.stderr[-2000:])

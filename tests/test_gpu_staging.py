@@ -134,3 +134,48 @@ def test_staged_evaluate_equals_plain_evaluate():
         finally:
             os.environ.pop('DLWPCS_HOST_STAGING', None)
     assert res[0] == res[1]
+
+
+def test_device_generator_in_another_dtype_trains_like_the_host_path():
+    """device-resident fp32 batches fed to a bf16 model (the reference's order: generator first, mixed precision
+    switched on at compile time) must be cast on the COMPUTE stream behind their producer, not on the copy stream: the
+    result has to equal the host-fed run bit for bit, also when the batch tensors are produced right before every step."""
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    dev = _dev()
+    backend.set_device('cuda:0')
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((12, 6, 8, 8, 4)).astype(np.float32)
+    y = rng.standard_normal((12, 6, 8, 8, 4)).astype(np.float32)
+
+    class DeviceBatches(object):
+        """Sequence-like: every item is assembled on the device by kernels of the compute stream (fp32)"""
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            xb = torch.from_numpy(x[4 * i:4 * i + 4]).to(dev)
+            yb = torch.from_numpy(y[4 * i:4 * i + 4]).to(dev)
+            for _ in range(20):                       # keep the producer busy on the compute stream
+                xb = xb * 1.0
+            return [xb], [yb]
+
+    res = []
+    for feed in ('host', 'device'):
+        backend.set_compute_dtype('bfloat16')
+        try:
+            np.random.seed(7)
+            m = build_cs_model((6, 8, 8, 4), 4, 'unet2', base_filter_number=4)
+        finally:
+            backend.set_compute_dtype('float32')
+        m.compile(optimizer='adam', loss='mse', metrics=['mae'])
+        if feed == 'host':
+            m.fit(x, y, batch_size=4, epochs=2, shuffle=False, verbose=0)
+        else:
+            m.fit(DeviceBatches(), epochs=2, verbose=0)
+        torch.cuda.synchronize()
+        res.append(_flat(m))
+        p = m.predict(x[:4] if feed == 'host' else torch.from_numpy(x[:4]).to(dev))
+        res.append(np.asarray(p))
+    assert np.array_equal(res[0], res[2])
+    assert np.array_equal(res[1], res[3])
