@@ -61,6 +61,7 @@ class Model(object):
         self.defer_wgrad_reduce = os.environ.get('DLWPCS_DEFER_REDUCE', '1') == '1'
         # one persistent launch for the weight gradients of all layers of a step (ops.wgrad_batch)
         self.batch_wgrad = os.environ.get('DLWPCS_WGRAD_BATCH', '1') == '1'
+        self.check_finite = os.environ.get('DLWPCS_CHECK_FINITE', '0') == '1'
         self._stager = None                 # pinned-memory / copy-stream feed of fit() on host arrays (keras/staging.py)
         # training step: output layer + loss + loss gradient + the layer's data gradient as one launch (ops.head_mse)
         self.fuse_head_loss = os.environ.get('DLWPCS_FUSE_HEAD', '1') == '1'
@@ -270,6 +271,7 @@ class Model(object):
         prediction."""
         from ..custom import CubeSphereConv2D
         values = {t.uid: v for t, v in zip(self.inputs, inputs)}
+        self._fused_outputs = set()         # uids whose entry of the returned list is the (2,) stats tensor of ops.head_mse
         pm = self._premask if self._premask_on() else {}
         for i, st in enumerate(self._plan):
             if st[0] == 'fused_conv':
@@ -295,6 +297,7 @@ class Model(object):
                     tgt, wgt = fuse_targets[out_uid]
                     values[out_uid] = ops.head_mse(args[0], tgt, lay.equatorial_kernel, lay.polar_kernel, lay.equatorial_bias,
                                                    lay.polar_bias, wgt, lay.flip_north_pole, premask=head_pm)
+                    self._fused_outputs.add(out_uid)
                     continue
                 if head_pm is not None:
                     # pointwise / 'valid' convolution on a pre-masked source: the layer's own call with the mask handed down
@@ -375,6 +378,13 @@ class Model(object):
     def compile(self, optimizer='adam', loss=None, metrics=None, loss_weights=None, **kwargs):
         self.optimizer = optimizers.get(optimizer)
         mp_dtype = getattr(self.optimizer, '_mixed_precision', None)
+        if mp_dtype is not None and mp_dtype != backend.compute_dtype() and mp_dtype != self.compute_dtype:
+            # the global policy was changed again after the optimizer was tagged by enable_mixed_precision_graph_rewrite():
+            # the tag still wins (the switch travels with the optimizer, like TF's rewrite), but say so
+            import warnings
+            warnings.warn('compile(): the optimizer was returned by enable_mixed_precision_graph_rewrite(); the model is put '
+                          'into the %s mode although the global policy is %s now (pass a fresh optimizer to avoid this)'
+                          % (mp_dtype, backend.compute_dtype()))
         if mp_dtype is not None and mp_dtype != self.compute_dtype:
             # optimizer came out of enable_mixed_precision_graph_rewrite() AFTER this model was constructed
             self.compute_dtype = mp_dtype
@@ -449,8 +459,9 @@ class Model(object):
         finally:
             if fuse is not None:
                 ops.DIRECT_PARAM_GRADS = False
-        stats = [o if (o.dim() == 1 and o.numel() == 2 and fuse is not None) else ops.mse_mae(o, t, w)
-                 for o, t, w in zip(outs, targets, self.loss_weights)]
+        fused = getattr(self, '_fused_outputs', set()) if fuse is not None else set()
+        stats = [o if out.uid in fused else ops.mse_mae(o, t, w)
+                 for out, o, t, w in zip(self.outputs, outs, targets, self.loss_weights)]
         if train:
             dev = stats[0].device
             ones = [ops.unit_seed(dev) for _ in stats]
@@ -695,6 +706,13 @@ class Model(object):
                     if count == 0 and epoch == initial_epoch:
                         self._check_shapes(dx, self.inputs, 'input')
                         self._check_shapes(dt, self.outputs, 'target')
+                    if self.check_finite:
+                        # The fused activation evaluates ReLU(alpha, max) as min(max(x, alpha x), max): a NaN pre-activation
+                        # comes out as `max`, so a NaN in the data does not necessarily reach the loss.  DLWPCS_CHECK_FINITE=1
+                        # checks every batch on the device (one reduction + a host sync per step).
+                        for a in list(dx) + list(dt):
+                            if not bool(torch.isfinite(a).all()):
+                                raise FloatingPointError('non-finite values in batch %d of epoch %d' % (bi, epoch))
                     stats = self.train_on_device_batch(dx, dt)
                     sums += stats
                     count += 1

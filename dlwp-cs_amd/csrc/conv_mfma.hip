@@ -518,7 +518,8 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     auto quad = [&](auto fast_tag, const f32x16 &a, int jq) {
         float4 v4 = make_float4(a[4 * jq], a[4 * jq + 1], a[4 * jq + 2], a[4 * jq + 3]);
         if constexpr (MODE == MODE_ZERO) return v4;         // data gradient: never an activation (2.5 instructions per value)
-        if constexpr (decltype(fast_tag)::value) {
+        if constexpr (decltype(fast_tag)::value == 2) return v4;    // no activation: identity (a NaN stays a NaN)
+        if constexpr (decltype(fast_tag)::value == 1) {
             // v_max_f32 / v_min_f32 as (pure) asm: fmaxf / fminf -- and v_med3_f32 with an infinite operand, which LLVM folds
             // back into them -- put a canonicalising `v_max x, x` in front of every value that comes out of an accumulator
             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -615,12 +616,15 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         TL_MARK();
         const rsrc_t d_out = out_of(gq);
         const rsrc_t d_0 = DIRECT ? d0_of(gq) : d_out, d_1 = DIRECT ? d1_of(gq) : d_out;
-        if (fast_act) {
+        if (P.act != DLWPCS_ACT_LEAKY_CLIP) {
 #pragma unroll
-            for (int i = 0; i < NSLICE; ++i) epi_slice(std::true_type{}, i, gq, d_out, d_0, d_1, A);
+            for (int i = 0; i < NSLICE; ++i) epi_slice(std::integral_constant<int, 2>{}, i, gq, d_out, d_0, d_1, A);
+        } else if (fast_act) {
+#pragma unroll
+            for (int i = 0; i < NSLICE; ++i) epi_slice(std::integral_constant<int, 1>{}, i, gq, d_out, d_0, d_1, A);
         } else {
 #pragma unroll
-            for (int i = 0; i < NSLICE; ++i) epi_slice(std::false_type{}, i, gq, d_out, d_0, d_1, A);
+            for (int i = 0; i < NSLICE; ++i) epi_slice(std::integral_constant<int, 0>{}, i, gq, d_out, d_0, d_1, A);
         }
         TL_MARK();
     };
@@ -639,7 +643,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 #pragma unroll
                 for (int jq = 0; jq < 4; ++jq) {
                     const int co = cot + 8 * jq + 4 * half;
-                    const float4 v4 = quad(std::false_type{}, acc[mt][nt], jq);
+                    const float4 v4 = quad(std::integral_constant<int, 0>{}, acc[mt][nt], jq);
                     if (m >= gq.npix) continue;
                     if (wide) {
                         if (co < P.Cout) {
@@ -1014,7 +1018,15 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
                 dv[i] = to_f4(dvr[i]);
-                if (MASK) { yv[i] = to_f4(yvr[i]); vmask(dv[i], yv[i], P.alpha, P.vmax); }
+                if (MASK) {
+                    yv[i] = to_f4(yvr[i]); vmask(dv[i], yv[i], P.alpha, P.vmax);
+                    if constexpr (sizeof(T) == 2) {
+                        // bf16 mode: dz is a bf16 tensor everywhere else (hand-over, pre-masked gradients, the bf16 kernels):
+                        // round the product here too, so that every path multiplies the same numbers
+                        dv[i].x = bf2f(f2bf(dv[i].x)); dv[i].y = bf2f(f2bf(dv[i].y));
+                        dv[i].z = bf2f(f2bf(dv[i].z)); dv[i].w = bf2f(f2bf(dv[i].w));
+                    }
+                }
                 dv[i] = vsel(dok[i], dv[i]);
             }
             // DLWPCS_CONV_REUSE_DZ (fp32 tensors, C_out % 4 == 0): the workers of ci tile 0 see every dZ element exactly

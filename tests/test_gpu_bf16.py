@@ -11,8 +11,8 @@ Tolerances (written out, per tensor kind; eps = 2^-8 = one bf16 ulp at 1.0):
   * bf16-stored results of a contraction (y):  max|d| <= eps * max|ref|  (rounding to nearest = eps/2 of the element,
     plus a possible 1-ulp flip where fp32 and fp64 accumulation straddle a rounding boundary); dsrc: 3 eps (5 eps under
     the fused 2x2 upsample adjoint), because the halo / upsample adjoint sums several bf16-stored terms;
-  * fp32-stored results of a contraction over bf16 operands (dW, db): 5e-3 relative to max|ref| (dz = dy * act'(y) is
-    itself rounded to bf16 before it enters the bf16 matrix product; 2e-5 when the fp32 matrix path is taken).
+  * fp32-stored results of a contraction over bf16 operands (dW, db): 2e-5 relative to max|ref| -- dz = dy * act'(y) is rounded
+    to bf16 before it enters the matrix product, and the oracle is fed exactly that dz, so only the fp32 summation order differs.
 """
 import numpy as np
 import pytest
@@ -255,8 +255,12 @@ def test_conv_forward_and_backward_bf16(case):
     for n in ('eq', 'pol', 'np'):
         if dw[n] is not None:
             assert dw[n].grad.dtype == torch.float32
-            assert rel_err(host(dw[n].grad), tw[n].grad.numpy()) < 5e-3, 'dW ' + n
-            assert rel_err(host(db[n].grad), tb[n].grad.numpy()) < 5e-3, 'db ' + n
+            # the oracle multiplies exactly the bf16 x and dz the device does; partial sums are fp32: only the fp32
+            # summation order is left (measured <= 6e-6 on these cases; the bias sum of few channels gets its natural floor)
+            assert rel_err(host(dw[n].grad), tw[n].grad.numpy()) < 2e-5, 'dW ' + n
+            bref = tb[n].grad.numpy()
+            den = max(np.abs(bref).max(), np.sqrt(B * 6 * No * No))
+            assert np.abs(host(db[n].grad) - bref).max() / den < 2e-5, 'db ' + n
 
 
 @pytest.mark.parametrize('C0,Cout', [(14, 32), (32, 32), (5, 8)])

@@ -234,11 +234,12 @@ def test_cfg5_rollout_full_size_bf16():
     model, convs = _build_unet2(96, 26, 26, 32, 'bfloat16')
     dlwp = DLWPFunctional(is_convolutional=True, time_dim=2)
     dlwp.build_model(model, loss='mse', optimizer='adam')
-    series = dlwp.predict_timeseries(x, 6, keep_time_dim=True)           # 3 model applications
-    assert series.shape[0] == 3 and np.isfinite(series).all()
-    series = series.reshape((3, B_FULL, 6, 96, 96, 26))
+    # the full configuration: 40 forecast steps = 20 model applications at batch 32 (26 channels = 13 variables x 2 steps)
+    series = dlwp.predict_timeseries(x, 40, keep_time_dim=True)
+    assert series.shape[0] == 20 and np.isfinite(series).all()
+    series = series.reshape((20, B_FULL, 6, 96, 96, 26))
     state = x
-    for s in range(3):
+    for s in range(20):
         state = model.predict(state, batch_size=B_FULL)
         assert np.array_equal(series[s], state), s
     # oracle on one sample, first application (bf16 activations: 3e-2 of the output range, as in test_gpu_bf16)

@@ -45,7 +45,11 @@ def _run(case, bf16):
     rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
     rnd = (lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()) if bf16 else (lambda a: a)
     n0 = N // 2 if up0 else N
-    x0 = rnd(rng.standard_normal((B, 6, n0, n0, C0)) * 3.0)
+    x0 = rng.standard_normal((B, 6, n0, n0, C0)) * 3.0
+    # every case also has inputs beyond +-100 (pre-activations far above max_value and alpha * x above it for the negative
+    # side would be a different kernel bug each): the activation's clip region and its zero-gradient branch are always hit
+    x0.reshape(-1)[::97] *= 60.0
+    x0 = rnd(x0)
     x1 = rnd(rng.standard_normal((B, 6, N, N, C1))) if C1 else None
     w = {n: (rng.standard_normal((k, k, C0 + C1, Cout)) / np.sqrt(k * k * (C0 + C1))).astype(np.float32) for n in ('eq', 'pol', 'np')}
     b = {n: (rng.standard_normal((Cout,)) * 0.1).astype(np.float32) for n in ('eq', 'pol', 'np')}
@@ -91,7 +95,9 @@ def _run(case, bf16):
         yref.backward(torch.tensor(gy, dtype=torch.float64))
     y.backward(torch.tensor(gy, dtype=torch.float32).to(adt).to(dev))
     tol_x = ((5 if up0 else 3) * EPS) if bf16 else 1e-5
-    tol_w = 5e-3 if bf16 else 1e-5
+    # bf16: the oracle is fed exactly the bf16 x and dz the device multiplies, partial sums are fp32 -> what is left is the
+    # fp32 summation order (2e-5 of max|ref|, like the fp32 mode's 1e-5 plus the rounding of the bf16-rounded kernels)
+    tol_w = 2e-5 if bf16 else 1e-5
     assert err(d0.grad, t0.grad) <= tol_x
     if C1:
         assert err(d1.grad, t1.grad) <= tol_x

@@ -391,3 +391,54 @@ def test_saved_model_keeps_its_compute_dtype(tmp_path):
     model.save(path)
     assert load_model(path, compile=False).compute_dtype == 'bfloat16'
     assert clone_model(model).compute_dtype == 'bfloat16'
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N2: forecast metadata on the cubed sphere (reference DLWP/verify.py:291-325), pinned to the reference function (g11)
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _MetaDs(object):
+    """what the function reads of an xarray.Dataset: `.dims` {name: size}, `ds[name]` -> coordinate values"""
+    def __init__(self, coords):
+        self._c = dict(coords)
+        self.dims = {k: len(v) for k, v in self._c.items()}
+
+    def __getitem__(self, k):
+        return self._c[k]
+
+
+def _verify_meta(level):
+    c = {'sample': np.arange('2001-01-01T00', '2001-01-01T18', 6, dtype='datetime64[h]').astype('datetime64[ns]'),
+         'face': np.arange(6), 'height': np.arange(2), 'width': np.arange(2)}
+    if level:
+        c['variable'] = np.array(['z', 't', 'u'])
+        c['level'] = np.array([500.0, 850.0])
+    else:
+        c['varlev'] = np.array(['z/500', 't/850', 'u/500', 'tcwv/0', 'z/1000'])
+    return _MetaDs(c)
+
+
+def test_add_metadata_to_forecast_cs_matches_reference(golden_dir):
+    from DLWP.verify import add_metadata_to_forecast_cs
+    g = np.load(os.path.join(golden_dir, 'g11_verify.npz'))
+    f_hour = g['f_hour']
+    assert len(g['cases']) == 8
+    for key in g['cases']:
+        key = str(key)
+        level, cl, td = int(key[3]), int(key[7]), int(key[11])
+        r = add_metadata_to_forecast_cs(g[key + '_in'], f_hour, _verify_meta(level), f_hour_timedelta_type=bool(td),
+                                        channels_last=bool(cl))
+        assert tuple(r.dims) == tuple(str(d) for d in g[key + '_dims'])
+        assert r.values.shape == g[key + '_values'].shape and np.array_equal(r.values, g[key + '_values'])
+        for d in r.dims:
+            c = np.asarray(r.coords[d])
+            if key + '_coord_%s_dtype' % d in g:
+                assert str(c.dtype) == str(g[key + '_coord_%s_dtype' % d])
+                c = c.astype(np.int64)
+            assert np.array_equal(c, g[key + '_coord_' + d]), (key, d)
+        assert r.name == 'forecast'
+        # the record slices like the reference's DataArray
+        one = r.isel(f_hour=1, time=0)
+        assert one.dims == r.dims[2:] and np.array_equal(one.values, g[key + '_values'][1, 0])
+    with pytest.raises(ValueError):
+        add_metadata_to_forecast_cs(g['lev0_cl1_td0_in'], f_hour[:-1], _verify_meta(0), channels_last=True)
