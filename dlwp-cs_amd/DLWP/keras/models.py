@@ -62,6 +62,8 @@ class Model(object):
         # one persistent launch for the weight gradients of all layers of a step (ops.wgrad_batch)
         self.batch_wgrad = os.environ.get('DLWPCS_WGRAD_BATCH', '1') == '1'
         self.check_finite = os.environ.get('DLWPCS_CHECK_FINITE', '0') == '1'
+        # the optimizer inside the reduction of the batched weight gradients (dlwpcs_wgrad_batch_adam; world size 1)
+        self.fuse_adam = os.environ.get('DLWPCS_FUSE_ADAM', '1') == '1'
         self._stager = None                 # pinned-memory / copy-stream feed of fit() on host arrays (keras/staging.py)
         # training step: output layer + loss + loss gradient + the layer's data gradient as one launch (ops.head_mse)
         self.fuse_head_loss = os.environ.get('DLWPCS_FUSE_HEAD', '1') == '1'
@@ -446,7 +448,10 @@ class Model(object):
             vals += [float(s[0, 1])]
         return vals
 
-    def _loss_and_backward(self, inputs, targets, train=True):
+    def _loss_and_backward(self, inputs, targets, train=True, fuse_update=None):
+        """fuse_update = grad_scale | None: with a value, the optimizer step may ride in the reduction of the batched weight
+        gradients (ops.flush_wgrad_batch); self._update_done says whether it did."""
+        self._update_done = False
         if len(targets) != len(self.outputs):
             raise ValueError('Error when checking model target: expected %d target arrays, got %d'
                              % (len(self.outputs), len(targets)))
@@ -475,7 +480,16 @@ class Model(object):
             ops.drop_wgrad_batch()
             try:
                 torch.autograd.backward(stats, ones)
-                ops.flush_wgrad_batch()
+                adam = None
+                if (fuse_update is not None and self.fuse_adam and not ops._deferred and self.optimizer is not None
+                        and self._world == 1):
+                    opt = self.optimizer
+                    opt._ensure_state(self._flat_params)
+                    if not torch.cuda.is_current_stream_capturing():
+                        opt.sync_hyper(fuse_update)
+                    adam = (self._flat_params, self._flat_grads, opt._m, opt._v, opt._step, opt._hyper,
+                            sum(w.numel() for w in self.weights))
+                self._update_done = ops.flush_wgrad_batch(adam)
                 ops.flush_deferred_reduce(dev)
             finally:
                 ops.DIRECT_PARAM_GRADS = False
@@ -496,6 +510,7 @@ class Model(object):
     def _train_step_eager(self, inputs, targets):
         self._flat_grads.zero_()
         self._grads_clean = False                               # the gradients stay readable after an eager step
+        # (an eager step keeps its gradients readable: the optimizer is not fused into the reduction here)
         stats = self._loss_and_backward(inputs, targets, True)
         self._apply_gradients()
         return stats
@@ -556,8 +571,11 @@ class Model(object):
         mode = 'thread_local' if self._world > 1 else 'global'
         try:
             with torch.cuda.graph(g1, capture_error_mode=mode):
-                stats = self._loss_and_backward(static_in, static_tg, True)
-                if self._world == 1:    # no exchange step: the update rides in the same graph (no inter-graph gap)
+                stats = self._loss_and_backward(static_in, static_tg, True,
+                                                fuse_update=grad_scale if self._world == 1 else None)
+                if self._world == 1 and not self._update_done:
+                    # no exchange step: the update rides in the same graph (no inter-graph gap); normally INSIDE the reduction
+                    # of the batched weight gradients, as a launch of its own when those do not cover every parameter
                     self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
             if self._world == 1:
                 g2 = None

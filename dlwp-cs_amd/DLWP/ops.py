@@ -126,11 +126,33 @@ def drop_wgrad_batch():
     del _wb_pending[:]
 
 
-def flush_wgrad_batch():
-    if _wb_pending:
-        pending = list(_wb_pending)
-        del _wb_pending[:]
-        wgrad_batch(pending)
+def flush_wgrad_batch(adam=None):
+    """Run the queued layers.  adam = (flat params, flat grads, m, v, state {t-1, ticket}, hyper {lr, b1, b2, eps, scale},
+    number of parameter elements) asks for the optimizer fused into the reduction (dlwpcs_wgrad_batch_adam): done -- and True
+    returned -- when the queued layers cover every parameter exactly once; otherwise the gradients are left in the flat buffer
+    as usual and the caller runs its optimizer launch."""
+    if not _wb_pending:
+        return False
+    pending = list(_wb_pending)
+    del _wb_pending[:]
+    if adam is not None and len(pending) <= nat.WGRAD_BATCH_MAX:
+        p, g, m, v, state, hyper, n_elems = adam
+        seen, covered = set(), 0
+        for ent in pending:
+            for t in ent[5]:
+                if t is not None:
+                    if t.data_ptr() in seen:
+                        covered = -1
+                        break
+                    seen.add(t.data_ptr())
+                    covered += t.numel()
+            if covered < 0:
+                break
+        if covered == n_elems:
+            wgrad_batch(pending, adam=(p, g, m, v, state, hyper))
+            return True
+    wgrad_batch(pending)
+    return False
 
 
 def _wb_items(entries):
@@ -147,7 +169,7 @@ def _wb_items(entries):
     return arr, tuple(key)
 
 
-def wgrad_batch(entries):
+def wgrad_batch(entries, adam=None):
     """entries: [(ConvDesc, src0, src1 | None, dz, halo table | None, (dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np)[, y])] with
     fp32 gradient tensors that are ACCUMULATED into (None where the layer has no such parameter).  dz is the gradient
     w.r.t. the layer's pre-activation output (already masked) -- or, with the optional 7th element y (the layer's saved
@@ -174,6 +196,12 @@ def wgrad_batch(entries):
             _wb_plans[key] = hit
         host, plan_dev, ws_bytes = hit
         ws = _workspace(ws_bytes, dev, 'wgrad_batch')
+        if adam is not None:
+            p, g, m, v, state, hyper = adam
+            check(lib().dlwpcs_wgrad_batch_adam(arr, len(chunk), host, ptr(plan_dev), ptr(ws), ws.numel(), ptr(p), ptr(g), ptr(m),
+                                                ptr(v), g.numel(), ptr(state), ptr(hyper), stream_ptr()),
+                  'dlwpcs_wgrad_batch_adam')
+            continue
         check(lib().dlwpcs_wgrad_batch(arr, len(chunk), host, ptr(plan_dev), ptr(ws), ws.numel(), stream_ptr()),
               'dlwpcs_wgrad_batch')
 

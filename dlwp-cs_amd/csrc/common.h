@@ -83,6 +83,17 @@ __device__ __forceinline__ float act_leaky_clip_grad_from_y(float y, float alpha
     return y < 0.f ? alpha : ((y > 0.f && y < vmax) ? 1.f : 0.f);
 }
 
+// TF2.1-keras Adam, one element; contraction off so that every kernel built on it produces the same bits
+__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float lr_t, float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p = p - lr_t * m / (sqrtf(v) + eps);
+}
+__device__ __forceinline__ float adam_lr_t(float lr, float b1, float b2, float t) {
+    return lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+}
+
 // ---- bf16 storage (DLWPCS_BF16): raw 16-bit patterns in memory, fp32 in registers ------------------------------
 typedef unsigned short bf16_t;
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }

@@ -674,19 +674,12 @@ __global__ void __launch_bounds__(256) mse_stage2_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------------------------------
 // TF2.1-keras Adam on flat buffers
 // ---------------------------------------------------------------------------------------------------------------
-// one element; contraction off so that every kernel built on it produces the same bits
-__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float lr_t, float b1, float b2, float eps) {
-#pragma clang fp contract(off)
-    m = b1 * m + (1.f - b1) * g;
-    v = b2 * v + (1.f - b2) * g * g;
-    p = p - lr_t * m / (sqrtf(v) + eps);
-}
 __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, size_t n,
                                                    const int32_t *__restrict__ step, float lr, float b1, float b2,
                                                    float eps, float gscale) {
     const float t = (float)(*step + 1);
-    const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    const float lr_t = adam_lr_t(lr, b1, b2, t);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float pi = p[i], mi = m[i], vi = v[i];
         adam_elem(pi, g[i] * gscale, mi, vi, lr_t, b1, b2, eps);
@@ -707,7 +700,7 @@ __global__ void __launch_bounds__(256) adam_fused_kernel(float *__restrict__ p, 
     if (hyper != nullptr) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; gscale = hyper[4]; }
     const int32_t t0 = *(volatile int32_t *)state;
     const float t = (float)(t0 + 1);
-    const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    const float lr_t = adam_lr_t(lr, b1, b2, t);
     const size_t nv = n / VEC;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
         VT4 gi = reinterpret_cast<const VT4 *>(g)[i], mi = reinterpret_cast<const VT4 *>(m)[i];

@@ -74,6 +74,13 @@ struct WbPtrs {
     const void *src0[WB_MAX_LAYERS], *src1[WB_MAX_LAYERS], *dz[WB_MAX_LAYERS], *y[WB_MAX_LAYERS];
     const int32_t *table[WB_MAX_LAYERS];
 };
+// optimizer fused into the reduction (dlwpcs_wgrad_batch_adam): every reduced gradient element is consumed on the spot
+struct WbAdam {
+    float *p, *g, *m, *v;           // flat buffers; the items' dw_* / db_* point INTO g, the other three share its offsets
+    const int32_t *state;           // {t, ticket}: the weight-gradient launch before this one has already incremented t
+    const float *hyper;             // {lr, beta1, beta2, eps, grad_scale}
+    int32_t on, pad;
+};
 struct WbRedPtrs {
     float *dw_eq[WB_MAX_LAYERS], *dw_pol[WB_MAX_LAYERS], *dw_np[WB_MAX_LAYERS];
     float *db_eq[WB_MAX_LAYERS], *db_pol[WB_MAX_LAYERS], *db_np[WB_MAX_LAYERS];
@@ -457,7 +464,7 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
 }
 
 __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict__ plan, const WbPtrs ptrs, float *__restrict__ ws,
-                                                          long long *dbg) {
+                                                          long long *dbg, int32_t *adam_state) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WbHeader *H = reinterpret_cast<const WbHeader *>(plan);
     const WbLayer *layers = reinterpret_cast<const WbLayer *>(plan + H->off_layers);
@@ -491,6 +498,11 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
             default:          wb_segment<1, 8, 4, 1, 1, 2>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
         }
     }
+    // optimizer fused into the reduction that follows: the step counter {t, ticket} moves on here (last worker to finish)
+    if (adam_state != nullptr && threadIdx.x == 0) {
+        const int done = atomicAdd(adam_state + 1, 1);
+        if (done == (int)gridDim.x - 1) { adam_state[1] = 0; adam_state[0] += 1; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -503,10 +515,41 @@ constexpr int WB_RED_OUT = 64, WB_RED_PH = 4;
 template <int VEC, bool ALIGNED>
 __device__ __forceinline__ void wb_reduce_body(const WbLayer &L, const WbGroup *__restrict__ groups, const float *__restrict__ ws,
                                                float *dw_eq, float *dw_pol, float *dw_np, float *db_eq, float *db_pol,
-                                               float *db_np, int block) {
+                                               float *db_np, int block, const WbAdam &A) {
     typedef float VT __attribute__((ext_vector_type(VEC)));
-    // destination update: one 16-B access when the caller's gradient tensors are 16-B aligned, else element by element
-    auto accum = [](float *dst, VT v) {
+    float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gscale = 1.f;
+    if (A.on) {
+        b1 = A.hyper[1]; b2 = A.hyper[2]; eps = A.hyper[3]; gscale = A.hyper[4];
+        lr_t = adam_lr_t(A.hyper[0], b1, b2, (float)A.state[0]);
+    }
+    // destination update: one 16-B access when the caller's gradient tensors are 16-B aligned, else element by element;
+    // with the optimizer fused in, the finished gradient (what the buffer held + the reduced sum) is consumed here: Adam
+    // element update (the arithmetic of adam_fused_kernel, same bits), gradient cleared for the next step
+    auto accum = [&](float *dst, VT v) {
+        if (A.on) {
+            const size_t i = (size_t)(dst - A.g);
+            if constexpr (ALIGNED || VEC == 1) {            // (the four flat buffers share their 16-B alignment)
+                VT gv = *reinterpret_cast<VT *>(dst), pv = *reinterpret_cast<VT *>(A.p + i);
+                VT mv = *reinterpret_cast<VT *>(A.m + i), vv = *reinterpret_cast<VT *>(A.v + i);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float pk = pv[k], mk = mv[k], vk = vv[k];
+                    adam_elem(pk, (gv[k] + v[k]) * gscale, mk, vk, lr_t, b1, b2, eps);
+                    pv[k] = pk; mv[k] = mk; vv[k] = vk;
+                }
+                *reinterpret_cast<VT *>(A.p + i) = pv; *reinterpret_cast<VT *>(A.m + i) = mv; *reinterpret_cast<VT *>(A.v + i) = vv;
+                *reinterpret_cast<VT *>(dst) = (VT)0.f;
+                return;
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float pk = A.p[i + k], mk = A.m[i + k], vk = A.v[i + k];
+                adam_elem(pk, (dst[k] + v[k]) * gscale, mk, vk, lr_t, b1, b2, eps);
+                A.p[i + k] = pk; A.m[i + k] = mk; A.v[i + k] = vk;
+                dst[k] = 0.f;
+            }
+            return;
+        }
         if constexpr (ALIGNED || VEC == 1) { VT *q = reinterpret_cast<VT *>(dst); *q = *q + v; }
         else {
 #pragma unroll
@@ -562,7 +605,8 @@ __device__ __forceinline__ void wb_reduce_body(const WbLayer &L, const WbGroup *
     }
 }
 
-__global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__ plan, const WbRedPtrs R, const float *__restrict__ ws) {
+__global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__ plan, const WbRedPtrs R, const float *__restrict__ ws,
+                                                        const WbAdam A) {
     const WbHeader *H = reinterpret_cast<const WbHeader *>(plan);
     const WbLayer *layers = reinterpret_cast<const WbLayer *>(plan + H->off_layers);
     const WbGroup *groups = reinterpret_cast<const WbGroup *>(plan + H->off_groups);
@@ -571,16 +615,16 @@ __global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__
 #pragma unroll
     for (int k = 1; k < WB_MAX_LAYERS; ++k) l += (k < (int)H->n_layers && b >= R.first[k]) ? 1 : 0;
     if (!((R.live >> l) & 1u)) return;
-    const WbLayer L = load_uniform(layers[l]);
+    const WbLayer L = layers[l];            // (block-uniform index: scalar loads)
     const int blk = (int)(b - R.first[l]);
     const bool al = ((((uintptr_t)R.dw_eq[l] | (uintptr_t)R.dw_pol[l] | (uintptr_t)R.dw_np[l] | (uintptr_t)R.db_eq[l] |
                        (uintptr_t)R.db_pol[l] | (uintptr_t)R.db_np[l]) & 15) == 0);
     if (L.Cout % 4 == 0 && al)
-        wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk);
+        wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A);
     else if (L.Cout % 4 == 0)       // (the plan sized this layer's workgroups for 4 outputs per thread)
-        wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk);
+        wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A);
     else
-        wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk);
+        wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -869,8 +913,36 @@ extern "C" int dlwpcs_wgrad_batch_plan(const dlwpcs_wgrad_item *items, int n_ite
     return DLWPCS_OK;
 }
 
+static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                            void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream);
+
 extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                   void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
+    WbAdam none{};
+    return wgrad_batch_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, none, nullptr, stream);
+}
+
+extern "C" int dlwpcs_wgrad_batch_adam(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                                       void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
+                                       int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream) {
+    if (!items || !p || !g || !m || !v || !state_dev || !hyper_dev) return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: null pointer");
+    // every destination must lie inside g, no destination may be named twice (a layer applied twice takes the unfused path)
+    for (int l = 0; l < n_items; ++l) {
+        const void *ds[6] = {items[l].dw_eq, items[l].dw_pol, items[l].dw_np, items[l].db_eq, items[l].db_pol, items[l].db_np};
+        for (int k = 0; k < 6; ++k)
+            if (ds[k] && ((const float *)ds[k] < g || (const float *)ds[k] >= g + n))
+                return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: item %d: gradient tensor outside the flat gradient buffer", l);
+        for (int k = 0; k < l; ++k)
+            if (items[k].dw_eq == items[l].dw_eq)
+                return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch_adam: items %d and %d share their gradients (use dlwpcs_wgrad_batch + dlwpcs_adam_step_dev)", k, l);
+    }
+    WbAdam A{};
+    A.p = p; A.g = g; A.m = m; A.v = v; A.state = state_dev; A.hyper = hyper_dev; A.on = 1;
+    return wgrad_batch_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, A, state_dev, stream);
+}
+
+static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                            void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream) {
     if (!items || !plan_host || !plan_dev || !workspace) return fail(DLWPCS_E_INVALID, "wgrad_batch: null pointer");
     const WbHeader *H = (const WbHeader *)plan_host;
     if (H->magic != WB_MAGIC || (int)H->n_layers != n_items) return fail(DLWPCS_E_INVALID, "wgrad_batch: plan does not match the items");
@@ -913,7 +985,8 @@ extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, c
 #ifdef DLWPCS_WB_TIMING
     { const char *e = getenv("DLWPCS_DBG_PTR"); dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-    hipLaunchKernelGGL(wgrad_batch_kernel, dim3(H->n_workers), dim3(512), lds, s, (const char *)plan_dev, ptrs, (float *)workspace, dbg);
+    hipLaunchKernelGGL(wgrad_batch_kernel, dim3(H->n_workers), dim3(512), lds, s, (const char *)plan_dev, ptrs, (float *)workspace, dbg,
+                       adam_state);
     if (pidx >= 0) prof_end(pidx, s);
     int rc = check_launch("wgrad_batch");
     if (rc) return rc;
@@ -932,7 +1005,7 @@ extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, c
         pidx = -1;
         if (prof_enabled()) pidx = prof_begin("wb_reduce_kernel", 0.0, (double)H->ws_floats * 4.0, s);
         hipLaunchKernelGGL(wb_reduce_kernel, dim3(H->red_first[WB_MAX_LAYERS]), dim3(256), 0, s, (const char *)plan_dev, R,
-                           (const float *)workspace);
+                           (const float *)workspace, adam);
         if (pidx >= 0) prof_end(pidx, s);
         pending &= ~live;
     }

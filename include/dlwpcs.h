@@ -254,6 +254,17 @@ int dlwpcs_wgrad_batch_sizes(const dlwpcs_wgrad_item *items, int n_items, size_t
 int dlwpcs_wgrad_batch_plan(const dlwpcs_wgrad_item *items, int n_items, void *plan_host, size_t plan_bytes);
 int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                        void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
+/* The same with the optimizer fused into the reduction (one launch less, the gradients never travel through HBM again):
+ * every dw_* / db_* must be a view into the flat gradient buffer g (n floats); p, m, v are the flat parameter / Adam-state
+ * buffers with the same offsets.  A reduced element is consumed on the spot: g' = (g[i] + sum of partial sums) *
+ * grad_scale -> the Adam update of dlwpcs_adam_step_dev (same arithmetic, same bits) -> g[i] = 0.  Elements of g that no
+ * item covers are NOT updated (alignment padding; a caller with parameters outside the items uses dlwpcs_wgrad_batch +
+ * dlwpcs_adam_step_dev instead).  state_dev = {t - 1, ticket} as for dlwpcs_adam_step_fused (the weight-gradient launch
+ * increments t, the reduction reads it), hyper_dev = {lr, beta1, beta2, eps, grad_scale}.  Items that share their gradient
+ * tensors (a layer applied twice) are rejected with DLWPCS_E_UNSUPPORTED. */
+int dlwpcs_wgrad_batch_adam(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                            void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
+                            int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
  * Generic (any kernel size / stride / dilation / 'same') per-face convolution on an ALREADY PADDED channels_last

@@ -229,3 +229,40 @@ def test_unet2_training_with_and_without_the_convention(graphs):
     cos = float(np.dot(d_off, d_on) / (np.linalg.norm(d_off) * np.linalg.norm(d_on)))
     assert cos > 0.995, cos
     assert abs(s_on[0, 0] - s_off[0, 0]) <= 2e-3 * abs(s_off[0, 0])
+
+
+def test_optimizer_fused_into_the_reduction_gives_the_same_bits():
+    """dlwpcs_wgrad_batch_adam (hipGraph-replayed steps) against reduction + dlwpcs_adam_step_dev: same element arithmetic"""
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    dev = _dev()
+    backend.set_device('cuda:0')
+    N, C, B = 16, 14, 4
+    rng = np.random.default_rng(1)
+    x = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    t = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
+    w0, out = None, []
+    for fuse in ('0', '1'):
+        os.environ['DLWPCS_FUSE_ADAM'] = fuse
+        try:
+            backend.set_compute_dtype('bfloat16')
+            try:
+                np.random.seed(5)
+                model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=32)
+            finally:
+                backend.set_compute_dtype('float32')
+            model.compile(optimizer='adam', loss='mse', metrics=['mae'])
+            if w0 is None:
+                w0 = model.get_weights()
+            model.set_weights(w0)
+            for _ in range(5):                      # eager warm-up, capture, three replays
+                stats = model.train_on_device_batch([x], [t])
+            torch.cuda.synchronize()
+            assert model._update_done == (fuse == '1')
+            assert model.optimizer.iterations == 5
+            assert float(model._flat_grads.abs().max()) == 0.0
+            out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
+        finally:
+            os.environ.pop('DLWPCS_FUSE_ADAM', None)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
