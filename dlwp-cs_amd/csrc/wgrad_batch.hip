@@ -102,6 +102,31 @@ struct WbRedPtrs {
 #define WB_ACC(slot, a, b) do { } while (0)
 #endif
 
+// Consumer schedule of one K slab: the 2 * TAPS + 2 transpose reads of the NEXT slab interleaved with the TAPS MFMAs of this
+// one (an in-order wave can issue ~5 other instructions in the shadow of a 32x32x16 MFMA; all reads first, then all MFMAs --
+// the schedule of wgrad_bf16_kernel -- measured ~600 cycles per slab of 9 MFMAs, twice the matrix time).
+#ifndef DLWPCS_WB_SCHED
+#define DLWPCS_WB_SCHED 1
+#endif
+template <int N> __device__ __forceinline__ void wb_sched_pairs() {
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // two LDS transpose reads in its shadow
+        wb_sched_pairs<N - 1>();
+    }
+}
+#if DLWPCS_WB_SCHED == 1
+#define WB_SCHED() do {                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      /* the dZ fragment of the next slab */ \
+        wb_sched_pairs<TAPS>();                                                           \
+    } while (0)
+#else
+#define WB_SCHED() do {                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * TAPS + 2, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);                             \
+    } while (0)
+#endif
+
 // a plan record -> scalar registers (the plan is the same for every lane; read through a reference the fields would be
 // re-fetched with vector loads inside the loops, behind vmcnt(0) waits)
 template <typename T> __device__ __forceinline__ T load_uniform(const T &g) {
@@ -398,13 +423,11 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
             frag(si + 1, fa[1], fb[1]);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fa[0][tap], fb[0]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TAPS + 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);
+            WB_SCHED();
             frag(si + 2, fa[0], fb[0]);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fa[1][tap], fb[1]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TAPS + 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);
+            WB_SCHED();
         }
 #ifdef DLWPCS_WB_TIMING
         { const long long tn = __builtin_amdgcn_s_memtime(); WB_ACC(1, tprev, tn); tprev = tn; }
@@ -716,12 +739,12 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
     if (G.lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: LDS tile of %zu bytes exceeds 160 KiB", G.lds);
     // Cost model (cycles per item and CU), fitted to the s_memtime accounting of tools/wb_timing.py on MI355X (eleven layer
     // shapes of the U-Net, +-7 %): when the producers set the period an item costs ~3300 cycles plus its bytes at 23 B/clk
-    // (plus ~45 per 4-B load instruction of a thread); when the consumers do, ~615 cycles per 16-pixel slab of 9 taps (260
+    // (plus ~45 per 4-B load instruction of a thread); when the consumers do, ~530 cycles per 16-pixel slab of 9 taps (260
     // for a 1x1 kernel; the slab count per wave is rounded up to even) plus ~1200.
     static double fix = -1, bpc = -1, slab3 = -1, slab1 = -1, ld4 = -1, cfix = -1;
     if (fix < 0) {
         const char *e = getenv("DLWPCS_WB_COST");
-        fix = 3300.0; bpc = 23.0; slab3 = 615.0; slab1 = 260.0; ld4 = 45.0; cfix = 1200.0;
+        fix = 3300.0; bpc = 23.0; slab3 = 530.0; slab1 = 260.0; ld4 = 45.0; cfix = 1200.0;
         if (e) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &fix, &bpc, &slab3, &slab1, &ld4, &cfix);
     }
     const int nslab = L.pix_cap / 16;
