@@ -25,7 +25,7 @@ import shutil
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 PRE = os.path.join(R, 'profiles', '%s_bench_unet2_b32' % TAG)
 
 
@@ -49,28 +49,50 @@ def summarize(sel, nsteps, title):
     return '\n'.join(out)
 
 
-def main():
-    pdir = os.path.join(R, 'gpurun_out', 'prof_%s' % TAG)
+def step_summaries(pdir, modes):
+    """modes: [(is_bf16 | None, title)]; a step (training step or rollout) starts at its pack_batch launch"""
     trace = glob.glob(os.path.join(pdir, '**', '*kernel_trace.csv'), recursive=True)[0]
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    idx = [i for i, r in enumerate(rows) if 'adam_fused_kernel' in r['Kernel_Name']]
+    idx = [i for i, r in enumerate(rows) if 'pack_batch_kernel' in r['Kernel_Name']]
     steps = []
-    for a, b in zip(idx[:-1], idx[1:]):           # a step = the kernels after one optimizer launch up to the next one
-        seg = rows[a + 1:b + 1]
-        bf = any('unsigned short' in r['Kernel_Name'] or 'wgrad_bf16' in r['Kernel_Name'] for r in seg)
-        steps.append((a + 1, b + 1, bf))
+    for a, b in zip(idx[:-1], idx[1:]):
+        seg = rows[a:b]
+        bf = any('unsigned short' in r['Kernel_Name'] or 'wgrad_b' in r['Kernel_Name'] or 'pw_' in r['Kernel_Name'] for r in seg)
+        steps.append((a, b, bf))
     txt = []
-    for want, title in ((True, 'bf16 mode (headline)'), (False, 'f32 mode (companion)')):
-        st = [s for s in steps if s[2] == want]
+    for want, title in modes:
+        st = [s for s in steps if want is None or s[2] == want]
+        if not st:
+            continue
         # hipGraph-replayed steps all have the same launch count: keep the most common length (drops warm-up / eager steps)
         lens = collections.Counter(s[1] - s[0] for s in st)
         common = lens.most_common(1)[0][0]
         st = [s for s in st if s[1] - s[0] == common][-40:]
         sel = [r for s in st for r in rows[s[0]:s[1]]]
-        txt.append(summarize(sel, len(st), 'rocprofv3 --kernel-trace --stats of `python bench.py` on 1 MI355X, ' + title +
-                             ', hipGraph-replayed steps'))
+        txt.append(summarize(sel, len(st), title))
+    return txt
+
+
+def main():
+    pdir = os.path.join(R, 'gpurun_out', 'prof_%s' % TAG)
+    head = 'rocprofv3 --kernel-trace --stats of `python bench.py` on 1 MI355X, '
+    txt = step_summaries(pdir, ((True, head + 'bf16 mode (headline), hipGraph-replayed steps'),
+                                (False, head + 'f32 mode (companion), hipGraph-replayed steps')))
     open(PRE + '_kernel_summary.txt', 'w').write('\n\n'.join(txt) + '\n')
+    # BASELINE configs 2 and 5: their own traces (tools/gpu_profile.sh)
+    for wl, name, title in (('encoder6', 'encoder6_b32', '`python bench.py --workload encoder6 --channels 7 --dtype f32` (BASELINE config 2), '
+                                                          'hipGraph-replayed steps'),
+                            ('rollout', 'rollout_b32', '`python bench.py --workload rollout` (BASELINE config 5: one step = one 40-step '
+                                                        'rollout = 20 forward passes), eager launches')):
+        d2 = os.path.join(R, 'gpurun_out', 'prof_%s_%s' % (TAG, wl))
+        if glob.glob(os.path.join(d2, '**', '*kernel_trace.csv'), recursive=True):
+            t2 = step_summaries(d2, ((None, 'rocprofv3 --kernel-trace --stats of ' + title),))
+            pre2 = os.path.join(R, 'profiles', '%s_bench_%s' % (TAG, name))
+            open(pre2 + '_kernel_summary.txt', 'w').write('\n\n'.join(t2) + '\n')
+            st2 = glob.glob(os.path.join(d2, '**', '*kernel_stats.csv'), recursive=True)
+            if st2:
+                shutil.copy(st2[0], pre2 + '_kernel_stats.csv')
     stats = glob.glob(os.path.join(pdir, '**', '*kernel_stats.csv'), recursive=True)
     if stats:
         shutil.copy(stats[0], PRE + '_kernel_stats.csv')
