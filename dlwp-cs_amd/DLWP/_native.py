@@ -29,6 +29,7 @@ CONV_ACCUMULATE_WGRAD = 1
 CONV_PREPACKED = 2
 CONV_REUSE_DZ = 4
 CONV_DEFER_REDUCE = 8
+CONV_DEFER_RING0 = 16
 PACK_FWD, PACK_BWD, PACK_BIAS = 0, 1, 2
 WGRAD_BATCH_MAX = 24
 
@@ -112,6 +113,9 @@ PROTOTYPES = {
     'dlwpcs_avgpool2_bwd_add': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_avgpool2_bwd_masked': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
                                            c_void_p]),
+    'dlwpcs_avgpool2_bwd_ring': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
+                                         c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'dlwpcs_conv_ring_info': (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_size_t), ctypes.POINTER(c_int)]),
     'dlwpcs_upsample2_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_upsample2_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_concat2': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),

@@ -64,6 +64,8 @@ class Model(object):
         self.check_finite = os.environ.get('DLWPCS_CHECK_FINITE', '0') == '1'
         # the optimizer inside the reduction of the batched weight gradients (dlwpcs_wgrad_batch_adam; world size 1)
         self.fuse_adam = os.environ.get('DLWPCS_FUSE_ADAM', '1') == '1'
+        # ring fix-up of a pooled tensor's gradient inside the pooling adjoint (dlwpcs_avgpool2_bwd_ring)
+        self.fold_ring = os.environ.get('DLWPCS_FOLD_RING', '1') == '1'
         self._stager = None                 # pinned-memory / copy-stream feed of fit() on host arrays (keras/staging.py)
         # training step: output layer + loss + loss gradient + the layer's data gradient as one launch (ops.head_mse)
         self.fuse_head_loss = os.environ.get('DLWPCS_FUSE_HEAD', '1') == '1'
@@ -217,6 +219,22 @@ class Model(object):
                         capable[u] = False         # a consumer that cannot mask: the tensor keeps plain gradients
         self._premask = {u: produced[u] for u in produced if capable[u]}
         self._src_mask = src_mask
+        # Ring fix-up folded into the pooling adjoint: the pooled tensor of a masked 'pool_skip' step whose ONLY reader is one
+        # fused convolution (as its plain source 0) -- that convolution's data gradient leaves the halo ring to the pooling node
+        readers = {}
+        for i, st in enumerate(steps):
+            ins = [st[3], st[4]] if st[0] == 'fused_conv' else ([st[3]] if st[0] == 'pool_skip' else list(st[3]))
+            for u in ins:
+                if u is not None:
+                    readers.setdefault(u, []).append(i)
+        self._defer_ring = set()
+        for i, st in enumerate(steps):
+            if st[0] != 'pool_skip' or not (src_mask.get(i) and st[3] in self._premask):
+                continue
+            r = readers.get(st[1], [])
+            if len(r) == 1 and st[1] not in out_uids and steps[r[0]][0] == 'fused_conv' and steps[r[0]][3] == st[1] \
+                    and steps[r[0]][4] != st[1] and not steps[r[0]][5]:
+                self._defer_ring.add(r[0])
 
     def _premask_on(self):
         return (self.compute_dtype == 'bfloat16' and torch.is_grad_enabled()
@@ -282,7 +300,8 @@ class Model(object):
                 values[out_uid] = lay.fused_call(values[s0], None if s1 is None else values[s1], up0=up0, halo=True,
                                                  act=act, alpha=alpha, vmax=vmax,
                                                  premask0=pm.get(s0) if m0 else None, premask1=pm.get(s1) if m1 else None,
-                                                 dy_premasked=out_uid in pm)
+                                                 dy_premasked=out_uid in pm,
+                                                 defer_ring0=bool(pm) and self.fold_ring and i in self._defer_ring)
             elif st[0] == 'pool_skip':
                 _, out_uid, lay, in_uid = st
                 values[out_uid], values[in_uid] = ops.avgpool2_skip(values[in_uid],
@@ -478,6 +497,7 @@ class Model(object):
             ops.WGRAD_BATCH = self.batch_wgrad and not self.wgrad_side_stream
             ops.drop_deferred_reduce()
             ops.drop_wgrad_batch()
+            ops.drop_pending_rings()
             try:
                 torch.autograd.backward(stats, ones)
                 adam = None
@@ -498,6 +518,9 @@ class Model(object):
                 ops.WGRAD_BATCH = False
                 ops.drop_deferred_reduce()
                 ops.drop_wgrad_batch()
+                if ops._pending_ring:
+                    ops.drop_pending_rings()
+                    raise RuntimeError('a deferred ring fix-up was not consumed by its pooling node (plan error)')
                 ops.join_side_stream(stats[0].device)
         if len(stats) == 1:
             return stats[0].detach().view(1, 2)                 # no copy launch for the single-output case

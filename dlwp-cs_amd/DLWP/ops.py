@@ -206,6 +206,18 @@ def wgrad_batch(entries, adam=None):
               'dlwpcs_wgrad_batch')
 
 
+# Deferred ring fix-up (DLWPCS_CONV_DEFER_RING0): a data-gradient call whose source 0 is a pooled tensor with no other
+# consumer leaves the halo ring of that source in its workspace; the pooling adjoint that receives the gradient next adds it
+# while it spreads the gradient (dlwpcs_avgpool2_bwd_ring) -- one launch less per pooling level.  Keyed by the address of the
+# gradient tensor the convolution's backward returns; DLWP.keras.Model asks for it only where its plan guarantees that the next
+# reader of that tensor is the pooling node, and clears the table around every backward pass.
+_pending_ring = {}
+
+
+def drop_pending_rings():
+    _pending_ring.clear()
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -384,8 +396,9 @@ class _CSConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, ksize, halo, up0, flip, act, alpha, vmax,
-                c0_valid=0, premask0=None, premask1=None, dy_premasked=False):
-        """premask0 / premask1 = (negative_slope, max_value) | None: src0 / src1 is the output of an activated layer that expects
+                c0_valid=0, premask0=None, premask1=None, dy_premasked=False, defer_ring0=False):
+        """defer_ring0: the gradient of source 0 goes to a pooling node that adds the halo ring itself (see _pending_ring).
+        premask0 / premask1 = (negative_slope, max_value) | None: src0 / src1 is the output of an activated layer that expects
         its gradient PRE-MASKED (multiplied by act'(src)): the backward applies it to dsrc0 / dsrc1.  dy_premasked: the gradient
         THIS node receives is already dz = dy * act'(y) (every consumer of y honours premask).  See dlwpcs_conv_bwd_data_masked."""
         require_device(src0, 'cs_conv')
@@ -436,6 +449,7 @@ class _CSConv(torch.autograd.Function):
             raise ValueError('cs_conv: both sources must share the activation parameters of their masks')
         ctx.premask = (premask0, premask1)
         ctx.dy_premasked = bool(dy_premasked) and act != nat.ACT_NONE
+        ctx.defer_ring0 = bool(defer_ring0)
         ctx.packed = packed
         ctx.desc = d
         ctx.tables = (table, inv)
@@ -481,6 +495,11 @@ class _CSConv(torch.autograd.Function):
             batching = (direct and WGRAD_BATCH and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(dn))
             defer = direct and DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM and d.B > 0 and not batching
             ws = _workspace(nbytes, dev, 'defer%d' % len(_deferred)) if defer else _workspace(nbytes, dev)
+            ring = None
+            if ctx.defer_ring0 and dsrc0 is not None and pm0 is None and halo_ring_info(dn) is not None:
+                ring = halo_ring_info(dn)
+                dn.flags |= nat.CONV_DEFER_RING0
+                ws = _workspace(nbytes, dev, 'ring%d' % len(_pending_ring))      # stays intact until the pooling adjoint ran
             if dsrc0 is not None or dsrc1 is not None:
                 wq = ctx.packed[3] if ctx.packed is not None else w_eq
                 pm = pm0 if pm0 is not None else pm1
@@ -489,9 +508,12 @@ class _CSConv(torch.autograd.Function):
                                                         ptr(dsrc1), ptr(src0 if pm0 is not None else None),
                                                         ptr(src1 if pm1 is not None else None), ma, mv, ptr(inv), ptr(ws),
                                                         ws.numel(), stream_ptr()), 'dlwpcs_conv_bwd_data_masked')
+                if ring is not None:
+                    _pending_ring[dsrc0.data_ptr()] = (ws, ring[0], ring[1], nat.halo_tables(d.N, 1, dev)[1])
+                    dn.flags &= ~nat.CONV_DEFER_RING0
             dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np = _weight_gradients(
                 dn, src0, src1, dz, None, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp)
-            return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 11
+            return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 12
         no_dgrad = dsrc0 is None and dsrc1 is None        # (first layer: the batched kernel applies act' itself)
         batching = (direct and WGRAD_BATCH and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(d)
                     and (d.act == nat.ACT_NONE or (no_dgrad and d.ksize == 3)))
@@ -519,7 +541,21 @@ class _CSConv(torch.autograd.Function):
             batch_mask_ok=no_dgrad)
         if reuse_dz:
             run_bwd_data()
-        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 11
+        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 12
+
+
+_ring_info_cache = {}
+
+
+def halo_ring_info(d):
+    """(byte offset of the padded gradient in the workspace, its channel count) if a data-gradient call on `d` with
+    CONV_DEFER_RING0 leaves the fix-up of source 0 to the caller, else None (dlwpcs_conv_ring_info)."""
+    key = (d.B, d.N, d.C0, d.C1, d.Cout, d.ksize, d.halo, d.up0, d.dtype, d.c0_valid)
+    if key not in _ring_info_cache:
+        off, ch = ctypes.c_size_t(), ctypes.c_int()
+        ok = lib().dlwpcs_conv_ring_info(ctypes.byref(d), ctypes.byref(off), ctypes.byref(ch))
+        _ring_info_cache[key] = (off.value, ch.value) if ok else None
+    return _ring_info_cache[key]
 
 
 def conv_packed_buffers(ksize, cin, cout, dtype_tag, device, bias=True):
@@ -558,7 +594,8 @@ def pack_batch(items_dev, n_items):
 
 
 def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1=None, ksize=3, halo=True, up0=False,
-            flip_north_pole=True, act=nat.ACT_NONE, alpha=0.0, vmax=0.0, premask0=None, premask1=None, dy_premasked=False):
+            flip_north_pole=True, act=nat.ACT_NONE, alpha=0.0, vmax=0.0, premask0=None, premask1=None, dy_premasked=False,
+            defer_ring0=False):
     if (w_np is None) != (b_np is None) and b_eq is not None:
         raise ValueError('cs_conv: north-pole kernel and bias must be given together')
     # Network inputs with a channel count that is not a multiple of the 16-B vector (7 variables; optionally 14 = 7 x 2):
@@ -578,7 +615,7 @@ def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1
             c0_valid = cin_w
     return _CSConv.apply(src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, int(ksize), bool(halo), bool(up0),
                          bool(flip_north_pole), int(act), float(alpha), float(vmax), int(c0_valid), premask0, premask1,
-                         bool(dy_premasked))
+                         bool(dy_premasked), bool(defer_ring0))
 
 
 # ------------------------------------------------------------------------------------------------------------------ #
@@ -759,9 +796,18 @@ class _AvgPool2Skip(torch.autograd.Function):
                 check(lib().dlwpcs_act_bwd(ptr(dx), ptr(x), ptr(dx), dx.numel(), nat.ACT_LEAKY_CLIP, float(ctx.premask[0]),
                                            float(ctx.premask[1]), nat.dtype_tag(dx), stream_ptr()), 'dlwpcs_act_bwd')
                 return dx, None
+            ring = _pending_ring.pop(dy.data_ptr(), None)
             dy = _c(dy)
             dskip = _c(dskip) if dskip is not None else None
             dx = torch.empty((B, 6, N, N, C), dtype=dy.dtype, device=dy.device)
+            if ring is not None:
+                # dy holds the interior contributions of its producer's data gradient; the halo ring is still in that call's
+                # workspace: added here, no fix-up launch
+                rws, roff, rch, rinv = ring
+                check(lib().dlwpcs_avgpool2_bwd_ring(ptr(dy), ptr(dskip), ptr(x), ptr(dx), B, N, C, float(ctx.premask[0]),
+                                                     float(ctx.premask[1]), nat.dtype_tag(dy), rws.data_ptr() + roff, ptr(rinv),
+                                                     rch, 0, stream_ptr()), 'dlwpcs_avgpool2_bwd_ring')
+                return dx, None
             check(lib().dlwpcs_avgpool2_bwd_masked(ptr(dy), ptr(dskip), ptr(x), ptr(dx), B, N, C, float(ctx.premask[0]),
                                                    float(ctx.premask[1]), nat.dtype_tag(dy), stream_ptr()),
                   'dlwpcs_avgpool2_bwd_masked')

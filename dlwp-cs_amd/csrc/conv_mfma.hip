@@ -66,6 +66,7 @@ struct ConvKParams {
     uint32_t m_thr1;            // bf16_mask_threshold(m_vmax)
     int *direct_done;           // HOST pointer: set to 1 by launch_conv_cfg when the kernel it launched honours d0 / d1
     int *mask_done;             // HOST pointer: bit 0 / 1 set when the launched kernel masks what it stores to d0 / d1
+    int dry_run;                // host only: choose the configuration, report direct_done / mask_done, launch nothing
     int abl;                    // development only (-DDLWPCS_TIMELINE): epilogue ablation bits
     int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
     int tile_rows_max;          // rows reserved in LDS
@@ -696,6 +697,8 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) frag_mma<T>(acc[mt][nt], fb[cur][nt], fa[cur][mt]);   // D[co][pixel]
+            // (round 3: spreading the reads behind the individual MFMAs -- (MFMA, 2 reads), (MFMA, 1), (MFMA, 1) -- as in the batched
+            // weight-gradient kernel measured +-0 here: three MFMAs already hide four reads)
             __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);                          // DS reads of step s+1 first
             __builtin_amdgcn_sched_group_barrier(0x008, MmaPerFrag<T>::N * MT * NT, 0);       // then the MFMAs of step s
         }
@@ -2113,6 +2116,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     if (gx < 1) gx = 1;
     if (gx > P.ntiles) gx = P.ntiles;
     dim3 grid((unsigned)gx, (unsigned)gy);
+    if (P.dry_run) return DLWPCS_OK;
     int pidx = -1;
     if (prof_enabled()) {
         char tag[160];
@@ -2532,7 +2536,7 @@ static int conv_bwd_data_impl(const dlwpcs_conv_desc *d, const void *dy, const v
                               const void *w_eq, const void *w_pol, const void *w_np,
                               void *dsrc0, void *dsrc1, const void *m0, const void *m1, float m_alpha, float m_vmax,
                               const int32_t *inv_table_dev, void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream,
-                              const char *who) {
+                              const char *who, int *ring_query = nullptr) {
     int rc = validate(d, who);
     if (rc) return rc;
     const bool prepacked = (d->flags & DLWPCS_CONV_PREPACKED) != 0;
@@ -2600,7 +2604,9 @@ static int conv_bwd_data_impl(const dlwpcs_conv_desc *d, const void *dy, const v
     // no halo, no upsample, one source: the virtual input IS the source -> write its gradient in place (no routing pass)
     const bool whole = !d->halo && !d->up0 && d->C1 == 0 && dsrc0;
     if (whole) P.out = dsrc0;
+    P.dry_run = ring_query ? 1 : 0;
     rc = dispatch_conv(d->dtype, d->ksize, vec_width(d->Cout, 0, d->dtype), P, conv_work(d), s);
+    if (ring_query) { *ring_query = (!rc && direct_done && P.d0 && !m0) ? 1 : 0; return rc; }
     if (rc) return rc;
     if (whole) return finish_masks(true, false);
     // dxv is the gradient of the (halo-padded, if halo) virtual input: (B,6,Nv,Nv,Cin), Nv = No + k - 1
@@ -2617,7 +2623,9 @@ static int conv_bwd_data_impl(const dlwpcs_conv_desc *d, const void *dy, const v
         return finish_masks(false, todo1 && !rm1);
     }
     if (dsrc0) {
-        if (direct0) {
+        if (direct0 && !m0 && (d->flags & DLWPCS_CONV_DEFER_RING0)) {
+            // the caller folds this fix-up into its next pass over dsrc0 (dlwpcs_avgpool2_bwd_ring): the ring stays in dxv
+        } else if (direct0) {
             rc = launch_ring_fix(dxv, dsrc0, inv_table_dev, d->B, d->N, Cin, 0, d->C0, d->dtype, s, rm0, m_alpha, m_vmax);
             if (rm0) todo0 = false;
         } else {
@@ -2656,6 +2664,24 @@ extern "C" int dlwpcs_conv_bwd_data_masked(const dlwpcs_conv_desc *d, const void
                                            void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
     return conv_bwd_data_impl(d, dz, nullptr, true, w_eq, w_pol, w_np, dsrc0, dsrc1, m0, m1, m_alpha, m_vmax, inv_table_dev, workspace,
                               workspace_bytes, stream, "conv_bwd_data_masked");
+}
+
+extern "C" int dlwpcs_conv_ring_info(const dlwpcs_conv_desc *d, size_t *dxv_offset, int *channels) {
+    if (validate(d, "conv_ring_info") != DLWPCS_OK || !dxv_offset || !channels) return 0;
+    if (!d->halo || d->ksize != 3 || d->up0 || d->B < 1) return 0;
+    const WsLayout L = ws_layout(d);
+    // the configuration choice of the data-gradient launch itself, without launching (placeholder non-null pointers)
+    int q = 0;
+    char dummy = 0;
+    dlwpcs_conv_desc dd = *d;
+    dd.act = DLWPCS_ACT_NONE;
+    dd.flags |= DLWPCS_CONV_PREPACKED;
+    const int rc = conv_bwd_data_impl(&dd, &dummy, nullptr, true, &dummy, nullptr, nullptr, &dummy, d->C1 > 0 ? &dummy : nullptr, nullptr,
+                                      nullptr, 0.f, 0.f, (const int32_t *)&dummy, &dummy, L.total, nullptr, "conv_ring_info", &q);
+    if (rc || !q) return 0;
+    *dxv_offset = L.dxv;
+    *channels = d->C0 + d->C1;
+    return 1;
 }
 
 extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *src0, const void *src1, const void *dy,

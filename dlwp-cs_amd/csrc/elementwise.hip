@@ -385,21 +385,54 @@ __global__ void __launch_bounds__(256) avgpool2_bwd_add_kernel(const V *__restri
 }
 
 // pre-masked gradients: dx = act'(m) * (dskip + 0.25 * dy spread), m = the pooled tensor itself (output of the activated layer
-// that produced it); dskip may be null (no skip connection)
+// that produced it); dskip may be null (no skip connection).
+// ring != nullptr: dy is the gradient of the POOLED tensor as the data-gradient kernel of its consumer wrote it directly
+// (interior contributions only, DLWPCS_CONV_DEFER_RING0); the halo-ring cells that gathered from a border cell of the pooled
+// grid are added here (ring = that call's padded gradient (B,6,No+2,No+2,CTV vectors), channel window at choffV; inv = inverse
+// halo table of the No grid) -- the fix-up launch of its own is gone.
 template <typename V>
 __global__ void __launch_bounds__(256) avgpool2_bwd_masked_kernel(const V *__restrict__ dy, const V *__restrict__ dskip,
                                                                   const V *__restrict__ m, V *__restrict__ dx, size_t total,
-                                                                  int CV, int N, float m_alpha, float m_vmax) {
-    const int No = N / 2;
+                                                                  int CV, int N, float m_alpha, float m_vmax,
+                                                                  const V *__restrict__ ring, const int32_t *__restrict__ inv,
+                                                                  int CTV, int choffV) {
+    const int No = N / 2, Mo = No + 2;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int cv = (int)(e % CV);
         size_t pix = e / CV;
         const int xx = (int)(pix % N); pix /= N;
         const int yy = (int)(pix % N);
         const size_t plane = pix / N;
-        auto g = vscale(VT<V>::ld(dy + ((plane * No + yy / 2) * No + xx / 2) * CV + cv), 0.25f);
-        if (dskip) g = vadd(VT<V>::ld(dskip + e), g);
-        VT<V>::st(dx + e, vmaskacc(g, VT<V>::ld(m + e), m_alpha, m_vmax));
+        const int yp = yy / 2, xp = xx / 2;
+        // the table entry first: the ring loads that depend on it are then in flight together with the streaming loads below
+        const bool border = ring != nullptr && ((yp == 0) | (yp == No - 1) | (xp == 0) | (xp == No - 1));
+        const size_t b = plane / 6;
+        const int f = (int)(plane - b * 6);
+        int4 t = make_int4(-1, -1, -1, -1);
+        if (border) t = *reinterpret_cast<const int4 *>(inv + (size_t)((f * No + yp) * No + xp) * 4);
+        auto gp = VT<V>::ld(dy + ((plane * No + yp) * No + xp) * CV + cv);
+        auto sk = vzero<VT<V>::N>();
+        if (dskip) sk = VT<V>::ld(dskip + e);
+        auto mm = vzero<VT<V>::N>();
+        if (m) mm = VT<V>::ld(m + e);
+        if (border) {
+            const V *base = ring + b * (size_t)(6 * Mo * Mo) * CTV + choffV + cv;
+            auto rs = vzero<VT<V>::N>();
+            if (t.x >= 0) rs = vadd(rs, VT<V>::ld(base + (size_t)t.x * CTV));
+            if (t.y >= 0) rs = vadd(rs, VT<V>::ld(base + (size_t)t.y * CTV));
+            if (t.z >= 0) rs = vadd(rs, VT<V>::ld(base + (size_t)t.z * CTV));
+            if (t.w >= 0) rs = vadd(rs, VT<V>::ld(base + (size_t)t.w * CTV));
+            // like the fix-up kernel: the bf16 value it would have stored (interior + ring, rounded) is what gets pooled
+            gp = vadd(gp, rs);
+            if constexpr (sizeof(V) == 2 * VT<V>::N) {
+#pragma unroll
+                for (int i = 0; i < VT<V>::N; ++i) gp.v[i] = bf2f(f2bf(gp.v[i]));
+            }
+        }
+        auto g = vscale(gp, 0.25f);
+        if (dskip) g = vadd(sk, g);
+        if (m) g = vmaskacc(g, mm, m_alpha, m_vmax);
+        VT<V>::st(dx + e, g);
     }
 }
 
@@ -906,18 +939,41 @@ extern "C" int dlwpcs_avgpool2_bwd_add(const void *dy, const void *dskip, void *
     });
     return check_launch("avgpool2_bwd_add");
 }
+static int avgpool2_bwd_masked_impl(const void *dy, const void *dskip, const void *m, void *dx, int B, int N, int C,
+                                    float m_alpha, float m_vmax, int dtype, const void *ring, const int32_t *inv, int ring_channels,
+                                    int ring_choff, dlwpcs_stream_t stream);
+
 extern "C" int dlwpcs_avgpool2_bwd_masked(const void *dy, const void *dskip, const void *m, void *dx, int B, int N, int C,
                                           float m_alpha, float m_vmax, int dtype, dlwpcs_stream_t stream) {
+    return avgpool2_bwd_masked_impl(dy, dskip, m, dx, B, N, C, m_alpha, m_vmax, dtype, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int dlwpcs_avgpool2_bwd_ring(const void *dy, const void *dskip, const void *m, void *dx, int B, int N, int C,
+                                        float m_alpha, float m_vmax, int dtype, const void *ring, const int32_t *inv_half_dev,
+                                        int ring_channels, int ring_choff, dlwpcs_stream_t stream) {
+    REQUIRE(ring && inv_half_dev, "avgpool2_bwd_ring: null ring / inverse table");
+    REQUIRE(ring_channels >= C && ring_choff >= 0 && ring_choff + C <= ring_channels, "avgpool2_bwd_ring: channel window %d + %d of %d",
+            ring_choff, C, ring_channels);
+    return avgpool2_bwd_masked_impl(dy, dskip, m, dx, B, N, C, m_alpha, m_vmax, dtype, ring, inv_half_dev, ring_channels, ring_choff,
+                                    stream);
+}
+
+static int avgpool2_bwd_masked_impl(const void *dy, const void *dskip, const void *m, void *dx, int B, int N, int C,
+                                    float m_alpha, float m_vmax, int dtype, const void *ring, const int32_t *inv, int ring_channels,
+                                    int ring_choff, dlwpcs_stream_t stream) {
     REQUIRE_DTYPE(dtype, "avgpool2_bwd_masked");
-    REQUIRE(dy && m && dx, "avgpool2_bwd_masked: null pointer");
+    REQUIRE(dy && dx && (m || ring), "avgpool2_bwd_masked: null pointer");
     REQUIRE(B >= 0 && N >= 2 && N % 2 == 0 && C >= 1, "avgpool2_bwd_masked: bad shape B=%d N=%d C=%d", B, N, C);
     REQUIRE(m_alpha >= 0.f && m_vmax >= 0.f, "avgpool2_bwd_masked: activation needs negative_slope >= 0 and max_value >= 0");
     if (B == 0) return DLWPCS_OK;
-    dispatch_vec(dtype, C, [&](auto tag, int w) {
+    int g = 8;
+    while (g > 1 && (C % g || (ring && (ring_channels % g || ring_choff % g)))) g >>= 1;
+    dispatch_vec(dtype, g, [&](auto tag, int w) {
         using V = decltype(tag);
         const size_t total = (size_t)B * 6 * N * N * (C / w);
         hipLaunchKernelGGL(avgpool2_bwd_masked_kernel<V>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, (const V *)dy,
-                           (const V *)dskip, (const V *)m, (V *)dx, total, C / w, N, m_alpha, m_vmax);
+                           (const V *)dskip, (const V *)m, (V *)dx, total, C / w, N, m_alpha, m_vmax, (const V *)ring, inv,
+                           ring_channels / w, ring_choff / w);
     });
     return check_launch("avgpool2_bwd_masked");
 }

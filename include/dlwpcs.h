@@ -107,6 +107,11 @@ int dlwpcs_pad_bwd(const void *dy, void *dx, int B, int N, int C, int p, int dty
                                           * same stream with the same desc and workspace (act != NONE): where the bf16
                                           * weight-gradient kernel applies it leaves dz = dy * act'(y) in the workspace
                                           * and bwd_data reads that instead of dy and y; otherwise the flag is ignored */
+#define DLWPCS_CONV_DEFER_RING0     16   /* conv_bwd_data[_masked], halo, source 0 written directly and not masked: the border
+                                          * fix-up launch of source 0 is left out -- dsrc0 holds the interior contributions, the
+                                          * halo ring stays in the workspace (dlwpcs_conv_ring_info) and the caller's next pass
+                                          * over dsrc0 adds it (dlwpcs_avgpool2_bwd_ring).  Only where dlwpcs_conv_ring_info
+                                          * returns 1 for the descriptor; ignored otherwise */
 #define DLWPCS_CONV_DEFER_REDUCE     8   /* conv_bwd_weights: run the weight-gradient kernel only and leave the per-worker
                                           * partial sums in the workspace (dw_* / db_* are not touched); the caller keeps
                                           * that workspace untouched until it has run dlwpcs_wgrad_reduce_batch over the
@@ -187,6 +192,10 @@ int dlwpcs_conv_bwd_data_masked(const dlwpcs_conv_desc *d, const void *dz,
                                 void *dsrc0, void *dsrc1, const void *m0, const void *m1, float m_alpha, float m_vmax,
                                 const int32_t *inv_table_dev,
                                 void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
+
+/* 1 if a data-gradient call on d with DLWPCS_CONV_DEFER_RING0 defers the fix-up of source 0; then *dxv_offset = byte offset of
+ * the padded gradient (B,6,N+2,N+2,channels) inside that call's workspace and *channels = C0 + C1 (source 0 = the first C0). */
+int dlwpcs_conv_ring_info(const dlwpcs_conv_desc *d, size_t *dxv_offset, int *channels);
 
 /* Gradients w.r.t. kernels and biases (deterministic: fixed-order partial sums, no atomics).
  * dw_*: HWIO like the kernels; db_*: (Cout,) or NULL.  dw_np/db_np NULL unless independent north pole. */
@@ -308,6 +317,13 @@ int dlwpcs_avgpool2_bwd_add(const void *dy, const void *dskip, void *dx, int B, 
  * ReLU(m_alpha, m_vmax)), dskip may be NULL (no skip connection).  dx may alias dskip. */
 int dlwpcs_avgpool2_bwd_masked(const void *dy, const void *dskip, const void *m, void *dx, int B, int N, int C,
                                float m_alpha, float m_vmax, int dtype, dlwpcs_stream_t stream);
+/* The same, with dy = the pooled tensor's gradient as a data-gradient call with DLWPCS_CONV_DEFER_RING0 left it: the ring cells
+ * (`ring` = that call's workspace + dxv_offset, `ring_channels` per cell, the pooled tensor's window starting at `ring_choff`;
+ * inv_half_dev = dlwpcs_halo_inverse_table(N/2, 1)) are added to the border cells of the N/2 grid on the fly.  m may be NULL
+ * here (no mask: plain pooling adjoint + fix-up). */
+int dlwpcs_avgpool2_bwd_ring(const void *dy, const void *dskip, const void *m, void *dx, int B, int N, int C,
+                             float m_alpha, float m_vmax, int dtype, const void *ring, const int32_t *inv_half_dev,
+                             int ring_channels, int ring_choff, dlwpcs_stream_t stream);
 /* x: (B,6,N,N,C) -> y: (B,6,2N,2N,C), nearest;  backward sums 2x2 blocks */
 int dlwpcs_upsample2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
 int dlwpcs_upsample2_bwd(const void *dy, void *dx, int B, int N, int C, int dtype, dlwpcs_stream_t stream);

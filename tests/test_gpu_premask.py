@@ -266,3 +266,86 @@ def test_optimizer_fused_into_the_reduction_gives_the_same_bits():
             os.environ.pop('DLWPCS_FUSE_ADAM', None)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize('B,N,Cin,Cout', [(2, 24, 32, 64), (3, 12, 64, 128), (2, 16, 32, 32)])
+def test_ring_fix_folded_into_the_pooling_adjoint(B, N, Cin, Cout):
+    """dlwpcs_conv_bwd_data_masked with DLWPCS_CONV_DEFER_RING0 + dlwpcs_avgpool2_bwd_ring against the same call with its own
+    ring fix-up launch + dlwpcs_avgpool2_bwd_masked: the same bits (the ring is added to the bf16 interior value in the same
+    order and rounded to bf16 before the pooling adjoint uses it)"""
+    import ctypes
+    from DLWP import _native as nat, ops
+    dev = _dev()
+    rng = np.random.default_rng(N * 7 + Cin)
+    lib = nat.lib()
+    d = nat.ConvDesc(B=B, N=N, C0=Cin, C1=0, Cout=Cout, ksize=3, halo=1, up0=0, flip_north_pole=1, act=0, alpha=0., vmax=0.,
+                     dtype=nat.BF16, flags=0, c0_valid=0)
+    info = ops.halo_ring_info(d)
+    assert info is not None
+    dz = _bf(rng.standard_normal((B, 6, N, N, Cout)))
+    w = [torch.tensor(rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin), dtype=torch.float32, device=dev)
+         for _ in range(2)]
+    xfull = _bf(rng.standard_normal((B, 6, 2 * N, 2 * N, Cin)) * 6.0)       # the pooling node's input (mask) ...
+    dskip = _bf(rng.standard_normal((B, 6, 2 * N, 2 * N, Cin)))             # ... and the gradient of its alias
+    table, inv = nat.halo_tables(N, 1, dev)
+    nbytes = lib.dlwpcs_conv_workspace_bytes(ctypes.byref(d))
+    out = []
+    for fold in (False, True):
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        dsrc = torch.empty((B, 6, N, N, Cin), dtype=torch.bfloat16, device=dev)
+        dx = torch.empty_like(xfull)
+        d.flags = nat.CONV_DEFER_RING0 if fold else 0
+        nat.check(lib.dlwpcs_conv_bwd_data_masked(ctypes.byref(d), nat.ptr(dz), nat.ptr(w[0]), nat.ptr(w[1]), None,
+                                                  nat.ptr(dsrc), None, None, None, 0.0, 0.0, nat.ptr(inv), nat.ptr(ws),
+                                                  ws.numel(), nat.stream_ptr()), 'bwd_data_masked')
+        if fold:
+            nat.check(lib.dlwpcs_avgpool2_bwd_ring(nat.ptr(dsrc), nat.ptr(dskip), nat.ptr(xfull), nat.ptr(dx), B, 2 * N, Cin,
+                                                   ALPHA, VMAX, nat.BF16, ws.data_ptr() + info[0], nat.ptr(inv), info[1], 0,
+                                                   nat.stream_ptr()), 'avgpool2_bwd_ring')
+        else:
+            nat.check(lib.dlwpcs_avgpool2_bwd_masked(nat.ptr(dsrc), nat.ptr(dskip), nat.ptr(xfull), nat.ptr(dx), B, 2 * N, Cin,
+                                                     ALPHA, VMAX, nat.BF16, nat.stream_ptr()), 'avgpool2_bwd_masked')
+        torch.cuda.synchronize()
+        out.append((_f32(dx), _f32(dsrc)))
+    assert np.array_equal(out[0][0], out[1][0])
+    # the deferred call really left the ring out (otherwise this test proves nothing)
+    edge = np.zeros((N, N), bool)
+    edge[0, :] = edge[-1, :] = edge[:, 0] = edge[:, -1] = True
+    assert not np.array_equal(out[0][1][:, :, edge], out[1][1][:, :, edge])
+    assert np.array_equal(out[0][1][:, :, ~edge], out[1][1][:, :, ~edge])
+
+
+def test_unet2_training_with_the_ring_folded_gives_the_same_bits():
+    """DLWPCS_FOLD_RING on/off on a bf16 unet2 (eager warm-up, capture, replays): two ring fix-up launches less, same weights"""
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    from DLWP import _native as nat
+    dev = _dev()
+    backend.set_device('cuda:0')
+    N, C, B = 16, 14, 4
+    rng = np.random.default_rng(3)
+    x = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    t = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
+    w0, out = None, []
+    for fold in ('0', '1'):
+        os.environ['DLWPCS_FOLD_RING'] = fold
+        try:
+            backend.set_compute_dtype('bfloat16')
+            try:
+                np.random.seed(5)
+                model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=32)
+            finally:
+                backend.set_compute_dtype('float32')
+            model.compile(optimizer='adam', loss='mse', metrics=['mae'])
+            if w0 is None:
+                w0 = model.get_weights()
+            model.set_weights(w0)
+            assert len(model._defer_ring) == 2          # the first convolution of each of the two lower levels
+            for _ in range(5):
+                stats = model.train_on_device_batch([x], [t])
+            torch.cuda.synchronize()
+            out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
+        finally:
+            os.environ.pop('DLWPCS_FOLD_RING', None)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
