@@ -81,11 +81,16 @@ struct WbAdam {
     const float *hyper;             // {lr, beta1, beta2, eps, grad_scale}
     int32_t on, pad;
 };
+// what the reduction needs of a layer, by value in the kernel arguments (its dependent chain of memory round trips is what
+// the reduction's ~20 us are made of: plan header -> layer record -> group record -> partial sums -> optimizer state)
+struct WbRedLayer { int32_t KS, Cin, Cout, want_bias, TC, TN, ncot, group_base, flip; };
 struct WbRedPtrs {
     float *dw_eq[WB_MAX_LAYERS], *dw_pol[WB_MAX_LAYERS], *dw_np[WB_MAX_LAYERS];
     float *db_eq[WB_MAX_LAYERS], *db_pol[WB_MAX_LAYERS], *db_np[WB_MAX_LAYERS];
     uint32_t first[WB_MAX_LAYERS + 1];
     uint32_t live;                               // bit l: layer l is reduced by this launch
+    uint32_t n_layers, off_groups;
+    WbRedLayer lay[WB_MAX_LAYERS];
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -530,115 +535,122 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
 
 // ------------------------------------------------------------------------------------------------------------------
 // Reduction: a workgroup owns 64 groups of VEC consecutive output channels of one (layer, tap, ci) row (or of the bias
-// vector) x 4 slot phases: thread (o, ph) adds the partial sums ph, ph + 4, ... of its (ci group, co group) and face class in
-// slot order, the four phases are combined through LDS in phase order -- a fixed order, no atomics.
+// vector) x the 3 face classes (equatorial, face 4, face 5): thread (o, c) adds the partial sums of its (ci group, co group)
+// and class in slot order and updates that class's destination -- a fixed order, no atomics.  Where the two pole classes
+// share their weights, class 2 hands its sum to class 1 through LDS.  (Three light waves per workgroup, all of them resident
+// at once: the first version -- 4 slot phases x 3 classes per thread, 140 VGPRs -- ran in two rounds of workgroups.)
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int WB_RED_OUT = 64, WB_RED_PH = 4;
+constexpr int WB_RED_OUT = 64, WB_RED_THREADS = 3 * WB_RED_OUT;
 
 template <int VEC, bool ALIGNED>
-__device__ __forceinline__ void wb_reduce_body(const WbLayer &L, const WbGroup *__restrict__ groups, const float *__restrict__ ws,
+__device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGroup *__restrict__ groups, const float *__restrict__ ws,
                                                float *dw_eq, float *dw_pol, float *dw_np, float *db_eq, float *db_pol,
                                                float *db_np, int block, const WbAdam &A) {
     typedef float VT __attribute__((ext_vector_type(VEC)));
+    constexpr bool VECIO = ALIGNED || VEC == 1;         // (the four flat buffers share their 16-B alignment)
     float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gscale = 1.f;
     if (A.on) {
         b1 = A.hyper[1]; b2 = A.hyper[2]; eps = A.hyper[3]; gscale = A.hyper[4];
         lr_t = adam_lr_t(A.hyper[0], b1, b2, (float)A.state[0]);
     }
-    // destination update: one 16-B access when the caller's gradient tensors are 16-B aligned, else element by element;
-    // with the optimizer fused in, the finished gradient (what the buffer held + the reduced sum) is consumed here: Adam
-    // element update (the arithmetic of adam_fused_kernel, same bits), gradient cleared for the next step
-    auto accum = [&](float *dst, VT v) {
-        if (A.on) {
-            const size_t i = (size_t)(dst - A.g);
-            if constexpr (ALIGNED || VEC == 1) {            // (the four flat buffers share their 16-B alignment)
-                VT gv = *reinterpret_cast<VT *>(dst), pv = *reinterpret_cast<VT *>(A.p + i);
-                VT mv = *reinterpret_cast<VT *>(A.m + i), vv = *reinterpret_cast<VT *>(A.v + i);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    float pk = pv[k], mk = mv[k], vk = vv[k];
-                    adam_elem(pk, (gv[k] + v[k]) * gscale, mk, vk, lr_t, b1, b2, eps);
-                    pv[k] = pk; mv[k] = mk; vv[k] = vk;
-                }
-                *reinterpret_cast<VT *>(A.p + i) = pv; *reinterpret_cast<VT *>(A.m + i) = mv; *reinterpret_cast<VT *>(A.v + i) = vv;
-                *reinterpret_cast<VT *>(dst) = (VT)0.f;
-                return;
-            }
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                float pk = A.p[i + k], mk = A.m[i + k], vk = A.v[i + k];
-                adam_elem(pk, (dst[k] + v[k]) * gscale, mk, vk, lr_t, b1, b2, eps);
-                A.p[i + k] = pk; A.m[i + k] = mk; A.v[i + k] = vk;
-                dst[k] = 0.f;
-            }
-            return;
-        }
-        if constexpr (ALIGNED || VEC == 1) { VT *q = reinterpret_cast<VT *>(dst); *q = *q + v; }
-        else {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) dst[k] += v[k];
-        }
-    };
-    const int KS = L.KS, TAPS = KS * KS, Cin = L.cin_logical, Cout = L.Cout;
+    const int KS = L.KS, TAPS = KS * KS, Cin = L.Cin, Cout = L.Cout;
     const int nW = TAPS * Cin * Cout;
-    const int o = (int)threadIdx.x % WB_RED_OUT, ph = (int)threadIdx.x / WB_RED_OUT;
+    const int o = (int)threadIdx.x % WB_RED_OUT, c = (int)threadIdx.x / WB_RED_OUT;
     const int e = (block * WB_RED_OUT + o) * VEC;
     const bool is_w = e < nW, is_b = !is_w && L.want_bias && e < nW + Cout;
-    const int TC = 32 * L.CT, TN = 32 * L.NT;
-    VT s[3];
-    s[0] = 0.f; s[1] = 0.f; s[2] = 0.f;
-    if (is_w) {
-        const int co = e % Cout, ci = (e / Cout) % Cin, tap = e / (Cout * Cin);
-        const int cit = ci / TC, cot = co / TN, lci = ci - cit * TC, lco = co - cot * TN;
-        const int ty = tap / KS, tx = tap - ty * KS;
-        const int tap5 = L.flip ? (KS - 1 - ty) * KS + tx : tap;    // face 5 ran with the row-reversed kernel
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const WbGroup g = groups[L.group_base + (cit * L.ncot + cot) * 3 + c];
-            const float *p = ws + g.off + (size_t)(((c == 2 ? tap5 : tap) * TC + lci) * TN + lco);
-#pragma unroll 4
-            for (int j = ph; j < g.count; j += WB_RED_PH) s[c] += *reinterpret_cast<const VT *>(p + (size_t)j * g.stride);
-        }
-    } else if (is_b) {
+    const int TC = L.TC, TN = L.TN;
+    // this thread's destination; the two pole sums share one where the layer has no north-pole parameters of its own
+    float *dst = nullptr;
+    bool shared_pole = false;
+    if (is_w) { dst = c == 0 ? dw_eq + e : (c == 1 ? dw_pol + e : (dw_np ? dw_np + e : nullptr)); shared_pole = dw_np == nullptr; }
+    if (is_b) {
         const int co = e - nW;
-        const int cot = co / TN, lco = co - cot * TN;
+        float *base = c == 0 ? db_eq : (c == 1 ? db_pol : db_np);
+        dst = base ? base + co : nullptr; shared_pole = db_np == nullptr;
+    }
+    // what the destination holds (and, with the optimizer fused in, the parameter and its two moments) is fetched BEFORE the
+    // partial sums: independent of them, so the round trips overlap
+    VT gv = 0.f, pv = 0.f, mv = 0.f, vv = 0.f;
+    const size_t ai = (A.on && dst) ? (size_t)(dst - A.g) : 0;
+    if (dst != nullptr) {
+        if constexpr (VECIO) {
+            gv = *reinterpret_cast<const VT *>(dst);
+            if (A.on) {
+                pv = *reinterpret_cast<const VT *>(A.p + ai); mv = *reinterpret_cast<const VT *>(A.m + ai);
+                vv = *reinterpret_cast<const VT *>(A.v + ai);
+            }
+        } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const WbGroup g = groups[L.group_base + cot * 3 + c];         // ci group 0 carries the bias sums
-            const float *p = ws + g.off + (size_t)TAPS * TC * TN + lco;
-#pragma unroll 4
-            for (int j = ph; j < g.count; j += WB_RED_PH) s[c] += *reinterpret_cast<const VT *>(p + (size_t)j * g.stride);
+            for (int k = 0; k < VEC; ++k) {
+                gv[k] = dst[k];
+                if (A.on) { pv[k] = A.p[ai + k]; mv[k] = A.m[ai + k]; vv[k] = A.v[ai + k]; }
+            }
         }
     }
-    __shared__ VT red[3][WB_RED_PH][WB_RED_OUT];
-    red[0][ph][o] = s[0]; red[1][ph][o] = s[1]; red[2][ph][o] = s[2];
+    VT s = 0.f;
+    if (is_w || is_b) {
+        int gi;
+        size_t off;
+        if (is_w) {
+            const int co = e % Cout, ci = (e / Cout) % Cin, tap = e / (Cout * Cin);
+            const int cit = ci / TC, cot = co / TN, lci = ci - cit * TC, lco = co - cot * TN;
+            const int ty = tap / KS, tx = tap - ty * KS;
+            const int tap5 = L.flip ? (KS - 1 - ty) * KS + tx : tap;    // face 5 ran with the row-reversed kernel
+            gi = L.group_base + (cit * L.ncot + cot) * 3 + c;
+            off = (size_t)(((c == 2 ? tap5 : tap) * TC + lci) * TN + lco);
+        } else {
+            const int co = e - nW;
+            const int cot = co / TN, lco = co - cot * TN;
+            gi = L.group_base + cot * 3 + c;                             // ci group 0 carries the bias sums
+            off = (size_t)TAPS * TC * TN + lco;
+        }
+        const WbGroup g = groups[gi];
+        const float *p = ws + g.off + off;
+#pragma unroll 8
+        for (int j = 0; j < g.count; ++j) s += *reinterpret_cast<const VT *>(p + (size_t)j * g.stride);
+    }
+    __shared__ VT red[WB_RED_OUT];
+    if (c == 2) red[o] = s;
     __syncthreads();
-    if (ph != 0 || (!is_w && !is_b)) return;
+    if (dst == nullptr) return;
+    if (c == 1 && shared_pole) s = s + red[o];
+    // destination update; with the optimizer fused in, the finished gradient (what the buffer held + the reduced sum) is
+    // consumed here: Adam element update (the arithmetic of adam_fused_kernel, same bits), gradient cleared for the next step
+    VT out;
+    if (A.on) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) s[c] = ((red[c][0][o] + red[c][1][o]) + red[c][2][o]) + red[c][3][o];
-    if (is_w) {
-        auto add = [&](float *dst, VT v) { accum(dst + e, v); };
-        add(dw_eq, s[0]);
-        if (dw_np) { add(dw_pol, s[1]); add(dw_np, s[2]); } else add(dw_pol, s[1] + s[2]);
+        for (int k = 0; k < VEC; ++k) {
+            float pk = pv[k], mk = mv[k], vk = vv[k];
+            adam_elem(pk, (gv[k] + s[k]) * gscale, mk, vk, lr_t, b1, b2, eps);
+            pv[k] = pk; mv[k] = mk; vv[k] = vk;
+        }
+        out = 0.f;
     } else {
-        const int co = e - nW;
-        auto add = [&](float *dst, VT v) { if (dst) accum(dst + co, v); };
-        add(db_eq, s[0]);
-        if (db_np) { add(db_pol, s[1]); add(db_np, s[2]); } else add(db_pol, s[1] + s[2]);
+        out = gv + s;
+    }
+    if constexpr (VECIO) {
+        *reinterpret_cast<VT *>(dst) = out;
+        if (A.on) {
+            *reinterpret_cast<VT *>(A.p + ai) = pv; *reinterpret_cast<VT *>(A.m + ai) = mv; *reinterpret_cast<VT *>(A.v + ai) = vv;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            dst[k] = out[k];
+            if (A.on) { A.p[ai + k] = pv[k]; A.m[ai + k] = mv[k]; A.v[ai + k] = vv[k]; }
+        }
     }
 }
 
-__global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__ plan, const WbRedPtrs R, const float *__restrict__ ws,
+__global__ void __launch_bounds__(WB_RED_THREADS) wb_reduce_kernel(const char *__restrict__ plan, const WbRedPtrs R, const float *__restrict__ ws,
                                                         const WbAdam A) {
-    const WbHeader *H = reinterpret_cast<const WbHeader *>(plan);
-    const WbLayer *layers = reinterpret_cast<const WbLayer *>(plan + H->off_layers);
-    const WbGroup *groups = reinterpret_cast<const WbGroup *>(plan + H->off_groups);
+    const WbGroup *groups = reinterpret_cast<const WbGroup *>(plan + R.off_groups);
     const uint32_t b = blockIdx.x;
     int l = 0;
 #pragma unroll
-    for (int k = 1; k < WB_MAX_LAYERS; ++k) l += (k < (int)H->n_layers && b >= R.first[k]) ? 1 : 0;
+    for (int k = 1; k < WB_MAX_LAYERS; ++k) l += (k < (int)R.n_layers && b >= R.first[k]) ? 1 : 0;
     if (!((R.live >> l) & 1u)) return;
-    const WbLayer L = layers[l];            // (block-uniform index: scalar loads)
+    const WbRedLayer L = R.lay[l];          // (block-uniform index into the kernel arguments: scalar loads)
     const int blk = (int)(b - R.first[l]);
     const bool al = ((((uintptr_t)R.dw_eq[l] | (uintptr_t)R.dw_pol[l] | (uintptr_t)R.dw_np[l] | (uintptr_t)R.db_eq[l] |
                        (uintptr_t)R.db_pol[l] | (uintptr_t)R.db_np[l]) & 15) == 0);
@@ -996,6 +1008,12 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
                  4.0 * L.KS * L.KS * L.cin_logical * L.Cout;
     }
     memcpy(R.first, H->red_first, sizeof(R.first));
+    R.n_layers = H->n_layers;
+    R.off_groups = H->off_groups;
+    for (int l = 0; l < n_items; ++l) {
+        const WbLayer &L = layers[l];
+        R.lay[l] = WbRedLayer{L.KS, L.cin_logical, L.Cout, L.want_bias, 32 * L.CT, 32 * L.NT, L.ncot, L.group_base, L.flip};
+    }
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = H->lds_bytes;
     if (lds > 64 * 1024) {
@@ -1027,7 +1045,7 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
         R.live = live;
         pidx = -1;
         if (prof_enabled()) pidx = prof_begin("wb_reduce_kernel", 0.0, (double)H->ws_floats * 4.0, s);
-        hipLaunchKernelGGL(wb_reduce_kernel, dim3(H->red_first[WB_MAX_LAYERS]), dim3(256), 0, s, (const char *)plan_dev, R,
+        hipLaunchKernelGGL(wb_reduce_kernel, dim3(H->red_first[WB_MAX_LAYERS]), dim3(WB_RED_THREADS), 0, s, (const char *)plan_dev, R,
                            (const float *)workspace, adam);
         if (pidx >= 0) prof_end(pidx, s);
         pending &= ~live;
