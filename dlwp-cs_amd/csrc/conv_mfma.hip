@@ -600,7 +600,10 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                 uint4 vm = v;
                 vmask_pk(vm, ymq[nt][mt][ps], P.m_alpha, P.m_thr1);
                 const bool on = (sel == 1 && P.m0 != nullptr) || (sel == 2 && P.m1 != nullptr);
-                v = on ? vm : v;
+                // component by component: `v = on ? vm : v` on the uint4 becomes a select of two STACK ADDRESSES in LLVM -- both
+                // values went to scratch memory and came back through a scratch load behind s_waitcnt vmcnt(0), which also
+                // waited for the stores of the previous slice (measured: 43.8 us against 26.1 us unmasked, 32 -> 32 at N = 48)
+                v.x = on ? vm.x : v.x; v.y = on ? vm.y : v.y; v.z = on ? vm.z : v.z; v.w = on ? vm.w : v.w;
             }
 #ifdef DLWPCS_TIMELINE
             if (P.abl & 1) boff = ST_SKIP;          // ablation: no global stores
@@ -618,6 +621,19 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     };
     auto epilogue_lines = [&](const Geo &gq, const auto &A) {
         TL_MARK();
+        if constexpr (MOUT) {
+            // Every mask value is waited for HERE, before the first store of the epilogue: with loads and stores both in flight
+            // hipcc cannot count (gfx9 has one vmcnt for both and they complete out of order), so each later use of a mask
+            // register became s_waitcnt vmcnt(0) -- one store round trip per slice, six per tile (measured: 43.8 us against
+            // 26.1 us unmasked on the 32 -> 32 layer at N = 48).  The empty asm redefines the registers: nothing pending on them.
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int ps = 0; ps < NPS; ++ps)
+                        asm volatile("" : "+v"(ymq[nt][mt][ps].x), "+v"(ymq[nt][mt][ps].y), "+v"(ymq[nt][mt][ps].z), "+v"(ymq[nt][mt][ps].w));
+        }
         const rsrc_t d_out = out_of(gq);
         const rsrc_t d_0 = DIRECT ? d0_of(gq) : d_out, d_1 = DIRECT ? d1_of(gq) : d_out;
         if (P.act != DLWPCS_ACT_LEAKY_CLIP) {
@@ -711,7 +727,12 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         mask_load(gq);
         for (int ch = 0; ch < nchunks; ++ch, ++g) {
             TL_MARK();
-            __syncthreads();                // B_g: chunk g has been written by the producers
+            // B_g: chunk g has been written by the producers.  A RAW barrier behind an explicit LDS wait: __syncthreads() makes
+            // hipcc drain vmcnt(0) first, i.e. wait for the previous tile's epilogue stores to be acknowledged and -- MOUT -- for
+            // the mask values requested a moment ago (measured on the 32 -> 32 data gradient at N = 48: 43.8 us masked against
+            // 26.1 plain, nearly all of it this wait).  The consumers only owe the producers their LDS reads.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             TL_MARK();
             mma_chunk(ch);
         }
