@@ -220,6 +220,11 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
         long long *tdbg = (dbg && ptid == 0) ? dbg + ((size_t)blockIdx.x * 2 + 0) * 8 : nullptr;
         long long tacc[4] = {0, 0, 0, 0};
 #endif
+        // (Round 3, measured and dropped: src / dz / table reach this noinline function as GENERIC pointers, so every load below is
+        // a FLAT instruction, which counts in lgkmcnt too -- the LDS wait in commit() therefore also waits for the loads of the
+        // next item.  Casting them to the global address space (global_load, the producers really two items ahead) measured
+        // 159 against 156 us; fetching the table entries of rebuild() branch-free, all in flight at once, 152 against 150 us.
+        // The kernel is bound by its consumers; producer LDS writes that land in their MFMA phase cost more than the waiting.)
         int xoff[IT_X];
         int cur_combo = -1;
         auto rebuild = [&](const Item &it) {
