@@ -994,14 +994,32 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
             const Item nxt = item_of(k + 1);
             if (cur.combo != cur_combo) rebuild(cur);              // uniform, a few times per worker
             const T *sb = src_base + (size_t)cur.b * sample_elems;
-            // ---- X tile: every load in flight at once
+            // ---- X tile: every load in flight at once.  (VW = 1, odd channel counts: 56 scalar loads per item -- with their
+            // offsets and the dZ registers that spilled ~170 dwords; there the tile goes through the registers in XG groups and
+            // dZ in DG halves, each written to LDS before the next is fetched.  The vector instantiations are one group.)
+            constexpr int XG = VW == 1 ? 4 : (VW == 2 && MASK ? 2 : 1), XN = IT_X / XG;
+            constexpr int DG = VW == 1 ? 2 : 1, DN = IT_DY / DG;
+            static_assert(IT_X % XG == 0 && IT_DY % DG == 0, "register groups must divide the slot counts");
             V xv[IT_X];
             bool xok[IT_X];
+            auto x_store = [&](int i0) {
 #pragma unroll
-            for (int i = 0; i < IT_X; ++i) {
-                const int o = xoff[i];
-                xv[i] = *reinterpret_cast<const V *>(sb + (uint32_t)max(o, 0));
-                xok[i] = o >= 0;
+                for (int u = 0; u < XN; ++u) {
+                    const int i = i0 + u;
+                    const int e = ptid + i * NCT;
+                    if (e < cur.nitems) st_f32(buf + (e / QX) * XS + (ptid % QX) * VW, vsel(xok[i], xv[i]));
+                }
+            };
+#pragma unroll
+            for (int g = 0; g < XG; ++g) {
+#pragma unroll
+                for (int u = 0; u < XN; ++u) {
+                    const int i = g * XN + u;
+                    const int o = xoff[i];
+                    xv[i] = *reinterpret_cast<const V *>(sb + (uint32_t)max(o, 0));
+                    xok[i] = o >= 0;
+                }
+                if constexpr (XG > 1) { x_store(g * XN); asm volatile("" ::: "memory"); }
             }
             // ---- dZ tile [pix][32 output channels of tile cot] = dy * act'(y), zero beyond npix / Cout
             const size_t rowbase = (((size_t)cur.b * 6 + cur.f) * face_pix + cur.m0) * P.Cout;
@@ -1010,77 +1028,85 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
             float4 dv[IT_DY], yv[MASK ? IT_DY : 1];
             DV dvr[IT_DY], yvr[MASK ? IT_DY : 1];
             bool dok[IT_DY];
-            if (vec_dy) {
+            auto dz_store = [&](int i0) {
 #pragma unroll
-                for (int i = 0; i < IT_DY; ++i) {
+                for (int u = 0; u < DN; ++u) {
+                    const int i = i0 + u;
                     const int e = ptid + i * NCT;
-                    const int kk = e >> 3, co = cot * 32 + (e & 7) * 4;
-                    const bool ok = kk < cur.npix && co < P.Cout;
-                    const size_t o = ok ? (size_t)kk * P.Cout + co : 0;
-                    dvr[i] = *reinterpret_cast<const DV *>(dyb + o);
-                    if (MASK) yvr[i] = *reinterpret_cast<const DV *>(yb + o);
-                    dok[i] = ok;
+                    if (e * 4 < pix_cap * 32) *reinterpret_cast<float4 *>(buf + x_floats + e * 4) = dv[i];
+                    if (want_bias) { bsum.x += dv[i].x; bsum.y += dv[i].y; bsum.z += dv[i].z; bsum.w += dv[i].w; }
                 }
-            } else {
-                // C_out % 4 != 0 (e.g. the 14-channel head): scalar gather, 4 consecutive tile floats per slot
+            };
 #pragma unroll
-                for (int i = 0; i < IT_DY; ++i) {
-                    T gs[4], ys[4];
+            for (int h = 0; h < DG; ++h) {
+                if (vec_dy) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e4 = (ptid + i * NCT) * 4 + u;
-                        const int kk = e4 >> 5, co = cot * 32 + (e4 & 31);
-                        const bool ok = kk < cur.npix && co < P.Cout;
-                        const size_t o = ok ? (size_t)kk * P.Cout + co : 0;
-                        gs[u] = ok ? dyb[o] : (T)0;
-                        ys[u] = MASK ? yb[o] : (T)0;
-                    }
-                    dvr[i] = pack4(gs[0], gs[1], gs[2], gs[3]);
-                    if (MASK) yvr[i] = pack4(ys[0], ys[1], ys[2], ys[3]);
-                    dok[i] = true;
-                }
-            }
-            PL_MARK();
-            // dZ = dy * act'(y), applied only after EVERY load of the item has been issued
-#pragma unroll
-            for (int i = 0; i < IT_DY; ++i) {
-                dv[i] = to_f4(dvr[i]);
-                if (MASK) {
-                    yv[i] = to_f4(yvr[i]); vmask(dv[i], yv[i], P.alpha, P.vmax);
-                    if constexpr (sizeof(T) == 2) {
-                        // bf16 mode: dz is a bf16 tensor everywhere else (hand-over, pre-masked gradients, the bf16 kernels):
-                        // round the product here too, so that every path multiplies the same numbers
-                        dv[i].x = bf2f(f2bf(dv[i].x)); dv[i].y = bf2f(f2bf(dv[i].y));
-                        dv[i].z = bf2f(f2bf(dv[i].z)); dv[i].w = bf2f(f2bf(dv[i].w));
-                    }
-                }
-                dv[i] = vsel(dok[i], dv[i]);
-            }
-            // DLWPCS_CONV_REUSE_DZ (fp32 tensors, C_out % 4 == 0): the workers of ci tile 0 see every dZ element exactly
-            // once -> they hand dz to the data-gradient kernel that follows
-            if constexpr (MASK && sizeof(T) == 4) {
-                if (W.dz_out != nullptr && cit == 0 && vec_dy) {
-                    float *dzb = reinterpret_cast<float *>(W.dz_out) + rowbase;
-#pragma unroll
-                    for (int i = 0; i < IT_DY; ++i) {
+                    for (int u = 0; u < DN; ++u) {
+                        const int i = h * DN + u;
                         const int e = ptid + i * NCT;
                         const int kk = e >> 3, co = cot * 32 + (e & 7) * 4;
-                        if (kk < cur.npix && co < P.Cout) *reinterpret_cast<float4 *>(dzb + (size_t)kk * P.Cout + co) = dv[i];
+                        const bool ok = kk < cur.npix && co < P.Cout;
+                        const size_t o = ok ? (size_t)kk * P.Cout + co : 0;
+                        dvr[i] = *reinterpret_cast<const DV *>(dyb + o);
+                        if (MASK) yvr[i] = *reinterpret_cast<const DV *>(yb + o);
+                        dok[i] = ok;
+                    }
+                } else {
+                    // C_out % 4 != 0 (e.g. the 14-channel head): scalar gather, 4 consecutive tile floats per slot
+#pragma unroll
+                    for (int u = 0; u < DN; ++u) {
+                        const int i = h * DN + u;
+                        T gs[4], ys[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int e4 = (ptid + i * NCT) * 4 + q;
+                            const int kk = e4 >> 5, co = cot * 32 + (e4 & 31);
+                            const bool ok = kk < cur.npix && co < P.Cout;
+                            const size_t o = ok ? (size_t)kk * P.Cout + co : 0;
+                            gs[q] = ok ? dyb[o] : (T)0;
+                            ys[q] = MASK ? yb[o] : (T)0;
+                        }
+                        dvr[i] = pack4(gs[0], gs[1], gs[2], gs[3]);
+                        if (MASK) yvr[i] = pack4(ys[0], ys[1], ys[2], ys[3]);
+                        dok[i] = true;
                     }
                 }
+                if (h == DG - 1) PL_MARK();
+                // dZ = dy * act'(y), applied only after EVERY load of the item (of the half) has been issued
+#pragma unroll
+                for (int u = 0; u < DN; ++u) {
+                    const int i = h * DN + u;
+                    dv[i] = to_f4(dvr[i]);
+                    if (MASK) {
+                        yv[i] = to_f4(yvr[i]); vmask(dv[i], yv[i], P.alpha, P.vmax);
+                        if constexpr (sizeof(T) == 2) {
+                            // bf16 mode: dz is a bf16 tensor everywhere else (hand-over, pre-masked gradients, the bf16 kernels):
+                            // round the product here too, so that every path multiplies the same numbers
+                            dv[i].x = bf2f(f2bf(dv[i].x)); dv[i].y = bf2f(f2bf(dv[i].y));
+                            dv[i].z = bf2f(f2bf(dv[i].z)); dv[i].w = bf2f(f2bf(dv[i].w));
+                        }
+                    }
+                    dv[i] = vsel(dok[i], dv[i]);
+                }
+                // DLWPCS_CONV_REUSE_DZ (fp32 tensors, C_out % 4 == 0): the workers of ci tile 0 see every dZ element exactly
+                // once -> they hand dz to the data-gradient kernel that follows
+                if constexpr (MASK && sizeof(T) == 4) {
+                    if (W.dz_out != nullptr && cit == 0 && vec_dy) {
+                        float *dzb = reinterpret_cast<float *>(W.dz_out) + rowbase;
+#pragma unroll
+                        for (int u = 0; u < DN; ++u) {
+                            const int i = h * DN + u;
+                            const int e = ptid + i * NCT;
+                            const int kk = e >> 3, co = cot * 32 + (e & 7) * 4;
+                            if (kk < cur.npix && co < P.Cout) *reinterpret_cast<float4 *>(dzb + (size_t)kk * P.Cout + co) = dv[i];
+                        }
+                    }
+                }
+                if constexpr (DG > 1) { dz_store(h * DN); asm volatile("" ::: "memory"); }
             }
             // ---- registers -> LDS
-#pragma unroll
-            for (int i = 0; i < IT_X; ++i) {
-                const int e = ptid + i * NCT;
-                if (e < cur.nitems) st_f32(buf + (e / QX) * XS + (ptid % QX) * VW, vsel(xok[i], xv[i]));
-            }
-#pragma unroll
-            for (int i = 0; i < IT_DY; ++i) {
-                const int e = ptid + i * NCT;
-                if (e * 4 < pix_cap * 32) *reinterpret_cast<float4 *>(buf + x_floats + e * 4) = dv[i];
-                if (want_bias) { bsum.x += dv[i].x; bsum.y += dv[i].y; bsum.z += dv[i].z; bsum.w += dv[i].w; }
-            }
+            if constexpr (XG == 1) x_store(0);
+            if constexpr (DG == 1) dz_store(0);
             PL_MARK();
             __syncthreads();            // B_k: item k is in LDS
             cur = nxt;
