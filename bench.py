@@ -390,6 +390,28 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
 
     for _ in range(max(args.warmup, 3)):      # >= 3: eager warm-up, graph capture, first replay
         run_step(st)
+    # N > 1: the exchange as ONE all-reduce behind the backward pass, or in two buckets with the first one in flight during the
+    # encoder-side half of the backward pass (Model.exchange_buckets).  Which is faster depends on how RCCL's workgroups share
+    # the CUs with the persistent kernels: both are timed here (untimed region, every rank takes the same MAX-over-ranks
+    # decision), the faster one is what the timed region below runs; both numbers go into the JSON line.
+    bucket_trials = None
+    if world > 1 and st['train'] and os.environ.get('DLWPCS_EXCHANGE_BUCKETS') is None:
+        bucket_trials = {}
+        for nb in (1, 2):
+            model.exchange_buckets = nb
+            model._graphs.clear()
+            model._seen_batch.clear()
+            for _ in range(4):
+                run_step(st)
+            timed(20)
+            bucket_trials[nb] = timed(100) / 100
+        best = min(bucket_trials, key=bucket_trials.get)
+        if best != model.exchange_buckets:
+            model.exchange_buckets = best
+            model._graphs.clear()
+            model._seen_batch.clear()
+            for _ in range(4):
+                run_step(st)
     k_elapsed = timed(args.steps)             # the contract's window: exactly K steps
     est = k_elapsed / args.steps
     per_block = max(args.steps, int(np.ceil(args.min_block_s / max(est, 1e-9))))
@@ -420,6 +442,16 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
         self_check['smi_utilization_percent'] = None
         self_check['smi_note'] = 'torch.cuda.utilization unavailable: %s' % type(exc).__name__
     ar_us = allreduce_probe(model, world) if st['train'] else None
+    # how much of the exchange the step actually waits for: the same blocks with the all-reduce calls turned into no-ops
+    # (DLWPCS_EXCHANGE_SKIP: timing only -- the replicas diverge, so this runs after everything that is reported)
+    noex_s = None
+    if world > 1 and st['train']:
+        os.environ['DLWPCS_EXCHANGE_SKIP'] = '1'
+        try:
+            timed(per_block)
+            noex_s = float(np.median([timed(per_block) / per_block for _ in range(3)]))
+        finally:
+            os.environ.pop('DLWPCS_EXCHANGE_SKIP', None)
     # the roofline pass runs eager optimisation steps (gradient all-reduce included): EVERY rank takes part
     agg = roofline_pass(st) if with_roofline else None
     if rank != 0:
@@ -458,8 +490,18 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
         result['exchange'] = {'allreduce_us': None if ar_us is None else round(ar_us, 1),
                               'bytes': int(model._flat_grads.numel() * 4) if st['train'] else 0,
                               'backend': torch.distributed.get_backend(), 'rccl_ranks': torch.distributed.get_world_size(),
-                              'overlap': 'none: the all-reduce runs between the fwd+bwd graph and the optimizer graph; '
-                                         'allreduce_us is therefore fully exposed in ms_per_step'}
+                              'buckets': 2 if (st['train'] and getattr(model, '_did_split', False)) else 1,
+                              'bucket_trials_ms_per_step': None if not bucket_trials else
+                              {str(k): round(1e3 * v, 4) for k, v in bucket_trials.items()},
+                              'exposed_us': None if noex_s is None else round(1e6 * (step_s - noex_s), 1),
+                              'ms_per_step_without_exchange': None if noex_s is None else round(1e3 * noex_s, 4),
+                              'overlap': 'buckets = 2: the decoder-side gradients are summed over the ranks (RCCL, the process '
+                                         'group\'s stream) while the encoder-side half of the backward pass and its weight '
+                                         'gradients run; the second bucket and the optimizer graph wait for both.  buckets = 1: '
+                                         'one all-reduce between the fwd+bwd graph and the optimizer graph.  Both were timed '
+                                         '(bucket_trials_ms_per_step), the faster one ran. '
+                                         'allreduce_us = ONE all-reduce of the whole buffer on an idle GPU; exposed_us = '
+                                         'ms_per_step minus the same step with the all-reduce calls skipped'}
     if with_roofline and agg:
         # per kernel: the roofline that bounds it = the larger of (algorithmic flops / matrix peak of the instruction it
         # issues) and (algorithmic bytes / HBM peak); frac = that bound time / measured time

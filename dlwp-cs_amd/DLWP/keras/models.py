@@ -66,6 +66,12 @@ class Model(object):
         self.fuse_adam = os.environ.get('DLWPCS_FUSE_ADAM', '1') == '1'
         # ring fix-up of a pooled tensor's gradient inside the pooling adjoint (dlwpcs_avgpool2_bwd_ring)
         self.fold_ring = os.environ.get('DLWPCS_FOLD_RING', '1') == '1'
+        # data-parallel exchange in two buckets (exchange_buckets = 2 / DLWPCS_EXCHANGE_BUCKETS=2): the gradients of the
+        # decoder-side layers are summed over the ranks WHILE the encoder-side half of the backward pass runs.  Default 1: one
+        # all-reduce behind the whole backward pass -- whether the overlap pays depends on how RCCL's workgroups share the
+        # CUs with the persistent one-workgroup-per-CU kernels, which only a multi-GPU node can show; bench.py times both
+        # at N > 1 and runs the faster.  (The split step also runs at world size 1, for the tests.)
+        self.exchange_buckets = int(os.environ.get('DLWPCS_EXCHANGE_BUCKETS', '1'))
         self._stager = None                 # pinned-memory / copy-stream feed of fit() on host arrays (keras/staging.py)
         # training step: output layer + loss + loss gradient + the layer's data gradient as one launch (ops.head_mse)
         self.fuse_head_loss = os.environ.get('DLWPCS_FUSE_HEAD', '1') == '1'
@@ -236,6 +242,44 @@ class Model(object):
                     and steps[r[0]][4] != st[1] and not steps[r[0]][5]:
                 self._defer_ring.add(r[0])
 
+    def _plan_exchange(self):
+        """Two-bucket exchange: (first step of bucket A, element offset of bucket A in the flat gradient buffer) or None.
+        Bucket A = the weights of the steps from the cut on (the decoder side: their gradients are final first), bucket B the
+        rest; the cut is the latest step from which on at least 40 % of the parameters lie.  The flat buffers are in layer
+        (= execution) order, so each bucket is one contiguous slice -- checked, None if a model breaks that."""
+        if self._exchange_cut is not None:
+            return self._exchange_cut or None
+        self._exchange_cut = False
+        if self._flat_grads is None:
+            return None
+        base = self._flat_grads.data_ptr()
+        spans = []                      # per step: (lo, hi) element range of its layer's gradients in the flat buffer
+        for st in self._plan:
+            ws = [w for w in getattr(st[2], '_weights', []) if w.requires_grad and w.grad is not None]
+            if ws:
+                lo = min((w.grad.data_ptr() - base) // 4 for w in ws)
+                hi = max((w.grad.data_ptr() - base) // 4 + w.numel() for w in ws)
+                spans.append((lo, hi))
+            else:
+                spans.append(None)
+        total = sum(hi - lo for sp in spans if sp for lo, hi in [sp])
+        if total == 0:
+            return None
+        acc, cut = 0, None
+        for i in range(len(spans) - 1, 0, -1):
+            if spans[i]:
+                acc += spans[i][1] - spans[i][0]
+                if acc >= 0.4 * total:
+                    cut = i
+                    break
+        if cut is None or not any(spans[:cut]):
+            return None
+        lo_a = min(sp[0] for sp in spans[cut:] if sp)
+        if any(sp and sp[1] > lo_a for sp in spans[:cut]):
+            return None                 # a layer applied on both sides, or an unusual layer order: single bucket
+        self._exchange_cut = (cut, int(lo_a) // 64 * 64)
+        return self._exchange_cut
+
     def _premask_on(self):
         return (self.compute_dtype == 'bfloat16' and torch.is_grad_enabled()
                 and os.environ.get('DLWPCS_PREMASK', '1') == '1')
@@ -293,7 +337,20 @@ class Model(object):
         values = {t.uid: v for t, v in zip(self.inputs, inputs)}
         self._fused_outputs = set()         # uids whose entry of the returned list is the (2,) stats tensor of ops.head_mse
         pm = self._premask if self._premask_on() else {}
+        cut = getattr(self, '_record_cut', None)
+        self._cut_tensors = []
         for i, st in enumerate(self._plan):
+            if cut is not None and i == cut:
+                # split backward pass (two-bucket exchange): the tensors alive here that a step from here on READS -- the
+                # first half of the backward pass stops at them (an aliased skip tensor is its alias by now)
+                need, seen = set(), set()
+                for s2 in self._plan[cut:]:
+                    ins = [s2[3], s2[4]] if s2[0] == 'fused_conv' else ([s2[3]] if s2[0] == 'pool_skip' else list(s2[3]))
+                    need.update(u for u in ins if u is not None)
+                for u, v in values.items():
+                    if u in need and isinstance(v, torch.Tensor) and v.requires_grad and id(v) not in seen:
+                        seen.add(id(v))
+                        self._cut_tensors.append(v)
             if st[0] == 'fused_conv':
                 _, out_uid, lay, s0, s1, up0, act, alpha, vmax = st
                 m0, m1 = self._src_mask[i]
@@ -306,6 +363,8 @@ class Model(object):
                 _, out_uid, lay, in_uid = st
                 values[out_uid], values[in_uid] = ops.avgpool2_skip(values[in_uid],
                                                                      pm.get(in_uid) if self._src_mask[i] else None)
+                if cut is not None and i < cut:
+                    values[in_uid] = ops.detour(values[in_uid])     # split backward pass: see ops._Detour
             else:
                 _, out_uid, lay, in_uids, takes_list = st
                 args = [values[u] for u in in_uids]
@@ -391,7 +450,9 @@ class Model(object):
                 k += 1
             l._rebind(new)
         self._flat_params, self._flat_grads = flat, grads
+        self._flat_len = off
         self._n_params = total
+        self._exchange_cut = None
 
     # -------------------------------------------------------------------------------------------------------------- #
     # compile / train
@@ -470,7 +531,24 @@ class Model(object):
     def _loss_and_backward(self, inputs, targets, train=True, fuse_update=None):
         """fuse_update = grad_scale | None: with a value, the optimizer step may ride in the reduction of the batched weight
         gradients (ops.flush_wgrad_batch); self._update_done says whether it did."""
+        gen = self._loss_and_backward_gen(inputs, targets, train, fuse_update, split=False)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as e:
+            return e.value
+
+    def _split_wanted(self):
+        """Two-bucket exchange for this step?"""
+        return self.exchange_buckets == 2 and self._plan_exchange() is not None
+
+    def _loss_and_backward_gen(self, inputs, targets, train=True, fuse_update=None, split=False):
+        """Generator form of the step: with split=True (and a usable cut, see _plan_exchange) it yields ONCE, after the
+        gradients of bucket A (decoder side) are final in the flat gradient buffer, so that the caller can start their
+        all-reduce -- or end a hipGraph capture -- before the encoder-side half of the backward pass is issued.  Returns the
+        stats tensor (StopIteration.value)."""
         self._update_done = False
+        self._did_split = False
         if len(targets) != len(self.outputs):
             raise ValueError('Error when checking model target: expected %d target arrays, got %d'
                              % (len(self.outputs), len(targets)))
@@ -478,9 +556,12 @@ class Model(object):
         if train and self.fuse_head_loss:
             fuse = {o.uid: (t, w) for o, t, w in zip(self.outputs, targets, self.loss_weights)}
             ops.DIRECT_PARAM_GRADS = True       # (head_mse_applicable checks it: the fused step needs the flat gradient buffer)
+        cutplan = self._plan_exchange() if (train and split) else None
+        self._record_cut = cutplan[0] if cutplan else None
         try:
             outs = self._forward(inputs, fuse_targets=fuse)
         finally:
+            self._record_cut = None
             if fuse is not None:
                 ops.DIRECT_PARAM_GRADS = False
         fused = getattr(self, '_fused_outputs', set()) if fuse is not None else set()
@@ -499,10 +580,23 @@ class Model(object):
             ops.drop_wgrad_batch()
             ops.drop_pending_rings()
             try:
-                torch.autograd.backward(stats, ones)
+                cut = [t for t in self._cut_tensors] if cutplan else []
+                self._cut_tensors = []
+                if cut:
+                    # bucket A: backward pass down to the cut, its weight gradients reduced; then the caller's turn
+                    gcut = torch.autograd.grad(stats, cut, ones, allow_unused=True)
+                    ops.flush_wgrad_batch(None)
+                    ops.flush_deferred_reduce(dev)
+                    self._did_split = True
+                    yield None
+                    pairs = [(t, g) for t, g in zip(cut, gcut) if g is not None]
+                    if pairs:
+                        torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+                else:
+                    torch.autograd.backward(stats, ones)
                 adam = None
                 if (fuse_update is not None and self.fuse_adam and not ops._deferred and self.optimizer is not None
-                        and self._world == 1):
+                        and self._world == 1 and not cut):
                     opt = self.optimizer
                     opt._ensure_state(self._flat_params)
                     if not torch.cuda.is_current_stream_capturing():
@@ -526,6 +620,11 @@ class Model(object):
             return stats[0].detach().view(1, 2)                 # no copy launch for the single-output case
         return torch.stack([s.detach() for s in stats])
 
+    def _exchange_slices(self):
+        """(bucket A, bucket B) views of the flat gradient buffer (see _plan_exchange)."""
+        lo = self._plan_exchange()[1]
+        return self._flat_grads[lo:], self._flat_grads[:lo]
+
     def _apply_gradients(self):
         scale = parallel.allreduce_gradients(self._flat_grads)  # RCCL over xGMI: one flat 2.7 MB buffer per step
         self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=scale)
@@ -534,6 +633,24 @@ class Model(object):
         self._flat_grads.zero_()
         self._grads_clean = False                               # the gradients stay readable after an eager step
         # (an eager step keeps its gradients readable: the optimizer is not fused into the reduction here)
+        if self._split_wanted():
+            gen = self._loss_and_backward_gen(inputs, targets, True, None, split=True)
+            ha = None
+            try:
+                next(gen)                                       # ... the gradients of bucket A are final
+                ha = parallel.allreduce_start(self._exchange_slices()[0])
+                next(gen)
+                raise RuntimeError('the split step yielded twice')
+            except StopIteration as e:
+                stats = e.value
+            if self._did_split:
+                hb = parallel.allreduce_start(self._exchange_slices()[1])
+                parallel.allreduce_wait(ha)
+                parallel.allreduce_wait(hb)
+                self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0 / self._world)
+                return stats
+            self._apply_gradients()
+            return stats
         stats = self._loss_and_backward(inputs, targets, True)
         self._apply_gradients()
         return stats
@@ -563,7 +680,16 @@ class Model(object):
         self.optimizer.sync_hyper(g['grad_scale'])             # lr / betas changed since the last replay? (20-byte copy)
         g['fwd_bwd'].replay()
         if g['update'] is not None:
-            parallel.allreduce_gradients(self._flat_grads)      # between the two graphs (scale is baked into 'update')
+            if g.get('bwd_b') is not None:
+                # two buckets: the decoder-side gradients travel while the encoder-side half of the backward pass runs
+                sa, sb = self._exchange_slices()
+                ha = parallel.allreduce_start(sa)
+                g['bwd_b'].replay()
+                hb = parallel.allreduce_start(sb)
+                parallel.allreduce_wait(ha)
+                parallel.allreduce_wait(hb)
+            else:
+                parallel.allreduce_gradients(self._flat_grads)  # between the two graphs (scale is baked into 'update')
             g['update'].replay()
         self._grads_clean = True                                # the optimizer launch also cleared the gradient buffer
         return g['stats']
@@ -579,6 +705,8 @@ class Model(object):
         self.optimizer.sync_hyper(grad_scale)                   # the captured Adam launch reads them from device memory
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        g1b = None
+        split = self._split_wanted()
         # the gradient buffer is cleared by the optimizer launch of the previous replay (DLWPCS_ADAM_ZERO_GRAD), once
         # here for the first one: the step graph needs no fill launch
         self._flat_grads.zero_()
@@ -593,14 +721,34 @@ class Model(object):
         # capture rules then (a foreign call must not invalidate the capture).
         mode = 'thread_local' if self._world > 1 else 'global'
         try:
-            with torch.cuda.graph(g1, capture_error_mode=mode):
-                stats = self._loss_and_backward(static_in, static_tg, True,
-                                                fuse_update=grad_scale if self._world == 1 else None)
-                if self._world == 1 and not self._update_done:
-                    # no exchange step: the update rides in the same graph (no inter-graph gap); normally INSIDE the reduction
-                    # of the batched weight gradients, as a launch of its own when those do not cover every parameter
-                    self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
-            if self._world == 1:
+            if split:
+                # forward + decoder-side backward | encoder-side backward: two graphs, the first bucket's all-reduce is
+                # started between them (train_on_device_batch)
+                gen = self._loss_and_backward_gen(static_in, static_tg, True, None, split=True)
+                stats = None
+                with torch.cuda.graph(g1, capture_error_mode=mode):
+                    try:
+                        next(gen)
+                    except StopIteration as e:
+                        stats = e.value
+                if stats is None:
+                    g1b = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1b, pool=g1.pool(), capture_error_mode=mode):
+                        try:
+                            next(gen)
+                            raise RuntimeError('the split step yielded twice')
+                        except StopIteration as e:
+                            stats = e.value
+            else:
+                with torch.cuda.graph(g1, capture_error_mode=mode):
+                    stats = self._loss_and_backward(static_in, static_tg, True,
+                                                    fuse_update=grad_scale if self._world == 1 else None)
+                    if self._world == 1 and not self._update_done:
+                        # no exchange step: the update rides in the same graph (no inter-graph gap); normally INSIDE the
+                        # reduction of the batched weight gradients, as a launch of its own when those do not cover every
+                        # parameter
+                        self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
+            if self._world == 1 and not split:
                 g2 = None
             else:
                 with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
@@ -608,7 +756,7 @@ class Model(object):
         finally:
             if gc_was_enabled:
                 gc.enable()
-        entry = {'fwd_bwd': g1, 'update': g2, 'inputs': static_in, 'targets': static_tg, 'stats': stats,
+        entry = {'fwd_bwd': g1, 'bwd_b': g1b, 'update': g2, 'inputs': static_in, 'targets': static_tg, 'stats': stats,
                  'grad_scale': grad_scale}
         self._graphs[key] = entry
         return entry

@@ -831,6 +831,25 @@ def avgpool2_skip(x, premask=None):
     return _AvgPool2Skip.apply(x, premask)
 
 
+class _Detour(torch.autograd.Function):
+    """Identity with a node of its own in the autograd graph, no launch in either direction.  The split backward pass of the
+    two-bucket exchange (DLWP.keras.Model) stops at the skip tensors; they are the SECOND output of the pooling node, and
+    torch.autograd.grad(..., inputs=[that output]) would run every node that reaches the pooling node through its FIRST output
+    as well (needed-ness is per node, not per edge) -- the whole encoder.  Behind a detour the capture point is a node only the
+    decoder reaches."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def detour(x):
+    return _Detour.apply(x)
+
+
 class _Upsample2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

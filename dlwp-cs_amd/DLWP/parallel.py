@@ -27,9 +27,31 @@ def allreduce_gradients(flat_grads):
     the update equals the gradient of the mean loss over the global batch (equal per-rank batch sizes).
     """
     w = world()[1]
-    if w > 1:
+    if w > 1 and exchange_enabled():
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     return 1.0 / w
+
+
+def exchange_enabled():
+    """False under DLWPCS_EXCHANGE_SKIP=1 (bench.py's timing of a step WITHOUT its exchange, to report how much of the
+    all-reduce is exposed; the replicas diverge, never set it for real training)."""
+    import os
+    return os.environ.get('DLWPCS_EXCHANGE_SKIP', '0') != '1'
+
+
+def allreduce_start(flat_slice):
+    """Start the sum of one bucket of the flat gradient buffer over all ranks and return a handle for allreduce_wait (None at
+    world size 1).  The collective runs on the process group's own stream behind everything enqueued on the current stream
+    so far (RCCL; with gloo on a helper thread), so the launches that follow on the current stream overlap it."""
+    if world()[1] > 1 and exchange_enabled() and flat_slice.numel():
+        return dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
+def allreduce_wait(handle):
+    """The current stream waits for the bucket (RCCL: a stream dependency, no host block)."""
+    if handle is not None:
+        handle.wait()
 
 
 def shard_bounds(n, rank=None, world_size=None):

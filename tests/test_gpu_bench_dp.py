@@ -29,6 +29,8 @@ def test_bench_two_ranks_share_one_gpu():
     assert r['scaling'] == 'weak' and 'roofline' in r and 'cpu_baseline' not in r
     ex = r['exchange']
     assert ex['rccl_ranks'] == 2 and ex['backend'] == 'gloo' and ex['allreduce_us'] > 0 and ex['bytes'] > 0
+    assert ex['buckets'] in (1, 2) and set(ex['bucket_trials_ms_per_step']) == {'1', '2'}
+    assert ex['exposed_us'] is not None and ex['ms_per_step_without_exchange'] > 0
     assert len(r['timing']['block_ms_per_step']) == 3 and r['ms_per_step'] > 0
 
 
