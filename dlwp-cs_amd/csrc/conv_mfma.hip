@@ -755,28 +755,40 @@ __device__ __forceinline__ void pack_weights_range(const float *__restrict__ w_e
                                                    const float *__restrict__ w_np, T *__restrict__ out,
                                                    int KS, int Cin, int Cout, int K, int Ncol, int CG, int NTtot,
                                                    int flip, int transposed, size_t total, size_t first, size_t stride) {
+    // one 16-B lane entry (J consecutive K values of one column) per thread and iteration: the index arithmetic happens once
+    // per entry and the store is one 16-B write (element by element -- seven divisions and a 2-byte store per value -- the
+    // per-step packing of a whole model was ~11 us of integer arithmetic)
     constexpr int J = 16 / (int)sizeof(T);
     const int TAPS = KS * KS;
-    for (size_t e = first; e < total; e += stride) {
+    const size_t entries = total / J;
+    for (size_t e = first; e < entries; e += stride) {
         unsigned r = (unsigned)e;             // totals are a few million at most: 32-bit divisions (64-bit ones cost ~10x)
-        const int j = r % J; r /= J;
         const int n = r % 32; r /= 32;
         const int hf = r % 2; r /= 2;
         const int tap = r % TAPS; r /= TAPS;
         const int cg = r % CG; r /= CG;
         const int nt = r % NTtot; r /= NTtot;
         const int v = (int)r;
-        const int k = (cg * 2 + hf) * J + j, col = nt * 32 + n;
-        float val = 0.f;
-        if (k < K && col < Ncol) {
-            const float *w = v == 0 ? w_eq : (v == 1 ? w_pol : (w_np ? w_np : w_pol));
-            int ty = tap / KS, tx = tap % KS;
-            int ci = k, co = col;
-            if (transposed) { ty = KS - 1 - ty; tx = KS - 1 - tx; ci = col; co = k; }
-            if (v == 2 && flip) ty = KS - 1 - ty;
-            val = w[((size_t)(ty * KS + tx) * Cin + ci) * Cout + co];
+        const int k0 = (cg * 2 + hf) * J, col = nt * 32 + n;
+        const float *w = v == 0 ? w_eq : (v == 1 ? w_pol : (w_np ? w_np : w_pol));
+        int ty = tap / KS, tx = tap % KS;
+        if (transposed) { ty = KS - 1 - ty; tx = KS - 1 - tx; }
+        if (v == 2 && flip) ty = KS - 1 - ty;
+        const size_t tbase = (size_t)(ty * KS + tx) * Cin;
+        float val[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int k = k0 + j;
+            // forward: (ci, co) = (k, col); data gradient: (ci, co) = (col, k)
+            const size_t idx = transposed ? (tbase + col) * Cout + k : (tbase + k) * Cout + col;
+            val[j] = (k < K && col < Ncol) ? w[idx] : 0.f;
         }
-        if constexpr (sizeof(T) == 4) out[e] = val; else out[e] = f2bf(val);
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4 *>(out + e * J) = make_float4(val[0], val[1], val[2], val[3]);
+        } else {
+            *reinterpret_cast<uint4 *>(out + e * J) = make_uint4(f2bf2(val[0], val[1]), f2bf2(val[2], val[3]),
+                                                                f2bf2(val[4], val[5]), f2bf2(val[6], val[7]));
+        }
     }
 }
 
@@ -2445,8 +2457,12 @@ extern "C" int dlwpcs_pack_batch(const dlwpcs_pack_item *items_dev, int n_items,
     if (n_items < 0 || (n_items > 0 && !items_dev)) return fail(DLWPCS_E_INVALID, "pack_batch: bad arguments");
     if (n_items == 0) return DLWPCS_OK;
     if (n_items > 65535) return fail(DLWPCS_E_UNSUPPORTED, "pack_batch: more than 65535 items");
-    // 256 x n_items workgroups: the largest U-Net layer packs ~0.9 M values per direction, small layers exit at once
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(256, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
+    // 96 x n_items workgroups (the largest U-Net layer packs ~0.9 M values = ~110 k 16-B entries per direction, 4-5 per thread;
+    // small layers' surplus workgroups exit at once).  Measured on the unet2 step, 32 / 64 / 96 / 128 / 192 / 448 per item:
+    // 11.5 / 8.9 / 8.5 / 9.7 / 8.9 / 9.7 us.
+    static int gx = 0;
+    if (!gx) { const char *e = getenv("DLWPCS_PACK_GRID"); gx = e ? atoi(e) : 96; if (gx < 1) gx = 1; }
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)gx, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
     return check_launch("pack_batch");
 }
 
