@@ -479,6 +479,16 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                     bq[nt][jq] = P.bias ? *reinterpret_cast<const float4 *>(P.bias + (size_t)gq.v * P.NTtot * 32 +
                                                                              min(nt0 + wn * NT + nt, P.NTtot - 1) * 32 + 8 * jq + 4 * half)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            // The quads are waited for HERE, inside the (rare) branch: the empty asm redefines the registers, so nothing is
+            // pending on them at the join.  Otherwise the accumulator set-up below -- every tile -- sits behind a
+            // s_waitcnt vmcnt(0) (a load MAY be in flight; with the previous tile's stores in flight too the counter cannot be
+            // split), i.e. behind the acknowledgement of the previous epilogue's stores: ~1000 of a 5750-cycle tile period
+            // (s_memtime marks, 32 -> 32 at N = 48).
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq)
+                    asm volatile("" : "+v"(bq[nt][jq].x), "+v"(bq[nt][jq].y), "+v"(bq[nt][jq].z), "+v"(bq[nt][jq].w));
         }
         // the accumulators start at the bias (row = output channel in the MFMA's D[co][pixel] layout): no add in the epilogue
 #pragma unroll

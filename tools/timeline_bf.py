@@ -36,3 +36,15 @@ for which, t in (('consumer', tall[:, :32]), ('producer', tall[:, 32:])):
     d = np.diff(t[:, :k], axis=1).astype(np.float64)
     print('%s marks %d..%d  total median %.0f cycles' % (which, nz.min(), nz.max(), np.median(t[:, k - 1] - t[:, 0])))
     print('   ' + ' '.join('%6.0f' % np.median(d[:, i]) for i in range(min(k - 1, 31))))
+# absolute picture: offsets from the earliest mark of any workgroup (~ kernel start), in cycles
+t0 = min(tall[:, 0][tall[:, 0] > 0].min(), tall[:, 32][tall[:, 32] > 0].min())
+for which, t in (('consumer', tall[:, :32]), ('producer', tall[:, 32:])):
+    nz = (t > 0).sum(axis=1)
+    live = nz > 1
+    first = (t[live, 0] - t0).astype(np.float64)
+    second = (t[live, 1] - t0).astype(np.float64)
+    last = np.array([t[i, nz[i] - 1] - t0 for i in np.where(live)[0]], dtype=np.float64)
+    print('%s: first mark at %.0f / %.0f / %.0f (min/median/max), second mark %.0f / %.0f / %.0f, last mark %.0f / %.0f / %.0f, '
+          'marks per workgroup %d..%d' % (which, first.min(), np.median(first), first.max(), second.min(), np.median(second),
+                                         second.max(), last.min(), np.median(last), last.max(), nz[live].min(), nz[live].max()))
+print('kernel (HIP events around the backward call, dgrad mode only): %.1f us' % (1e3 * ev0.elapsed_time(ev1)) if mode == 'dgrad' else '')
