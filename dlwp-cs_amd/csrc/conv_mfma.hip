@@ -724,7 +724,9 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) frag_mma<T>(acc[mt][nt], fb[cur][nt], fa[cur][mt]);   // D[co][pixel]
             // (round 3: spreading the reads behind the individual MFMAs -- (MFMA, 2 reads), (MFMA, 1), (MFMA, 1) -- as in the batched
-            // weight-gradient kernel measured +-0 here: three MFMAs already hide four reads)
+            // weight-gradient kernel measured +-0 here: three MFMAs already hide four reads.  Keeping the 18 weight fragments of a
+            // one-chunk layer in 72 VGPRs (3 reads per 3 MFMAs instead of 4; a template variant of its own): the 32 -> 32 data
+            // gradient at N = 48 alone 28.5 -> 27.8 us, the whole training step +6 us -- dropped.)
             __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);                          // DS reads of step s+1 first
             __builtin_amdgcn_sched_group_barrier(0x008, MmaPerFrag<T>::N * MT * NT, 0);       // then the MFMAs of step s
         }
