@@ -66,6 +66,8 @@ class Model(object):
         self.fuse_adam = os.environ.get('DLWPCS_FUSE_ADAM', '1') == '1'
         # ring fix-up of a pooled tensor's gradient inside the pooling adjoint (dlwpcs_avgpool2_bwd_ring)
         self.fold_ring = os.environ.get('DLWPCS_FOLD_RING', '1') == '1'
+        # 2x2 average pooling written by the epilogue of the convolution in front of it (dlwpcs_conv_fwd_pool)
+        self.fuse_pool = os.environ.get('DLWPCS_FUSE_POOL', '1') == '1'
         # data-parallel exchange in two buckets (exchange_buckets = 2 / DLWPCS_EXCHANGE_BUCKETS=2): the gradients of the
         # decoder-side layers are summed over the ranks WHILE the encoder-side half of the backward pass runs.  Default 1: one
         # all-reduce behind the whole backward pass -- whether the overlap pays depends on how RCCL's workgroups share the
@@ -233,6 +235,14 @@ class Model(object):
             for u in ins:
                 if u is not None:
                     readers.setdefault(u, []).append(i)
+        # 2x2 pooling as a second output of the producing convolution (dlwpcs_conv_fwd_pool): the fused convolutions whose
+        # output's NEXT reader is a 'pool_skip' step (the by-product is taken by that step right away, see ops._POOLED)
+        self._pool_producers = set()
+        for i, st in enumerate(steps):
+            if st[0] == 'fused_conv':
+                r = readers.get(st[1], [])
+                if r and steps[r[0]][0] == 'pool_skip' and steps[r[0]][3] == st[1]:
+                    self._pool_producers.add(i)
         self._defer_ring = set()
         for i, st in enumerate(steps):
             if st[0] != 'pool_skip' or not (src_mask.get(i) and st[3] in self._premask):
@@ -339,6 +349,7 @@ class Model(object):
         pm = self._premask if self._premask_on() else {}
         cut = getattr(self, '_record_cut', None)
         self._cut_tensors = []
+        ops._POOLED.clear()
         for i, st in enumerate(self._plan):
             if cut is not None and i == cut:
                 # split backward pass (two-bucket exchange): the tensors alive here that a step from here on READS -- the
@@ -358,7 +369,8 @@ class Model(object):
                                                  act=act, alpha=alpha, vmax=vmax,
                                                  premask0=pm.get(s0) if m0 else None, premask1=pm.get(s1) if m1 else None,
                                                  dy_premasked=out_uid in pm,
-                                                 defer_ring0=bool(pm) and self.fold_ring and i in self._defer_ring)
+                                                 defer_ring0=bool(pm) and self.fold_ring and i in self._defer_ring,
+                                                 want_pool=self.fuse_pool and i in self._pool_producers)
             elif st[0] == 'pool_skip':
                 _, out_uid, lay, in_uid = st
                 values[out_uid], values[in_uid] = ops.avgpool2_skip(values[in_uid],

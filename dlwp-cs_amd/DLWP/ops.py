@@ -212,6 +212,10 @@ def wgrad_batch(entries, adam=None):
 # gradient tensor the convolution's backward returns; DLWP.keras.Model asks for it only where its plan guarantees that the next
 # reader of that tensor is the pooling node, and clears the table around every backward pass.
 _pending_ring = {}
+# Pooled by-products of the convolutions that ran with want_pool (dlwpcs_conv_fwd_pool), keyed by the address of the full-size
+# output; the pooling node that follows takes its entry (DLWP.keras.Model asks for it only when the next reader of that
+# output is such a node, and clears the table at the start of every forward pass).
+_POOLED = {}
 
 
 def drop_pending_rings():
@@ -396,8 +400,10 @@ class _CSConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, ksize, halo, up0, flip, act, alpha, vmax,
-                c0_valid=0, premask0=None, premask1=None, dy_premasked=False, defer_ring0=False):
-        """defer_ring0: the gradient of source 0 goes to a pooling node that adds the halo ring itself (see _pending_ring).
+                c0_valid=0, premask0=None, premask1=None, dy_premasked=False, defer_ring0=False, want_pool=False):
+        """want_pool: the 2x2 average pooling of y is produced as a by-product (dlwpcs_conv_fwd_pool) and parked in _POOLED for
+        the pooling node that follows (avgpool2_skip), which then launches nothing in its forward pass.
+        defer_ring0: the gradient of source 0 goes to a pooling node that adds the halo ring itself (see _pending_ring).
         premask0 / premask1 = (negative_slope, max_value) | None: src0 / src1 is the output of an activated layer that expects
         its gradient PRE-MASKED (multiplied by act'(src)): the backward applies it to dsrc0 / dsrc1.  dy_premasked: the gradient
         THIS node receives is already dz = dy * act'(y) (every consumer of y honours premask).  See dlwpcs_conv_bwd_data_masked."""
@@ -436,15 +442,20 @@ class _CSConv(torch.autograd.Function):
         packed = PREPACKED.get(id(w_eq))
         if packed is not None and packed[0] != d.dtype:
             packed = None
+        yp = None
+        if want_pool and halo and No % 2 == 0:
+            yp = torch.empty((B, 6, No // 2, No // 2, Cout), dtype=src0.dtype, device=src0.device)
+        wargs = ((ptr(packed[1]), 0, 0, ptr(packed[2]) if b_eq is not None else 0, 0, 0) if packed is not None else
+                 (ptr(w_eq), ptr(w_pol), ptr(w_np), ptr(b_eq), ptr(b_pol), ptr(b_np)))
         if packed is not None:
             d.flags |= nat.CONV_PREPACKED
-            check(lib().dlwpcs_conv_fwd(ctypes.byref(d), ptr(src0), ptr(src1), ptr(packed[1]), 0, 0,
-                                        ptr(packed[2]) if b_eq is not None else 0, 0, 0, ptr(y), ptr(table), ptr(ws),
-                                        ws.numel(), stream_ptr()), 'dlwpcs_conv_fwd')
+        if yp is not None:
+            check(lib().dlwpcs_conv_fwd_pool(ctypes.byref(d), ptr(src0), ptr(src1), *wargs, ptr(y), ptr(yp), ptr(table), ptr(ws),
+                                             ws.numel(), stream_ptr()), 'dlwpcs_conv_fwd_pool')
+            _POOLED[y.data_ptr()] = yp
         else:
-            check(lib().dlwpcs_conv_fwd(ctypes.byref(d), ptr(src0), ptr(src1), ptr(w_eq), ptr(w_pol), ptr(w_np),
-                                        ptr(b_eq), ptr(b_pol), ptr(b_np), ptr(y), ptr(table), ptr(ws), ws.numel(),
-                                        stream_ptr()), 'dlwpcs_conv_fwd')
+            check(lib().dlwpcs_conv_fwd(ctypes.byref(d), ptr(src0), ptr(src1), *wargs, ptr(y), ptr(table), ptr(ws),
+                                        ws.numel(), stream_ptr()), 'dlwpcs_conv_fwd')
         if premask0 is not None and premask1 is not None and tuple(premask0) != tuple(premask1):
             raise ValueError('cs_conv: both sources must share the activation parameters of their masks')
         ctx.premask = (premask0, premask1)
@@ -513,7 +524,7 @@ class _CSConv(torch.autograd.Function):
                     dn.flags &= ~nat.CONV_DEFER_RING0
             dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np = _weight_gradients(
                 dn, src0, src1, dz, None, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp)
-            return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 12
+            return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 13
         no_dgrad = dsrc0 is None and dsrc1 is None        # (first layer: the batched kernel applies act' itself)
         batching = (direct and WGRAD_BATCH and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(d)
                     and (d.act == nat.ACT_NONE or (no_dgrad and d.ksize == 3)))
@@ -541,7 +552,7 @@ class _CSConv(torch.autograd.Function):
             batch_mask_ok=no_dgrad)
         if reuse_dz:
             run_bwd_data()
-        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 12
+        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 13
 
 
 _ring_info_cache = {}
@@ -595,7 +606,7 @@ def pack_batch(items_dev, n_items):
 
 def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1=None, ksize=3, halo=True, up0=False,
             flip_north_pole=True, act=nat.ACT_NONE, alpha=0.0, vmax=0.0, premask0=None, premask1=None, dy_premasked=False,
-            defer_ring0=False):
+            defer_ring0=False, want_pool=False):
     if (w_np is None) != (b_np is None) and b_eq is not None:
         raise ValueError('cs_conv: north-pole kernel and bias must be given together')
     # Network inputs with a channel count that is not a multiple of the 16-B vector (7 variables; optionally 14 = 7 x 2):
@@ -615,7 +626,7 @@ def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1
             c0_valid = cin_w
     return _CSConv.apply(src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, int(ksize), bool(halo), bool(up0),
                          bool(flip_north_pole), int(act), float(alpha), float(vmax), int(c0_valid), premask0, premask1,
-                         bool(dy_premasked), bool(defer_ring0))
+                         bool(dy_premasked), bool(defer_ring0), bool(want_pool))
 
 
 # ------------------------------------------------------------------------------------------------------------------ #
@@ -777,8 +788,10 @@ class _AvgPool2Skip(torch.autograd.Function):
         if N % 2:
             raise ValueError('avgpool2: odd face size %d' % N)
         x = _c(x)
-        y = torch.empty((B, 6, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
-        check(lib().dlwpcs_avgpool2_fwd(ptr(x), ptr(y), B, N, C, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_avgpool2_fwd')
+        y = _POOLED.pop(x.data_ptr(), None)         # the producing convolution pooled in its epilogue (want_pool)
+        if y is None or tuple(y.shape) != (B, 6, N // 2, N // 2, C) or y.dtype != x.dtype:
+            y = torch.empty((B, 6, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
+            check(lib().dlwpcs_avgpool2_fwd(ptr(x), ptr(y), B, N, C, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_avgpool2_fwd')
         ctx.shape = (B, N, C)
         ctx.dtype = x.dtype
         ctx.premask = premask

@@ -67,6 +67,12 @@ struct ConvKParams {
     int *direct_done;           // HOST pointer: set to 1 by launch_conv_cfg when the kernel it launched honours d0 / d1
     int *mask_done;             // HOST pointer: bit 0 / 1 set when the launched kernel masks what it stores to d0 / d1
     int dry_run;                // host only: choose the configuration, report direct_done / mask_done, launch nothing
+    // Forward pass with the 2x2 average pooling of the output as a SECOND output (Azure/train_cs.py:282,287: AveragePooling3D
+    // behind the block's last convolution): (B,6,No/2,No/2,Cout), written by the epilogue out of the LDS patches (launch_conv_cfg
+    // checks the tiling: every consumer wave owns whole pairs of rows).  pool_done: HOST pointer, set to 1 when the launched
+    // kernel does it.
+    void *pool_out;
+    int *pool_done;
     int abl;                    // development only (-DDLWPCS_TIMELINE): epilogue ablation bits
     int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
     int tile_rows_max;          // rows reserved in LDS
@@ -437,6 +443,39 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         return (mm < gq.npix && c < P.Cout) ? (uint32_t)off * ES : ST_SKIP;
     };
 
+    constexpr int PROW = 32 * ES + 16;          // patch row: one pixel's 32 channels + pad
+    // pooling as a second output: one patch per M tile of the wave (all of them are read back once the wave's rows are complete)
+    const bool pooling = MODE != MODE_ZERO && P.pool_out != nullptr;
+    char *const patch0 = smem + patch_base + wave * (32 * PROW) * (pooling ? MT : 1);
+    const int patch_step = pooling ? 32 * PROW : 0;
+    // ---- pooled second output.  The wave's MT * 32 pixels are whole pairs of tile rows: pooled pixel pp of the wave is the
+    // mean of local pixels i00 = 2 * (pp / (No/2)) * No + 2 * (pp % (No/2)), i00 + 1, i00 + No, i00 + No + 1, read from the
+    // wave's MT patches (bf16 / fp32 values exactly as stored to `out`), summed like avgpool2_fwd_kernel: (a + b) + (c + d),
+    // x 0.25, rounded once -- the same bits as the separate launch.
+    constexpr int PITEMS = MT * 8 * LPP;            // 16-B vectors of the wave's pooled pixels
+    constexpr int PNP = (PITEMS + 63) / 64;         // passes
+    uint32_t plds0[PNP], plds1[PNP], pgo[NT][PNP];  // LDS offsets of i00 / i00 + No, byte offset in one sample of pool_out
+    auto pool_setup = [&](const Geo &gq) {
+        const int hN = P.No >> 1;
+#pragma unroll
+        for (int ps = 0; ps < PNP; ++ps) {
+            const int item = ps * 64 + lane;
+            const int pp = item / LPP, q = item % LPP;
+            const int prow = pp / hN, pcol = pp - prow * hN;
+            const int i00 = 2 * prow * P.No + 2 * pcol, i10 = i00 + P.No;
+            plds0[ps] = (uint32_t)((i00 >> 5) * (32 * PROW) + (i00 & 31) * PROW + q * 16);
+            plds1[ps] = (uint32_t)((i10 >> 5) * (32 * PROW) + (i10 & 31) * PROW + q * 16);
+            const int gm = gq.m0 + wm * MT * 32 + i00;
+            const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = (nt0 + wn * NT + nt) * 32 + q * (16 / ES);
+                const bool ok = pp < MT * 8 && wm * MT * 32 + i00 < gq.npix && c < P.Cout;
+                pgo[nt][ps] = ok ? (uint32_t)((((gq.f * hN + (oy >> 1)) * hN + (ox >> 1)) * P.Cout + c) * ES) : ST_SKIP;
+            }
+            if (pp >= MT * 8) { plds0[ps] = 0; plds1[ps] = 0; }
+        }
+    };
     // ---- per-tile set-up: LDS addresses and store offsets (rebuilt at (face, band) changes), bias quads (reloaded at face
     // variant changes), accumulators = bias
     auto setup = [&](const Geo &gq) {
@@ -453,6 +492,9 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                     base = ((oy - gq.y0) * P.W2 + ox) * RB;
                 }
                 abase[mt] = base + half * 16;
+            }
+            if constexpr (MODE != MODE_ZERO) {
+                if (pooling) pool_setup(gq);
             }
             if constexpr (SOFF) {
                 ssel = 0;
@@ -513,10 +555,8 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     //
     // Per (n tile, m tile) pair: 4 x "one quad -> patch" then NPS x "one store pass out of the patch" (epi_slice, called
     // with compile-time-constant i from a fully unrolled loop).
-    constexpr int PROW = 32 * ES + 16;          // patch row: one pixel's 32 channels + pad
     constexpr int SPP = 4 + NPS;                // slices per (n tile, m tile) pair
     constexpr int NSLICE = NT * MT * SPP;
-    char *const patch = smem + patch_base + wave * (32 * PROW);
     // no activation == ReLU(alpha = 1, max = +inf): the epilogue applies the activation unconditionally and stays
     // straight-line (a branch per quad chops it into 5-instruction blocks whose dependent chains cannot interleave).
     // FAST (0 <= alpha <= 1, max >= 0, i.e. every activation of the reference's models and "none"): the activation is
@@ -587,9 +627,36 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
                     }
         }
     };
+    auto pool_pass = [&](int nt, rsrc_t d_pool) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < PNP; ++ps) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(patch0 + plds0[ps]);
+            const uint4 b = *reinterpret_cast<const uint4 *>(patch0 + plds0[ps] + PROW);
+            const uint4 c = *reinterpret_cast<const uint4 *>(patch0 + plds1[ps]);
+            const uint4 d = *reinterpret_cast<const uint4 *>(patch0 + plds1[ps] + PROW);
+            uint4 o;
+            if constexpr (ES == 4) {
+                auto avg = [](uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+                    return __float_as_uint(((__uint_as_float(x) + __uint_as_float(y)) + (__uint_as_float(z) + __uint_as_float(w))) * 0.25f);
+                };
+                o = make_uint4(avg(a.x, b.x, c.x, d.x), avg(a.y, b.y, c.y, d.y), avg(a.z, b.z, c.z, d.z), avg(a.w, b.w, c.w, d.w));
+            } else {
+                auto avg2 = [](uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+                    const float lo = ((bf_lo(x) + bf_lo(y)) + (bf_lo(z) + bf_lo(w))) * 0.25f;
+                    const float hi = ((bf_hi(x) + bf_hi(y)) + (bf_hi(z) + bf_hi(w))) * 0.25f;
+                    return f2bf2(lo, hi);
+                };
+                o = make_uint4(avg2(a.x, b.x, c.x, d.x), avg2(a.y, b.y, c.y, d.y), avg2(a.z, b.z, c.z, d.z), avg2(a.w, b.w, c.w, d.w));
+            }
+            bst128(o, d_pool, pgo[nt][ps]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     auto epi_slice = [&](auto fast_tag, int i, const Geo &gq, rsrc_t d_out, rsrc_t d_0, rsrc_t d_1, const auto &A) {
         const int pr = i / SPP, k = i % SPP;
         const int nt = pr / MT, mt = pr % MT;
+        char *const patch = patch0 + mt * patch_step;
         if (k < 4) {
             const float4 v4 = quad(fast_tag, A[mt][nt], k);
             char *pp = patch + l31 * PROW + (8 * k + 4 * half) * ES;
@@ -629,6 +696,11 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             if (ps == NPS - 1) __builtin_amdgcn_wave_barrier();
         }
     };
+    auto pool_of = [&](const Geo &gq) {
+        const int ppix = 6 * (P.No >> 1) * (P.No >> 1);
+        return make_rsrc(pooling ? reinterpret_cast<T *>(P.pool_out) + (size_t)gq.b * ppix * P.Cout : nullptr,
+                         (uint32_t)(ppix * P.Cout * ES));
+    };
     auto epilogue_lines = [&](const Geo &gq, const auto &A) {
         TL_MARK();
         if constexpr (MOUT) {
@@ -646,16 +718,20 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
         }
         const rsrc_t d_out = out_of(gq);
         const rsrc_t d_0 = DIRECT ? d0_of(gq) : d_out, d_1 = DIRECT ? d1_of(gq) : d_out;
-        if (P.act != DLWPCS_ACT_LEAKY_CLIP) {
+        const rsrc_t d_pool = pool_of(gq);
+        // (the pooled output is written when the slices of an n tile are through: its patches are complete then)
+        auto run = [&](auto tag) {
 #pragma unroll
-            for (int i = 0; i < NSLICE; ++i) epi_slice(std::integral_constant<int, 2>{}, i, gq, d_out, d_0, d_1, A);
-        } else if (fast_act) {
-#pragma unroll
-            for (int i = 0; i < NSLICE; ++i) epi_slice(std::integral_constant<int, 1>{}, i, gq, d_out, d_0, d_1, A);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NSLICE; ++i) epi_slice(std::integral_constant<int, 0>{}, i, gq, d_out, d_0, d_1, A);
-        }
+            for (int i = 0; i < NSLICE; ++i) {
+                epi_slice(tag, i, gq, d_out, d_0, d_1, A);
+                if constexpr (MODE != MODE_ZERO) {
+                    if ((i + 1) % (MT * SPP) == 0 && pooling) pool_pass(i / (MT * SPP), d_pool);
+                }
+            }
+        };
+        if (P.act != DLWPCS_ACT_LEAKY_CLIP) run(std::integral_constant<int, 2>{});
+        else if (fast_act) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 0>{});
         TL_MARK();
     };
     // fallback (odd channel counts, or no LDS room for the patches): quads / scalars straight from the accumulators
@@ -2145,7 +2221,14 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     { const char *e = getenv("DLWPCS_ABL"); P.abl = e ? atoi(e) : 0; }
 #endif
     const size_t in_b = (size_t)P.tile_rows_max * P.W2 * (KC * ES + 16), w_b = (size_t)NTB * (KC / CGW) * KS * KS * 1024;
-    const size_t buf = in_b + w_b, patch_b = (size_t)(WM * WN) * 32 * (32 * ES + 16);
+    // pooled second output: every consumer wave must own whole PAIRS of tile rows (its 32 * MT pixels and the tile a multiple of
+    // two rows, all tiles full), whole 32-channel output tiles, and LDS room for one patch per M tile -- else the caller pools
+    // with a launch of its own (pool_done stays 0)
+    bool pool = MODE != MODE_ZERO && P.pool_out != nullptr && P.No % 2 == 0 && pix % (2 * P.No) == 0 && (32 * MT) % (2 * P.No) == 0 &&
+                face_pix % pix == 0 && P.Cout % 32 == 0 && P.Cout % (16 / ES) == 0;
+    const size_t buf = in_b + w_b;
+    size_t patch_b = (size_t)(WM * WN) * 32 * (32 * ES + 16);
+    if (pool && 2 * buf + patch_b * MT <= 160 * 1024) patch_b *= MT; else pool = false;
     size_t lds = 2 * buf + patch_b;                                              // + wave-private epilogue patches
     P.patches = 1;
     P.wstat = 0;
@@ -2153,7 +2236,9 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     if (nchunks > 2 && nchunks <= 4 && (tune_bits() & TUNE_CONV_WSTAT) && 2 * in_b + nchunks * w_b + patch_b <= 160 * 1024) {
         P.wstat = nchunks;                                                       // one resident weight area per chunk
         lds = 2 * in_b + nchunks * w_b + patch_b;
-    } else if (lds > 160 * 1024) { lds = 2 * buf; P.patches = 0; }               // large faces: direct quad stores instead
+    } else if (lds > 160 * 1024) { lds = 2 * buf; P.patches = 0; pool = false; } // large faces: direct quad stores instead
+    if (!pool) P.pool_out = nullptr;
+    if (P.pool_done) *P.pool_done = pool ? 1 : 0;
     if (MODE == MODE_ZERO && KS == 3 && P.patches && P.Cout % (16 / ES) == 0 && P.dsplit % (16 / ES) == 0) {
         if (P.direct_done) *P.direct_done = (P.d0 || P.d1) ? 1 : 0;             // the line-store epilogue honours d0 / d1
     } else {
@@ -2535,11 +2620,43 @@ static int head_mse_impl(const dlwpcs_conv_desc *d, const void *x, const void *w
     return check_launch("head_mse_step");
 }
 
+static int conv_fwd_impl(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
+                         const void *w_eq, const void *w_pol, const void *w_np,
+                         const void *b_eq, const void *b_pol, const void *b_np,
+                         void *y, const int32_t *table_dev,
+                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream, void *y_pooled, int *pool_done);
+
 extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
                                const void *w_eq, const void *w_pol, const void *w_np,
                                const void *b_eq, const void *b_pol, const void *b_np,
                                void *y, const int32_t *table_dev,
                                void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
+    return conv_fwd_impl(d, src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, y, table_dev, workspace, workspace_bytes, stream,
+                         nullptr, nullptr);
+}
+
+extern "C" int dlwpcs_avgpool2_fwd(const void *x, void *y, int B, int N, int C, int dtype, dlwpcs_stream_t stream);
+
+extern "C" int dlwpcs_conv_fwd_pool(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
+                                    const void *w_eq, const void *w_pol, const void *w_np,
+                                    const void *b_eq, const void *b_pol, const void *b_np,
+                                    void *y, void *y_pooled, const int32_t *table_dev,
+                                    void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
+    if (!y_pooled) return fail(DLWPCS_E_INVALID, "conv_fwd_pool: null pointer");
+    if (!d || !d->halo || d->N % 2) return fail(DLWPCS_E_INVALID, "conv_fwd_pool: needs a halo convolution on an even face size");
+    int done = 0;
+    int rc = conv_fwd_impl(d, src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, y, table_dev, workspace, workspace_bytes, stream,
+                           y_pooled, &done);
+    if (rc || done || d->B == 0) return rc;
+    // the tiling of this shape cannot pool in the epilogue: the pooling launch of its own, same result
+    return dlwpcs_avgpool2_fwd(y, y_pooled, d->B, d->N, d->Cout, d->dtype, stream);
+}
+
+static int conv_fwd_impl(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
+                         const void *w_eq, const void *w_pol, const void *w_np,
+                         const void *b_eq, const void *b_pol, const void *b_np,
+                         void *y, const int32_t *table_dev,
+                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream, void *y_pooled, int *pool_done) {
     int rc = validate(d, "conv_fwd");
     if (rc) return rc;
     if (!src0 || !w_eq || (!w_pol && !(d->flags & DLWPCS_CONV_PREPACKED)) || !y || !workspace)
@@ -2571,6 +2688,7 @@ extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, cons
     P.CG = ceil_div(Cin, cgw_of(d->dtype)); P.NTtot = NTtot; P.up0 = d->up0;
     P.mode = d->halo ? MODE_HALO : MODE_DIRECT;
     P.act = d->act; P.alpha = d->alpha; P.vmax = d->vmax;
+    P.pool_out = y_pooled; P.pool_done = pool_done;
     if (pw_applies(d)) {
         PwParams Q{};
         Q.in = (const bf16_t *)src0; Q.wpk = (const bf16_t *)wpk; Q.bias = b_eq ? bpk : nullptr; Q.out = (bf16_t *)y;

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DLWPCS_VERSION 102            /* 0.1.2: dlwpcs_wgrad_batch*, pre-masked gradients (dlwpcs_*_masked) */
+#define DLWPCS_VERSION 103            /* 0.1.3: dlwpcs_wgrad_batch*, pre-masked gradients (dlwpcs_*_masked), dlwpcs_conv_fwd_pool */
 
 /* error codes */
 #define DLWPCS_OK             0
@@ -167,6 +167,15 @@ int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d,
                     const void *b_eq, const void *b_pol, const void *b_np,
                     void *y, const int32_t *table_dev,
                     void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
+/* dlwpcs_conv_fwd + the 2x2 average pooling of its output (AveragePooling3D((1,2,2)) behind the block's last convolution,
+ * Azure/train_cs.py:282,287) as a SECOND output y_pooled (B,6,N/2,N/2,Cout): written by the convolution's epilogue where the
+ * tiling allows (every consumer wave owns whole pairs of rows: the U-Net levels at N = 48 / 24), by dlwpcs_avgpool2_fwd behind
+ * it otherwise -- the same bits either way.  Halo convolutions on even face sizes. */
+int dlwpcs_conv_fwd_pool(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
+                         const void *w_eq, const void *w_pol, const void *w_np,
+                         const void *b_eq, const void *b_pol, const void *b_np,
+                         void *y, void *y_pooled, const int32_t *table_dev,
+                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
 
 /* Gradients w.r.t. the sources.  dy: gradient w.r.t. the (post-activation) output y; y: the saved forward output
  * (needed when act != NONE: dz = dy * act'(.) is applied on load), NULL otherwise.

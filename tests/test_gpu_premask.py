@@ -349,3 +349,84 @@ def test_unet2_training_with_the_ring_folded_gives_the_same_bits():
             os.environ.pop('DLWPCS_FOLD_RING', None)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+@pytest.mark.parametrize('B,N,C0,C1,up0,Cout', [(2, 48, 32, 0, 0, 32), (3, 24, 64, 0, 0, 64), (2, 24, 32, 0, 0, 64),
+                                                 (2, 48, 14, 0, 0, 32), (2, 12, 64, 0, 0, 128), (2, 24, 64, 64, 1, 64),
+                                                 (1, 20, 16, 0, 0, 32), (2, 16, 8, 0, 0, 24)])
+def test_pooling_as_a_second_output_of_the_convolution(dtype, B, N, C0, C1, up0, Cout):
+    """dlwpcs_conv_fwd_pool against dlwpcs_conv_fwd + dlwpcs_avgpool2_fwd: the same bits in both outputs, whether the tiling lets
+    the epilogue pool (the U-Net levels at N = 48 / 24) or the call falls back to the pooling launch"""
+    import ctypes
+    from DLWP import _native as nat
+    dev = _dev()
+    rng = np.random.default_rng(N + C0 + Cout)
+    lib = nat.lib()
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    d = nat.ConvDesc(B=B, N=N, C0=C0, C1=C1, Cout=Cout, ksize=3, halo=1, up0=up0, flip_north_pole=1, act=nat.ACT_LEAKY_CLIP,
+                     alpha=ALPHA, vmax=VMAX, dtype=nat.BF16 if dtype == 'bf16' else nat.F32, flags=0, c0_valid=0)
+    n0 = N // 2 if up0 else N
+    s0 = torch.tensor(rng.standard_normal((B, 6, n0, n0, C0)) * 3, dtype=torch.float32, device=dev).to(tdt)
+    s1 = torch.tensor(rng.standard_normal((B, 6, N, N, C1)) * 3, dtype=torch.float32, device=dev).to(tdt) if C1 else None
+    cin = C0 + C1
+    w = [torch.tensor(rng.standard_normal((3, 3, cin, Cout)) / np.sqrt(9 * cin), dtype=torch.float32, device=dev) for _ in range(2)]
+    b = [torch.tensor(rng.standard_normal(Cout) * 0.2, dtype=torch.float32, device=dev) for _ in range(2)]
+    table = nat.halo_tables(N, 1, dev)[0]
+    ws = torch.empty(lib.dlwpcs_conv_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    y0 = torch.empty((B, 6, N, N, Cout), dtype=tdt, device=dev)
+    p0 = torch.empty((B, 6, N // 2, N // 2, Cout), dtype=tdt, device=dev)
+    y1, p1 = torch.full_like(y0, 7.0), torch.full_like(p0, 7.0)
+    args = (nat.ptr(s0), nat.ptr(s1), nat.ptr(w[0]), nat.ptr(w[1]), None, nat.ptr(b[0]), nat.ptr(b[1]), None)
+    nat.check(lib.dlwpcs_conv_fwd(ctypes.byref(d), *args, nat.ptr(y0), nat.ptr(table), nat.ptr(ws), ws.numel(), nat.stream_ptr()),
+              'conv_fwd')
+    nat.check(lib.dlwpcs_avgpool2_fwd(nat.ptr(y0), nat.ptr(p0), B, N, Cout, d.dtype, nat.stream_ptr()), 'avgpool2_fwd')
+    nat.check(lib.dlwpcs_conv_fwd_pool(ctypes.byref(d), *args, nat.ptr(y1), nat.ptr(p1), nat.ptr(table), nat.ptr(ws), ws.numel(),
+                                       nat.stream_ptr()), 'conv_fwd_pool')
+    torch.cuda.synchronize()
+    assert np.array_equal(_f32(y0), _f32(y1))
+    assert np.array_equal(_f32(p0), _f32(p1))
+    assert np.abs(_f32(p0)).max() > 0.1
+
+
+def test_unet2_training_with_the_pooling_fused_gives_the_same_bits():
+    """DLWPCS_FUSE_POOL on/off on a bf16 unet2 at N = 48 (where the epilogue can pool): no pooling launches in the forward pass,
+    same weights"""
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    from DLWP import _native as nat
+    dev = _dev()
+    backend.set_device('cuda:0')
+    N, C, B = 48, 14, 2
+    rng = np.random.default_rng(4)
+    x = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    t = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
+    w0, out = None, []
+    lib = nat.lib()
+    for fuse in ('0', '1'):
+        os.environ['DLWPCS_FUSE_POOL'] = fuse
+        try:
+            backend.set_compute_dtype('bfloat16')
+            try:
+                np.random.seed(5)
+                model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=32)
+            finally:
+                backend.set_compute_dtype('float32')
+            model.use_graphs = False
+            model.compile(optimizer='adam', loss='mse', metrics=['mae'])
+            if w0 is None:
+                w0 = model.get_weights()
+            model.set_weights(w0)
+            assert len(model._pool_producers) == 2
+            lib.dlwpcs_prof_reset()
+            lib.dlwpcs_prof_enable(1)
+            for _ in range(3):
+                stats = model.train_on_device_batch([x], [t])
+            torch.cuda.synchronize()
+            lib.dlwpcs_prof_enable(0)
+            lib.dlwpcs_prof_reset()
+            out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
+        finally:
+            os.environ.pop('DLWPCS_FUSE_POOL', None)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
