@@ -23,6 +23,7 @@ BF16 = 1
 MSE_TARGET_F32 = 0x100
 MSE_OVERWRITE = 0x200
 ADAM_ZERO_GRAD = 1
+HEAD_DEFER_STAGE2 = 2
 ACT_NONE = 0
 ACT_LEAKY_CLIP = 1
 CONV_ACCUMULATE_WGRAD = 1
@@ -68,6 +69,12 @@ class WgradItem(ctypes.Structure):
                                                                     'dw_np', 'db_eq', 'db_pol', 'db_np')]
 
 
+class LossTail(ctypes.Structure):
+    """struct dlwpcs_loss_tail (include/dlwpcs.h)"""
+    _fields_ = [('partial', ctypes.c_void_p), ('loss_out', ctypes.c_void_p), ('nblocks', ctypes.c_int32), ('inv_n', ctypes.c_float),
+                ('weight', ctypes.c_float), ('overwrite', ctypes.c_int32)]
+
+
 class GConvDesc(ctypes.Structure):
     """struct dlwpcs_gconv_desc (include/dlwpcs.h)"""
     _fields_ = [(n, ctypes.c_int32) for n in
@@ -105,6 +112,8 @@ PROTOTYPES = {
     'dlwpcs_wgrad_batch': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'dlwpcs_wgrad_batch_adam': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'dlwpcs_wgrad_batch_adam_tail': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dlwpcs_gconv_fwd': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),
     'dlwpcs_gconv_bwd_data': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 6),
     'dlwpcs_gconv_bwd_weights': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),
@@ -136,6 +145,8 @@ PROTOTYPES = {
     'dlwpcs_slice_channels': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_state_repack': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     'dlwpcs_head_mse_scratch_bytes': (c_size_t, []),
+    'dlwpcs_head_mse_tail': (c_int, [c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    'dlwpcs_loss_tail_run': (c_int, [c_void_p, c_void_p]),
     'dlwpcs_head_mse_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p]),
     'dlwpcs_head_mse_step_masked': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,

@@ -68,6 +68,8 @@ class Model(object):
         self.fold_ring = os.environ.get('DLWPCS_FOLD_RING', '1') == '1'
         # 2x2 average pooling written by the epilogue of the convolution in front of it (dlwpcs_conv_fwd_pool)
         self.fuse_pool = os.environ.get('DLWPCS_FUSE_POOL', '1') == '1'
+        # second stage of the fused head's loss reduction inside the step's last launch (dlwpcs_wgrad_batch_adam_tail)
+        self.fold_loss_tail = os.environ.get('DLWPCS_FOLD_LOSS_TAIL', '1') == '1'
         # data-parallel exchange in two buckets (exchange_buckets = 2 / DLWPCS_EXCHANGE_BUCKETS=2): the gradients of the
         # decoder-side layers are summed over the ranks WHILE the encoder-side half of the backward pass runs.  Default 1: one
         # all-reduce behind the whole backward pass -- whether the overlap pays depends on how RCCL's workgroups share the
@@ -570,10 +572,17 @@ class Model(object):
             ops.DIRECT_PARAM_GRADS = True       # (head_mse_applicable checks it: the fused step needs the flat gradient buffer)
         cutplan = self._plan_exchange() if (train and split) else None
         self._record_cut = cutplan[0] if cutplan else None
+        # the loss's last reduction stage rides in the step's last launch when that is the fused reduction + optimizer
+        ops.finish_loss_tail()
+        ops.DEFER_LOSS_TAIL = bool(train and fuse_update is not None and self.fuse_adam and self.batch_wgrad and self.fold_loss_tail
+                                   and self.optimizer is not None and self._world == 1 and not cutplan)
         try:
             outs = self._forward(inputs, fuse_targets=fuse)
         finally:
             self._record_cut = None
+            ops.DEFER_LOSS_TAIL = False
+            if not train:
+                ops.finish_loss_tail()
             if fuse is not None:
                 ops.DIRECT_PARAM_GRADS = False
         fused = getattr(self, '_fused_outputs', set()) if fuse is not None else set()
@@ -627,6 +636,7 @@ class Model(object):
                 if ops._pending_ring:
                     ops.drop_pending_rings()
                     raise RuntimeError('a deferred ring fix-up was not consumed by its pooling node (plan error)')
+                ops.finish_loss_tail()              # (no fused reduction + optimizer launch took it: its own launch)
                 ops.join_side_stream(stats[0].device)
         if len(stats) == 1:
             return stats[0].detach().view(1, 2)                 # no copy launch for the single-output case

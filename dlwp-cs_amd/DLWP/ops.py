@@ -126,6 +126,20 @@ def drop_wgrad_batch():
     del _wb_pending[:]
 
 
+# The fused head's loss is finished (second stage of its reduction) by the LAST launch of the training step when that is the
+# fused weight-gradient reduction + optimizer (dlwpcs_wgrad_batch_adam_tail): DEFER_LOSS_TAIL is set by DLWP.keras.Model for such
+# steps, _HeadMSE.forward then leaves a dlwpcs_loss_tail here; whoever ends the step without that launch runs finish_loss_tail().
+DEFER_LOSS_TAIL = False
+_pending_tail = []
+
+
+def finish_loss_tail():
+    """Run a deferred loss tail as a launch of its own (no fused reduction + optimizer launch took it)."""
+    while _pending_tail:
+        tail, keep = _pending_tail.pop()
+        check(lib().dlwpcs_loss_tail_run(ctypes.byref(tail), stream_ptr()), 'dlwpcs_loss_tail_run')
+
+
 def flush_wgrad_batch(adam=None):
     """Run the queued layers.  adam = (flat params, flat grads, m, v, state {t-1, ticket}, hyper {lr, b1, b2, eps, scale},
     number of parameter elements) asks for the optimizer fused into the reduction (dlwpcs_wgrad_batch_adam): done -- and True
@@ -198,6 +212,12 @@ def wgrad_batch(entries, adam=None):
         ws = _workspace(ws_bytes, dev, 'wgrad_batch')
         if adam is not None:
             p, g, m, v, state, hyper = adam
+            if len(_pending_tail) == 1:
+                tail, keep = _pending_tail.pop()            # the step's loss is finished by this launch
+                check(lib().dlwpcs_wgrad_batch_adam_tail(arr, len(chunk), host, ptr(plan_dev), ptr(ws), ws.numel(), ptr(p), ptr(g),
+                                                         ptr(m), ptr(v), g.numel(), ptr(state), ptr(hyper), ctypes.byref(tail),
+                                                         stream_ptr()), 'dlwpcs_wgrad_batch_adam_tail')
+                continue
             check(lib().dlwpcs_wgrad_batch_adam(arr, len(chunk), host, ptr(plan_dev), ptr(ws), ws.numel(), ptr(p), ptr(g), ptr(m),
                                                 ptr(v), g.numel(), ptr(state), ptr(hyper), stream_ptr()),
                   'dlwpcs_wgrad_batch_adam')
@@ -1087,16 +1107,23 @@ class _HeadMSE(torch.autograd.Function):
         out = torch.empty(2, dtype=torch.float32, device=x.device)
         dy = torch.empty((B, 6, N, N, Cout), dtype=x.dtype, device=x.device)
         dx = torch.empty_like(x)
+        defer = DEFER_LOSS_TAIL and not _pending_tail          # (one scratch buffer per device: one deferred tail at a time)
+        ow = 1 | (nat.HEAD_DEFER_STAGE2 if defer else 0)
         if premask is not None:
             check(lib().dlwpcs_head_mse_step_masked(ctypes.byref(d), ptr(x), ptr(packed[1]),
                                                     ptr(packed[2]) if b_eq is not None else 0, ptr(packed[3]), ptr(target),
-                                                    float(weight), ptr(dy), ptr(dx), ptr(out), 1, ptr(scratch),
+                                                    float(weight), ptr(dy), ptr(dx), ptr(out), ow, ptr(scratch),
                                                     float(premask[0]), float(premask[1]), stream_ptr()),
                   'dlwpcs_head_mse_step_masked')
         else:
             check(lib().dlwpcs_head_mse_step(ctypes.byref(d), ptr(x), ptr(packed[1]), ptr(packed[2]) if b_eq is not None else 0,
-                                             ptr(packed[3]), ptr(target), float(weight), ptr(dy), ptr(dx), ptr(out), 1,
+                                             ptr(packed[3]), ptr(target), float(weight), ptr(dy), ptr(dx), ptr(out), ow,
                                              ptr(scratch), stream_ptr()), 'dlwpcs_head_mse_step')
+        if defer:
+            tail = nat.LossTail()
+            check(lib().dlwpcs_head_mse_tail(ctypes.byref(d), float(weight), 1, ptr(scratch), ptr(out), ctypes.byref(tail)),
+                  'dlwpcs_head_mse_tail')
+            _pending_tail.append((tail, (scratch, out)))
         ctx.desc = d
         ctx.params = (w_eq, w_pol, None, b_eq, b_pol, None)
         ctx.save_for_backward(x, dy, dx)

@@ -70,6 +70,26 @@ __device__ __forceinline__ void bst64(const uint2 &v, rsrc_t r, uint32_t byte_of
 __device__ __forceinline__ void bst32(uint32_t v, rsrc_t r, uint32_t byte_off) {
     __builtin_amdgcn_raw_buffer_store_b32(v, r, byte_off, 0, ST_AUX);
 }
+// Second stage of the fused head's loss reduction (256 threads): the workgroup partials [nblocks][2] {sum of squares, sum of
+// absolute errors}, added in a fixed order in double precision -> loss_out = {weight * mse, mae}.  A launch of its own
+// (head_stage2_kernel) or the last workgroup of the weight-gradient reduction (dlwpcs_wgrad_batch_adam_tail): same code, same bits.
+__device__ __forceinline__ void loss_stage2_body(const float *__restrict__ partial, float *__restrict__ loss_out, int nblocks,
+                                                 float inv_n, float weight, int overwrite) {
+    __shared__ double s_sq[256], s_ab[256];
+    double sq = 0.0, ab = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { sq += partial[2 * i]; ab += partial[2 * i + 1]; }
+    s_sq[threadIdx.x] = sq; s_ab[threadIdx.x] = ab;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { s_sq[threadIdx.x] += s_sq[threadIdx.x + s]; s_ab[threadIdx.x] += s_ab[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float l0 = (float)(s_sq[0] * inv_n) * weight, l1 = (float)(s_ab[0] * inv_n);
+        loss_out[0] = overwrite ? l0 : loss_out[0] + l0;
+        loss_out[1] = overwrite ? l1 : loss_out[1] + l1;
+    }
+}
 __device__ __forceinline__ void bstv(const uint4 &v, rsrc_t r, uint32_t o) { bst128(v, r, o); }
 __device__ __forceinline__ void bstv(const uint2 &v, rsrc_t r, uint32_t o) { bst64(v, r, o); }
 __device__ __forceinline__ void bstv(uint32_t v, rsrc_t r, uint32_t o) { bst32(v, r, o); }

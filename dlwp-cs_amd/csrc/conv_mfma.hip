@@ -2151,20 +2151,7 @@ __global__ void __launch_bounds__(256) pw_head_train_kernel(HeadParams H) {
 
 __global__ void __launch_bounds__(256) head_stage2_kernel(const float *__restrict__ partial, float *__restrict__ loss_out,
                                                           int nblocks, float inv_n, float weight, int overwrite) {
-    __shared__ double s_sq[256], s_ab[256];
-    double sq = 0.0, ab = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) { sq += partial[2 * i]; ab += partial[2 * i + 1]; }
-    s_sq[threadIdx.x] = sq; s_ab[threadIdx.x] = ab;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) { s_sq[threadIdx.x] += s_sq[threadIdx.x + s]; s_ab[threadIdx.x] += s_ab[threadIdx.x + s]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const float l0 = (float)(s_sq[0] * inv_n) * weight, l1 = (float)(s_ab[0] * inv_n);
-        loss_out[0] = overwrite ? l0 : loss_out[0] + l0;
-        loss_out[1] = overwrite ? l1 : loss_out[1] + l1;
-    }
+    loss_stage2_body(partial, loss_out, nblocks, inv_n, weight, overwrite);
 }
 
 static bool pw_applies(const dlwpcs_conv_desc *d) {
@@ -2563,6 +2550,23 @@ extern "C" int dlwpcs_pack_batch(const dlwpcs_pack_item *items_dev, int n_items,
     return check_launch("pack_batch");
 }
 
+extern "C" int dlwpcs_head_mse_tail(const dlwpcs_conv_desc *d, float weight, int overwrite, void *scratch, float *loss_out,
+                                    dlwpcs_loss_tail *tail) {
+    if (!d || !scratch || !loss_out || !tail) return fail(DLWPCS_E_INVALID, "head_mse_tail: null pointer");
+    if (!pw_applies(d)) return fail(DLWPCS_E_UNSUPPORTED, "head_mse_tail: not a layer dlwpcs_head_mse_step serves");
+    const double n = (double)d->B * 6 * d->N * d->N * d->Cout;
+    tail->partial = (const float *)scratch; tail->loss_out = loss_out;
+    tail->nblocks = (int)pw_grid((long)d->B * 6 * d->N * d->N / 16);
+    tail->inv_n = (float)(1.0 / n); tail->weight = weight; tail->overwrite = overwrite & 1;
+    return DLWPCS_OK;
+}
+extern "C" int dlwpcs_loss_tail_run(const dlwpcs_loss_tail *tail, dlwpcs_stream_t stream) {
+    if (!tail || !tail->partial || !tail->loss_out || tail->nblocks < 1) return fail(DLWPCS_E_INVALID, "loss_tail_run: bad tail");
+    hipLaunchKernelGGL(head_stage2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tail->partial, tail->loss_out, tail->nblocks,
+                       tail->inv_n, tail->weight, tail->overwrite);
+    return check_launch("loss_tail_run");
+}
+
 extern "C" size_t dlwpcs_head_mse_scratch_bytes(void) { return (size_t)2048 * 2 * sizeof(float); }
 
 static int head_mse_impl(const dlwpcs_conv_desc *d, const void *x, const void *wpk_fwd, const void *bias_pk,
@@ -2615,8 +2619,11 @@ static int head_mse_impl(const dlwpcs_conv_desc *d, const void *x, const void *w
     if (d->Cout <= 16) hipLaunchKernelGGL((pw_head_train_kernel<1>), dim3(grid), dim3(256), 0, s, H);
     else hipLaunchKernelGGL((pw_head_train_kernel<2>), dim3(grid), dim3(256), 0, s, H);
     if (pidx >= 0) prof_end(pidx, s);
-    hipLaunchKernelGGL(head_stage2_kernel, dim3(1), dim3(256), 0, s, (const float *)scratch, loss_out, (int)grid,
-                       (float)(1.0 / n), weight, overwrite);
+    // DLWPCS_HEAD_DEFER_STAGE2: the caller finishes the loss (dlwpcs_head_mse_tail + dlwpcs_loss_tail_run, or inside the
+    // weight-gradient reduction: dlwpcs_wgrad_batch_adam_tail)
+    if (!(overwrite & DLWPCS_HEAD_DEFER_STAGE2))
+        hipLaunchKernelGGL(head_stage2_kernel, dim3(1), dim3(256), 0, s, (const float *)scratch, loss_out, (int)grid,
+                           (float)(1.0 / n), weight, overwrite & 1);
     return check_launch("head_mse_step");
 }
 

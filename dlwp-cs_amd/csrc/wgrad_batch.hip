@@ -647,8 +647,15 @@ __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGrou
     }
 }
 
-__global__ void __launch_bounds__(WB_RED_THREADS) wb_reduce_kernel(const char *__restrict__ plan, const WbRedPtrs R, const float *__restrict__ ws,
-                                                        const WbAdam A) {
+// `tail` (optional): the second stage of the fused head's loss reduction rides in one extra workgroup (the launch then has 256
+// threads per workgroup, the reduction's use the first 192)
+__global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__ plan, const WbRedPtrs R, const float *__restrict__ ws,
+                                                        const WbAdam A, const dlwpcs_loss_tail tail, uint32_t red_blocks) {
+    if (blockIdx.x >= red_blocks) {
+        loss_stage2_body(tail.partial, tail.loss_out, tail.nblocks, tail.inv_n, tail.weight, tail.overwrite);
+        return;
+    }
+    if (threadIdx.x >= WB_RED_THREADS) return;
     const WbGroup *groups = reinterpret_cast<const WbGroup *>(plan + R.off_groups);
     const uint32_t b = blockIdx.x;
     int l = 0;
@@ -954,7 +961,8 @@ extern "C" int dlwpcs_wgrad_batch_plan(const dlwpcs_wgrad_item *items, int n_ite
 }
 
 static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
-                            void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream);
+                            void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream,
+                            const dlwpcs_loss_tail *tail = nullptr);
 
 extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                   void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
@@ -962,9 +970,30 @@ extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, c
     return wgrad_batch_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, none, nullptr, stream);
 }
 
+static int wgrad_batch_adam_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                                 void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
+                                 int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream, const dlwpcs_loss_tail *tail);
+
 extern "C" int dlwpcs_wgrad_batch_adam(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                        void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
                                        int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream) {
+    return wgrad_batch_adam_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, p, g, m, v, n, state_dev, hyper_dev,
+                                 stream, nullptr);
+}
+
+extern "C" int dlwpcs_wgrad_batch_adam_tail(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                                            void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
+                                            int32_t *state_dev, const float *hyper_dev, const dlwpcs_loss_tail *tail,
+                                            dlwpcs_stream_t stream) {
+    if (tail && (!tail->partial || !tail->loss_out || tail->nblocks < 1))
+        return fail(DLWPCS_E_INVALID, "wgrad_batch_adam_tail: bad loss tail");
+    return wgrad_batch_adam_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, p, g, m, v, n, state_dev, hyper_dev,
+                                 stream, tail);
+}
+
+static int wgrad_batch_adam_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                                 void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
+                                 int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream, const dlwpcs_loss_tail *tail) {
     if (!items || !p || !g || !m || !v || !state_dev || !hyper_dev) return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: null pointer");
     // every destination must lie inside g, no destination may be named twice (a layer applied twice takes the unfused path)
     for (int l = 0; l < n_items; ++l) {
@@ -978,11 +1007,12 @@ extern "C" int dlwpcs_wgrad_batch_adam(const dlwpcs_wgrad_item *items, int n_ite
     }
     WbAdam A{};
     A.p = p; A.g = g; A.m = m; A.v = v; A.state = state_dev; A.hyper = hyper_dev; A.on = 1;
-    return wgrad_batch_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, A, state_dev, stream);
+    return wgrad_batch_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, A, state_dev, stream, tail);
 }
 
 static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
-                            void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream) {
+                            void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream,
+                            const dlwpcs_loss_tail *tail) {
     if (!items || !plan_host || !plan_dev || !workspace) return fail(DLWPCS_E_INVALID, "wgrad_batch: null pointer");
     const WbHeader *H = (const WbHeader *)plan_host;
     if (H->magic != WB_MAGIC || (int)H->n_layers != n_items) return fail(DLWPCS_E_INVALID, "wgrad_batch: plan does not match the items");
@@ -1050,8 +1080,11 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
         R.live = live;
         pidx = -1;
         if (prof_enabled()) pidx = prof_begin("wb_reduce_kernel", 0.0, (double)H->ws_floats * 4.0, s);
-        hipLaunchKernelGGL(wb_reduce_kernel, dim3(H->red_first[WB_MAX_LAYERS]), dim3(WB_RED_THREADS), 0, s, (const char *)plan_dev, R,
-                           (const float *)workspace, adam);
+        const uint32_t rb = H->red_first[WB_MAX_LAYERS];
+        dlwpcs_loss_tail tl{};
+        if (tail) tl = *tail;
+        hipLaunchKernelGGL(wb_reduce_kernel, dim3(rb + (tail ? 1u : 0u)), dim3(tail ? 256 : WB_RED_THREADS), 0, s,
+                           (const char *)plan_dev, R, (const float *)workspace, adam, tl, rb);
         if (pidx >= 0) prof_end(pidx, s);
         pending &= ~live;
     }

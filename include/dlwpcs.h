@@ -283,6 +283,12 @@ int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, const void *
 int dlwpcs_wgrad_batch_adam(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                             void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
                             int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream);
+/* ... and, tail != NULL, the deferred second stage of the fused head's loss (DLWPCS_HEAD_DEFER_STAGE2) in the same launch. */
+struct dlwpcs_loss_tail;
+int dlwpcs_wgrad_batch_adam_tail(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                                 void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
+                                 int32_t *state_dev, const float *hyper_dev, const struct dlwpcs_loss_tail *tail,
+                                 dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
  * Generic (any kernel size / stride / dilation / 'same') per-face convolution on an ALREADY PADDED channels_last
@@ -377,6 +383,20 @@ int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float *loss_out, 
  * output layer; the prediction itself is not written.  wpk_fwd / bias_pk / wpk_bwd are dlwpcs_pack_batch outputs;
  * loss_out[0] = weight * mse, loss_out[1] = mae (overwrite != 0: assigned, else added); scratch >= dlwpcs_head_mse_scratch_bytes(). */
 size_t dlwpcs_head_mse_scratch_bytes(void);
+/* OR-ed into `overwrite`: the launch that finishes the loss (second stage of its reduction) is left to the caller --
+ * dlwpcs_head_mse_tail describes it; dlwpcs_loss_tail_run runs it as a launch of its own, dlwpcs_wgrad_batch_adam_tail as one
+ * extra workgroup of the weight-gradient reduction that ends the training step (same code, same bits). */
+#define DLWPCS_HEAD_DEFER_STAGE2 2
+typedef struct dlwpcs_loss_tail {
+    const float *partial;        /* the scratch of dlwpcs_head_mse_step: [nblocks][2] workgroup sums */
+    float *loss_out;
+    int nblocks;
+    float inv_n, weight;
+    int overwrite;
+} dlwpcs_loss_tail;
+int dlwpcs_head_mse_tail(const dlwpcs_conv_desc *d, float weight, int overwrite, void *scratch, float *loss_out,
+                         dlwpcs_loss_tail *tail);
+int dlwpcs_loss_tail_run(const dlwpcs_loss_tail *tail, dlwpcs_stream_t stream);
 int dlwpcs_head_mse_step(const dlwpcs_conv_desc *d, const void *x, const void *wpk_fwd, const void *bias_pk,
                          const void *wpk_bwd, const float *target, float weight, void *dy, void *dx, float *loss_out,
                          int overwrite, void *scratch, dlwpcs_stream_t stream);
