@@ -73,6 +73,7 @@ struct ConvKParams {
     // kernel does it.
     void *pool_out;
     int *pool_done;
+    int colsplit;               // pooled output, faces whose row is exactly one wave's 32 * MT pixels (N = 96): see launch_conv_cfg
     int abl;                    // development only (-DDLWPCS_TIMELINE): epilogue ablation bits
     int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
     int tile_rows_max;          // rows reserved in LDS
@@ -399,6 +400,17 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     // NOTE: no s_setprio(1) here: a prioritised wave waiting for the busy matrix pipe still wins its SIMD's issue
     // arbitration and starves the co-resident producer wave's address arithmetic.
 
+    // pixel `loc` (0 .. 32 * MT - 1) of this wave -> its index in the tile (row-major, rows of No pixels).  Normally the wave owns
+    // 32 * MT consecutive tile pixels.  P.colsplit (pooled second output on faces whose ROW is 32 * MT pixels, tile = 4 rows, 4
+    // consumer waves): wave wm owns the half-rows [ (wm & 1) * No/2, + No/2 ) of tile rows 2 * (wm >> 1) and + 1 -- whole
+    // 2 x 2 pooling blocks again.
+    auto tile_pix = [&](int loc) __attribute__((always_inline)) {
+        const int lin = wm * MT * 32 + loc;
+        const int hN = P.No >> 1;
+        const int r = loc >= hN ? 1 : 0;
+        const int cs = (2 * (wm >> 1) + r) * P.No + (wm & 1) * hN + (loc - r * hN);
+        return P.colsplit ? cs : lin;
+    };
     f32x16 acc[MT][NT];
     constexpr int LPP = 32 * ES / 16;           // epilogue: lanes per pixel on the way out (16 B each): 8 fp32 / 4 bf16
     constexpr int PPP = 64 / LPP;               // pixels per store pass
@@ -422,7 +434,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     uint32_t ssel = 0;
     auto store_off = [&](const Geo &gq, int nt, int mt, int ps, uint32_t &sel) __attribute__((always_inline)) {
         const int px = ps * PPP + lane / LPP, q = lane % LPP;
-        const int mm = (wm * MT + mt) * 32 + px;
+        const int mm = tile_pix(mt * 32 + px);
         const int c = (nt0 + wn * NT + nt) * 32 + q * (16 / ES);
         const int gm = gq.m0 + mm;
         int off = (gq.f * face_pix + gm) * P.Cout + c;
@@ -457,23 +469,23 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     uint32_t plds0[PNP], plds1[PNP], pgo[NT][PNP];  // LDS offsets of i00 / i00 + No, byte offset in one sample of pool_out
     auto pool_setup = [&](const Geo &gq) {
         const int hN = P.No >> 1;
+        const int Wl = P.colsplit ? hN : P.No, hW = Wl >> 1;        // the wave's pixels as rows of Wl (local, row-major)
 #pragma unroll
         for (int ps = 0; ps < PNP; ++ps) {
             const int item = ps * 64 + lane;
-            const int pp = item / LPP, q = item % LPP;
-            const int prow = pp / hN, pcol = pp - prow * hN;
-            const int i00 = 2 * prow * P.No + 2 * pcol, i10 = i00 + P.No;
+            const int pp = min(item / LPP, MT * 8 - 1), q = item % LPP;
+            const int prow = pp / hW, pcol = pp - prow * hW;
+            const int i00 = 2 * prow * Wl + 2 * pcol, i10 = i00 + Wl;
             plds0[ps] = (uint32_t)((i00 >> 5) * (32 * PROW) + (i00 & 31) * PROW + q * 16);
             plds1[ps] = (uint32_t)((i10 >> 5) * (32 * PROW) + (i10 & 31) * PROW + q * 16);
-            const int gm = gq.m0 + wm * MT * 32 + i00;
+            const int gm = gq.m0 + tile_pix(i00);
             const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int c = (nt0 + wn * NT + nt) * 32 + q * (16 / ES);
-                const bool ok = pp < MT * 8 && wm * MT * 32 + i00 < gq.npix && c < P.Cout;
+                const bool ok = item / LPP < MT * 8 && tile_pix(i00) < gq.npix && c < P.Cout;
                 pgo[nt][ps] = ok ? (uint32_t)((((gq.f * hN + (oy >> 1)) * hN + (ox >> 1)) * P.Cout + c) * ES) : ST_SKIP;
             }
-            if (pp >= MT * 8) { plds0[ps] = 0; plds1[ps] = 0; }
         }
     };
     // ---- per-tile set-up: LDS addresses and store offsets (rebuilt at (face, band) changes), bias quads (reloaded at face
@@ -483,7 +495,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             cur_combo = gq.combo;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int m = (wm * MT + mt) * 32 + l31;
+                const int m = tile_pix(mt * 32 + l31);
                 int base = 0;
                 if (m < gq.npix) {
                     const int gm = gq.m0 + m;
@@ -2211,7 +2223,11 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     // pooled second output: every consumer wave must own whole PAIRS of tile rows (its 32 * MT pixels and the tile a multiple of
     // two rows, all tiles full), whole 32-channel output tiles, and LDS room for one patch per M tile -- else the caller pools
     // with a launch of its own (pool_done stays 0)
-    bool pool = MODE != MODE_ZERO && P.pool_out != nullptr && P.No % 2 == 0 && pix % (2 * P.No) == 0 && (32 * MT) % (2 * P.No) == 0 &&
+    // (... or, faces whose row is exactly one wave's 32 * MT pixels -- N = 96 -- with four consumer waves on a 4-row tile: the
+    // waves take half-rows of two rows each instead, P.colsplit)
+    const bool rowpairs = (32 * MT) % (2 * P.No) == 0 && pix % (2 * P.No) == 0;
+    const bool halfrows = !rowpairs && 32 * MT == P.No && WM == 4 && WN == 1 && pix == 4 * P.No && P.No % 4 == 0;
+    bool pool = MODE != MODE_ZERO && P.pool_out != nullptr && P.No % 2 == 0 && (rowpairs || halfrows) &&
                 face_pix % pix == 0 && P.Cout % 32 == 0 && P.Cout % (16 / ES) == 0;
     const size_t buf = in_b + w_b;
     size_t patch_b = (size_t)(WM * WN) * 32 * (32 * ES + 16);
@@ -2225,6 +2241,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
         lds = 2 * in_b + nchunks * w_b + patch_b;
     } else if (lds > 160 * 1024) { lds = 2 * buf; P.patches = 0; pool = false; } // large faces: direct quad stores instead
     if (!pool) P.pool_out = nullptr;
+    P.colsplit = (pool && halfrows) ? 1 : 0;
     if (P.pool_done) *P.pool_done = pool ? 1 : 0;
     if (MODE == MODE_ZERO && KS == 3 && P.patches && P.Cout % (16 / ES) == 0 && P.dsplit % (16 / ES) == 0) {
         if (P.direct_done) *P.direct_done = (P.d0 || P.d1) ? 1 : 0;             // the line-store epilogue honours d0 / d1

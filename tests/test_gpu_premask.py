@@ -354,7 +354,8 @@ def test_unet2_training_with_the_ring_folded_gives_the_same_bits():
 @pytest.mark.parametrize('dtype', ['bf16', 'f32'])
 @pytest.mark.parametrize('B,N,C0,C1,up0,Cout', [(2, 48, 32, 0, 0, 32), (3, 24, 64, 0, 0, 64), (2, 24, 32, 0, 0, 64),
                                                  (2, 48, 14, 0, 0, 32), (2, 12, 64, 0, 0, 128), (2, 24, 64, 64, 1, 64),
-                                                 (1, 20, 16, 0, 0, 32), (2, 16, 8, 0, 0, 24)])
+                                                 (1, 20, 16, 0, 0, 32), (2, 16, 8, 0, 0, 24), (2, 96, 32, 0, 0, 32),
+                                                 (1, 96, 26, 0, 0, 32), (1, 96, 64, 0, 0, 64)])
 def test_pooling_as_a_second_output_of_the_convolution(dtype, B, N, C0, C1, up0, Cout):
     """dlwpcs_conv_fwd_pool against dlwpcs_conv_fwd + dlwpcs_avgpool2_fwd: the same bits in both outputs, whether the tiling lets
     the epilogue pool (the U-Net levels at N = 48 / 24) or the call falls back to the pooling launch"""
