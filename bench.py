@@ -312,7 +312,8 @@ def run_step(st):
     state = st['dx'][0]                    # one "step" = one 40-step rollout of the batch, state resident in HBM
     model = st['model']
     for i in range(st['n_fwd']):
-        state = model.predict_on_device(state, repack=(i == 0))
+        # (padded_io: from the second pass on the state travels with its 26 channels padded to 32 -- zero channels -- per pixel)
+        state = model.predict_on_device(state, repack=(i == 0), padded_io=os.environ.get('DLWPCS_PADDED_IO', '1') == '1')
     st['last'] = state
 
 

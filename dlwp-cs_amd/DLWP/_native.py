@@ -31,6 +31,7 @@ CONV_PREPACKED = 2
 CONV_REUSE_DZ = 4
 CONV_DEFER_REDUCE = 8
 CONV_DEFER_RING0 = 16
+CONV_OUT_PADDED = 32
 PACK_FWD, PACK_BWD, PACK_BIAS = 0, 1, 2
 WGRAD_BATCH_MAX = 24
 

@@ -253,14 +253,14 @@ class CubeSphereConv2D(Layer):
                 and self.data_format == 'channels_last' and self.activation is None)
 
     def fused_call(self, src0, src1=None, up0=False, halo=True, act=ACT_NONE, alpha=0.0, vmax=0.0, premask0=None,
-                   premask1=None, dy_premasked=False, defer_ring0=False, want_pool=False):
+                   premask1=None, dy_premasked=False, defer_ring0=False, want_pool=False, out_padded=False):
         """pad -> conv (-> ReLU) with optional upsample/concat on the input side, as one kernel (channels_last).
         premask0 / premask1 / dy_premasked: the pre-masked gradient convention of the training step (ops._CSConv)."""
         return ops.cs_conv(src0, self.equatorial_kernel, self.polar_kernel, self.north_pole_kernel,
                            self.equatorial_bias, self.polar_bias, self.north_pole_bias, src1=src1,
                            ksize=self.kernel_size[0], halo=halo, up0=up0, flip_north_pole=self.flip_north_pole,
                            act=act, alpha=alpha, vmax=vmax, premask0=premask0, premask1=premask1,
-                           dy_premasked=dy_premasked, defer_ring0=defer_ring0, want_pool=want_pool)
+                           dy_premasked=dy_premasked, defer_ring0=defer_ring0, want_pool=want_pool, out_padded=out_padded)
 
     def call(self, inputs, **kwargs):
         channels_first = self.data_format == 'channels_first'

@@ -420,8 +420,11 @@ class _CSConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, ksize, halo, up0, flip, act, alpha, vmax,
-                c0_valid=0, premask0=None, premask1=None, dy_premasked=False, defer_ring0=False, want_pool=False):
-        """want_pool: the 2x2 average pooling of y is produced as a by-product (dlwpcs_conv_fwd_pool) and parked in _POOLED for
+                c0_valid=0, premask0=None, premask1=None, dy_premasked=False, defer_ring0=False, want_pool=False,
+                out_padded=False):
+        """out_padded (inference only, the pointwise bf16 output layer): y gets ceil8(C_out) channels per pixel, the padding
+        zero (DLWPCS_CONV_OUT_PADDED) -- what the first layer takes back as a padded source in a rollout.
+        want_pool: the 2x2 average pooling of y is produced as a by-product (dlwpcs_conv_fwd_pool) and parked in _POOLED for
         the pooling node that follows (avgpool2_skip), which then launches nothing in its forward pass.
         defer_ring0: the gradient of source 0 goes to a pooling node that adds the halo ring itself (see _pending_ring).
         premask0 / premask1 = (negative_slope, max_value) | None: src0 / src1 is the output of an activated layer that expects
@@ -453,7 +456,11 @@ class _CSConv(torch.autograd.Function):
         w_np = _c(w_np) if w_np is not None else None
         d = _make_desc(B, N, C0, C1, Cout, ksize, halo, up0, flip, act, alpha, vmax, nat.dtype_tag(src0), c0_valid)
         No = N if halo else N - ksize + 1
-        y = torch.empty((B, 6, No, No, Cout), dtype=src0.dtype, device=src0.device)
+        if out_padded:
+            if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (src0, src1, w_eq)):
+                raise RuntimeError('cs_conv: out_padded is an inference-only layout')
+            d.flags |= nat.CONV_OUT_PADDED
+        y = torch.empty((B, 6, No, No, (Cout + 7) // 8 * 8 if out_padded else Cout), dtype=src0.dtype, device=src0.device)
         table = inv = None
         if halo:
             table, inv = nat.halo_tables(N, (ksize - 1) // 2, src0.device)
@@ -544,7 +551,7 @@ class _CSConv(torch.autograd.Function):
                     dn.flags &= ~nat.CONV_DEFER_RING0
             dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np = _weight_gradients(
                 dn, src0, src1, dz, None, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp)
-            return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 13
+            return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 14
         no_dgrad = dsrc0 is None and dsrc1 is None        # (first layer: the batched kernel applies act' itself)
         batching = (direct and WGRAD_BATCH and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(d)
                     and (d.act == nat.ACT_NONE or (no_dgrad and d.ksize == 3)))
@@ -572,7 +579,7 @@ class _CSConv(torch.autograd.Function):
             batch_mask_ok=no_dgrad)
         if reuse_dz:
             run_bwd_data()
-        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 13
+        return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 14
 
 
 _ring_info_cache = {}
@@ -626,7 +633,7 @@ def pack_batch(items_dev, n_items):
 
 def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1=None, ksize=3, halo=True, up0=False,
             flip_north_pole=True, act=nat.ACT_NONE, alpha=0.0, vmax=0.0, premask0=None, premask1=None, dy_premasked=False,
-            defer_ring0=False, want_pool=False):
+            defer_ring0=False, want_pool=False, out_padded=False):
     if (w_np is None) != (b_np is None) and b_eq is not None:
         raise ValueError('cs_conv: north-pole kernel and bias must be given together')
     # Network inputs with a channel count that is not a multiple of the 16-B vector (7 variables; optionally 14 = 7 x 2):
@@ -646,7 +653,7 @@ def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1
             c0_valid = cin_w
     return _CSConv.apply(src0, src1, w_eq, w_pol, w_np, b_eq, b_pol, b_np, int(ksize), bool(halo), bool(up0),
                          bool(flip_north_pole), int(act), float(alpha), float(vmax), int(c0_valid), premask0, premask1,
-                         bool(dy_premasked), bool(defer_ring0), bool(want_pool))
+                         bool(dy_premasked), bool(defer_ring0), bool(want_pool), bool(out_padded))
 
 
 # ------------------------------------------------------------------------------------------------------------------ #

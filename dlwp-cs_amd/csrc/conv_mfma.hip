@@ -2713,16 +2713,21 @@ static int conv_fwd_impl(const dlwpcs_conv_desc *d, const void *src0, const void
     P.mode = d->halo ? MODE_HALO : MODE_DIRECT;
     P.act = d->act; P.alpha = d->alpha; P.vmax = d->vmax;
     P.pool_out = y_pooled; P.pool_done = pool_done;
+    if ((d->flags & DLWPCS_CONV_OUT_PADDED) && !pw_applies(d))
+        return fail(DLWPCS_E_UNSUPPORTED, "conv_fwd: DLWPCS_CONV_OUT_PADDED serves the bf16 pointwise output layer only");
     if (pw_applies(d)) {
         PwParams Q{};
         Q.in = (const bf16_t *)src0; Q.wpk = (const bf16_t *)wpk; Q.bias = b_eq ? bpk : nullptr; Q.out = (bf16_t *)y;
         Q.ngroups = (long)d->B * 6 * d->N * d->N / 16; Q.groups_per_face = d->N * d->N / 16; Q.Cout = d->Cout;
+        // padded rows: the packed weights and biases of the channels beyond C_out are zero, so the kernel simply writes
+        // ceil8(C_out) channels per pixel (the head has no activation; act(0) = 0 anyway)
+        if (d->flags & DLWPCS_CONV_OUT_PADDED) Q.Cout = (d->Cout + 7) / 8 * 8;
         Q.alpha = d->alpha; Q.vmax = d->vmax;
         int pidx = -1;
         if (prof_enabled()) { const Work wk = conv_work(d); pidx = prof_begin("pw_fwd_kernel", wk.flops, wk.bytes, s); }
         const bool actv = d->act != DLWPCS_ACT_NONE;
         const dim3 pgrid(pw_grid(Q.ngroups));
-        if (d->Cout <= 16) {
+        if (Q.Cout <= 16) {
             if (actv) hipLaunchKernelGGL((pw_fwd_kernel<true, 1>), pgrid, dim3(256), 0, s, Q);
             else hipLaunchKernelGGL((pw_fwd_kernel<false, 1>), pgrid, dim3(256), 0, s, Q);
         } else {

@@ -112,6 +112,11 @@ int dlwpcs_pad_bwd(const void *dy, void *dx, int B, int N, int C, int p, int dty
                                           * halo ring stays in the workspace (dlwpcs_conv_ring_info) and the caller's next pass
                                           * over dsrc0 adds it (dlwpcs_avgpool2_bwd_ring).  Only where dlwpcs_conv_ring_info
                                           * returns 1 for the descriptor; ignored otherwise */
+#define DLWPCS_CONV_OUT_PADDED      32   /* conv_fwd of the pointwise bf16 output layer (k = 1, 32 -> even C_out in 8..32, no halo): y has
+                                        * C_out rounded up to a multiple of 8 channels per pixel, the padding written as zeros -- the
+                                        * layout a following dlwpcs_conv_fwd takes as its source with c0_valid = C_out (an
+                                        * autoregressive rollout feeds the output straight back, Azure/train_cs.py:401-406,
+                                        * DLWP/model/models.py:446-454); DLWPCS_E_UNSUPPORTED for any other layer */
 #define DLWPCS_CONV_DEFER_REDUCE     8   /* conv_bwd_weights: run the weight-gradient kernel only and leave the per-worker
                                           * partial sums in the workspace (dw_* / db_* are not touched); the caller keeps
                                           * that workspace untouched until it has run dlwpcs_wgrad_reduce_batch over the

@@ -431,3 +431,46 @@ def test_unet2_training_with_the_pooling_fused_gives_the_same_bits():
             os.environ.pop('DLWPCS_FUSE_POOL', None)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_rollout_with_padded_state_gives_the_same_series():
+    """bf16 rollout of a 26-channel unet2 (BASELINE config 5's layout, small face): the state padded to 32 channels between the
+    passes (DLWPCS_CONV_OUT_PADDED head, c0_valid first layer) against the plain 26-channel state -- the same bits, through
+    predict_on_device and through DLWPFunctional-style rollout_on_device"""
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    dev = _dev()
+    backend.set_device('cuda:0')
+    N, C, B = 16, 26, 2
+    rng = np.random.default_rng(9)
+    backend.set_compute_dtype('bfloat16')
+    try:
+        np.random.seed(3)
+        model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=32)
+    finally:
+        backend.set_compute_dtype('float32')
+    x = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    outs = []
+    for padded in (False, True):
+        s = x
+        for i in range(3):
+            s = model.predict_on_device(s, repack=(i == 0), padded_io=padded)
+        torch.cuda.synchronize()
+        assert s.shape[-1] == (32 if padded else 26)
+        if padded:
+            assert float(s[..., 26:].float().abs().max()) == 0.0
+        outs.append(_f32(s[..., :26]))
+    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 1e-3
+    series = []
+    xh = x.float().cpu().numpy()
+    for flag in ('0', '1'):
+        os.environ['DLWPCS_PADDED_IO'] = flag
+        try:
+            out = np.full((3, B, 6, N, N, C), np.nan, dtype=np.float32)
+            model.rollout_on_device(xh, 3, 1, out)
+            series.append(out)
+        finally:
+            os.environ.pop('DLWPCS_PADDED_IO', None)
+    assert np.array_equal(series[0], series[1])
+    assert np.array_equal(series[0][-1], outs[0])
