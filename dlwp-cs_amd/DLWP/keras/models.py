@@ -70,6 +70,10 @@ class Model(object):
         self.fuse_pool = os.environ.get('DLWPCS_FUSE_POOL', '1') == '1'
         # second stage of the fused head's loss reduction inside the step's last launch (dlwpcs_wgrad_batch_adam_tail)
         self.fold_loss_tail = os.environ.get('DLWPCS_FOLD_LOSS_TAIL', '1') == '1'
+        # hipGraph-replayed steps: the reduction + optimizer launch also refreshes the packed bf16 operands, the step starts
+        # without the packing launch (dlwpcs_wgrad_batch_adam_tail with pack items)
+        self.fuse_pack = os.environ.get('DLWPCS_FUSE_PACK', '1') == '1'
+        self._packed_ok = False             # the packed operands hold the current parameters (see _ensure_packed)
         # data-parallel exchange in two buckets (exchange_buckets = 2 / DLWPCS_EXCHANGE_BUCKETS=2): the gradients of the
         # decoder-side layers are summed over the ranks WHILE the encoder-side half of the backward pass runs.  Default 1: one
         # all-reduce behind the whole backward pass -- whether the overlap pays depends on how RCCL's workgroups share the
@@ -306,7 +310,7 @@ class Model(object):
         st = getattr(self, '_pack_cache', None)
         if st is not None and st['key'] == key:
             return st
-        entries, table = [], {}
+        entries, table, by_grad = [], {}, {}
         for lay in self.layers:
             if not isinstance(lay, CubeSphereConv2D) or not lay.built or not lay._is_mfma_config():
                 continue
@@ -318,8 +322,10 @@ class Model(object):
             entries.append((we, lay.polar_kernel, lay.north_pole_kernel, lay.equatorial_bias, lay.polar_bias,
                             lay.north_pole_bias, bufs, lay.kernel_size[0], lay.flip_north_pole, tag))
             table[id(we)] = (tag, bufs[0], bufs[1], bufs[2])
+            if we.grad is not None:
+                by_grad[we.grad.data_ptr()] = entries[-1]
         st = {'key': key, 'items': ops.make_pack_items(entries, device) if entries else None, 'n': len(entries),
-              'table': table, 'keep': entries}
+              'table': table, 'keep': entries, 'by_grad': by_grad}
         self._pack_cache = st
         return st
 
@@ -333,6 +339,8 @@ class Model(object):
             if st['n'] and (repack or not st.get('packed')):
                 ops.pack_batch(st['items'], st['n'])
                 st['packed'] = True
+                st['packed_version'] = self._flat_params._version if self._flat_params is not None else None
+                self._packed_ok = True
             ops.PREPACKED = st['table']
             try:
                 return self._run_plan(inputs, fuse_targets)
@@ -550,10 +558,11 @@ class Model(object):
             vals += [float(s[0, 1])]
         return vals
 
-    def _loss_and_backward(self, inputs, targets, train=True, fuse_update=None):
+    def _loss_and_backward(self, inputs, targets, train=True, fuse_update=None, skip_pack=False):
         """fuse_update = grad_scale | None: with a value, the optimizer step may ride in the reduction of the batched weight
-        gradients (ops.flush_wgrad_batch); self._update_done says whether it did."""
-        gen = self._loss_and_backward_gen(inputs, targets, train, fuse_update, split=False)
+        gradients (ops.flush_wgrad_batch); self._update_done says whether it did (self._pack_done: and refreshed the packed
+        operands)."""
+        gen = self._loss_and_backward_gen(inputs, targets, train, fuse_update, split=False, skip_pack=skip_pack)
         try:
             while True:
                 next(gen)
@@ -564,7 +573,7 @@ class Model(object):
         """Two-bucket exchange for this step?"""
         return self.exchange_buckets == 2 and self._plan_exchange() is not None
 
-    def _loss_and_backward_gen(self, inputs, targets, train=True, fuse_update=None, split=False):
+    def _loss_and_backward_gen(self, inputs, targets, train=True, fuse_update=None, split=False, skip_pack=False):
         """Generator form of the step: with split=True (and a usable cut, see _plan_exchange) it yields ONCE, after the
         gradients of bucket A (decoder side) are final in the flat gradient buffer, so that the caller can start their
         all-reduce -- or end a hipGraph capture -- before the encoder-side half of the backward pass is issued.  Returns the
@@ -584,8 +593,10 @@ class Model(object):
         ops.finish_loss_tail()
         ops.DEFER_LOSS_TAIL = bool(train and fuse_update is not None and self.fuse_adam and self.batch_wgrad and self.fold_loss_tail
                                    and self.optimizer is not None and self._world == 1 and not cutplan)
+        self._pack_done = False
         try:
-            outs = self._forward(inputs, fuse_targets=fuse)
+            # skip_pack: the packed operands are current (_ensure_packed) and this step's own last launch keeps them so
+            outs = self._forward(inputs, repack=not skip_pack, fuse_targets=fuse)
         finally:
             self._record_cut = None
             ops.DEFER_LOSS_TAIL = False
@@ -632,7 +643,11 @@ class Model(object):
                         opt.sync_hyper(fuse_update)
                     adam = (self._flat_params, self._flat_grads, opt._m, opt._v, opt._step, opt._hyper,
                             sum(w.numel() for w in self.weights))
-                self._update_done = ops.flush_wgrad_batch(adam)
+                lookup = None
+                if adam is not None and self.fuse_pack and self.prepack_weights:
+                    lookup = self._pack_state(dev).get('by_grad', {}).get
+                self._update_done = ops.flush_wgrad_batch(adam, lookup)
+                self._pack_done = bool(self._update_done and ops.PACK_FUSED)
                 ops.flush_deferred_reduce(dev)
             finally:
                 ops.DIRECT_PARAM_GRADS = False
@@ -658,6 +673,7 @@ class Model(object):
     def _apply_gradients(self):
         scale = parallel.allreduce_gradients(self._flat_grads)  # RCCL over xGMI: one flat 2.7 MB buffer per step
         self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=scale)
+        self._packed_ok = False
 
     def _train_step_eager(self, inputs, targets):
         self._flat_grads.zero_()
@@ -678,6 +694,7 @@ class Model(object):
                 parallel.allreduce_wait(ha)
                 parallel.allreduce_wait(hb)
                 self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0 / self._world)
+                self._packed_ok = False
                 return stats
             self._apply_gradients()
             return stats
@@ -708,6 +725,8 @@ class Model(object):
         if not self._grads_clean:
             self._flat_grads.zero_()                            # an eager step / manual backward ran since the last replay
         self.optimizer.sync_hyper(g['grad_scale'])             # lr / betas changed since the last replay? (20-byte copy)
+        if g.get('no_pack'):
+            self._ensure_packed(g['inputs'][0].device)          # (a launch only if something else changed the parameters)
         g['fwd_bwd'].replay()
         if g['update'] is not None:
             if g.get('bwd_b') is not None:
@@ -722,6 +741,7 @@ class Model(object):
                 parallel.allreduce_gradients(self._flat_grads)  # between the two graphs (scale is baked into 'update')
             g['update'].replay()
         self._grads_clean = True                                # the optimizer launch also cleared the gradient buffer
+        self._packed_ok = bool(g.get('no_pack'))                # ... and, in a step without packing launch, kept the packed copies
         return g['stats']
 
     def _capture(self, key, inputs, targets):
@@ -736,6 +756,7 @@ class Model(object):
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         g1b = None
+        no_pack_entry = False
         split = self._split_wanted()
         # the gradient buffer is cleared by the optimizer launch of the previous replay (DLWPCS_ADAM_ZERO_GRAD), once
         # here for the first one: the step graph needs no fill launch
@@ -770,14 +791,31 @@ class Model(object):
                         except StopIteration as e:
                             stats = e.value
             else:
-                with torch.cuda.graph(g1, capture_error_mode=mode):
-                    stats = self._loss_and_backward(static_in, static_tg, True,
-                                                    fuse_update=grad_scale if self._world == 1 else None)
-                    if self._world == 1 and not self._update_done:
-                        # no exchange step: the update rides in the same graph (no inter-graph gap); normally INSIDE the
-                        # reduction of the batched weight gradients, as a launch of its own when those do not cover every
-                        # parameter
-                        self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
+                # world size 1: the step's last launch (reduction + optimizer) can keep the packed operands current, the captured
+                # step then starts without the packing launch; captured again WITH it if that launch turns out not to cover
+                # every layer
+                no_pack = (self._world == 1 and self.fuse_pack and self.fuse_adam and self.batch_wgrad and self.prepack_weights
+                           and self.compute_dtype == 'bfloat16' and static_in[0].is_cuda)
+                if no_pack:
+                    self._ensure_packed(static_in[0].device)
+                    gtry = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gtry, capture_error_mode=mode):
+                        stats = self._loss_and_backward(static_in, static_tg, True, fuse_update=grad_scale, skip_pack=True)
+                    if self._update_done and self._pack_done:
+                        g1 = gtry
+                        no_pack_entry = True
+                    else:
+                        no_pack = False
+                        del gtry
+                if not no_pack:
+                    with torch.cuda.graph(g1, capture_error_mode=mode):
+                        stats = self._loss_and_backward(static_in, static_tg, True,
+                                                        fuse_update=grad_scale if self._world == 1 else None)
+                        if self._world == 1 and not self._update_done:
+                            # no exchange step: the update rides in the same graph (no inter-graph gap); normally INSIDE the
+                            # reduction of the batched weight gradients, as a launch of its own when those do not cover
+                            # every parameter
+                            self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
             if self._world == 1 and not split:
                 g2 = None
             else:
@@ -787,7 +825,7 @@ class Model(object):
             if gc_was_enabled:
                 gc.enable()
         entry = {'fwd_bwd': g1, 'bwd_b': g1b, 'update': g2, 'inputs': static_in, 'targets': static_tg, 'stats': stats,
-                 'grad_scale': grad_scale}
+                 'grad_scale': grad_scale, 'no_pack': no_pack_entry}
         self._graphs[key] = entry
         return entry
 
@@ -1026,6 +1064,18 @@ class Model(object):
         if outs is None:
             outs = [np.empty((0,) + tuple(o.shape[1:]), dtype=np.float32) for o in self.outputs]
         return outs[0] if self._single_output else outs
+
+    def _ensure_packed(self, device):
+        """A captured step without a packing launch relies on the packed operands being current: true after such a step itself
+        (its optimizer launch refreshed them), not after anything else that changed the parameters -- an optimizer launch of its
+        own (eager steps, other graphs; they clear _packed_ok) or in-place torch operations on the parameter tensors (set_weights,
+        load_weights: they move the flat buffer's version counter)."""
+        st = self._pack_state(device)
+        if st['n'] and not (self._packed_ok and st.get('packed') and st.get('packed_version') == self._flat_params._version):
+            ops.pack_batch(st['items'], st['n'])
+            st['packed'] = True
+            st['packed_version'] = self._flat_params._version
+            self._packed_ok = True
 
     def predict_on_device(self, inputs, repack=True, padded_io=False):
         """Forward pass on device tensors without host round trips (used by the device-resident rollout).

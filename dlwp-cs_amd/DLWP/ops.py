@@ -140,11 +140,18 @@ def finish_loss_tail():
         check(lib().dlwpcs_loss_tail_run(ctypes.byref(tail), stream_ptr()), 'dlwpcs_loss_tail_run')
 
 
-def flush_wgrad_batch(adam=None):
+PACK_FUSED = False          # did the last flush_wgrad_batch refresh the packed operands inside its optimizer launch?
+
+
+def flush_wgrad_batch(adam=None, pack_lookup=None):
     """Run the queued layers.  adam = (flat params, flat grads, m, v, state {t-1, ticket}, hyper {lr, b1, b2, eps, scale},
     number of parameter elements) asks for the optimizer fused into the reduction (dlwpcs_wgrad_batch_adam): done -- and True
     returned -- when the queued layers cover every parameter exactly once; otherwise the gradients are left in the flat buffer
-    as usual and the caller runs its optimizer launch."""
+    as usual and the caller runs its optimizer launch.  pack_lookup (with adam): address of a layer's equatorial-kernel gradient
+    -> its make_pack_items entry; when every queued layer has one, the launch also refreshes the packed bf16 operands
+    (PACK_FUSED says whether it did)."""
+    global PACK_FUSED
+    PACK_FUSED = False
     if not _wb_pending:
         return False
     pending = list(_wb_pending)
@@ -163,7 +170,13 @@ def flush_wgrad_batch(adam=None):
             if covered < 0:
                 break
         if covered == n_elems:
-            wgrad_batch(pending, adam=(p, g, m, v, state, hyper))
+            packs = None
+            if pack_lookup is not None:
+                packs = [pack_lookup(ent[5][0].data_ptr()) for ent in pending]
+                if any(pk is None for pk in packs):
+                    packs = None
+            wgrad_batch(pending, adam=(p, g, m, v, state, hyper), packs=packs)
+            PACK_FUSED = packs is not None
             return True
     wgrad_batch(pending)
     return False
@@ -183,7 +196,7 @@ def _wb_items(entries):
     return arr, tuple(key)
 
 
-def wgrad_batch(entries, adam=None):
+def wgrad_batch(entries, adam=None, packs=None):
     """entries: [(ConvDesc, src0, src1 | None, dz, halo table | None, (dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np)[, y])] with
     fp32 gradient tensors that are ACCUMULATED into (None where the layer has no such parameter).  dz is the gradient
     w.r.t. the layer's pre-activation output (already masked) -- or, with the optional 7th element y (the layer's saved
@@ -212,11 +225,23 @@ def wgrad_batch(entries, adam=None):
         ws = _workspace(ws_bytes, dev, 'wgrad_batch')
         if adam is not None:
             p, g, m, v, state, hyper = adam
+            tail = None
             if len(_pending_tail) == 1:
                 tail, keep = _pending_tail.pop()            # the step's loss is finished by this launch
+            if tail is not None or packs is not None:
+                pk_arr = None
+                if packs is not None:
+                    pk_arr = (nat.PackItem * len(chunk))()
+                    for it, (we, wp, wn, be, bp, bn, bufs, ksize, flip, tag) in zip(pk_arr, packs[lo:lo + len(chunk)]):
+                        it.w_eq, it.w_pol, it.w_np = ptr(we), ptr(wp), ptr(wn)
+                        it.b_eq, it.b_pol, it.b_np = ptr(be), ptr(bp), ptr(bn)
+                        it.wpk_fwd, it.bias_pk, it.wpk_bwd = ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2])
+                        it.ksize, it.Cin, it.Cout = int(ksize), int(we.shape[2]), int(we.shape[3])
+                        it.flip_north_pole, it.dtype, it.reserved = int(flip), int(tag), 0
                 check(lib().dlwpcs_wgrad_batch_adam_tail(arr, len(chunk), host, ptr(plan_dev), ptr(ws), ws.numel(), ptr(p), ptr(g),
-                                                         ptr(m), ptr(v), g.numel(), ptr(state), ptr(hyper), ctypes.byref(tail),
-                                                         stream_ptr()), 'dlwpcs_wgrad_batch_adam_tail')
+                                                         ptr(m), ptr(v), g.numel(), ptr(state), ptr(hyper),
+                                                         ctypes.byref(tail) if tail is not None else None, pk_arr, stream_ptr()),
+                      'dlwpcs_wgrad_batch_adam_tail')
                 continue
             check(lib().dlwpcs_wgrad_batch_adam(arr, len(chunk), host, ptr(plan_dev), ptr(ws), ws.numel(), ptr(p), ptr(g), ptr(m),
                                                 ptr(v), g.numel(), ptr(state), ptr(hyper), stream_ptr()),

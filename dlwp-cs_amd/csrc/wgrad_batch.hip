@@ -84,6 +84,10 @@ struct WbAdam {
 // what the reduction needs of a layer, by value in the kernel arguments (its dependent chain of memory round trips is what
 // the reduction's ~20 us are made of: plan header -> layer record -> group record -> partial sums -> optimizer state)
 struct WbRedLayer { int32_t KS, Cin, Cout, want_bias, TC, TN, ncot, group_base, flip; };
+// optimizer fused in + weight packing fused in: where the layer's packed bf16 operands (dlwpcs_pack_batch outputs) live; the
+// reduction writes the updated values into them in place, so the next pass starts without a packing launch
+struct WbRedPack { bf16_t *wf, *wb; float *bp; int32_t CGf, NTf, CGb, NTb; };
+struct WbPackArgs { WbRedPack l[WB_MAX_LAYERS]; };
 struct WbRedPtrs {
     float *dw_eq[WB_MAX_LAYERS], *dw_pol[WB_MAX_LAYERS], *dw_np[WB_MAX_LAYERS];
     float *db_eq[WB_MAX_LAYERS], *db_pol[WB_MAX_LAYERS], *db_np[WB_MAX_LAYERS];
@@ -550,7 +554,7 @@ constexpr int WB_RED_OUT = 64, WB_RED_THREADS = 3 * WB_RED_OUT;
 template <int VEC, bool ALIGNED>
 __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGroup *__restrict__ groups, const float *__restrict__ ws,
                                                float *dw_eq, float *dw_pol, float *dw_np, float *db_eq, float *db_pol,
-                                               float *db_np, int block, const WbAdam &A) {
+                                               float *db_np, int block, const WbAdam &A, const WbRedPack &K) {
     typedef float VT __attribute__((ext_vector_type(VEC)));
     constexpr bool VECIO = ALIGNED || VEC == 1;         // (the four flat buffers share their 16-B alignment)
     float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gscale = 1.f;
@@ -593,6 +597,7 @@ __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGrou
         }
     }
     VT s = 0.f;
+    int w_co = 0, w_ci = 0, w_ty = 0, w_tx = 0;         // (weight element of this thread, for the fused packing below)
     if (is_w || is_b) {
         int gi;
         size_t off;
@@ -600,6 +605,7 @@ __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGrou
             const int co = e % Cout, ci = (e / Cout) % Cin, tap = e / (Cout * Cin);
             const int cit = ci / TC, cot = co / TN, lci = ci - cit * TC, lco = co - cot * TN;
             const int ty = tap / KS, tx = tap - ty * KS;
+            w_co = co; w_ci = ci; w_ty = ty; w_tx = tx;
             const int tap5 = L.flip ? (KS - 1 - ty) * KS + tx : tap;    // face 5 ran with the row-reversed kernel
             gi = L.group_base + (cit * L.ncot + cot) * 3 + c;
             off = (size_t)(((c == 2 ? tap5 : tap) * TC + lci) * TN + lco);
@@ -633,6 +639,40 @@ __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGrou
     } else {
         out = gv + s;
     }
+    // The packed bf16 operands of the layer (dlwpcs_pack_batch layout, see pack_weights_range in conv_mfma.hip) follow the
+    // parameter: forward fragments [v][n tile][ci group of 16][tap][half][32 columns = co][8 = ci], data-gradient fragments
+    // [v][n tile = ci / 32][co group of 16][tap, flipped][half][32 columns = ci][8 = co]; v = face variant (equatorial, south
+    // pole, north pole = the pole weights again with the tap rows reversed when flip_north_pole), biases [v][32 * n tiles] fp32.
+    if (A.on && K.wf != nullptr) {
+        const int v0 = c, v1 = (c == 1 && shared_pole) ? 2 : -1;
+#pragma unroll
+        for (int iv = 0; iv < 2; ++iv) {
+            const int vv = iv == 0 ? v0 : v1;
+            if (vv < 0) continue;
+            if (is_w) {
+                const int TAPS2 = KS * KS;
+                const int tyv = (vv == 2 && L.flip) ? KS - 1 - w_ty : w_ty;
+                {   // forward fragments: VEC consecutive co of one 32-column tile, 16 B apart
+                    const int cg = w_ci >> 4, hf = (w_ci >> 3) & 1, j = w_ci & 7;
+                    const size_t base = (size_t)(((((vv * K.NTf + (w_co >> 5)) * K.CGf + cg) * TAPS2 + tyv * KS + w_tx) * 2 + hf) * 32);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) K.wf[(base + ((w_co + k) & 31)) * 8 + j] = f2bf(pv[k]);
+                }
+                {   // data-gradient fragments: VEC consecutive co = consecutive elements of one 16-B entry
+                    const int cg = w_co >> 4, hf = (w_co >> 3) & 1, j = w_co & 7;
+                    const int ey = KS - 1 - tyv, ex = KS - 1 - w_tx;
+                    bf16_t *q = K.wb + ((size_t)(((((vv * K.NTb + (w_ci >> 5)) * K.CGb + cg) * TAPS2 + ey * KS + ex) * 2 + hf) * 32) +
+                                        (w_ci & 31)) * 8 + j;
+                    if constexpr (VEC == 4) *reinterpret_cast<uint2 *>(q) = make_uint2(f2bf2(pv[0], pv[1]), f2bf2(pv[2], pv[3]));
+                    else q[0] = f2bf(pv[0]);
+                }
+            } else if (K.bp != nullptr) {
+                const int co = e - nW;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) K.bp[vv * K.NTf * 32 + co + k] = pv[k];
+            }
+        }
+    }
     if constexpr (VECIO) {
         *reinterpret_cast<VT *>(dst) = out;
         if (A.on) {
@@ -650,7 +690,8 @@ __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGrou
 // `tail` (optional): the second stage of the fused head's loss reduction rides in one extra workgroup (the launch then has 256
 // threads per workgroup, the reduction's use the first 192)
 __global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__ plan, const WbRedPtrs R, const float *__restrict__ ws,
-                                                        const WbAdam A, const dlwpcs_loss_tail tail, uint32_t red_blocks) {
+                                                        const WbAdam A, const dlwpcs_loss_tail tail, uint32_t red_blocks,
+                                                        const WbPackArgs PK) {
     if (blockIdx.x >= red_blocks) {
         loss_stage2_body(tail.partial, tail.loss_out, tail.nblocks, tail.inv_n, tail.weight, tail.overwrite);
         return;
@@ -667,11 +708,11 @@ __global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__
     const bool al = ((((uintptr_t)R.dw_eq[l] | (uintptr_t)R.dw_pol[l] | (uintptr_t)R.dw_np[l] | (uintptr_t)R.db_eq[l] |
                        (uintptr_t)R.db_pol[l] | (uintptr_t)R.db_np[l]) & 15) == 0);
     if (L.Cout % 4 == 0 && al)
-        wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A);
+        wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
     else if (L.Cout % 4 == 0)       // (the plan sized this layer's workgroups for 4 outputs per thread)
-        wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A);
+        wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
     else
-        wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A);
+        wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -962,7 +1003,7 @@ extern "C" int dlwpcs_wgrad_batch_plan(const dlwpcs_wgrad_item *items, int n_ite
 
 static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                             void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream,
-                            const dlwpcs_loss_tail *tail = nullptr);
+                            const dlwpcs_loss_tail *tail = nullptr, const dlwpcs_pack_item *pack_host = nullptr);
 
 extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                   void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
@@ -972,28 +1013,30 @@ extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, c
 
 static int wgrad_batch_adam_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                  void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
-                                 int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream, const dlwpcs_loss_tail *tail);
+                                 int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream, const dlwpcs_loss_tail *tail,
+                                 const dlwpcs_pack_item *pack_host);
 
 extern "C" int dlwpcs_wgrad_batch_adam(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                        void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
                                        int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream) {
     return wgrad_batch_adam_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, p, g, m, v, n, state_dev, hyper_dev,
-                                 stream, nullptr);
+                                 stream, nullptr, nullptr);
 }
 
 extern "C" int dlwpcs_wgrad_batch_adam_tail(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                             void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
                                             int32_t *state_dev, const float *hyper_dev, const dlwpcs_loss_tail *tail,
-                                            dlwpcs_stream_t stream) {
+                                            const dlwpcs_pack_item *pack_items_host, dlwpcs_stream_t stream) {
     if (tail && (!tail->partial || !tail->loss_out || tail->nblocks < 1))
         return fail(DLWPCS_E_INVALID, "wgrad_batch_adam_tail: bad loss tail");
     return wgrad_batch_adam_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, p, g, m, v, n, state_dev, hyper_dev,
-                                 stream, tail);
+                                 stream, tail, pack_items_host);
 }
 
 static int wgrad_batch_adam_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                  void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
-                                 int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream, const dlwpcs_loss_tail *tail) {
+                                 int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream, const dlwpcs_loss_tail *tail,
+                                 const dlwpcs_pack_item *pack_host) {
     if (!items || !p || !g || !m || !v || !state_dev || !hyper_dev) return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: null pointer");
     // every destination must lie inside g, no destination may be named twice (a layer applied twice takes the unfused path)
     for (int l = 0; l < n_items; ++l) {
@@ -1007,12 +1050,12 @@ static int wgrad_batch_adam_impl(const dlwpcs_wgrad_item *items, int n_items, co
     }
     WbAdam A{};
     A.p = p; A.g = g; A.m = m; A.v = v; A.state = state_dev; A.hyper = hyper_dev; A.on = 1;
-    return wgrad_batch_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, A, state_dev, stream, tail);
+    return wgrad_batch_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, A, state_dev, stream, tail, pack_host);
 }
 
 static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                             void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream,
-                            const dlwpcs_loss_tail *tail) {
+                            const dlwpcs_loss_tail *tail, const dlwpcs_pack_item *pack_host) {
     if (!items || !plan_host || !plan_dev || !workspace) return fail(DLWPCS_E_INVALID, "wgrad_batch: null pointer");
     const WbHeader *H = (const WbHeader *)plan_host;
     if (H->magic != WB_MAGIC || (int)H->n_layers != n_items) return fail(DLWPCS_E_INVALID, "wgrad_batch: plan does not match the items");
@@ -1083,8 +1126,25 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
         const uint32_t rb = H->red_first[WB_MAX_LAYERS];
         dlwpcs_loss_tail tl{};
         if (tail) tl = *tail;
+        WbPackArgs PK{};
+        if (pack_host && adam.on) {
+            for (int l = 0; l < n_items; ++l) {
+                const dlwpcs_pack_item &pk = pack_host[l];
+                const WbLayer &L = layers[l];
+                // the packed operands must belong to the parameters this item's gradients update
+                const float *pw = adam.p + ((const float *)items[l].dw_eq - adam.g);
+                if (pk.dtype != DLWPCS_BF16 || pk.ksize != L.KS || pk.Cin != L.cin_logical || pk.Cout != L.Cout ||
+                    (const float *)pk.w_eq != pw || !pk.wpk_fwd || !pk.wpk_bwd || (pk.flip_north_pole != 0) != (L.flip != 0) ||
+                    (L.want_bias && !pk.bias_pk))
+                    return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: pack item %d does not describe the layer of gradient item %d", l, l);
+                WbRedPack &K = PK.l[l];
+                K.wf = (bf16_t *)pk.wpk_fwd; K.wb = (bf16_t *)pk.wpk_bwd; K.bp = (float *)pk.bias_pk;
+                K.CGf = (pk.Cin + 15) / 16; K.NTf = (pk.Cout + 31) / 32;
+                K.CGb = (pk.Cout + 15) / 16; K.NTb = (pk.Cin + 31) / 32;
+            }
+        }
         hipLaunchKernelGGL(wb_reduce_kernel, dim3(rb + (tail ? 1u : 0u)), dim3(tail ? 256 : WB_RED_THREADS), 0, s,
-                           (const char *)plan_dev, R, (const float *)workspace, adam, tl, rb);
+                           (const char *)plan_dev, R, (const float *)workspace, adam, tl, rb, PK);
         if (pidx >= 0) prof_end(pidx, s);
         pending &= ~live;
     }

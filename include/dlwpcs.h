@@ -288,12 +288,18 @@ int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, const void *
 int dlwpcs_wgrad_batch_adam(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                             void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
                             int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream);
-/* ... and, tail != NULL, the deferred second stage of the fused head's loss (DLWPCS_HEAD_DEFER_STAGE2) in the same launch. */
+/* ... and what else ends a training step, in the same launch:
+ *  tail != NULL: the deferred second stage of the fused head's loss (DLWPCS_HEAD_DEFER_STAGE2);
+ *  pack_items_host != NULL (HOST array, one dlwpcs_pack_item per gradient item, same order; bf16): every updated parameter is also
+ *  written -- rounded to bf16 -- into its places in the layer's packed operands (wpk_fwd / wpk_bwd / bias_pk, the outputs of
+ *  dlwpcs_pack_batch), so that the next pass needs no packing launch.  The packed buffers must hold a full dlwpcs_pack_batch
+ *  result already (the zero padding is not rewritten); w_eq of pack item i must be the parameter tensor that dw_eq of gradient
+ *  item i belongs to (same offset in p as dw_eq has in g). */
 struct dlwpcs_loss_tail;
 int dlwpcs_wgrad_batch_adam_tail(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                  void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
                                  int32_t *state_dev, const float *hyper_dev, const struct dlwpcs_loss_tail *tail,
-                                 dlwpcs_stream_t stream);
+                                 const dlwpcs_pack_item *pack_items_host, dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
  * Generic (any kernel size / stride / dilation / 'same') per-face convolution on an ALREADY PADDED channels_last

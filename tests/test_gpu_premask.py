@@ -474,3 +474,66 @@ def test_rollout_with_padded_state_gives_the_same_series():
             os.environ.pop('DLWPCS_PADDED_IO', None)
     assert np.array_equal(series[0], series[1])
     assert np.array_equal(series[0][-1], outs[0])
+
+
+def _packed_snapshot(model, dev):
+    st = model._pack_state(dev)
+    return [b.clone() for ent in st['keep'] for b in ent[6] if b is not None]
+
+
+def test_packed_operands_refreshed_by_the_optimizer_launch():
+    """DLWPCS_FUSE_PACK: hipGraph-replayed steps start without the packing launch, the reduction + optimizer launch writes the
+    updated parameters into the packed bf16 operands.  (1) after replays the packed buffers equal what dlwpcs_pack_batch makes
+    of the current parameters, bit for bit; (2) the same weights as with the packing launch, also when eager steps (another
+    batch size: an optimizer launch of its own) and set_weights come between replays"""
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    from DLWP import ops
+    dev = _dev()
+    backend.set_device('cuda:0')
+    N, C = 16, 14
+    rng = np.random.default_rng(11)
+    mk = lambda B: (torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(torch.bfloat16),
+                    torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev))
+    (x4, t4), (x2, t2) = mk(4), mk(2)
+    w0, out = None, []
+    for fuse in ('0', '1'):
+        os.environ['DLWPCS_FUSE_PACK'] = fuse
+        try:
+            backend.set_compute_dtype('bfloat16')
+            try:
+                np.random.seed(5)
+                model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=32)
+            finally:
+                backend.set_compute_dtype('float32')
+            model.compile(optimizer='adam', loss='mse', metrics=['mae'])
+            if w0 is None:
+                w0 = model.get_weights()
+            model.set_weights(w0)
+            for _ in range(4):                                  # eager, capture, two replays
+                model.train_on_device_batch([x4], [t4])
+            g = next(iter(model._graphs.values()))
+            assert g['no_pack'] == (fuse == '1')
+            if fuse == '1':
+                torch.cuda.synchronize()
+                assert model._packed_ok
+                have = _packed_snapshot(model, dev)
+                st = model._pack_state(dev)
+                ops.pack_batch(st['items'], st['n'])
+                torch.cuda.synchronize()
+                for a, b in zip(have, _packed_snapshot(model, dev)):
+                    assert torch.equal(a, b)
+            model.train_on_device_batch([x2], [t2])             # another shape: eager step, optimizer launch of its own
+            if fuse == '1':
+                assert not model._packed_ok
+            model.train_on_device_batch([x4], [t4])             # replay: must repack first
+            model.set_weights([w * 0.5 for w in model.get_weights()])
+            stats = None
+            for _ in range(2):
+                stats = model.train_on_device_batch([x4], [t4])
+            torch.cuda.synchronize()
+            out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
+        finally:
+            os.environ.pop('DLWPCS_FUSE_PACK', None)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])

@@ -50,11 +50,14 @@ def summarize(sel, nsteps, title):
 
 
 def step_summaries(pdir, modes):
-    """modes: [(is_bf16 | None, title)]; a step (training step or rollout) starts at its pack_batch launch"""
+    """modes: [(is_bf16 | None, title)]; see the step delimiters below"""
     trace = glob.glob(os.path.join(pdir, '**', '*kernel_trace.csv'), recursive=True)[0]
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    idx = [i for i, r in enumerate(rows) if 'pack_batch_kernel' in r['Kernel_Name']]
+    # a training step ENDS with its optimizer launch (the weight-gradient reduction + Adam, or the Adam kernel); a rollout (no
+    # optimizer) starts at its weight-packing launch
+    ends = [i + 1 for i, r in enumerate(rows) if 'wb_reduce_kernel' in r['Kernel_Name'] or 'adam_fused_kernel' in r['Kernel_Name']]
+    idx = ends if len(ends) > 2 else [i for i, r in enumerate(rows) if 'pack_batch_kernel' in r['Kernel_Name']]
     steps = []
     for a, b in zip(idx[:-1], idx[1:]):
         seg = rows[a:b]

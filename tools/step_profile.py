@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel summary of one training step out of a rocprofv3 --kernel-trace CSV (a step starts at its pack_batch launch).
+"""Per-kernel summary of one training step out of a rocprofv3 --kernel-trace CSV (a step ends at its optimizer launch).
 usage: tools/step_profile.py <dir with *kernel_trace.csv> [--order]"""
 import collections
 import csv
@@ -16,7 +16,9 @@ def main():
     trace = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    idx = [i for i, r in enumerate(rows) if 'pack_batch_kernel' in r['Kernel_Name']]     # a step starts with the weight packing
+    # a training step ends with its optimizer launch; a rollout (none) starts with the weight packing
+    ends = [i + 1 for i, r in enumerate(rows) if 'wb_reduce_kernel' in r['Kernel_Name'] or 'adam_fused_kernel' in r['Kernel_Name']]
+    idx = ends if len(ends) > 2 else [i for i, r in enumerate(rows) if 'pack_batch_kernel' in r['Kernel_Name']]
     steps = [rows[a:b] for a, b in zip(idx[:-1], idx[1:])]
     n = collections.Counter(len(s) for s in steps).most_common(1)[0][0]
     steps = [s for s in steps if len(s) == n][-30:]
