@@ -84,6 +84,7 @@ struct ConvKParams {
 // Scheduling tunables, bit set.  Defaults are the measured-best values; DLWPCS_TUNE=<int> overrides them for A/B runs.
 //   1: weight-gradient kernels: producer waves run at s_setprio 2 (they are the second-dispatched, i.e. arbitration-losing,
 //      half of the workgroup and the consumers wait for them at every barrier)
+//      (default since round 3: fp32 step -1.9 %, encoder6 -1.6 % on top of bit 2; the bf16 step runs the batched kernel instead)
 //   2: forward / data-gradient kernel: the same for its producer waves (default since round 3: with the consumers' waits for
 //      store acknowledgements gone the producers' issue slots matter again: fp32 step -1.1 %, encoder6 -1.2 %, rollout -0.7 %,
 //      bf16 step -0.2 %)
@@ -96,7 +97,7 @@ enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS
        TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64 };
 static int tune_bits() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_CONV_PRODUCER_PRIO | TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT); }
+    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_WG_PRODUCER_PRIO | TUNE_CONV_PRODUCER_PRIO | TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT); }
     return v;
 }
 
