@@ -7,7 +7,9 @@ strings, variable-length strings (global heap) or numeric arrays.  New-style com
 object headers are read as well; chunked / filtered datasets and dense link / attribute storage are not (clear error).
 
 This stack carries neither h5py nor TensorFlow; the reader exists so that weights and models written by the reference
-(TensorFlow 2.1 + h5py) load into the engine without a conversion step.  Read-only, no dependencies beyond numpy.
+(TensorFlow 2.1 + h5py) load into the engine without a conversion step, the writer at the end of the file so that what the engine
+saves under the reference's file names (`save_weights(save_format='h5')`, `<name>.keras`) is an HDF5 file Keras / h5py can open.
+No dependencies beyond numpy.
 Layout knowledge: HDF5 File Format Specification version 2.0/3.0 (public document); validated against files written by the
 real HDF5 library (tests/golden/gen_golden_h5.py, run with h5py 3.3 / libhdf5 1.10.6 in the build container).
 """
@@ -466,3 +468,229 @@ def read_keras_weights(path):
             ws.append((wname, np.asarray(g[wname].read())))
         layers.append((lname, ws))
     return layers, (None if cfg is None else _as_str(cfg))
+
+
+# ---------------------------------------------------------------------------------------------------------------------- #
+# Writer: the same subset, as h5py's default `libver='earliest'` lays it out (version 0 superblock, version 1 object headers,
+# old-style groups: one v1 B-tree node + one symbol node + a local heap per group, contiguous datasets, attributes as header
+# messages).  Enough for what Keras writes in `save_weights(save_format='h5')` / `model.save()` -- and read back by the real
+# HDF5 library: tests/test_hdf5_writer.py opens the files with h5py 3.3 / libhdf5 1.10.6 where the build container has them.
+# ---------------------------------------------------------------------------------------------------------------------- #
+
+_ATTR_LIMIT = 64512         # keras' HDF5_OBJECT_HEADER_LIMIT: larger attributes are split into name0, name1, ...
+
+
+def _pad8(b):
+    return b + b'\x00' * (-len(b) % 8)
+
+
+class _WGroup(object):
+    def __init__(self):
+        self.attrs = []             # [(name, value)]: bytes | str | list of bytes/str | numpy array / scalar
+        self.children = {}          # name -> _WGroup | numpy array
+
+    def group(self, name):
+        g = self.children.get(name)
+        if g is None:
+            g = self.children[name] = _WGroup()
+        return g
+
+
+def _dataspace_msg(shape):
+    shape = tuple(int(v) for v in shape)
+    return struct.pack('<BBB5x', 1, len(shape), 0) + b''.join(struct.pack('<Q', v) for v in shape)
+
+
+def _datatype_msg(dtype):
+    dtype = np.dtype(dtype)
+    if dtype.kind == 'S':
+        # fixed-length string, null-padded, ASCII (what h5py makes of numpy 'S' arrays)
+        return struct.pack('<BBBBI', 0x13, 0x01, 0, 0, max(dtype.itemsize, 1))
+    if dtype.kind == 'f' and dtype.itemsize in (4, 8):
+        if dtype.itemsize == 4:
+            return struct.pack('<BBBBI', 0x11, 0x20, 31, 0, 4) + struct.pack('<HHBBBBI', 0, 32, 23, 8, 0, 23, 127)
+        return struct.pack('<BBBBI', 0x11, 0x20, 63, 0, 8) + struct.pack('<HHBBBBI', 0, 64, 52, 11, 0, 52, 1023)
+    if dtype.kind in 'iu' and dtype.itemsize in (1, 2, 4, 8):
+        return struct.pack('<BBBBI', 0x10, 0x08 if dtype.kind == 'i' else 0x00, 0, 0, dtype.itemsize) + \
+            struct.pack('<HH', 0, 8 * dtype.itemsize)
+    raise HDF5Error('writer: dtype %s is not supported' % dtype)
+
+
+def _attr_value(v):
+    """-> numpy array (fixed-length bytes, or numeric) in the form h5py would store it (FIXED-length strings, as h5py 2.10 did
+    for the reference's TensorFlow 2.1 environment)"""
+    if isinstance(v, str):
+        v = v.encode('utf8')
+    if isinstance(v, (bytes, np.bytes_)):
+        return np.array(bytes(v), dtype='S%d' % max(len(v), 1))
+    if isinstance(v, (list, tuple)):
+        if len(v) == 0:
+            return np.zeros((0,), dtype=np.float64)             # h5py stores an empty list as a float64 array of shape (0,)
+        if all(isinstance(x, (str, bytes, np.bytes_)) for x in v):
+            bs = [x.encode('utf8') if isinstance(x, str) else bytes(x) for x in v]
+            return np.array(bs, dtype='S%d' % max(max(len(x) for x in bs), 1))
+    return np.asarray(v)
+
+
+def _attr_msg(name, value):
+    arr = _attr_value(value)
+    nm = name.encode('utf8') + b'\x00'
+    dt, ds = _datatype_msg(arr.dtype), _dataspace_msg(arr.shape)
+    data = arr.tobytes()
+    if arr.dtype.kind == 'S' and arr.dtype.itemsize == 0:
+        data = b'\x00' * max(arr.size, 1)
+    return struct.pack('<BBHHH', 1, 0, len(nm), len(dt), len(ds)) + _pad8(nm) + _pad8(dt) + _pad8(ds) + data
+
+
+def _split_attr(name, value):
+    """keras' save_attributes_to_hdf5_group: a list attribute beyond the object-header limit becomes name0, name1, ..."""
+    arr = _attr_value(value)
+    if arr.nbytes <= _ATTR_LIMIT or arr.ndim == 0:
+        if arr.nbytes > 0xFF00:
+            raise HDF5Error('writer: attribute %r of %d bytes does not fit an object-header message' % (name, arr.nbytes))
+        return [(name, value)]
+    n = 1
+    chunks = np.array_split(arr, n)
+    while any(c.nbytes > _ATTR_LIMIT for c in chunks):
+        n += 1
+        chunks = np.array_split(arr, n)
+    return [('%s%d' % (name, i), list(c)) for i, c in enumerate(chunks)]
+
+
+class _Writer(object):
+    def __init__(self, leaf_k, internal_k=16):
+        self.buf = bytearray(96)                # superblock, patched at the end
+        self.leaf_k, self.internal_k = leaf_k, internal_k
+
+    def alloc(self, data):
+        self.buf += b'\x00' * (-len(self.buf) % 8)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    @staticmethod
+    def header(messages):
+        """version 1 object header: [(type, body)]"""
+        body = b''
+        for mtype, mbody in messages:
+            mbody = _pad8(mbody)
+            body += struct.pack('<HHB3x', mtype, len(mbody), 0) + mbody
+        return struct.pack('<BBHII4x', 1, 0, len(messages), 1, len(body)) + body
+
+    def dataset(self, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype.byteorder == '>':
+            arr = arr.astype(arr.dtype.newbyteorder('<'))
+        raw = arr.tobytes()
+        data_addr = self.alloc(raw) if raw else UNDEF
+        layout = struct.pack('<BBQQ', 3, 1, data_addr, len(raw))                    # version 3, contiguous
+        fill = struct.pack('<BBBB', 2, 2, 0, 0)                                     # version 2, late allocation, undefined
+        return self.alloc(self.header([(0x01, _dataspace_msg(arr.shape)), (0x03, _datatype_msg(arr.dtype)), (0x05, fill),
+                                       (0x08, layout)]))
+
+    def group(self, g):
+        """-> (object header address, B-tree address, local heap address)"""
+        links = []
+        for name in sorted(g.children, key=lambda s: s.encode('utf8')):             # symbol nodes are sorted by name (strcmp)
+            child = g.children[name]
+            links.append((name, self.group(child)[0] if isinstance(child, _WGroup) else self.dataset(child)))
+        if len(links) > 2 * self.leaf_k:
+            raise HDF5Error('writer: %d links in one group exceed the symbol-node capacity' % len(links))
+        # local heap: the link names, 8-byte aligned, the empty string at offset 0; the tail is one free block
+        heap, offs = bytearray(8), []
+        for name, _ in links:
+            offs.append(len(heap))
+            heap += _pad8(name.encode('utf8') + b'\x00')
+        free_off = len(heap)
+        heap += struct.pack('<QQ', 1, 32) + b'\x00' * 16                            # free block: next = 1 (none), size 32
+        heap_hdr_addr = self.alloc(b'')
+        heap_addr = self.alloc(b'HEAP' + struct.pack('<B3xQQQ', 0, len(heap), free_off, heap_hdr_addr + 32) + bytes(heap))
+        # one symbol node with every link, one leaf B-tree node pointing at it
+        snod = b'SNOD' + struct.pack('<BBH', 1, 0, len(links))
+        for (name, addr), off in zip(links, offs):
+            snod += struct.pack('<QQII16x', off, addr, 0, 0)
+        snod += b'\x00' * (8 + 2 * self.leaf_k * 40 - len(snod))
+        snod_addr = self.alloc(snod)
+        tree = b'TREE' + struct.pack('<BBHQQ', 0, 0, 1 if links else 0, UNDEF, UNDEF)
+        if links:
+            tree += struct.pack('<QQQ', 0, snod_addr, offs[-1])
+        tree += b'\x00' * (24 + (4 * self.internal_k + 1) * 8 - len(tree))
+        tree_addr = self.alloc(tree)
+        msgs = [(0x11, struct.pack('<QQ', tree_addr, heap_addr))]
+        for name, value in g.attrs:
+            for n2, v2 in _split_attr(name, value):
+                msgs.append((0x0C, _attr_msg(n2, v2)))
+        return self.alloc(self.header(msgs)), tree_addr, heap_addr
+
+    def finish(self, root):
+        hdr, tree, heap = self.group(root)
+        self.buf += b'\x00' * (-len(self.buf) % 8)
+        sb = SIGNATURE + struct.pack('<BBBBBBBBHHI', 0, 0, 0, 0, 0, 8, 8, 0, self.leaf_k, self.internal_k, 0)
+        sb += struct.pack('<QQQQ', 0, UNDEF, len(self.buf), UNDEF)
+        sb += struct.pack('<QQII', 0, hdr, 1, 0) + struct.pack('<QQ', tree, heap)   # root entry, cached symbol-table addresses
+        assert len(sb) == 96
+        self.buf[:96] = sb
+        return bytes(self.buf)
+
+
+def _max_links(g):
+    n = len(g.children)
+    for c in g.children.values():
+        if isinstance(c, _WGroup):
+            n = max(n, _max_links(c))
+    return n
+
+
+def write_tree(path, root):
+    """root: _WGroup.  Atomic (temporary file + rename)."""
+    import os
+    k = 4
+    while 2 * k < _max_links(root):
+        k *= 2
+    data = _Writer(k).finish(root)
+    tmp = '%s.tmp%d' % (path, os.getpid())
+    with open(tmp, 'wb') as f:
+        f.write(data)
+    os.replace(tmp, path)
+
+
+def write_keras_file(path, layers, model_config=None, training_config=None, keras_version='2.2.4-tf', backend='tensorflow',
+                     optimizer_weights=None, extra_attrs=None):
+    """
+    Write what Keras writes (keras.engine.saving.save_weights_to_hdf5_group / save_model_to_hdf5, TF 2.1): `layers` is the
+    ordered list [(layer_name, [(weight_name, ndarray), ...])] of ALL layers (weightless ones with an empty list).
+    model_config None: a weights file (`model.save_weights(path, save_format='h5')`, reference DLWP/custom.py:186) -- root
+    attributes layer_names / backend / keras_version, one group per layer with attribute weight_names and one dataset per weight
+    at <layer>/<weight name> (a weight name like 'conv/kernel:0' makes a sub-group, as in h5py).  With model_config (JSON str):
+    a model file (`model.save(path)`, DLWP/util.py:139) -- the same tree under /model_weights, model_config and training_config
+    as root attributes; optimizer_weights [(name, ndarray)] (keras: the optimizer's `weights` in order -- iterations, then the
+    slots) go to /optimizer_weights with attribute weight_names; extra_attrs [(name, value)] are added to the root.
+    """
+    root = _WGroup()
+    wroot = root
+    if model_config is not None:
+        root.attrs += [('keras_version', keras_version), ('backend', backend), ('model_config', model_config)]
+        if training_config is not None:
+            root.attrs.append(('training_config', training_config))
+        wroot = root.group('model_weights')
+        if optimizer_weights:
+            og = root.group('optimizer_weights')
+            og.attrs.append(('weight_names', [n for n, _ in optimizer_weights]))
+            for wname, arr in optimizer_weights:
+                parts = wname.split('/')
+                h = og
+                for p in parts[:-1]:
+                    h = h.group(p)
+                h.children[parts[-1]] = np.asarray(arr)
+    root.attrs += list(extra_attrs or [])
+    wroot.attrs += [('layer_names', [n for n, _ in layers]), ('backend', backend), ('keras_version', keras_version)]
+    for lname, ws in layers:
+        g = wroot.group(lname)
+        g.attrs.append(('weight_names', [n for n, _ in ws]))
+        for wname, arr in ws:
+            parts = wname.split('/')
+            h = g
+            for p in parts[:-1]:
+                h = h.group(p)
+            h.children[parts[-1]] = np.asarray(arr)
+    write_tree(path, root)

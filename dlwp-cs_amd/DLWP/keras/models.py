@@ -1237,13 +1237,35 @@ class Model(object):
     # -------------------------------------------------------------------------------------------------------------- #
     # persistence: native npz containers (no pickle); HDF5 files written by keras / h5py are READ by DLWP.keras.hdf5_lite
     # -------------------------------------------------------------------------------------------------------------- #
+    @staticmethod
+    def _wants_hdf5(filepath, save_format):
+        """keras' rule (TF 2.1 saving_utils): save_format 'h5' / 'hdf5' / 'keras', or no format and a file name ending in
+        .h5 / .hdf5 / .keras; 'npz' / 'native' force the engine's container."""
+        if save_format is not None:
+            fmt = str(save_format).lower()
+            if fmt in ('h5', 'hdf5', 'keras'):
+                return True
+            if fmt in ('npz', 'native', 'dlwpcs'):
+                return False
+            raise ValueError("save_format %r: the engine writes 'h5' (Keras HDF5 layout) or 'npz' (native container)" % (save_format,))
+        return str(filepath).lower().endswith(('.h5', '.hdf5', '.keras'))
+
+    def _keras_layer_weights(self):
+        """[(layer name, [(weight name, array)])] of ALL layers, what keras' save_weights_to_hdf5_group iterates"""
+        return [(l.name, list(zip(l._weight_names, l.get_weights())) if l._weights else []) for l in self.layers]
+
     def save_weights(self, filepath, overwrite=True, save_format=None):
-        """Native weights file: an uncompressed numpy `.npz` container (whatever the extension; `save_format` is accepted for
-        call compatibility with reference DLWP/custom.py:186) holding one array per weight plus their keras names.  Loaded
-        with allow_pickle=False -- nothing in the file can execute code."""
+        """`save_format='h5'` (reference DLWP/custom.py:186) or a name ending in .h5 / .hdf5 / .keras: an HDF5 file in Keras'
+        layout (DLWP.keras.hdf5_lite.write_keras_file; opens with h5py / `keras.Model.load_weights`).  Otherwise the native
+        weights file: an uncompressed numpy `.npz` container holding one array per weight plus their keras names, loaded with
+        allow_pickle=False.  load_weights reads both."""
         if not overwrite and os.path.exists(filepath):
             return
         from . import serialization
+        if self._wants_hdf5(filepath, save_format):
+            from . import hdf5_lite
+            hdf5_lite.write_keras_file(filepath, self._keras_layer_weights())
+            return
         names = [n for l in self._weight_layers() for n in l._weight_names]
         layers = [[l.name, len(l._weights)] for l in self._weight_layers()]
         serialization.save_container(filepath, self.get_weights(), {'format': 'dlwpcs-weights-2', 'names': names,
@@ -1340,12 +1362,42 @@ class Model(object):
         return cls(inputs=ins[0] if config.get('single_input') else ins,
                    outputs=outs[0] if config.get('single_output') else outs, name=config.get('name'))
 
-    def save(self, filepath, overwrite=True, include_optimizer=True, **kwargs):
-        """Model file (`.keras` of DLWP.util.save_model): npz container with the graph config (JSON, engine format and the
-        keras functional format), the weights, the compile arguments and the optimizer state."""
+    def _save_hdf5(self, filepath, include_optimizer):
+        """keras' save_model_to_hdf5: model_config / training_config as root attributes, /model_weights, /optimizer_weights
+        (Adam: iterations, then every weight's m, then every weight's v -- the order of OptimizerV2.weights)"""
+        from . import hdf5_lite
+        tc = opt_w = None
+        if self._compiled:
+            ocfg = dict(self.optimizer.get_config())
+            tc = json.dumps({'optimizer_config': {'class_name': 'Adam', 'config': ocfg}, 'loss': self.loss,
+                             'metrics': list(self.metrics), 'weighted_metrics': None, 'sample_weight_mode': None,
+                             'loss_weights': self.loss_weights})
+            st = self.optimizer.state_dict() if include_optimizer else None
+            if st is not None:
+                base = self._flat_params.data_ptr()
+                ms, vs = [], []
+                for l in self._weight_layers():
+                    for w, wn in zip(l._weights, l._weight_names):
+                        o = (w.data_ptr() - base) // 4
+                        ms.append(('Adam/%s/m:0' % wn[:-2], st['m'][o:o + w.numel()].reshape(tuple(w.shape))))
+                        vs.append(('Adam/%s/v:0' % wn[:-2], st['v'][o:o + w.numel()].reshape(tuple(w.shape))))
+                opt_w = [('Adam/iter:0', np.asarray(st['step'], dtype=np.int64))] + ms + vs
+        hdf5_lite.write_keras_file(filepath, self._keras_layer_weights(), model_config=json.dumps(self.to_keras_config()),
+                                   training_config=tc, optimizer_weights=opt_w,
+                                   extra_attrs=[('dlwpcs_compute_dtype', self.compute_dtype)])
+
+    def save(self, filepath, overwrite=True, include_optimizer=True, save_format=None, **kwargs):
+        """Model file.  A name ending in .keras / .h5 / .hdf5 (the `<name>.keras` of DLWP.util.save_model, reference
+        util.py:139) or save_format='h5': an HDF5 file in Keras' layout -- graph as `model_config`, weights, compile arguments
+        as `training_config`, Adam state as `optimizer_weights` -- that `keras.models.load_model` (with DLWP.custom as
+        custom_objects) and this engine's load_model both read.  save_format='npz' (or any other file name): the engine's
+        native npz container with the same content."""
         if not overwrite and os.path.exists(filepath):
             return
         from . import serialization
+        if self._wants_hdf5(filepath, save_format):
+            self._save_hdf5(filepath, include_optimizer)
+            return
         meta = {'format': 'dlwpcs-model-2', 'config': self.get_config(), 'keras_config': self.to_keras_config(),
                 'compile': None, 'compute_dtype': self.compute_dtype, 'n_weights': len(self.weights)}
         arrays = self.get_weights()
@@ -1471,6 +1523,28 @@ def _compile_from_keras_training_config(model, tc):
                   metrics=sorted(set(metrics)) or None)
 
 
+def _restore_adam_from_keras(model, group):
+    """/optimizer_weights of a keras model file: [iterations] + one m per weight + one v per weight, in the order of the model's
+    weights (OptimizerV2.weights of Adam; files without amsgrad).  Anything else is left alone (fresh optimizer state)."""
+    from . import hdf5_lite
+    names = hdf5_lite._attr_list(group, 'weight_names')
+    ws = [w for l in model._weight_layers() for w in l._weights]
+    if len(names) != 1 + 2 * len(ws):
+        return
+    arrs = [np.asarray(group[n].read()) for n in names]
+    base = model._flat_params.data_ptr()
+    m = np.zeros(model._flat_params.numel(), dtype=np.float32)
+    v = np.zeros_like(m)
+    for k, w in enumerate(ws):
+        a, b = arrs[1 + k], arrs[1 + len(ws) + k]
+        if tuple(a.shape) != tuple(w.shape) or tuple(b.shape) != tuple(w.shape):
+            return
+        o = (w.data_ptr() - base) // 4
+        m[o:o + w.numel()] = a.ravel()
+        v[o:o + w.numel()] = b.ravel()
+    model.optimizer.load_state_dict({'m': m, 'v': v, 'step': int(np.asarray(arrs[0]).ravel()[0])}, model._flat_params)
+
+
 def load_model(filepath, custom_objects=None, compile=True):
     """
     Load a model file: the engine's npz container (Model.save), or an HDF5 file written by keras' `model.save()` under
@@ -1485,9 +1559,14 @@ def load_model(filepath, custom_objects=None, compile=True):
         model = Model.from_keras_config(json.loads(cfg), custom_objects=custom_objects)
         model._set_weights_by_layer([(n, [a for _, a in ws]) for n, ws in layers], False, 'HDF5')
         f = hdf5_lite.File(filepath)
+        cd = f.attrs.get('dlwpcs_compute_dtype')
+        if cd is not None:
+            model.compute_dtype = hdf5_lite._as_str(cd)                       # (files written by this engine)
         tc = f.attrs.get('training_config')
         if compile and tc is not None:
             _compile_from_keras_training_config(model, json.loads(hdf5_lite._as_str(tc)))
+            if 'optimizer_weights' in f._links:
+                _restore_adam_from_keras(model, f['optimizer_weights'])
         return model
     arrays, meta = serialization.load_container(filepath)
     if meta.get('format') != 'dlwpcs-model-2':

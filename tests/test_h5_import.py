@@ -114,14 +114,16 @@ def test_native_container_roundtrip_has_no_pickle(tmp_path):
     from DLWP.keras.models import load_model
     model = _tiny()
     model.compile(optimizer='adam', loss='mse', metrics=['mae'])
-    w = str(tmp_path / 'weights.h5')                    # the reference's callback passes save_format='h5' (custom.py:186)
-    model.save_weights(w, save_format='h5')
+    w = str(tmp_path / 'weights.ckpt')                  # no HDF5 extension, no save_format: the native container
+    model.save_weights(w)
     with open(w, 'rb') as f:
         assert f.read(2) == b'PK'                       # zip container, not a pickle, not HDF5
     arrays, meta = serialization.load_container(w)
     assert meta['format'] == 'dlwpcs-weights-2' and len(arrays) == len(model.weights)
-    m = str(tmp_path / 'm.keras')
-    model.save(m)
+    m = str(tmp_path / 'm.model')
+    model.save(m, save_format='npz')
+    with open(m, 'rb') as f:
+        assert f.read(2) == b'PK'
     loaded = load_model(m)
     assert all(np.array_equal(a, b) for a, b in zip(model.get_weights(), loaded.get_weights()))
     assert loaded._compiled and loaded.metrics == ['mae']
