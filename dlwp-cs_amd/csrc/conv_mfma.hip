@@ -93,11 +93,14 @@ struct ConvKParams {
 //      output-channel groups (see launch_conv), instead of 128 per workgroup in 16-channel chunks
 //  32: data gradient with 64 output channels (= the layer's input channels): two groups of 32 with the 384-pixel tiling
 //  64: 3-4 channel chunks per tile: one resident LDS weight area per chunk (P.wstat), with the tiling that makes them fit
+// 256: forward / data-gradient kernel: late start of the workgroups with the shorter tile list, bits 12..17 = how late (see the
+//      kernel; default 3)
 enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_SPLIT_N = 16,
-       TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64 };
+       TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64, TUNE_CONV_STAGGER = 256 };
 static int tune_bits() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_WG_PRODUCER_PRIO | TUNE_CONV_PRODUCER_PRIO | TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT); }
+    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_WG_PRODUCER_PRIO | TUNE_CONV_PRODUCER_PRIO | TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT |
+                               TUNE_CONV_STAGGER | (3 << 12)); }
     return v;
 }
 
@@ -186,6 +189,15 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     // base moves; they are rebuilt at the few (face, band) changes.
     const uint32_t lw = xcd_remap(blockIdx.x, (uint32_t)G);
     const int t_first = (int)(((long)P.ntiles * lw) / G), t_last = (int)(((long)P.ntiles * (lw + 1)) / G);
+    // TUNE_CONV_STAGGER: the workgroups whose tile list is one shorter than the longest (4 against 5 tiles at N = 48: half of
+    // them) start ~1.3 us late -- (tune >> 12) & 63 sleeps of 1024 cycles.  They have a tile's worth of slack, and the chip's 256
+    // workgroups no longer hit memory and the matrix cores in lockstep at the start of the kernel (the first tile of a workgroup
+    // costs twice a later one).  Measured on the bf16 training step, 0 / 1 / 2 / 3 / 4 / 6 / 8 sleeps: 0.6842 / 0.6795 / 0.6781 /
+    // 0.6768 / 0.6775 / 0.6786 / 0.6797 ms; 16 sleeps +24 us.
+    if ((P.tune & TUNE_CONV_STAGGER) && (t_last - t_first) * G < P.ntiles) {
+#pragma unroll 1
+        for (int i = 0; i < ((P.tune >> 12) & 63); ++i) __builtin_amdgcn_s_sleep(16);
+    }
     struct Geo { int b, f, v, combo, m0, npix, y0, nitems; };
     auto geo_of = [&](int t) __attribute__((always_inline)) {
         Geo gq;
