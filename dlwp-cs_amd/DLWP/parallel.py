@@ -27,7 +27,7 @@ def allreduce_gradients(flat_grads):
     the update equals the gradient of the mean loss over the global batch (equal per-rank batch sizes).
     """
     w = world()[1]
-    if w > 1 and exchange_enabled():
+    if _exchange_wanted():
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     return 1.0 / w
 
@@ -39,11 +39,20 @@ def exchange_enabled():
     return os.environ.get('DLWPCS_EXCHANGE_SKIP', '0') != '1'
 
 
+def _exchange_wanted():
+    """world size > 1 -- or DLWPCS_EXCHANGE_FORCE=1 with a process group of ONE rank: the collectives are issued although they
+    change nothing, so that RCCL's stream / the async handles / the graph replays around them run on a single GPU (tests)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()) or not exchange_enabled():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('DLWPCS_EXCHANGE_FORCE', '0') == '1'
+
+
 def allreduce_start(flat_slice):
     """Start the sum of one bucket of the flat gradient buffer over all ranks and return a handle for allreduce_wait (None at
     world size 1).  The collective runs on the process group's own stream behind everything enqueued on the current stream
     so far (RCCL; with gloo on a helper thread), so the launches that follow on the current stream overlap it."""
-    if world()[1] > 1 and exchange_enabled() and flat_slice.numel():
+    if _exchange_wanted() and flat_slice.numel():
         return dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True)
     return None
 

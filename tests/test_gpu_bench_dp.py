@@ -81,3 +81,49 @@ print('RCCL_OK')
 ''' % ROOT
     out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'RCCL_OK' in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_bucketed_exchange_runs_over_rccl_on_one_gpu():
+    """The two-bucket step with REAL RCCL collectives (backend 'nccl', one rank, DLWPCS_EXCHANGE_FORCE=1): the first bucket's async
+    all-reduce is started between the two backward graphs, the second behind them, the optimizer graph waits for both handles.
+    One rank sums to itself, so the parameters must equal the plain single-process run bit for bit (fp32) -- what is exercised is
+    RCCL's stream against the hipGraph replays."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%r, 'dlwp-cs_amd'))
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+import numpy as np, torch, torch.distributed as dist
+from DLWP.keras import backend
+from DLWP.model.cs_unet import build_cs_model
+torch.cuda.set_device(0)
+backend.set_device('cuda:0')
+dev = torch.device('cuda', 0)
+rng = np.random.default_rng(2)
+x = torch.tensor(rng.standard_normal((4, 6, 8, 8, 4)), dtype=torch.float32, device=dev)
+t = torch.tensor(rng.standard_normal((4, 6, 8, 8, 4)), dtype=torch.float32, device=dev)
+def train(buckets, w0=None):
+    np.random.seed(3)
+    m = build_cs_model((6, 8, 8, 4), 4, 'unet2', base_filter_number=4)
+    m.exchange_buckets = buckets
+    m.compile(optimizer='adam', loss='mse')
+    if w0 is not None:
+        m.set_weights(w0)
+    w_init = m.get_weights()
+    for _ in range(5):
+        m.train_on_device_batch([x], [t])
+    torch.cuda.synchronize()
+    return w_init, m._flat_params.detach().cpu().numpy().copy(), m
+w0, plain, _ = train(1)
+dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29541', rank=0, world_size=1, device_id=dev)
+os.environ['DLWPCS_EXCHANGE_FORCE'] = '1'
+_, one, m1 = train(1, w0)
+_, two, m2 = train(2, w0)
+g = next(iter(m2._graphs.values()))
+assert g['bwd_b'] is not None and g['update'] is not None and m2._did_split
+assert np.array_equal(plain, one), np.abs(plain - one).max()
+assert np.abs(plain - two).max() <= 1e-6 * np.abs(plain).max()
+dist.destroy_process_group()
+print('RCCL_BUCKETS_OK')
+''' % ROOT
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'RCCL_BUCKETS_OK' in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
