@@ -444,15 +444,16 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
         self_check['smi_note'] = 'torch.cuda.utilization unavailable: %s' % type(exc).__name__
     ar_us = allreduce_probe(model, world) if st['train'] else None
     # how much of the exchange the step actually waits for: the same blocks with the all-reduce calls turned into no-ops
-    # (DLWPCS_EXCHANGE_SKIP: timing only -- the replicas diverge, so this runs after everything that is reported)
+    # (DLWP.parallel.SKIP_EXCHANGE_FOR_TIMING: timing only -- the replicas diverge, so this runs after everything that is reported)
     noex_s = None
     if world > 1 and st['train']:
-        os.environ['DLWPCS_EXCHANGE_SKIP'] = '1'
+        from DLWP import parallel as _par
+        _par.SKIP_EXCHANGE_FOR_TIMING = True
         try:
             timed(per_block)
             noex_s = float(np.median([timed(per_block) / per_block for _ in range(3)]))
         finally:
-            os.environ.pop('DLWPCS_EXCHANGE_SKIP', None)
+            _par.SKIP_EXCHANGE_FOR_TIMING = False
     # the roofline pass runs eager optimisation steps (gradient all-reduce included): EVERY rank takes part
     agg = roofline_pass(st) if with_roofline else None
     if rank != 0:

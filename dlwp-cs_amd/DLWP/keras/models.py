@@ -16,6 +16,7 @@ Execution model (MI355X-first, replaces TF's graph executor):
 import gc
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -186,6 +187,16 @@ class Model(object):
                               isinstance(t.layer, Concatenate)))
         self._plan = steps
         self.n_fused = len(fused)
+        # padded rollout state (rollout_on_device: the output layer writes ceil8(C) channels, that tensor comes back as the
+        # input): only when the model's single input is read by ONE step, a fused convolution taking it as its plain source 0
+        self._padded_io_ok = False
+        if len(self.inputs) == 1:
+            u = self.inputs[0].uid
+            rd = [st for st in steps
+                  if (st[0] == 'fused_conv' and u in (st[3], st[4])) or (st[0] == 'pool_skip' and st[3] == u)
+                  or (st[0] == 'layer' and u in st[3])]
+            self._padded_io_ok = (len(rd) == 1 and rd[0][0] == 'fused_conv' and rd[0][3] == u and rd[0][4] is None
+                                  and not rd[0][5] and u not in out_uids)
         self._plan_premask(steps, out_uids)
         # model outputs that no other node consumes (candidates for the fused head + loss step) and appear once
         uids = [o.uid for o in self.outputs]
@@ -628,7 +639,7 @@ class Model(object):
                     ops.flush_wgrad_batch(None)
                     ops.flush_deferred_reduce(dev)
                     self._did_split = True
-                    yield None
+                    yield None                      # (GeneratorExit here runs the `finally` below: the switches go back)
                     pairs = [(t, g) for t, g in zip(cut, gcut) if g is not None]
                     if pairs:
                         torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
@@ -658,7 +669,8 @@ class Model(object):
                 ops.drop_wgrad_batch()
                 if ops._pending_ring:
                     ops.drop_pending_rings()
-                    raise RuntimeError('a deferred ring fix-up was not consumed by its pooling node (plan error)')
+                    if sys.exc_info()[0] is None:   # (not on top of an exception of the backward pass itself)
+                        raise RuntimeError('a deferred ring fix-up was not consumed by its pooling node (plan error)')
                 ops.finish_loss_tail()              # (no fused reduction + optimizer launch took it: its own launch)
                 ops.join_side_stream(stats[0].device)
         if len(stats) == 1:
@@ -689,6 +701,8 @@ class Model(object):
                 raise RuntimeError('the split step yielded twice')
             except StopIteration as e:
                 stats = e.value
+            finally:
+                gen.close()                                     # (a failure between the halves: the step's global switches go back)
             if self._did_split:
                 hb = parallel.allreduce_start(self._exchange_slices()[1])
                 parallel.allreduce_wait(ha)
@@ -777,19 +791,22 @@ class Model(object):
                 # started between them (train_on_device_batch)
                 gen = self._loss_and_backward_gen(static_in, static_tg, True, None, split=True)
                 stats = None
-                with torch.cuda.graph(g1, capture_error_mode=mode):
-                    try:
-                        next(gen)
-                    except StopIteration as e:
-                        stats = e.value
-                if stats is None:
-                    g1b = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g1b, pool=g1.pool(), capture_error_mode=mode):
+                try:
+                    with torch.cuda.graph(g1, capture_error_mode=mode):
                         try:
                             next(gen)
-                            raise RuntimeError('the split step yielded twice')
                         except StopIteration as e:
                             stats = e.value
+                    if stats is None:
+                        g1b = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g1b, pool=g1.pool(), capture_error_mode=mode):
+                            try:
+                                next(gen)
+                                raise RuntimeError('the split step yielded twice')
+                            except StopIteration as e:
+                                stats = e.value
+                finally:
+                    gen.close()
             else:
                 # world size 1: the step's last launch (reduction + optimizer) can keep the packed operands current, the captured
                 # step then starts without the packing launch; captured again WITH it if that launch turns out not to cover
@@ -1065,6 +1082,17 @@ class Model(object):
             outs = [np.empty((0,) + tuple(o.shape[1:]), dtype=np.float32) for o in self.outputs]
         return outs[0] if self._single_output else outs
 
+    def invalidate_packed(self):
+        """Tell the model that its parameters were changed behind its back.  Replayed training steps without a packing launch
+        (`fuse_pack`) trust the packed bf16 operands their own optimizer launch left behind; they notice parameter changes made
+        by this class (`set_weights`, `load_weights`, eager steps, other graphs) and in-place torch operations on the flat
+        buffer's VIEWS that move its version counter -- NOT writes through `.data`, raw pointers, a native kernel, or another
+        object's optimizer on the same buffer.  After such a write call this method: the next pass packs first."""
+        self._packed_ok = False
+        st = getattr(self, '_pack_cache', None)
+        if st is not None:
+            st['packed'] = False
+
     def _ensure_packed(self, device):
         """A captured step without a packing launch relies on the packed operands being current: true after such a step itself
         (its optimizer launch refreshed them), not after anything else that changed the parameters -- an optimizer launch of its
@@ -1084,6 +1112,8 @@ class Model(object):
         output layer writes its rows padded with zero channels to the next multiple of 8 -- and such a tensor is accepted as the
         model's input (the first convolution reads 64-B aligned rows instead of 52-B ones: 85 -> 58 us at N = 96).  Slice
         `[..., :C]` to get the reference layout."""
+        if padded_io and not self._padded_io_ok:
+            raise ValueError('padded_io needs a model whose single input is read by one fused convolution as its plain source')
         self._padded_io = bool(padded_io)
         try:
             with torch.no_grad():
@@ -1111,7 +1141,7 @@ class Model(object):
                 series = torch.empty((steps * n_steps,) + tuple(state.shape), dtype=torch.float32, device=state.device)
                 shape0, C = tuple(state.shape), state.shape[-1]
                 self._padded_io = (state.dtype == torch.bfloat16 and C % 8 != 0          # (see predict_on_device)
-                                   and os.environ.get('DLWPCS_PADDED_IO', '1') == '1')
+                                   and self._padded_io_ok and os.environ.get('DLWPCS_PADDED_IO', '1') == '1')
                 try:
                     for t in range(steps):
                         if verbose > 0 and s == 0:

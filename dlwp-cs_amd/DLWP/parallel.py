@@ -32,11 +32,21 @@ def allreduce_gradients(flat_grads):
     return 1.0 / w
 
 
+# bench.py ONLY: time a step WITHOUT its exchange, to report how much of the all-reduce is exposed.  The replicas diverge while
+# this is set; it is a module attribute (not an environment variable) so that nothing can leak it into a real training run.
+SKIP_EXCHANGE_FOR_TIMING = False
+_skip_warned = False
+
+
 def exchange_enabled():
-    """False under DLWPCS_EXCHANGE_SKIP=1 (bench.py's timing of a step WITHOUT its exchange, to report how much of the
-    all-reduce is exposed; the replicas diverge, never set it for real training)."""
-    import os
-    return os.environ.get('DLWPCS_EXCHANGE_SKIP', '0') != '1'
+    global _skip_warned
+    if SKIP_EXCHANGE_FOR_TIMING:
+        if not _skip_warned and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            import warnings
+            warnings.warn('DLWP.parallel.SKIP_EXCHANGE_FOR_TIMING is set: gradients are NOT summed over the ranks (timing only)')
+            _skip_warned = True
+        return False
+    return True
 
 
 def _exchange_wanted():

@@ -589,7 +589,9 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
     // FAST (0 <= alpha <= 1, max >= 0, i.e. every activation of the reference's models and "none"): the activation is
     // min(max(x, alpha*x), max) -- 2.5 VALU instructions per value (v_max_f32, v_min_f32, half a packed multiply) instead of 4.5
     // (canonicalise, min, compare, select, half a multiply); the consumers' epilogue is VALU-issue bound.  (NOT med3(x, alpha*x, max): that is alpha*x,
-    // not max, once alpha*x itself exceeds max.  A NaN comes out as `max` on this path: v_min_f32 is IEEE minNum.)
+    // not max, once alpha*x itself exceeds max.)  NaN: keras' ReLU (Azure/train_cs.py:199) propagates it.  v_max_f32(NaN, alpha * NaN)
+    // is NaN (both operands), but v_min_f32 is IEEE minNum and would turn it into `max`; gfx950's v_minimum3_f32 is the IEEE-754-2019
+    // minimum (NaN if any operand is), same issue cost: a NaN pre-activation leaves the layer as NaN.
     const float e_alpha = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.alpha : 1.f;
     const float e_vmax = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.vmax : __builtin_inff();
     const bool fast_act = e_alpha >= 0.f && e_alpha <= 1.f && e_vmax >= 0.f;
@@ -604,7 +606,7 @@ __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const Co
             auto lc = [&](float x, float ax) {
                 float t, y;
                 asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(ax));
-                asm("v_min_f32 %0, %1, %2" : "=v"(y) : "v"(t), "v"(e_vmax));
+                asm("v_minimum3_f32 %0, %1, %2, %2" : "=v"(y) : "v"(t), "v"(e_vmax));
                 return y;
             };
             const f32x2 a01 = f32x2{v4.x, v4.y} * e_alpha, a23 = f32x2{v4.z, v4.w} * e_alpha;     // v_pk_mul_f32
@@ -1963,7 +1965,7 @@ __global__ void __launch_bounds__(256) pw_fwd_kernel(PwParams P) {
                                                                       b[t], 0, 0, 0);
                     if (ACT) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { const float x = d[k] < 0.f ? d[k] * P.alpha : d[k]; d[k] = fminf(x, P.vmax); }
+                        for (int k = 0; k < 4; ++k) { const float x = d[k] < 0.f ? d[k] * P.alpha : d[k]; d[k] = x > P.vmax ? P.vmax : x; }   // (NaN stays NaN)
                     }
                     const int co0 = t * 16 + q * 4, sidx = (n * Cout + co0) >> 1;
                     if (co0 + 4 <= Cout) { stage[sidx] = f2bf2(d[0], d[1]); stage[sidx + 1] = f2bf2(d[2], d[3]); }

@@ -135,8 +135,9 @@ typedef struct dlwpcs_conv_desc {
     int32_t act;            /* DLWPCS_ACT_* */
     float   alpha, vmax;    /* parameters of DLWPCS_ACT_LEAKY_CLIP.  For 0 <= alpha <= 1 and vmax > 0 (every activation of the
                              * reference's models) the fused convolution evaluates it as min(max(x, alpha*x), vmax): identical
-                             * for all finite and infinite x; a NaN input comes out as vmax (the select form used for other
-                             * alpha, by dlwpcs_act_fwd and by the oracle returns NaN).  alpha < 0 or vmax < 0: rejected. */
+                             * for all finite and infinite x, and a NaN stays a NaN like in keras' ReLU (the min is
+                             * gfx950's NaN-propagating v_minimum3_f32; the select form used for other alpha, by
+                             * dlwpcs_act_fwd and by the oracle returns NaN as well).  alpha < 0 or vmax < 0: rejected. */
     int32_t dtype;          /* DLWPCS_F32 | DLWPCS_BF16 (dtype of src*, y, dy, dsrc*; parameters are always fp32) */
     int32_t flags;          /* DLWPCS_CONV_* bits */
     int32_t c0_valid;       /* 0: every channel of src0 is real.  > 0 (C1 must be 0): src0 is stored with C0 channels per

@@ -199,6 +199,30 @@ def test_cfg3_forward_samples_match_oracle_and_are_batch_independent():
         assert rel_err(yi[0], y[i]) < 1e-6
 
 
+def test_cfg3_bf16_forward_samples_match_oracle():
+    """The same at the headline dtype: unet2 C48 base 32, x (32,6,48,48,14), bf16 activations.  Two samples of the 32-batch
+    against the fp64 oracle evaluated with the bf16-rounded input and kernels the device consumes; what is left is one bf16
+    rounding of the activations per layer, eleven layers deep: stated bound 2e-2 of the output range (observed ~5e-3), and a
+    sample's prediction inside the batch is BITWISE its prediction alone (no cross-sample arithmetic anywhere)."""
+    rng = np.random.default_rng(313)
+    bfr = lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64)
+    x = rng.standard_normal((B_FULL, 6, 48, 48, 14)).astype(np.float32)
+    params = orc.make_unet2_params(14, 14, base=32, seed=7)
+    model, convs = _build_unet2(48, 14, 14, 32, 'bfloat16')
+    model.compile(optimizer='adam', loss='mse')
+    _set_params(convs, params)
+    y = model.predict(x, batch_size=B_FULL)
+    pick = [5, 28]
+    pr = [{n: (bfr(v.numpy()) if 'kernel' in n else v.double()) for n, v in prm.items()} for prm in params]
+    yr = orc.unet2_forward(bfr(x[pick]), pr).numpy()
+    e = rel_err(y[pick], yr)
+    print('cfg3 bf16 forward vs oracle: %.3g' % e)
+    assert e < 2e-2
+    for i in pick:
+        yi = model.predict(x[i:i + 1], batch_size=1)
+        assert np.array_equal(yi[0], y[i])
+
+
 @pytest.mark.parametrize('dtype,tol', [('float32', RTOL), ('bfloat16', 2e-2)])
 def test_cfg3_gradient_is_linear_in_the_batch(dtype, tol):
     """grad of the 32-sample mean loss = mean of the four 8-sample gradients (fp32: 1e-5; bf16: activations are rounded

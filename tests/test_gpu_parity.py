@@ -227,6 +227,55 @@ def test_conv_activation_parameter_forms(alpha, vmax, dtype):
         assert rel_err(db[n].grad.cpu().numpy(), tb[n].grad.numpy()) < RTOL, 'db ' + n
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_nan_propagates_like_keras_relu(dtype):
+    """Non-finite pre-activations through the fused convolution + keras ReLU(0.1, 10) (Azure/train_cs.py:199): a NaN stays a NaN
+    (until round 3 the IEEE-minNum epilogue turned it into max_value), +inf clips to max_value, -inf stays -inf -- exactly where the
+    oracle says so -- and a NaN in a network's input reaches the loss as NaN."""
+    from DLWP import ops
+    from DLWP._native import ACT_LEAKY_CLIP
+    B, N, C0, Cout = 2, 12, 16, 32
+    rng = np.random.default_rng(5)
+    bf = dtype == torch.bfloat16
+    rnd = (lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()) if bf else (lambda a: a)
+    x0 = rnd(rng.standard_normal((B, 6, N, N, C0)))
+    x0[0, 0, 3, 4, 2] = np.nan          # interior cell
+    x0[0, 4, 0, 0, 5] = np.nan          # pole-face corner: reaches other faces through the halo
+    x0[1, 2, 6, 11, 1] = np.inf         # edge cell
+    x0[1, 5, 9, 2, 7] = -np.inf
+    w, b = _rand_conv_params(rng, 3, C0, Cout, False)
+    wr = {n: (None if v is None else rnd(v)) for n, v in w.items()}
+    t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64)
+    yref = orc.cs_conv2d(orc.cs_pad(t(x0), 1, 'channels_last'), t(wr['eq']), t(wr['pol']), None, t(b['eq']), t(b['pol']), None,
+                         data_format='channels_last', flip_north_pole=True, independent_north_pole=False)
+    yref = orc.relu_leaky_clip(yref, 0.1, 10.0).numpy()
+    dw = {n: (None if v is None else to_dev(v)) for n, v in w.items()}
+    db = {n: (None if v is None else to_dev(v)) for n, v in b.items()}
+    y = ops.cs_conv(to_dev(x0).to(dtype), dw['eq'], dw['pol'], None, db['eq'], db['pol'], None, ksize=3, halo=True,
+                    flip_north_pole=True, act=ACT_LEAKY_CLIP, alpha=0.1, vmax=10.0).float().cpu().numpy()
+    assert np.isnan(yref).sum() > 50 and np.isinf(yref).any() and (yref == 10.0).any()
+    assert np.array_equal(np.isnan(y), np.isnan(yref))
+    assert np.array_equal(np.isposinf(y), np.isposinf(yref)) and np.array_equal(np.isneginf(y), np.isneginf(yref))
+    fin = np.isfinite(yref)
+    assert np.abs(y[fin] - yref[fin]).max() < (2.0 ** -8 if bf else RTOL) * np.abs(yref[fin]).max()
+
+    # a NaN in the input of a network reaches the loss as NaN (both the inference and the training path)
+    from DLWP.keras import mixed_precision
+    mixed_precision.set_policy('mixed_bfloat16' if bf else 'float32')
+    try:
+        model, convs = _build_unet2(8, 8, 8, 8)
+        model.compile(optimizer='adam', loss='mse')
+        xs = rng.standard_normal((2, 6, 8, 8, 8)).astype(np.float32)
+        xs[1, 3, 4, 4, 0] = np.nan
+        ys = rng.standard_normal((2, 6, 8, 8, 8)).astype(np.float32)
+        pred = model.predict(xs)
+        assert np.isfinite(pred[0]).all() and np.isnan(pred[1]).any()
+        hist = model.fit(xs, ys, batch_size=2, epochs=1, verbose=0, shuffle=False)
+        assert np.isnan(hist.history['loss'][0])
+    finally:
+        mixed_precision.set_policy('float32')
+
+
 def test_conv_cfg1_golden(golden_dir):
     """BASELINE config 1 against the vector produced by the reference layers."""
     from DLWP import ops

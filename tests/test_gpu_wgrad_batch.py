@@ -215,12 +215,51 @@ def test_matches_the_per_layer_kernel():
         assert rel_err(_f64(lay.db[n]).numpy(), _f64(rb[n]).numpy()) <= TOL
 
 
+def _slice_of(lay, sl):
+    """the same layer restricted to the samples `sl` (views of the inputs, gradient tensors of its own)"""
+    B, N, C0, C1, up0, Cout, k, halo, flip, indep, bias, c0_valid = lay.cfg
+    from DLWP import _native as nat
+    part = Layer.__new__(Layer)
+    nb = len(range(*sl.indices(B)))
+    part.cfg = (nb,) + lay.cfg[1:]
+    part.x0 = lay.x0[sl]
+    part.x1 = None if lay.x1 is None else lay.x1[sl]
+    part.dz = lay.dz[sl]
+    part.dw = {n: torch.zeros_like(v) for n, v in lay.dw.items()}
+    part.db = {n: torch.zeros_like(v) for n, v in lay.db.items()}
+    part.d = nat.ConvDesc.from_buffer_copy(lay.d)
+    part.d.B = nb
+    part.table = lay.table
+    return part
+
+
 def test_full_size_batch_32():
-    """BASELINE config 3 geometry: the unet2 layer list at batch 32 (plan with 256 chains), spot-checked on two layers"""
+    """BASELINE config 3 geometry: the unet2 layer list at batch 32 (plan with 256 chains), ALL eleven layers: the 32-sample
+    launch equals the sum of four 8-sample launches (the weight gradient is linear in the samples; fp32 summation order is all
+    that differs), and every layer of the first 8-sample launch is checked against the fp64 oracle."""
     from DLWP import ops
     rng = np.random.default_rng(21)
     lays = [Layer(rng, 32, *cfg) for cfg in UNET2]
     ops.wgrad_batch([l.entry() for l in lays])
     torch.cuda.synchronize()
-    for i in (3, 10):
-        lays[i].check()
+    acc = [({n: torch.zeros_like(v, dtype=torch.float64) for n, v in l.dw.items()},
+            {n: torch.zeros_like(v, dtype=torch.float64) for n, v in l.db.items()}) for l in lays]
+    for s in range(0, 32, 8):
+        parts = [_slice_of(l, slice(s, s + 8)) for l in lays]
+        ops.wgrad_batch([q.entry() for q in parts])
+        torch.cuda.synchronize()
+        for q, (aw, ab) in zip(parts, acc):
+            for n in aw:
+                aw[n] += q.dw[n].double()
+            for n in ab:
+                ab[n] += q.db[n].double()
+        if s == 0:
+            for q in parts:
+                q.check()                       # fp64 oracle, 8 samples, every layer
+    for l, (aw, ab) in zip(lays, acc):
+        for n in aw:
+            e = rel_err(_f64(l.dw[n]).numpy(), aw[n].cpu().numpy())
+            assert e <= TOL, 'dW_%s of %r: %.3g' % (n, l.cfg, e)
+        for n in ab:
+            e = rel_err(_f64(l.db[n]).numpy(), ab[n].cpu().numpy())
+            assert e <= TOL, 'db_%s of %r: %.3g' % (n, l.cfg, e)
