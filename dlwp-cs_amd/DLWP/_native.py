@@ -115,6 +115,8 @@ PROTOTYPES = {
                                         c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     'dlwpcs_wgrad_batch_adam_tail': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dlwpcs_wgrad_batch_apply': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dlwpcs_gconv_fwd': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),
     'dlwpcs_gconv_bwd_data': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 6),
     'dlwpcs_gconv_bwd_weights': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),

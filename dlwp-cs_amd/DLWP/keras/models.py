@@ -569,11 +569,13 @@ class Model(object):
             vals += [float(s[0, 1])]
         return vals
 
-    def _loss_and_backward(self, inputs, targets, train=True, fuse_update=None, skip_pack=False):
+    def _loss_and_backward(self, inputs, targets, train=True, fuse_update=None, skip_pack=False, exchange=False):
         """fuse_update = grad_scale | None: with a value, the optimizer step may ride in the reduction of the batched weight
         gradients (ops.flush_wgrad_batch); self._update_done says whether it did (self._pack_done: and refreshed the packed
-        operands)."""
-        gen = self._loss_and_backward_gen(inputs, targets, train, fuse_update, split=False, skip_pack=skip_pack)
+        operands).  exchange=True (data parallel, with fuse_update): the gradient all-reduce is issued inside the step, between
+        the reduction and ONE launch that applies the update (ops.apply_wgrad_batch) -- the whole step is one launch sequence,
+        capturable as one hipGraph."""
+        gen = self._loss_and_backward_gen(inputs, targets, train, fuse_update, split=False, skip_pack=skip_pack, exchange=exchange)
         try:
             while True:
                 next(gen)
@@ -584,7 +586,33 @@ class Model(object):
         """Two-bucket exchange for this step?"""
         return self.exchange_buckets == 2 and self._plan_exchange() is not None
 
-    def _loss_and_backward_gen(self, inputs, targets, train=True, fuse_update=None, split=False, skip_pack=False):
+    def _adam_args(self, dev, fuse_update):
+        """(adam tuple, pack lookup) for the fused / applied optimizer launch"""
+        opt = self.optimizer
+        opt._ensure_state(self._flat_params)
+        if not torch.cuda.is_current_stream_capturing():
+            opt.sync_hyper(fuse_update)
+        adam = (self._flat_params, self._flat_grads, opt._m, opt._v, opt._step, opt._hyper, sum(w.numel() for w in self.weights))
+        lookup = None
+        if self.fuse_pack and self.prepack_weights:
+            lookup = self._pack_state(dev).get('by_grad', {}).get
+        return adam, lookup
+
+    def _apply_update(self, grad_scale, dev):
+        """The optimizer step behind an exchange: ONE launch (scale + Adam + gradient clear + packed operands + loss tail) when
+        the layers of the last backward pass cover every parameter, else the plain optimizer launch."""
+        ent = getattr(self, '_wb_done', None)
+        self._pack_done = False
+        if ent and self.fuse_adam and self.batch_wgrad and self.optimizer is not None:
+            adam, lookup = self._adam_args(dev, grad_scale)
+            if ops.apply_wgrad_batch(adam, lookup, entries=ent):
+                self._pack_done = bool(ops.PACK_FUSED)
+                return True
+        ops.finish_loss_tail()
+        self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
+        return False
+
+    def _loss_and_backward_gen(self, inputs, targets, train=True, fuse_update=None, split=False, skip_pack=False, exchange=False):
         """Generator form of the step: with split=True (and a usable cut, see _plan_exchange) it yields ONCE, after the
         gradients of bucket A (decoder side) are final in the flat gradient buffer, so that the caller can start their
         all-reduce -- or end a hipGraph capture -- before the encoder-side half of the backward pass is issued.  Returns the
@@ -602,8 +630,9 @@ class Model(object):
         self._record_cut = cutplan[0] if cutplan else None
         # the loss's last reduction stage rides in the step's last launch when that is the fused reduction + optimizer
         ops.finish_loss_tail()
+        dp_fused = bool(train and exchange and fuse_update is not None and not cutplan)
         ops.DEFER_LOSS_TAIL = bool(train and fuse_update is not None and self.fuse_adam and self.batch_wgrad and self.fold_loss_tail
-                                   and self.optimizer is not None and self._world == 1 and not cutplan)
+                                   and self.optimizer is not None and (self._world == 1 or dp_fused) and not cutplan)
         self._pack_done = False
         try:
             # skip_pack: the packed operands are current (_ensure_packed) and this step's own last launch keeps them so
@@ -645,21 +674,23 @@ class Model(object):
                         torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
                 else:
                     torch.autograd.backward(stats, ones)
-                adam = None
-                if (fuse_update is not None and self.fuse_adam and not ops._deferred and self.optimizer is not None
-                        and self._world == 1 and not cut):
-                    opt = self.optimizer
-                    opt._ensure_state(self._flat_params)
-                    if not torch.cuda.is_current_stream_capturing():
-                        opt.sync_hyper(fuse_update)
-                    adam = (self._flat_params, self._flat_grads, opt._m, opt._v, opt._step, opt._hyper,
-                            sum(w.numel() for w in self.weights))
-                lookup = None
-                if adam is not None and self.fuse_pack and self.prepack_weights:
-                    lookup = self._pack_state(dev).get('by_grad', {}).get
-                self._update_done = ops.flush_wgrad_batch(adam, lookup)
-                self._pack_done = bool(self._update_done and ops.PACK_FUSED)
-                ops.flush_deferred_reduce(dev)
+                if dp_fused:
+                    # data parallel: local reduction -> all-reduce of the flat buffer -> ONE launch that applies the update
+                    ops.flush_wgrad_batch(None)
+                    ops.flush_deferred_reduce(dev)
+                    self._wb_done = ops.flushed_wgrad_entries()
+                    parallel.allreduce_gradients(self._flat_grads)
+                    self._update_done = True
+                    self._apply_update(fuse_update, dev)
+                else:
+                    adam = lookup = None
+                    if (fuse_update is not None and self.fuse_adam and not ops._deferred and self.optimizer is not None
+                            and self._world == 1 and not cut):
+                        adam, lookup = self._adam_args(dev, fuse_update)
+                    self._update_done = ops.flush_wgrad_batch(adam, lookup)
+                    self._pack_done = bool(self._update_done and ops.PACK_FUSED)
+                    ops.flush_deferred_reduce(dev)
+                    self._wb_done = ops.flushed_wgrad_entries()
             finally:
                 ops.DIRECT_PARAM_GRADS = False
                 ops.WGRAD_SIDE_STREAM = False
@@ -784,7 +815,7 @@ class Model(object):
         gc.disable()
         # With a process group alive its watchdog thread issues HIP calls of its own: only THIS thread's calls are held to the
         # capture rules then (a foreign call must not invalidate the capture).
-        mode = 'thread_local' if self._world > 1 else 'global'
+        mode = 'thread_local' if (self._world > 1 or parallel.group_alive()) else 'global'
         try:
             if split:
                 # forward + decoder-side backward | encoder-side backward: two graphs, the first bucket's all-reduce is
@@ -808,36 +839,59 @@ class Model(object):
                 finally:
                     gen.close()
             else:
-                # world size 1: the step's last launch (reduction + optimizer) can keep the packed operands current, the captured
-                # step then starts without the packing launch; captured again WITH it if that launch turns out not to cover
-                # every layer
-                no_pack = (self._world == 1 and self.fuse_pack and self.fuse_adam and self.batch_wgrad and self.prepack_weights
-                           and self.compute_dtype == 'bfloat16' and static_in[0].is_cuda)
-                if no_pack:
-                    self._ensure_packed(static_in[0].device)
-                    gtry = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gtry, capture_error_mode=mode):
-                        stats = self._loss_and_backward(static_in, static_tg, True, fuse_update=grad_scale, skip_pack=True)
-                    if self._update_done and self._pack_done:
-                        g1 = gtry
-                        no_pack_entry = True
-                    else:
-                        no_pack = False
-                        del gtry
-                if not no_pack:
+                # One graph per step.  World size 1: the step's last launch is the fused reduction + optimizer.  Data parallel
+                # (round 4): local reduction -> all-reduce CAPTURED in the graph -> one launch that applies the update
+                # (scale + Adam + gradient clear + packed operands + loss tail): 31 + 1 launches and the collective, one replay,
+                # no inter-graph gap.  DLWPCS_DP_ONE_GRAPH=0 (or a capture that fails) falls back to two graphs with the
+                # all-reduce issued by the host between them.
+                # Either way the step's last launch can keep the packed operands current, the captured step then starts without
+                # the packing launch; captured again WITH it if that launch turns out not to cover every layer.
+                dp = parallel.exchange_wanted()
+                one = (not dp) or (parallel.exchange_capturable() and os.environ.get('DLWPCS_DP_ONE_GRAPH', '1') == '1')
+                done = False
+                if one:
+                    try:
+                        no_pack = (self.fuse_pack and self.fuse_adam and self.batch_wgrad and self.prepack_weights
+                                   and self.compute_dtype == 'bfloat16' and static_in[0].is_cuda)
+                        if no_pack:
+                            self._ensure_packed(static_in[0].device)
+                            gtry = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(gtry, capture_error_mode=mode):
+                                stats = self._loss_and_backward(static_in, static_tg, True, fuse_update=grad_scale, skip_pack=True,
+                                                                exchange=dp)
+                            if self._update_done and self._pack_done:
+                                g1 = gtry
+                                no_pack_entry = True
+                            else:
+                                no_pack = False
+                                del gtry
+                        if not no_pack:
+                            with torch.cuda.graph(g1, capture_error_mode=mode):
+                                stats = self._loss_and_backward(static_in, static_tg, True, fuse_update=grad_scale, exchange=dp)
+                                if not self._update_done:
+                                    # no exchange step: the update rides in the same graph (no inter-graph gap); normally INSIDE
+                                    # the reduction of the batched weight gradients, as a launch of its own when those do not
+                                    # cover every parameter
+                                    self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
+                        done = True
+                        g2 = None
+                    except Exception as exc:
+                        if not dp:
+                            raise
+                        import warnings
+                        warnings.warn('capturing the gradient all-reduce inside the step graph failed (%s: %s); falling back to '
+                                      'two graphs with the exchange between them' % (type(exc).__name__, exc))
+                        torch.cuda.synchronize()
+                        g1 = torch.cuda.CUDAGraph()
+                        no_pack_entry = False
+                        self._flat_grads.zero_()
+                if not done:
                     with torch.cuda.graph(g1, capture_error_mode=mode):
-                        stats = self._loss_and_backward(static_in, static_tg, True,
-                                                        fuse_update=grad_scale if self._world == 1 else None)
-                        if self._world == 1 and not self._update_done:
-                            # no exchange step: the update rides in the same graph (no inter-graph gap); normally INSIDE the
-                            # reduction of the batched weight gradients, as a launch of its own when those do not cover
-                            # every parameter
-                            self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
-            if self._world == 1 and not split:
-                g2 = None
-            else:
+                        stats = self._loss_and_backward(static_in, static_tg, True, fuse_update=None)
+            if g2 is not None:
+                dev = static_in[0].device
                 with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
-                    self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=grad_scale, zero_grads=True)
+                    self._apply_update(grad_scale, dev)
         finally:
             if gc_was_enabled:
                 gc.enable()

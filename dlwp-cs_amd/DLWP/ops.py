@@ -122,8 +122,12 @@ def wgrad_batch_supported(d):
     return bool(lib().dlwpcs_wgrad_batch_supported(ctypes.byref(d)))
 
 
+_wb_flushed = []            # the entries flush_wgrad_batch() has run since the last drop (apply_wgrad_batch names their gradients)
+
+
 def drop_wgrad_batch():
     del _wb_pending[:]
+    del _wb_flushed[:]
 
 
 # The fused head's loss is finished (second stage of its reduction) by the LAST launch of the training step when that is the
@@ -156,20 +160,10 @@ def flush_wgrad_batch(adam=None, pack_lookup=None):
         return False
     pending = list(_wb_pending)
     del _wb_pending[:]
+    _wb_flushed.extend(pending)
     if adam is not None and len(pending) <= nat.WGRAD_BATCH_MAX:
         p, g, m, v, state, hyper, n_elems = adam
-        seen, covered = set(), 0
-        for ent in pending:
-            for t in ent[5]:
-                if t is not None:
-                    if t.data_ptr() in seen:
-                        covered = -1
-                        break
-                    seen.add(t.data_ptr())
-                    covered += t.numel()
-            if covered < 0:
-                break
-        if covered == n_elems:
+        if _wb_covers(pending, n_elems):
             packs = None
             if pack_lookup is not None:
                 packs = [pack_lookup(ent[5][0].data_ptr()) for ent in pending]
@@ -180,6 +174,85 @@ def flush_wgrad_batch(adam=None, pack_lookup=None):
             return True
     wgrad_batch(pending)
     return False
+
+
+def _wb_covers(entries, n_elems):
+    """do the gradient tensors of `entries` cover n_elems parameter elements, each exactly once?"""
+    seen, covered = set(), 0
+    for ent in entries:
+        for t in ent[5]:
+            if t is not None:
+                if t.data_ptr() in seen:
+                    return False
+                seen.add(t.data_ptr())
+                covered += t.numel()
+    return covered == n_elems
+
+
+def flushed_wgrad_entries():
+    """the entries run by flush_wgrad_batch() since the last drop (a caller that applies the update after the backward pass's
+    clean-up keeps this list for apply_wgrad_batch)"""
+    return list(_wb_flushed)
+
+
+def apply_wgrad_batch(adam, pack_lookup=None, entries=None):
+    """Data-parallel tail of a training step (dlwpcs_wgrad_batch_apply): the layers flush_wgrad_batch() has run since the last
+    drop left their finished gradients in the flat buffer, the caller has summed it over the ranks; ONE launch now applies
+    grad_scale + Adam, clears the gradients, refreshes the packed bf16 operands (pack_lookup as for flush_wgrad_batch) and
+    finishes a deferred loss.  adam = (p, g, m, v, state {t, ticket}, hyper, number of parameter elements).  Returns False --
+    nothing launched -- when those layers do not cover every parameter exactly once (the caller runs its optimizer launch)."""
+    global PACK_FUSED
+    PACK_FUSED = False
+    entries = list(_wb_flushed) if entries is None else list(entries)
+    p, g, m, v, state, hyper, n_elems = adam
+    if not entries or len(entries) > nat.WGRAD_BATCH_MAX or not _wb_covers(entries, n_elems):
+        return False
+    dev = entries[0][3].device
+    arr, key = _wb_items(entries)
+    hit = _wb_plan(arr, len(entries), (str(dev), key), dev)
+    host, plan_dev, _ = hit
+    packs = None
+    if pack_lookup is not None:
+        packs = [pack_lookup(ent[5][0].data_ptr()) for ent in entries]
+        if any(pk is None for pk in packs):
+            packs = None
+    tail = None
+    if len(_pending_tail) == 1:
+        tail, keep = _pending_tail.pop()                        # the step's loss is finished by this launch
+    check(lib().dlwpcs_wgrad_batch_apply(arr, len(entries), host, ptr(plan_dev), ptr(p), ptr(g), ptr(m), ptr(v), g.numel(),
+                                         ptr(state), ptr(hyper), ctypes.byref(tail) if tail is not None else None,
+                                         _pack_array(packs) if packs is not None else None, stream_ptr()),
+          'dlwpcs_wgrad_batch_apply')
+    PACK_FUSED = packs is not None
+    return True
+
+
+def _pack_array(packs):
+    pk_arr = (nat.PackItem * len(packs))()
+    for it, (we, wp, wn, be, bp, bn, bufs, ksize, flip, tag) in zip(pk_arr, packs):
+        it.w_eq, it.w_pol, it.w_np = ptr(we), ptr(wp), ptr(wn)
+        it.b_eq, it.b_pol, it.b_np = ptr(be), ptr(bp), ptr(bn)
+        it.wpk_fwd, it.bias_pk, it.wpk_bwd = ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2])
+        it.ksize, it.Cin, it.Cout = int(ksize), int(we.shape[2]), int(we.shape[3])
+        it.flip_north_pole, it.dtype, it.reserved = int(flip), int(tag), 0
+    return pk_arr
+
+
+def _wb_plan(arr, n, key, dev):
+    """(host plan buffer, device plan tensor, workspace bytes) of an item list, built once per geometry"""
+    hit = _wb_plans.get(key)
+    if hit is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise nat.NativeError('the weight-gradient plan would have to be uploaded during graph capture; run one eager '
+                                  'step first')
+        pb, wb = ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib().dlwpcs_wgrad_batch_sizes(arr, n, ctypes.byref(pb), ctypes.byref(wb)), 'dlwpcs_wgrad_batch_sizes')
+        host = (ctypes.c_char * pb.value)()
+        check(lib().dlwpcs_wgrad_batch_plan(arr, n, host, pb.value), 'dlwpcs_wgrad_batch_plan')
+        plan_dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev)
+        hit = (host, plan_dev, wb.value)
+        _wb_plans[key] = hit
+    return hit
 
 
 def _wb_items(entries):
@@ -208,20 +281,7 @@ def wgrad_batch(entries, adam=None, packs=None):
     for lo in range(0, len(entries), nat.WGRAD_BATCH_MAX):
         chunk = entries[lo:lo + nat.WGRAD_BATCH_MAX]
         arr, key = _wb_items(chunk)
-        key = (str(dev), key)
-        hit = _wb_plans.get(key)
-        if hit is None:
-            if torch.cuda.is_current_stream_capturing():
-                raise nat.NativeError('the weight-gradient plan would have to be uploaded during graph capture; run one eager '
-                                      'step first')
-            pb, wb = ctypes.c_size_t(), ctypes.c_size_t()
-            check(lib().dlwpcs_wgrad_batch_sizes(arr, len(chunk), ctypes.byref(pb), ctypes.byref(wb)), 'dlwpcs_wgrad_batch_sizes')
-            host = (ctypes.c_char * pb.value)()
-            check(lib().dlwpcs_wgrad_batch_plan(arr, len(chunk), host, pb.value), 'dlwpcs_wgrad_batch_plan')
-            plan_dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev)
-            hit = (host, plan_dev, wb.value)
-            _wb_plans[key] = hit
-        host, plan_dev, ws_bytes = hit
+        host, plan_dev, ws_bytes = _wb_plan(arr, len(chunk), (str(dev), key), dev)
         ws = _workspace(ws_bytes, dev, 'wgrad_batch')
         if adam is not None:
             p, g, m, v, state, hyper = adam
@@ -229,15 +289,7 @@ def wgrad_batch(entries, adam=None, packs=None):
             if len(_pending_tail) == 1:
                 tail, keep = _pending_tail.pop()            # the step's loss is finished by this launch
             if tail is not None or packs is not None:
-                pk_arr = None
-                if packs is not None:
-                    pk_arr = (nat.PackItem * len(chunk))()
-                    for it, (we, wp, wn, be, bp, bn, bufs, ksize, flip, tag) in zip(pk_arr, packs[lo:lo + len(chunk)]):
-                        it.w_eq, it.w_pol, it.w_np = ptr(we), ptr(wp), ptr(wn)
-                        it.b_eq, it.b_pol, it.b_np = ptr(be), ptr(bp), ptr(bn)
-                        it.wpk_fwd, it.bias_pk, it.wpk_bwd = ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2])
-                        it.ksize, it.Cin, it.Cout = int(ksize), int(we.shape[2]), int(we.shape[3])
-                        it.flip_north_pole, it.dtype, it.reserved = int(flip), int(tag), 0
+                pk_arr = _pack_array(packs[lo:lo + len(chunk)]) if packs is not None else None
                 check(lib().dlwpcs_wgrad_batch_adam_tail(arr, len(chunk), host, ptr(plan_dev), ptr(ws), ws.numel(), ptr(p), ptr(g),
                                                          ptr(m), ptr(v), g.numel(), ptr(state), ptr(hyper),
                                                          ctypes.byref(tail) if tail is not None else None, pk_arr, stream_ptr()),

@@ -58,6 +58,22 @@ def _exchange_wanted():
     return dist.get_world_size() > 1 or os.environ.get('DLWPCS_EXCHANGE_FORCE', '0') == '1'
 
 
+def exchange_wanted():
+    """Does a training step of this process exchange its gradients (world size > 1, or the forced one-rank form of the tests)?"""
+    return _exchange_wanted()
+
+
+def exchange_capturable():
+    """Can the all-reduce be captured inside a hipGraph?  RCCL (backend 'nccl') collectives are stream operations; gloo's are
+    host-side and never capturable."""
+    return group_alive() and dist.get_backend() == 'nccl'
+
+
+def group_alive():
+    """A process group exists: its watchdog thread issues HIP calls of its own (graph captures then use thread-local error mode)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def allreduce_start(flat_slice):
     """Start the sum of one bucket of the flat gradient buffer over all ranks and return a handle for allreduce_wait (None at
     world size 1).  The collective runs on the process group's own stream behind everything enqueued on the current stream

@@ -79,7 +79,11 @@ struct WbAdam {
     float *p, *g, *m, *v;           // flat buffers; the items' dw_* / db_* point INTO g, the other three share its offsets
     const int32_t *state;           // {t, ticket}: the weight-gradient launch before this one has already incremented t
     const float *hyper;             // {lr, beta1, beta2, eps, grad_scale}
-    int32_t on, pad;
+    int32_t on;
+    // apply-only form (dlwpcs_wgrad_batch_apply, the data-parallel step): the partial sums were reduced into g by an earlier
+    // launch and g has been summed over the ranks since; this launch adds nothing, it consumes g -- and it moves the step counter
+    // on itself: t = state[0] + 1, the last workgroup to finish (ticket state[1]) stores it
+    int32_t apply_only;
 };
 // what the reduction needs of a layer, by value in the kernel arguments (its dependent chain of memory round trips is what
 // the reduction's ~20 us are made of: plan header -> layer record -> group record -> partial sums -> optimizer state)
@@ -560,7 +564,7 @@ __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGrou
     float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gscale = 1.f;
     if (A.on) {
         b1 = A.hyper[1]; b2 = A.hyper[2]; eps = A.hyper[3]; gscale = A.hyper[4];
-        lr_t = adam_lr_t(A.hyper[0], b1, b2, (float)A.state[0]);
+        lr_t = adam_lr_t(A.hyper[0], b1, b2, (float)(A.state[0] + A.apply_only));
     }
     const int KS = L.KS, TAPS = KS * KS, Cin = L.Cin, Cout = L.Cout;
     const int nW = TAPS * Cin * Cout;
@@ -598,7 +602,9 @@ __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGrou
     }
     VT s = 0.f;
     int w_co = 0, w_ci = 0, w_ty = 0, w_tx = 0;         // (weight element of this thread, for the fused packing below)
-    if (is_w || is_b) {
+    if (A.apply_only) {
+        if (is_w) { w_co = e % Cout; w_ci = (e / Cout) % Cin; const int tap = e / (Cout * Cin); w_ty = tap / KS; w_tx = tap - w_ty * KS; }
+    } else if (is_w || is_b) {
         int gi;
         size_t off;
         if (is_w) {
@@ -694,25 +700,36 @@ __global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__
                                                         const WbPackArgs PK) {
     if (blockIdx.x >= red_blocks) {
         loss_stage2_body(tail.partial, tail.loss_out, tail.nblocks, tail.inv_n, tail.weight, tail.overwrite);
-        return;
-    }
-    if (threadIdx.x >= WB_RED_THREADS) return;
-    const WbGroup *groups = reinterpret_cast<const WbGroup *>(plan + R.off_groups);
-    const uint32_t b = blockIdx.x;
-    int l = 0;
+    } else if (threadIdx.x < WB_RED_THREADS) {
+        const WbGroup *groups = reinterpret_cast<const WbGroup *>(plan + R.off_groups);
+        const uint32_t b = blockIdx.x;
+        int l = 0;
 #pragma unroll
-    for (int k = 1; k < WB_MAX_LAYERS; ++k) l += (k < (int)R.n_layers && b >= R.first[k]) ? 1 : 0;
-    if (!((R.live >> l) & 1u)) return;
-    const WbRedLayer L = R.lay[l];          // (block-uniform index into the kernel arguments: scalar loads)
-    const int blk = (int)(b - R.first[l]);
-    const bool al = ((((uintptr_t)R.dw_eq[l] | (uintptr_t)R.dw_pol[l] | (uintptr_t)R.dw_np[l] | (uintptr_t)R.db_eq[l] |
-                       (uintptr_t)R.db_pol[l] | (uintptr_t)R.db_np[l]) & 15) == 0);
-    if (L.Cout % 4 == 0 && al)
-        wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
-    else if (L.Cout % 4 == 0)       // (the plan sized this layer's workgroups for 4 outputs per thread)
-        wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
-    else
-        wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
+        for (int k = 1; k < WB_MAX_LAYERS; ++k) l += (k < (int)R.n_layers && b >= R.first[k]) ? 1 : 0;
+        if ((R.live >> l) & 1u) {
+            const WbRedLayer L = R.lay[l];          // (block-uniform index into the kernel arguments: scalar loads)
+            const int blk = (int)(b - R.first[l]);
+            const bool al = ((((uintptr_t)R.dw_eq[l] | (uintptr_t)R.dw_pol[l] | (uintptr_t)R.dw_np[l] | (uintptr_t)R.db_eq[l] |
+                               (uintptr_t)R.db_pol[l] | (uintptr_t)R.db_np[l]) & 15) == 0);
+            if (L.Cout % 4 == 0 && al)
+                wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
+            else if (L.Cout % 4 == 0)       // (the plan sized this layer's workgroups for 4 outputs per thread)
+                wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
+            else
+                wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
+        }
+    }
+    // apply-only form: the step counter moves on when the last workgroup is through (every workgroup read state[0] before it
+    // took its ticket; the ticket word goes back to 0 for the next launch)
+    // (the waves that ran the reduction body / the loss tail; a fourth, idle wave of a reduction workgroup has nothing to wait for)
+    if (A.apply_only && (threadIdx.x < WB_RED_THREADS || blockIdx.x >= red_blocks)) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int32_t *st = const_cast<int32_t *>(A.state);
+            const int done = atomicAdd(st + 1, 1);
+            if (done == (int)gridDim.x - 1) { st[1] = 0; st[0] += 1; }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1053,14 +1070,34 @@ static int wgrad_batch_adam_impl(const dlwpcs_wgrad_item *items, int n_items, co
     return wgrad_batch_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, A, state_dev, stream, tail, pack_host);
 }
 
+extern "C" int dlwpcs_wgrad_batch_apply(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                                        float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev, const float *hyper_dev,
+                                        const dlwpcs_loss_tail *tail, const dlwpcs_pack_item *pack_items_host, dlwpcs_stream_t stream) {
+    if (!items || !p || !g || !m || !v || !state_dev || !hyper_dev) return fail(DLWPCS_E_INVALID, "wgrad_batch_apply: null pointer");
+    if (tail && (!tail->partial || !tail->loss_out || tail->nblocks < 1)) return fail(DLWPCS_E_INVALID, "wgrad_batch_apply: bad loss tail");
+    for (int l = 0; l < n_items; ++l) {
+        const void *ds[6] = {items[l].dw_eq, items[l].dw_pol, items[l].dw_np, items[l].db_eq, items[l].db_pol, items[l].db_np};
+        for (int k = 0; k < 6; ++k)
+            if (ds[k] && ((const float *)ds[k] < g || (const float *)ds[k] >= g + n))
+                return fail(DLWPCS_E_INVALID, "wgrad_batch_apply: item %d: gradient tensor outside the flat gradient buffer", l);
+        for (int k = 0; k < l; ++k)
+            if (items[k].dw_eq == items[l].dw_eq)
+                return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch_apply: items %d and %d share their gradients", k, l);
+    }
+    WbAdam A{};
+    A.p = p; A.g = g; A.m = m; A.v = v; A.state = state_dev; A.hyper = hyper_dev; A.on = 1; A.apply_only = 1;
+    return wgrad_batch_impl(items, n_items, plan_host, plan_dev, nullptr, 0, A, nullptr, stream, tail, pack_items_host);
+}
+
 static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                             void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream,
                             const dlwpcs_loss_tail *tail, const dlwpcs_pack_item *pack_host) {
-    if (!items || !plan_host || !plan_dev || !workspace) return fail(DLWPCS_E_INVALID, "wgrad_batch: null pointer");
+    const bool apply_only = adam.apply_only != 0;
+    if (!items || !plan_host || !plan_dev || (!workspace && !apply_only)) return fail(DLWPCS_E_INVALID, "wgrad_batch: null pointer");
     const WbHeader *H = (const WbHeader *)plan_host;
     if (H->magic != WB_MAGIC || (int)H->n_layers != n_items) return fail(DLWPCS_E_INVALID, "wgrad_batch: plan does not match the items");
-    if (workspace_bytes < H->ws_floats * 4) return fail(DLWPCS_E_WORKSPACE, "wgrad_batch: workspace %zu < %llu bytes", workspace_bytes,
-                                                        (unsigned long long)H->ws_floats * 4);
+    if (!apply_only && workspace_bytes < H->ws_floats * 4)
+        return fail(DLWPCS_E_WORKSPACE, "wgrad_batch: workspace %zu < %llu bytes", workspace_bytes, (unsigned long long)H->ws_floats * 4);
     const WbLayer *layers = (const WbLayer *)((const char *)plan_host + H->off_layers);
     WbPtrs ptrs{};
     WbRedPtrs R{};
@@ -1071,10 +1108,10 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
         if (L.B != it.d.B || L.Nin != it.d.N || L.C0 != it.d.C0 || L.C1 != it.d.C1 || L.Cout != it.d.Cout || L.KS != it.d.ksize ||
             L.halo != it.d.halo || L.up0 != it.d.up0)
             return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d differs from the plan", l);
-        if (!it.src0 || !it.dz || !it.dw_eq || !it.dw_pol || (it.d.C1 > 0 && !it.src1) || (it.d.halo && !it.table_dev))
+        if (!it.dw_eq || !it.dw_pol || (!apply_only && (!it.src0 || !it.dz || (it.d.C1 > 0 && !it.src1) || (it.d.halo && !it.table_dev))))
             return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d: null pointer", l);
         if ((L.want_bias != 0) != (it.db_eq || it.db_pol || it.db_np) || (L.has_np != 0) != (it.dw_np != nullptr) ||
-            (L.mask != 0) != (it.y != nullptr))
+            (!apply_only && (L.mask != 0) != (it.y != nullptr)))
             return fail(DLWPCS_E_INVALID, "wgrad_batch: item %d: bias / north-pole / y pointers differ from the plan", l);
         ptrs.y[l] = it.y;
         ptrs.src0[l] = it.src0; ptrs.src1[l] = it.d.C1 > 0 ? it.src1 : it.src0; ptrs.dz[l] = it.dz; ptrs.table[l] = it.table_dev;
@@ -1099,16 +1136,19 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "wgrad_batch: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     int pidx = -1;
-    if (prof_enabled()) pidx = prof_begin("wgrad_batch_kernel", flops, bytes, s);
-    long long *dbg = nullptr;
+    int rc = DLWPCS_OK;
+    if (!apply_only) {
+        if (prof_enabled()) pidx = prof_begin("wgrad_batch_kernel", flops, bytes, s);
+        long long *dbg = nullptr;
 #ifdef DLWPCS_WB_TIMING
-    { const char *e = getenv("DLWPCS_DBG_PTR"); dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
+        { const char *e = getenv("DLWPCS_DBG_PTR"); dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-    hipLaunchKernelGGL(wgrad_batch_kernel, dim3(H->n_workers), dim3(512), lds, s, (const char *)plan_dev, ptrs, (float *)workspace, dbg,
-                       adam_state);
-    if (pidx >= 0) prof_end(pidx, s);
-    int rc = check_launch("wgrad_batch");
-    if (rc) return rc;
+        hipLaunchKernelGGL(wgrad_batch_kernel, dim3(H->n_workers), dim3(512), lds, s, (const char *)plan_dev, ptrs, (float *)workspace, dbg,
+                           adam_state);
+        if (pidx >= 0) prof_end(pidx, s);
+        rc = check_launch("wgrad_batch");
+        if (rc) return rc;
+    }
     // reduction rounds: items that share their destination (a layer applied twice) go into successive launches
     uint32_t pending = n_items >= 32 ? 0xffffffffu : ((1u << n_items) - 1u);
     while (pending) {
@@ -1122,7 +1162,7 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
         }
         R.live = live;
         pidx = -1;
-        if (prof_enabled()) pidx = prof_begin("wb_reduce_kernel", 0.0, (double)H->ws_floats * 4.0, s);
+        if (prof_enabled()) pidx = prof_begin(apply_only ? "wb_reduce_kernel(apply)" : "wb_reduce_kernel", 0.0, (double)H->ws_floats * 4.0, s);
         const uint32_t rb = H->red_first[WB_MAX_LAYERS];
         dlwpcs_loss_tail tl{};
         if (tail) tl = *tail;

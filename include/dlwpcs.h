@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DLWPCS_VERSION 103            /* 0.1.3: dlwpcs_wgrad_batch*, pre-masked gradients (dlwpcs_*_masked), dlwpcs_conv_fwd_pool */
+#define DLWPCS_VERSION 104            /* 0.1.4: dlwpcs_wgrad_batch_apply (data-parallel step tail), dlwpcs_conv_chain* */
 
 /* error codes */
 #define DLWPCS_OK             0
@@ -301,6 +301,17 @@ int dlwpcs_wgrad_batch_adam_tail(const dlwpcs_wgrad_item *items, int n_items, co
                                  void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
                                  int32_t *state_dev, const float *hyper_dev, const struct dlwpcs_loss_tail *tail,
                                  const dlwpcs_pack_item *pack_items_host, dlwpcs_stream_t stream);
+
+/* The data-parallel form of the step's last launch (reference counterpart: the multi-GPU model of DLWP/model/models.py:369-374,
+ * one optimizer step on the gradient of the GLOBAL batch): dlwpcs_wgrad_batch leaves the finished local gradients in g, the
+ * caller sums g over the ranks (RCCL all-reduce of the flat buffer), and this ONE launch then does what dlwpcs_wgrad_batch_adam_tail
+ * does after its reduction -- g * grad_scale -> Adam (same arithmetic, same bits) -> g = 0, packed bf16 operands refreshed, loss
+ * tail -- without reading any partial sum.  The items name the gradient tensors (dw_* / db_*: views into g) and the plan gives
+ * their geometry; src / dz / table pointers are ignored.  state_dev = {t, ticket}: this launch computes with t + 1 and its last
+ * workgroup stores it (the form of dlwpcs_adam_step_fused), so no earlier launch has to move the counter. */
+int dlwpcs_wgrad_batch_apply(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
+                             float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev, const float *hyper_dev,
+                             const struct dlwpcs_loss_tail *tail, const dlwpcs_pack_item *pack_items_host, dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
  * Generic (any kernel size / stride / dilation / 'same') per-face convolution on an ALREADY PADDED channels_last

@@ -127,3 +127,68 @@ print('RCCL_BUCKETS_OK')
 ''' % ROOT
     out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'RCCL_BUCKETS_OK' in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+def test_data_parallel_step_is_one_graph_with_the_exchange_captured():
+    """Round 4: the data-parallel step = the world-1 step with its last launch split at the exchange -- local reduction, all-reduce
+    CAPTURED inside the step's hipGraph, ONE launch that applies the update (scale + Adam + gradient clear + packed operands + loss
+    tail, dlwpcs_wgrad_batch_apply).  Exercised with real RCCL on one rank (DLWPCS_EXCHANGE_FORCE=1): one graph per step, and --
+    one rank sums to itself -- parameters BITWISE equal to the plain world-1 run, in fp32 and in bf16 (where the fused reduction +
+    Adam of the plain step and reduction | apply of this one must produce the same bits), also for the two-graph fallback
+    (DLWPCS_DP_ONE_GRAPH=0) and across a learning-rate change."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%r, 'dlwp-cs_amd'))
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+import numpy as np, torch, torch.distributed as dist
+from DLWP.keras import backend, mixed_precision
+from DLWP.model.cs_unet import build_cs_model
+torch.cuda.set_device(0)
+backend.set_device('cuda:0')
+dev = torch.device('cuda', 0)
+rng = np.random.default_rng(2)
+def data(N, C):
+    return (torch.tensor(rng.standard_normal((4, 6, N, N, C)), dtype=torch.float32, device=dev),
+            torch.tensor(rng.standard_normal((4, 6, N, N, C)), dtype=torch.float32, device=dev))
+def train(policy, N, C, base, x, t, w0=None):
+    np.random.seed(3)
+    mixed_precision.set_policy(policy)
+    try:
+        m = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=base)
+    finally:
+        mixed_precision.set_policy('float32')
+    m.compile(optimizer='adam', loss='mse', metrics=['mae'])
+    if w0 is not None:
+        m.set_weights(w0)
+    w_init = m.get_weights()
+    losses = []
+    xx = x.to(torch.bfloat16) if policy != 'float32' else x
+    for i in range(6):
+        if i == 4:
+            m.optimizer.lr = 3e-4
+        losses.append(m.train_on_device_batch([xx], [t]).clone())
+    torch.cuda.synchronize()
+    return w_init, m._flat_params.detach().cpu().numpy().copy(), torch.stack(losses).cpu().numpy(), m
+cases = [('float32', 8, 4, 4), ('mixed_bfloat16', 16, 8, 8)]
+plain = {}
+for pol, N, C, base in cases:
+    x, t = data(N, C)
+    plain[pol] = (x, t) + train(pol, N, C, base, x, t)[:3]
+dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29547', rank=0, world_size=1, device_id=dev)
+os.environ['DLWPCS_EXCHANGE_FORCE'] = '1'
+for pol, N, C, base in cases:
+    x, t, w0, ref, lref = plain[pol]
+    for one_graph in ('1', '0'):
+        os.environ['DLWPCS_DP_ONE_GRAPH'] = one_graph
+        _, got, lgot, m = train(pol, N, C, base, x, t, w0)
+        g = next(iter(m._graphs.values()))
+        assert (g['update'] is None) == (one_graph == '1'), (pol, one_graph)
+        assert np.array_equal(ref, got), (pol, one_graph, np.abs(ref - got).max())
+        assert np.array_equal(lref, lgot), (pol, one_graph)
+        if pol != 'float32':
+            assert m._wb_done and len(m._wb_done) == 11           # the apply launch covered every layer
+dist.destroy_process_group()
+print('DP_ONE_GRAPH_OK')
+''' % ROOT
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'DP_ONE_GRAPH_OK' in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
