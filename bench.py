@@ -363,6 +363,107 @@ def allreduce_probe(model, world, reps=20):
     return float(el.item()) * 1e6
 
 
+def time_without_exchange(st, timed, per_block):
+    """Seconds per step of the SAME step form with the all-reduce calls turned into no-ops (the collective is captured inside
+    the step graph, so the graphs are captured anew for this and once more afterwards)."""
+    from DLWP import parallel as _par
+    model = st['model']
+
+    def recapture():
+        model._graphs.clear()
+        model._seen_batch.clear()
+        for _ in range(4):
+            run_step(st)
+    _par.SKIP_EXCHANGE_FOR_TIMING = True
+    try:
+        recapture()
+        timed(per_block)
+        return float(np.median([timed(per_block) / per_block for _ in range(3)]))
+    finally:
+        _par.SKIP_EXCHANGE_FOR_TIMING = False
+        recapture()
+
+
+def graph_kernel_nodes(cuda_graph):
+    """Kernel nodes of a captured hipGraph (hipGraphGetNodes + hipGraphNodeGetType through ctypes), None where torch does not
+    hand out the raw graph."""
+    try:
+        raw = cuda_graph.raw_cuda_graph()
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+            return None
+        nodes = (ctypes.c_void_p * n.value)()
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n)) != 0:
+            return None
+        kinds = {}
+        for nd in nodes:
+            t = ctypes.c_int(-1)
+            hip.hipGraphNodeGetType(ctypes.c_void_p(nd), ctypes.byref(t))
+            kinds[t.value] = kinds.get(t.value, 0) + 1
+        return {'kernel': kinds.get(0, 0), 'memcpy': kinds.get(1, 0), 'memset': kinds.get(2, 0),
+                'other': sum(v for k, v in kinds.items() if k not in (0, 1, 2))}
+    except Exception:
+        return None
+
+
+def dp_form_probe(args, dtype, plain_ms):
+    """N = 1: the DATA-PARALLEL form of the step on this one GPU -- a process group of one rank over RCCL with
+    DLWPCS_EXCHANGE_FORCE=1, so that the step takes exactly the launch sequence it takes at N > 1 (local reduction -> all-reduce,
+    captured in the step graph -> ONE launch that applies the update) -- timed with the same blocks, next to the plain step."""
+    import socket
+    from DLWP import parallel as _par
+    own_group = not torch.distributed.is_initialized()
+    prev = os.environ.get('DLWPCS_EXCHANGE_FORCE')
+    try:
+        if own_group:
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                port = sk.getsockname()[1]
+            torch.distributed.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                                                 device_id=torch.device('cuda', torch.cuda.current_device()))
+        os.environ['DLWPCS_EXCHANGE_FORCE'] = '1'
+        os.environ['DLWPCS_KEEP_GRAPH'] = '1'               # (the step graph's nodes are counted below)
+        st = prepare(args, dtype, 0)
+        model = st['model']
+
+        def timed(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                run_step(st)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        for _ in range(5):
+            run_step(st)
+        est = timed(50) / 50
+        per_block = max(50, int(np.ceil(0.3 / max(est, 1e-9))))
+        ms = 1e3 * float(np.median([timed(per_block) / per_block for _ in range(3)]))
+        g = next(iter(model._graphs.values())) if model._graphs else None
+        graphs = 0 if g is None else 1 + (g.get('bwd_b') is not None) + (g.get('update') is not None)
+        nodes = None
+        if g is not None and graphs == 1:
+            nodes = graph_kernel_nodes(g['fwd_bwd'])
+        noex = 1e3 * time_without_exchange(st, timed, per_block)
+        return {'ms_per_step': round(ms, 4), 'vs_plain_step': round(ms / plain_ms, 4), 'graphs_per_step': graphs,
+                'launches': None if nodes is None else nodes['kernel'], 'graph_nodes': nodes,
+                'exposed_us': round(1e3 * (ms - noex), 1), 'ms_per_step_without_exchange': round(noex, 4),
+                'backend': torch.distributed.get_backend(), 'ranks': torch.distributed.get_world_size(),
+                'note': 'the step as it runs at N > 1 (reduction | all-reduce captured in the step graph | one launch: scale + Adam '
+                        '+ gradient clear + packed operands + loss tail), here with a one-rank RCCL group: the collective itself '
+                        'moves nothing, what is measured is the form of the step'}
+    except Exception as exc:
+        return {'error': '%s: %s' % (type(exc).__name__, exc)}
+    finally:
+        os.environ.pop('DLWPCS_KEEP_GRAPH', None)
+        if prev is None:
+            os.environ.pop('DLWPCS_EXCHANGE_FORCE', None)
+        else:
+            os.environ['DLWPCS_EXCHANGE_FORCE'] = prev
+        if own_group and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+
+
 def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
     """Build the workload in `dtype`, warm up, time the contract's K steps and then >= 5 blocks of >= 0.5 s (each bracketed
     by barrier + synchronize, MAX over ranks); optionally the per-launch roofline pass and the PMC passes.  Returns the
@@ -447,13 +548,7 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
     # (DLWP.parallel.SKIP_EXCHANGE_FOR_TIMING: timing only -- the replicas diverge, so this runs after everything that is reported)
     noex_s = None
     if world > 1 and st['train']:
-        from DLWP import parallel as _par
-        _par.SKIP_EXCHANGE_FOR_TIMING = True
-        try:
-            timed(per_block)
-            noex_s = float(np.median([timed(per_block) / per_block for _ in range(3)]))
-        finally:
-            _par.SKIP_EXCHANGE_FOR_TIMING = False
+        noex_s = time_without_exchange(st, timed, per_block)
     # the roofline pass runs eager optimisation steps (gradient all-reduce included): EVERY rank takes part
     agg = roofline_pass(st) if with_roofline else None
     if rank != 0:
@@ -497,10 +592,13 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
                               {str(k): round(1e3 * v, 4) for k, v in bucket_trials.items()},
                               'exposed_us': None if noex_s is None else round(1e6 * (step_s - noex_s), 1),
                               'ms_per_step_without_exchange': None if noex_s is None else round(1e3 * noex_s, 4),
+                              'graphs_per_step': (lambda g: None if g is None else 1 + (g.get('bwd_b') is not None) +
+                                                  (g.get('update') is not None))(next(iter(model._graphs.values()), None)),
                               'overlap': 'buckets = 2: the decoder-side gradients are summed over the ranks (RCCL, the process '
                                          'group\'s stream) while the encoder-side half of the backward pass and its weight '
-                                         'gradients run; the second bucket and the optimizer graph wait for both.  buckets = 1: '
-                                         'one all-reduce between the fwd+bwd graph and the optimizer graph.  Both were timed '
+                                         'gradients run; the second bucket and the update graph wait for both.  buckets = 1: '
+                                         'reduction | ONE all-reduce captured inside the step graph | one launch that applies the '
+                                         'update (graphs_per_step = 1).  Both were timed '
                                          '(bucket_trials_ms_per_step), the faster one ran. '
                                          'allreduce_us = ONE all-reduce of the whole buffer on an idle GPU; exposed_us = '
                                          'ms_per_step minus the same step with the all-reduce calls skipped'}
@@ -611,6 +709,8 @@ def main():
     ap.add_argument('--no-configs', action='store_true',
                     help='N = 1, unet2: skip the extra measurements of BASELINE configs 2 (encoder6, fp32) and 5 (rollout, bf16)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-dp-form', action='store_true',
+                    help='N = 1: skip the measurement of the data-parallel form of the step (one-rank RCCL group)')
     ap.add_argument('--no-pmc', action='store_true', help='no rocprofv3 child passes (traffic / mfma_busy stay null)')
     ap.add_argument('--no-graphs', action='store_true')
     ap.add_argument('--pmc-out', default=None,
@@ -668,6 +768,8 @@ def main():
                      with_pmc=single and not args.no_pmc)
     if world > 1:
         torch.distributed.barrier()
+    if single and not args.no_dp_form and args.workload != 'rollout':
+        result['dp_form'] = dp_form_probe(args, args.dtype, result['ms_per_step'])
     if single and not args.no_companion:
         other = 'f32' if args.dtype == 'bf16' else 'bf16'
         comp = measure(args, other, rank, world, with_roofline=not args.no_roofline, with_pmc=not args.no_pmc)

@@ -29,6 +29,13 @@ from .engine import KTensor, Layer
 from .layers import AveragePooling3D, Concatenate, InputLayer, ReLU, UpSampling3D
 
 
+def _new_graph():
+    """DLWPCS_KEEP_GRAPH=1 (bench.py's launch census): the hipGraph object is kept so that its nodes can be counted."""
+    if os.environ.get('DLWPCS_KEEP_GRAPH', '0') == '1':
+        return torch.cuda.CUDAGraph(keep_graph=True)
+    return torch.cuda.CUDAGraph()
+
+
 def _as_list(x):
     if isinstance(x, (list, tuple)):
         return list(x)
@@ -799,7 +806,7 @@ class Model(object):
         grad_scale = 1.0 / self._world
         self.optimizer.sync_hyper(grad_scale)                   # the captured Adam launch reads them from device memory
         torch.cuda.synchronize()
-        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        g1, g2 = _new_graph(), _new_graph()
         g1b = None
         no_pack_entry = False
         split = self._split_wanted()
@@ -829,7 +836,7 @@ class Model(object):
                         except StopIteration as e:
                             stats = e.value
                     if stats is None:
-                        g1b = torch.cuda.CUDAGraph()
+                        g1b = _new_graph()
                         with torch.cuda.graph(g1b, pool=g1.pool(), capture_error_mode=mode):
                             try:
                                 next(gen)
@@ -855,7 +862,7 @@ class Model(object):
                                    and self.compute_dtype == 'bfloat16' and static_in[0].is_cuda)
                         if no_pack:
                             self._ensure_packed(static_in[0].device)
-                            gtry = torch.cuda.CUDAGraph()
+                            gtry = _new_graph()
                             with torch.cuda.graph(gtry, capture_error_mode=mode):
                                 stats = self._loss_and_backward(static_in, static_tg, True, fuse_update=grad_scale, skip_pack=True,
                                                                 exchange=dp)
@@ -882,7 +889,7 @@ class Model(object):
                         warnings.warn('capturing the gradient all-reduce inside the step graph failed (%s: %s); falling back to '
                                       'two graphs with the exchange between them' % (type(exc).__name__, exc))
                         torch.cuda.synchronize()
-                        g1 = torch.cuda.CUDAGraph()
+                        g1 = _new_graph()
                         no_pack_entry = False
                         self._flat_grads.zero_()
                 if not done:

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 rm -f gpurun_out/pmc_$TAG.json
 python bench.py --pmc-out gpurun_out/pmc_$TAG.json > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 echo "bench rc=$?"
-Q="--no-cpu-baseline --no-pmc --no-configs --no-roofline --steps 60 --warmup 10 --blocks 2 --min-block-s 0.1"
+Q="--no-cpu-baseline --no-pmc --no-configs --no-roofline --no-dp-form --steps 60 --warmup 10 --blocks 2 --min-block-s 0.1"
 rm -rf gpurun_out/prof_$TAG gpurun_out/prof_${TAG}_encoder6 gpurun_out/prof_${TAG}_rollout
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o r --output-format csv -- \
     python bench.py $Q > gpurun_out/prof_$TAG.log 2>&1
@@ -16,5 +16,5 @@ timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG}_encoder6 
     python bench.py $Q --no-companion --workload encoder6 --channels 7 --dtype f32 > gpurun_out/prof_${TAG}_encoder6.log 2>&1
 echo "rocprof encoder6 rc=$?"
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG}_rollout -o r --output-format csv -- \
-    python bench.py --no-cpu-baseline --no-pmc --no-configs --no-roofline --no-companion --workload rollout --steps 6 --warmup 2 --blocks 2 --min-block-s 0.05 > gpurun_out/prof_${TAG}_rollout.log 2>&1
+    python bench.py --no-cpu-baseline --no-pmc --no-configs --no-roofline --no-dp-form --no-companion --workload rollout --steps 6 --warmup 2 --blocks 2 --min-block-s 0.05 > gpurun_out/prof_${TAG}_rollout.log 2>&1
 echo "rocprof rollout rc=$?"
