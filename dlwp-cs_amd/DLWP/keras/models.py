@@ -81,6 +81,11 @@ class Model(object):
         # hipGraph-replayed steps: the reduction + optimizer launch also refreshes the packed bf16 operands, the step starts
         # without the packing launch (dlwpcs_wgrad_batch_adam_tail with pack items)
         self.fuse_pack = os.environ.get('DLWPCS_FUSE_PACK', '1') == '1'
+        # runs of same-tiling fused convolutions of a forward pass as ONE persistent launch (ops.CHAIN, dlwpcs_conv_chain_fwd): bf16
+        # models.  Built, bit-identical, bounded -- and measured SLOWER than the per-layer launches on MI355X (round 4, DESIGN.md 9:
+        # unet2 step 0.707 against 0.675 ms, C96 rollout 13.5 against 11.1 ms), so it is opt-in (DLWPCS_CHAIN=1 / use_chain = True).
+        # Always off when two ranks share a device (compile() checks): the launch needs its workgroups co-resident
+        self.use_chain = os.environ.get('DLWPCS_CHAIN', '0') == '1'
         self._packed_ok = False             # the packed operands hold the current parameters (see _ensure_packed)
         # data-parallel exchange in two buckets (exchange_buckets = 2 / DLWPCS_EXCHANGE_BUCKETS=2): the gradients of the
         # decoder-side layers are summed over the ranks WHILE the encoder-side half of the backward pass runs.  Default 1: one
@@ -360,10 +365,15 @@ class Model(object):
                 st['packed_version'] = self._flat_params._version if self._flat_params is not None else None
                 self._packed_ok = True
             ops.PREPACKED = st['table']
+            chain = self.use_chain and self.compute_dtype == 'bfloat16'
+            if chain:
+                ops.chain_begin()
             try:
                 return self._run_plan(inputs, fuse_targets)
             finally:
                 ops.PREPACKED = {}
+                if chain:
+                    ops.chain_end()
         return self._run_plan(inputs, fuse_targets)
 
     def _run_plan(self, inputs, fuse_targets=None):
@@ -390,6 +400,8 @@ class Model(object):
                     if u in need and isinstance(v, torch.Tensor) and v.requires_grad and id(v) not in seen:
                         seen.add(id(v))
                         self._cut_tensors.append(v)
+            if st[0] not in ('fused_conv', 'pool_skip'):
+                ops.chain_flush()               # (recorded convolutions run before anything else touches their outputs)
             if st[0] == 'fused_conv':
                 _, out_uid, lay, s0, s1, up0, act, alpha, vmax = st
                 m0, m1 = self._src_mask[i]
@@ -542,6 +554,8 @@ class Model(object):
         self._graphs.clear()
         self._seen_batch.clear()
         self._world = parallel.world()[1]
+        if self.use_chain and parallel.device_is_shared():
+            self.use_chain = False          # two ranks on one GPU: their persistent launches could keep each other from being resident
         parallel.broadcast_parameters(self._flat_params)     # identical replicas: rank 0's initial weights everywhere
         self._compiled = True
 
@@ -566,6 +580,7 @@ class Model(object):
     def _assemble_logs(self, sums, count):
         """sums: (n_out, 2) tensor of [weighted mse, mae] sums over `count` batches -> ordered keras values."""
         s = (sums / max(count, 1)).cpu().numpy()
+        ops.chain_check()
         w = np.asarray(self.loss_weights, dtype=np.float64)
         vals = [float(s[:, 0].sum())]
         if len(self.outputs) > 1:
@@ -1139,6 +1154,7 @@ class Model(object):
                         o[s:s + bs] = r.float().cpu().numpy()
             if staged:
                 down.flush()
+            ops.chain_check()
         if outs is None:
             outs = [np.empty((0,) + tuple(o.shape[1:]), dtype=np.float32) for o in self.outputs]
         return outs[0] if self._single_output else outs
@@ -1217,6 +1233,7 @@ class Model(object):
                 finally:
                     self._padded_io = False
                 out_series[:, s:s + bs] = series.cpu().numpy()
+                ops.chain_check()
 
     def _input_roles(self):
         """(main, [solar...], constants | None) indices into self.inputs: by the names the reference scripts use

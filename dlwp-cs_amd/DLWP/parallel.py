@@ -69,6 +69,21 @@ def exchange_capturable():
     return group_alive() and dist.get_backend() == 'nccl'
 
 
+def device_is_shared():
+    """Do two ranks of the process group run on the same GPU (the single-GPU multi-rank tests)?  Collective: every rank calls it."""
+    if not group_alive() or dist.get_world_size() < 2 or not torch.cuda.is_available():
+        return False
+    import socket
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    me = (socket.gethostname(), str(getattr(props, 'uuid', '')) or str(torch.cuda.current_device()), torch.cuda.current_device())
+    if dist.get_backend() == 'nccl':
+        # (RCCL refuses two ranks on one device anyway)
+        return False
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, me)
+    return len(set(everyone)) < len(everyone)
+
+
 def group_alive():
     """A process group exists: its watchdog thread issues HIP calls of its own (graph captures then use thread-local error mode)."""
     return dist.is_available() and dist.is_initialized()

@@ -17,7 +17,7 @@ TAG = os.environ.get('DLWPCS_LIB_TAG', '')          # development only: instrume
 OBJ = os.path.join(HERE, 'build' + ('_' + TAG if TAG else ''))
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdlwpcs%s.so' % ('_' + TAG if TAG else ''))
-SOURCES = ['halo_table.cpp', 'prof.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_generic.hip', 'wgrad_batch.hip']
+SOURCES = ['halo_table.cpp', 'prof.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_chain.hip', 'conv_generic.hip', 'wgrad_batch.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 CFLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-x', 'hip', '-Wall', '-Wno-unused-function'] + \
@@ -65,7 +65,7 @@ def build(force=False, verbose=True):
         if verbose and r.stderr.strip():
             print(r.stderr[-4000:])
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(LIB):
         # Link with g++ (like torch.utils.cpp_extension) so that WE choose which libamdhip64 is recorded as NEEDED:

@@ -1,0 +1,916 @@
+// Forward / data-gradient convolution of libdlwpcs (gfx950): the persistent, wave-specialised kernel BODY as a device function,
+// shared by the per-layer launch (conv_mfma.hip: conv_mfma_ws_kernel) and the multi-layer chain launch (conv_chain.hip).
+#pragma once
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "mfma_common.h"
+
+namespace dlwpcs {
+
+enum { MODE_DIRECT = 0, MODE_HALO = 1, MODE_ZERO = 2 };
+
+struct ConvKParams {
+    const void *src0, *src1;    // virtual-input sources, channels_last, element type T
+    const void *ymask;          // data-gradient mode: saved forward output (T), act' applied on load (or nullptr)
+    const void *wpk;            // packed weights [3][NTtot][CG][TAPS][2][32][16 B]: 4 fp32 / 8 bf16 per lane
+    const float *bias;          // packed bias [3][NTtot*32] fp32 or nullptr
+    void *out;                  // (B,6,No,No,Cout), element type T
+    const int32_t *table;       // (6, Nin+2, Nin+2) halo table (MODE_HALO, k=3)
+    int B, Nin, No;             // face size of V, face size of the output
+    int C0, C1, Cin, Cout;      // Cin = C0 + C1
+    int CG, NTtot;              // ceil(Cin/CGW) (CGW = 8 fp32 / 16 bf16 channels per MFMA operand group), ceil(Cout/32)
+    int up0;                    // src0 lives on the Nin/2 grid
+    int mode;
+    int act;                    // epilogue activation
+    float alpha, vmax;
+    int pix_per_block;          // valid pixels per workgroup (<= 32*MT*WM)
+    int nblk_face;              // workgroups per (sample, face)
+    int W2;                     // tile width = No + KS - 1
+    uint32_t magicW2, magicNo, magicN;
+    uint32_t magicB, magicNblk; // exact-division magics of B and nblk_face (0 when the divisor is 1)
+    int patches;                // LDS holds the wave-private epilogue patches (0: no room -> direct quad stores)
+    int wstat;                  // > 0: one resident LDS weight area per channel chunk (= the chunk count), see the kernel
+    // Data-gradient direct mode (MODE_ZERO, k = 3, halo): output channels [0, dsplit) belong to source 0, the rest to source
+    // 1; where d0 / d1 is non-null the INTERIOR cells of the padded gradient go straight to that source's gradient tensor
+    // (B,6,No-2,No-2,channels of the source) and only the halo ring is written to `out`
+    void *d0, *d1;
+    int dsplit;
+    // Pre-masked gradients (data gradient, direct mode, bf16, MOUT instantiations): where m0 / m1 is non-null the cells that go
+    // straight to d0 / d1 are multiplied by act'(m) first -- m0 / m1 are the SOURCES themselves (outputs of the activated layers
+    // that produced them, same shape as d0 / d1), so that the gradient arrives at those layers as dz = dy * act'(y) already
+    const void *m0, *m1;
+    float m_alpha, m_vmax;
+    uint32_t m_thr1;            // bf16_mask_threshold(m_vmax)
+    int *direct_done;           // HOST pointer: set to 1 by launch_conv_cfg when the kernel it launched honours d0 / d1
+    int *mask_done;             // HOST pointer: bit 0 / 1 set when the launched kernel masks what it stores to d0 / d1
+    int dry_run;                // host only: choose the configuration, report direct_done / mask_done, launch nothing
+    struct ConvPlanOut *plan;   // host only (conv_chain.hip): with dry_run, the finished parameter block + configuration go here
+    // Forward pass with the 2x2 average pooling of the output as a SECOND output (Azure/train_cs.py:282,287: AveragePooling3D
+    // behind the block's last convolution): (B,6,No/2,No/2,Cout), written by the epilogue out of the LDS patches (launch_conv_cfg
+    // checks the tiling: every consumer wave owns whole pairs of rows).  pool_done: HOST pointer, set to 1 when the launched
+    // kernel does it.
+    void *pool_out;
+    int *pool_done;
+    int colsplit;               // pooled output, faces whose row is exactly one wave's 32 * MT pixels (N = 96): see launch_conv_cfg
+    int abl;                    // development only (-DDLWPCS_TIMELINE): epilogue ablation bits
+    int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
+    int tile_rows_max;          // rows reserved in LDS
+    int ntiles;                 // B * 6 * nblk_face (persistent kernel)
+    long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
+};
+
+// What a chain launch needs of one layer: the parameter block launch_conv_cfg finished, which instantiation it chose (chain_cfg
+// below; -1 = none the chain kernel carries), its grid's y extent and its LDS bytes.
+struct ConvPlanOut { ConvKParams P; int cfg, gy; size_t lds; };
+enum { CHAIN_CFG_3_32_3141 = 0, CHAIN_CFG_3_32_3122, CHAIN_CFG_3_16_5114, CHAIN_CFG_3_16_3141_T8, CHAIN_CFG_3_32_3141_T8, CHAIN_NCFG };
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8, bool MOUT>
+constexpr int chain_cfg() {
+    if (!(sizeof(T) == 2 && KS == 3 && VW == 8 && MODE == MODE_HALO && !MASK && !MOUT)) return -1;
+    if (!TAIL8 && KC == 32 && MT == 3 && NT == 1 && WM == 4 && WN == 1) return CHAIN_CFG_3_32_3141;
+    if (!TAIL8 && KC == 32 && MT == 3 && NT == 1 && WM == 2 && WN == 2) return CHAIN_CFG_3_32_3122;
+    if (!TAIL8 && KC == 16 && MT == 5 && NT == 1 && WM == 1 && WN == 4) return CHAIN_CFG_3_16_5114;
+    if (TAIL8 && KC == 16 && MT == 3 && NT == 1 && WM == 4 && WN == 1) return CHAIN_CFG_3_16_3141_T8;
+    if (TAIL8 && KC == 32 && MT == 3 && NT == 1 && WM == 4 && WN == 1) return CHAIN_CFG_3_32_3141_T8;
+    return -1;
+}
+// (conv_mfma.hip) the forward layer `d` as a plan: validation, tiling and instantiation choice of dlwpcs_conv_fwd, nothing launched
+int conv_fwd_plan(const dlwpcs_conv_desc *d, const void *src0, const void *src1, const void *wpk_fwd, const void *bias_pk, void *y,
+                  void *y_pooled, const int32_t *table_dev, ConvPlanOut *out);
+
+// Scheduling tunables, bit set.  Defaults are the measured-best values; DLWPCS_TUNE=<int> overrides them for A/B runs.
+//   1: weight-gradient kernels: producer waves run at s_setprio 2 (they are the second-dispatched, i.e. arbitration-losing,
+//      half of the workgroup and the consumers wait for them at every barrier)
+//      (default since round 3: fp32 step -1.9 %, encoder6 -1.6 % on top of bit 2; the bf16 step runs the batched kernel instead)
+//   2: forward / data-gradient kernel: the same for its producer waves (default since round 3: with the consumers' waits for
+//      store acknowledgements gone the producers' issue slots matter again: fp32 step -1.1 %, encoder6 -1.2 %, rollout -0.7 %,
+//      bf16 step -0.2 %)
+//   4: forward / data-gradient kernel: weight fragments stay in LDS across tiles (see `wres` in the producer)
+//  16: forward / data-gradient kernel, more than 64 output channels: 64 per workgroup and the workgroups split over the
+//      output-channel groups (see launch_conv), instead of 128 per workgroup in 16-channel chunks
+//  32: data gradient with 64 output channels (= the layer's input channels): two groups of 32 with the 384-pixel tiling
+//  64: 3-4 channel chunks per tile: one resident LDS weight area per chunk (P.wstat), with the tiling that makes them fit
+// 256: forward / data-gradient kernel: late start of the workgroups with the shorter tile list, bits 12..17 = how late (see the
+//      kernel; default 3)
+enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_SPLIT_N = 16,
+       TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64, TUNE_CONV_STAGGER = 256 };
+static int tune_bits() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_WG_PRODUCER_PRIO | TUNE_CONV_PRODUCER_PRIO | TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT |
+                               TUNE_CONV_STAGGER | (3 << 12)); }
+    return v;
+}
+
+#ifdef DLWPCS_TIMELINE
+#define TL_MARK() do { if (tlp && tli < 32) tlp[tli++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PL_MARK() do { if (plp && pli < 32) plp[pli++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TL_MARK() do { } while (0)
+#define PL_MARK() do { } while (0)
+#endif
+
+// activation loads of the body: plain, or (CHAIN, see below) nontemporal = bypassing this CU's vector L1 (MI355X_MICROARCH.md, "Workgroup
+// dispatch, XCD placement & inter-workgroup visibility": `nt` loads are L2-served), for data another workgroup of the SAME launch
+// stored write-through before a barrier
+typedef unsigned int nt_q4 __attribute__((ext_vector_type(4)));
+typedef nt_q4 nt_q4_a4 __attribute__((aligned(4)));
+// (Measured, round 4: WITH the nontemporal loads the chained forward pass of the U-Net took 254 us against 190 us for ten launches,
+// the C96 rollout +18 % -- the halo rows two neighbouring tiles share and the inputs two N-tile groups share are re-read from HBM
+// instead of L1 / L2.  The chain launch therefore invalidates the CU's L1 ONCE per phase (agent-scope acquire behind the group
+// barrier, conv_chain.hip) and the body loads plainly; -DDLWPCS_CHAIN_NT restores the per-load bypass for A/B runs.)
+#ifdef DLWPCS_CHAIN_NT
+constexpr bool CHAIN_NT_LOADS = true;
+#else
+constexpr bool CHAIN_NT_LOADS = false;
+#endif
+template <bool CHAIN, typename V, typename T> __device__ __forceinline__ V ld_act(const T *p) {
+    if constexpr (!CHAIN || !CHAIN_NT_LOADS) {
+        return *reinterpret_cast<const V *>(p);
+    } else if constexpr (sizeof(V) == 16) {
+        V out;
+        if constexpr (alignof(V) >= 16) {
+            const nt_q4 r = __builtin_nontemporal_load((const __attribute__((address_space(1))) nt_q4 *)p);
+            __builtin_memcpy(&out, &r, 16);
+        } else {
+            const nt_q4 r = __builtin_nontemporal_load((const __attribute__((address_space(1))) nt_q4_a4 *)p);
+            __builtin_memcpy(&out, &r, 16);
+        }
+        return out;
+    } else if constexpr (sizeof(V) == 8) {
+        typedef unsigned int q2 __attribute__((ext_vector_type(2)));
+        const q2 r = __builtin_nontemporal_load((const __attribute__((address_space(1))) q2 *)p);
+        V out;
+        __builtin_memcpy(&out, &r, 8);
+        return out;
+    } else if constexpr (sizeof(V) == 4) {
+        const unsigned int r = __builtin_nontemporal_load((const __attribute__((address_space(1))) unsigned int *)p);
+        V out;
+        __builtin_memcpy(&out, &r, 4);
+        return out;
+    } else {
+        const unsigned short r = __builtin_nontemporal_load((const __attribute__((address_space(1))) unsigned short *)p);
+        V out;
+        __builtin_memcpy(&out, &r, 2);
+        return out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Forward / data-gradient kernel: persistent, wave-specialised.
+//
+// A workgroup = NCW consumer waves (one per SIMD: ds_read + MFMA only) + NCW producer waves (global -> LDS copies); one
+// workgroup per CU.  The (tile, channel chunk) pairs of the workgroup's static tile list form one stream; LDS holds
+// two chunk buffers:
+//     producers:  fill(0); B; fill(1); B; fill(2); B; ...          (B = workgroup barrier, one per chunk)
+//     consumers:           B; mma(0);  B; mma(1);  B; mma(2); ...
+// so chunk g+1 is being fetched while the matrix cores run chunk g, and a consumer's instruction stream between two
+// barriers is nothing but LDS fragment reads (double-buffered in registers) and MFMAs.
+//
+// Producer code is STRAIGHT-LINE per chunk: every address is computed with selects, every load of the chunk (weights,
+// input tile, and -- at a tile's first chunk -- the next tile's halo-table entries) is issued back to back and waited
+// for once.  This matters: with any branch between two loads hipcc waits vmcnt(0) per load (measured: 12 serialised L2
+// round trips, ~17k cycles per chunk, the consumers idle at every barrier).  MODE is a template parameter for that reason.
+//   MODE_HALO  : cube-sphere halo resolved through the (6,N+2,N+2) table          (forward, fused padding)
+//   MODE_DIRECT: input consumed as is ('valid' on an already padded tensor, 1x1)   (forward)
+//   MODE_ZERO  : zero border of width k-1 = full correlation                        (data gradient)
+//   MASK       : dz = dy * act'(y) applied while fetching                           (data gradient through an activation)
+// ------------------------------------------------------------------------------------------------------------------
+// T = element type of the activations in HBM / LDS (float, or bf16_t with bf16 MFMA); all LDS geometry is in BYTES and
+// identical for both: a pixel row holds KC channels (64 B at KC = 16 fp32 / 32 bf16) + 16 B pad.
+// TAIL8 (bf16, VW = 8, one source): the source's channel count is even and >= 8 but not a multiple of 8 (14 = 7 variables
+// x 2 steps, 26 = 13 x 2).  Pixel rows are then only 4-B aligned; the vector that would run past the last channel is loaded
+// as the pixel's LAST 8 channels (in bounds) and shifted into place, instead of falling back to 4-B loads (7 / 13 per pixel).
+// Who sets the tile period (s_memtime marks, 32 -> 32 channels at N = 48, cycles per tile): the consumers used to, with 2.2 k
+// of MFMA phase + 3.1 k of epilogue + 0.8 k of set-up against ~4 k for the producers.  Two attempts to run the epilogue
+// BESIDE the next tile's MFMAs (a second team of consumer waves: three waves per SIMD = 168 VGPRs, spilled; the epilogue cut
+// into slices between the MFMAs of the same wave: hipcc hoists the slices' arithmetic into clumps, and the extra VALU work in
+// the MFMA phase slows the co-resident producer wave) both measured slower and are gone.  What worked was making the
+// epilogue itself cheap -- it is VALU-issue bound, sharing its SIMD with a producer wave: accumulators start at the bias,
+// the activation is max + min instead of compare + select, store addresses are per-(face, band) constants -- 1.75 k + 0.44 k cycles now -- and then
+// the producers' address arithmetic per load was cut to one multiply-add (see `sup`): the two sides are now balanced within
+// ~10 % (4.4 k consumer vs ~4.9 k producer cycles per tile).
+// conv_ws_body: the work of worker `lw` of `G` (the workers of one launch -- or, in a chain launch, of one sample group -- share
+// the tile list -- P.B samples from sample `b0` on; `by` = which group of N tiles).  Every one of the workgroup's 2 * 64 * WM * WN threads calls it and RETURNS from it
+// (no early exits: a chain launch meets at a workgroup barrier behind it).  CHAIN: the activations this call reads may have been
+// written EARLIER IN THE SAME LAUNCH by other workgroups (write-through stores): their loads bypass this CU's L1
+// (nontemporal: L2-served), see conv_chain.hip.
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false, bool MOUT = false,
+          bool CHAIN = false>
+__device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, const uint32_t lw, const int G, const int by,
+                                             const int b0 = 0) {
+    static_assert(!TAIL8 || (VW == 8 && sizeof(T) == 2 && !MASK), "TAIL8: bf16 16-B vectors, forward only");
+    static_assert(!MOUT || (MODE == MODE_ZERO && KS == 3 && sizeof(T) == 2 && !MASK), "MOUT: bf16 data gradient, direct mode");
+    constexpr int ES = sizeof(T);
+    constexpr int CGW = 32 / ES;                    // channels per MFMA operand group (two 16-B half fragments)
+    constexpr int TAPS = KS * KS;
+    constexpr int RB = KC * ES + 16;                // LDS bytes per tile pixel
+    constexpr int KCG = KC / CGW;
+    constexpr int Q = KC / VW;
+    constexpr int NTB = NT * WN;
+    constexpr int NCT = 64 * WM * WN;               // consumer threads == producer threads
+    constexpr int WF4 = NTB * KCG * TAPS * 64;      // 16-B entries per weight chunk
+    constexpr int GF4 = TAPS * 64;
+    constexpr int ITS = 3 * KC / VW;                // input vectors per producer thread per chunk (3*NCT pixels)
+    constexpr int ITW = (WF4 + NCT - 1) / NCT;
+    static_assert(NCT % Q == 0, "thread -> channel-vector mapping must not depend on the item");
+    static_assert(KC % CGW == 0 && KC % VW == 0, "chunk must hold whole operand groups and whole vectors");
+    typedef typename VecT<T, VW>::type V;
+    const int in_bytes = P.tile_rows_max * P.W2 * RB;
+    // LDS: two chunk buffers [input tile | weight fragments], then the epilogue patches.  With 3-4 chunks per tile (P.wstat) the
+    // fragments get one RESIDENT area per chunk behind two input-only buffers instead: two buffers alternate between two
+    // different chunks' fragments and would re-fetch 18-37 KB every chunk (the 128 -> 64 forward layers ran weight-fetch-bound).
+    const int in_step = P.wstat ? in_bytes : in_bytes + WF4 * 16;     // distance between the two input buffers
+    const int w_base = P.wstat ? 2 * in_bytes : in_bytes;             // first weight area
+    const int w_step = P.wstat ? WF4 * 16 : in_bytes + WF4 * 16;      // distance between weight areas (per chunk / per buffer)
+    const int patch_base = P.wstat ? 2 * in_bytes + P.wstat * WF4 * 16 : 2 * (in_bytes + WF4 * 16);
+
+    const int tid = threadIdx.x;
+    const bool is_producer = tid >= NCT;
+    const int nt0 = by * NTB;
+    const int face_pix = P.No * P.No;
+    const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
+    const int nchunks = (P.CG + KCG - 1) / KCG;
+
+    // Tiles in (face, band)-major, SAMPLE-minor order; every workgroup owns one contiguous range (the ranges themselves
+    // are laid out XCD-aware: neighbouring ranges on the same XCD's L2).  Consecutive tiles of a workgroup are then the same
+    // tile position in consecutive samples: gather offsets, validity flags and LDS addresses stay put, only a scalar sample
+    // base moves; they are rebuilt at the few (face, band) changes.
+    const int t_first = (int)(((long)P.ntiles * lw) / G), t_last = (int)(((long)P.ntiles * (lw + 1)) / G);
+    // TUNE_CONV_STAGGER: the workgroups whose tile list is one shorter than the longest (4 against 5 tiles at N = 48: half of
+    // them) start ~1.3 us late -- (tune >> 12) & 63 sleeps of 1024 cycles.  They have a tile's worth of slack, and the chip's 256
+    // workgroups no longer hit memory and the matrix cores in lockstep at the start of the kernel (the first tile of a workgroup
+    // costs twice a later one).  Measured on the bf16 training step, 0 / 1 / 2 / 3 / 4 / 6 / 8 sleeps: 0.6842 / 0.6795 / 0.6781 /
+    // 0.6768 / 0.6775 / 0.6786 / 0.6797 ms; 16 sleeps +24 us.
+    if ((P.tune & TUNE_CONV_STAGGER) && (t_last - t_first) * G < P.ntiles) {
+#pragma unroll 1
+        for (int i = 0; i < ((P.tune >> 12) & 63); ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    struct Geo { int b, f, v, combo, m0, npix, y0, nitems; };
+    auto geo_of = [&](int t) __attribute__((always_inline)) {
+        Geo gq;
+        gq.combo = P.magicB ? __umulhi((uint32_t)t, P.magicB) : t;                      // t / B   (magic 0 <=> divisor 1)
+        gq.b = t - gq.combo * P.B + b0;             // (b0: first sample of this worker group's sub-batch, chain launches; addressing only)
+        gq.f = P.magicNblk ? __umulhi((uint32_t)gq.combo, P.magicNblk) : gq.combo;     // combo / nblk_face
+        const int blk = gq.combo - gq.f * P.nblk_face;
+        gq.v = gq.f < 4 ? 0 : (gq.f == 4 ? 1 : 2);
+        gq.m0 = blk * P.pix_per_block;
+        gq.npix = min(P.pix_per_block, face_pix - gq.m0);
+        gq.y0 = __umulhi((uint32_t)gq.m0, P.magicNo);
+        const int ylast = __umulhi((uint32_t)(gq.m0 + gq.npix - 1), P.magicNo);
+        gq.nitems = (ylast - gq.y0 + KS) * P.W2 * Q;
+        return gq;
+    };
+
+    if (is_producer) {
+        // =========================================== producers ===========================================
+        const int ptid = tid - NCT;
+        const int qv = (ptid % Q) * VW;
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.wpk);
+        if (P.tune & TUNE_CONV_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(2);
+#ifdef DLWPCS_TIMELINE
+        int pli = 0;
+        long long *plp = (P.dbg && ptid == 0 && by == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
+#endif
+        // Tile-invariant slot constants: slot i of this thread is tile pixel (ty, tx) in EVERY tile (only the band's first
+        // row y0, the face and the sample change), so the divisions happen once per kernel.  Packed per slot:
+        //   bits 4:0 = ty, bit 5 = column valid (MODE_ZERO border), bits 31:6 = OFF + offset of (ty, tx) from the band's
+        //   first row on the source grid (halo table row stride M / source row stride Nin).
+        constexpr int PADZ = (MODE == MODE_ZERO) ? KS - 1 : 0;
+        const int rstride = (MODE == MODE_HALO) ? P.Nin + KS - 1 : P.Nin;
+        const int OFF = PADZ * (rstride + 1);
+        const int nitems_cap = P.tile_rows_max * P.W2 * Q;
+        int slot_c[ITS];
+#pragma unroll
+        for (int i = 0; i < ITS; ++i) {
+            const int e = min(ptid + i * NCT, nitems_cap - 1);
+            const int pix = e / Q;
+            const int ty = __umulhi((uint32_t)pix, P.magicW2);
+            const int tx = pix - ty * P.W2;
+            const int vx = tx - PADZ;
+            const int xok = (vx >= 0) & (vx < P.Nin);
+            slot_c[i] = (((ty - PADZ) * rstride + vx + OFF) << 6) | (xok << 5) | ty;
+        }
+        // flat source index on the Nin grid (-1 = zero cell) of every item slot of a tile, all loads in flight at once;
+        // full-vector kernels (SUP) also keep (as an offset) the pixel index on the nearest-upsampled source's own grid (row r = face*Nin + y
+        // of the Nin grid -> row r/2 = face*g0 + y/2 of the Nin/2 grid, Nin = 2*g0 even; column x -> x/2), so that issuing a
+        // chunk's loads costs one multiply-add per vector
+        constexpr bool SUP = VW * ES == 16 && !MASK;     // (the act' mask's second load stream leaves no registers)
+        int sidx[ITS];
+        int sup[SUP ? ITS : 1];
+        auto upmap = [&](int ii) __attribute__((always_inline)) {
+            const int r = __umulhi((uint32_t)ii, P.magicN);
+            return (r >> 1) * g0 + ((ii - r * P.Nin) >> 1);
+        };
+        auto lookup = [&](const Geo &gq) __attribute__((always_inline)) {
+            const int base = (gq.f * rstride + gq.y0) * rstride - OFF;
+#pragma unroll
+            for (int i = 0; i < ITS; ++i) {
+                const int sc = slot_c[i];
+                const int a = base + (sc >> 6);
+                const bool live = ptid + i * NCT < gq.nitems;
+                int v0;
+                // (a slot beyond THIS band's rows would index past the band -- for the last band of face 5 past the end of
+                // the table: dead slots read entry 0)
+                if (MODE == MODE_HALO) v0 = P.table[live ? a : 0];
+                else if (MODE == MODE_DIRECT) v0 = a;
+                else {
+                    const int vy = gq.y0 + (sc & 31) - PADZ;
+                    v0 = ((vy >= 0) & (vy < P.Nin) & ((sc >> 5) & 1)) ? a : -1;
+                }
+                sidx[i] = live ? v0 : -1;
+            }
+            if constexpr (SUP) {
+                // kept as the DIFFERENCE to sidx: `up ? sup[i] : sidx[i]` becomes a select of two stack addresses in LLVM and
+                // sends both arrays (and the kernel arguments with them) to scratch memory
+#pragma unroll
+                for (int i = 0; i < ITS; ++i) sup[i] = sidx[i] >= 0 ? upmap(sidx[i]) - sidx[i] : 0;
+            }
+        };
+        int g = 0;
+        // Weight-stationary LDS: the weight fragments of (face variant, chunk) are the same for every tile, and consecutive
+        // tiles of a workgroup are the same (face, band) in consecutive samples.  wres[b] = what buffer b's weight area holds;
+        // a chunk whose fragments are already there skips their loads and LDS writes.  With one chunk per tile both buffers
+        // converge after two tiles, with an even chunk count chunk ch always lands in buffer ch & 1; other counts simply
+        // never match.  (Measured need: at 64 -> 64 channels the fragments were 74 of the 107 KB a tile pulled through the
+        // CU's load path, which is what bounds these kernels -- ~10 B/clk/CU -- not the matrix cores.)
+        int wres[4] = {-1, -1, -1, -1};     // by buffer (g & 1), or by chunk with resident areas (P.wstat)
+
+        // per-thread constants of a chunk: source, channel offset inside it, TAIL8 shift
+        auto chunk_src = [&](const Geo &gc, int ch, const T *&sb, int &cstride, int &cs_ld, int &sh, bool &c_ok, bool &up)
+            __attribute__((always_inline)) {
+            const T *s0b = reinterpret_cast<const T *>(P.src0) + (size_t)gc.b * 6 * g0 * g0 * P.C0;
+            const T *s1b = P.C1 > 0 ? reinterpret_cast<const T *>(P.src1) + (size_t)gc.b * 6 * P.Nin * P.Nin * P.C1 : s0b;
+            const int c = ch * KC + qv;
+            c_ok = c < P.Cin;
+            const bool from0 = c < P.C0;
+            sb = from0 ? s0b : s1b;
+            const int cs = from0 ? c : c - P.C0;              // channel inside the chosen source
+            cstride = from0 ? P.C0 : P.C1;
+            up = from0 && P.up0;
+            cs_ld = cs; sh = 0;
+            if constexpr (TAIL8) {
+                if (c_ok && cs + 8 > cstride) { sh = (cs + 8 - cstride) >> 1; cs_ld = cstride - 8; }
+            }
+        };
+        // weight fragments of (face variant v, chunk ch) -> registers -> the weight area of LDS buffer b
+        auto load_w = [&](int v, int ch, uint4 (&wv)[ITW]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < ITW; ++u) {
+                const int idx = min(ptid + u * NCT, WF4 - 1);
+                const int gg = idx / GF4, w = idx % GF4;
+                const int ntl = gg / KCG, cgl = gg % KCG;
+                const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
+                const bool ok = ntile < P.NTtot && cg < P.CG;
+                wv[u] = vsel(ok, wsrc[ok ? (((size_t)v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0]);
+            }
+        };
+        auto store_w = [&](int area, const uint4 (&wv)[ITW]) __attribute__((always_inline)) {
+            char *wa = smem + w_base + area * w_step;
+#pragma unroll
+            for (int u = 0; u < ITW; ++u) {
+                const int idx = ptid + u * NCT;
+                if (idx < WF4) reinterpret_cast<uint4 *>(wa)[idx] = wv[u];
+            }
+        };
+        // issue(): (rarely) the weight fragments -> LDS buffer g & 1, then every load of the chunk's input tile, back to back
+        auto issue = [&](const Geo &gc, int ch, V (&val)[ITS], V (&ymv)[MASK ? ITS : 1], uint32_t &okm) __attribute__((always_inline)) {
+            const int wkey = gc.v * 1024 + ch;
+            const int area = P.wstat ? ch : (g & 1);
+            const bool need_w = !(P.tune & TUNE_CONV_WEIGHTS_STAY) || wres[area] != wkey;
+            wres[area] = wkey;
+            if (need_w) {
+                // uniform and rare (weights stay): the fragments are fetched and written in a block of their own, all loads in
+                // flight at once (fetching them four at a time cost 2-3 serial L2 round trips on each workgroup's first tiles:
+                // +5 % on the whole training step)
+                uint4 wv[ITW];
+                load_w(gc.v, ch, wv);
+                store_w(area, wv);
+            }
+            const T *sb; int cstride, cs_ld, sh; bool c_ok, up;
+            chunk_src(gc, ch, sb, cstride, cs_ld, sh, c_ok, up);
+            const T *ymb = MASK ? reinterpret_cast<const T *>(P.ymask) + (size_t)gc.b * 6 * g0 * g0 * P.C0 : nullptr;
+            PL_MARK();
+            okm = 0;
+#pragma unroll
+            for (int i = 0; i < ITS; ++i) {
+                int idx = sidx[i];
+                if constexpr (SUP) idx += up ? sup[i] : 0;
+                const bool ok = c_ok && idx >= 0;
+                int pix = ok ? idx : 0;
+                if constexpr (!SUP) pix = up ? upmap(pix) : pix;
+                const size_t oo = ok ? (size_t)pix * cstride + cs_ld : 0;
+                if constexpr (TAIL8) val[i] = ld_act<CHAIN, uint4_a4>(sb + oo);
+                else val[i] = ld_act<CHAIN, V>(sb + oo);
+                if (MASK) ymv[i] = ld_act<CHAIN, V>(ymb + oo);
+                okm |= (uint32_t)ok << i;
+            }
+            PL_MARK();
+        };
+        // commit(): the loaded vectors -> LDS buffer g & 1, barrier B_g
+        auto commit = [&](const Geo &gc, int ch, V (&val)[ITS], V (&ymv)[MASK ? ITS : 1], uint32_t okm) __attribute__((always_inline)) {
+            char *buf = smem + (g & 1) * in_step;
+            if constexpr (TAIL8) {
+                const T *sb; int cstride, cs_ld, sh; bool c_ok, up;
+                chunk_src(gc, ch, sb, cstride, cs_ld, sh, c_ok, up);
+                if (sh) {
+#pragma unroll
+                    for (int i = 0; i < ITS; ++i) val[i] = vshl_dwords(val[i], sh);
+                }
+            }
+            // act' mask only after EVERY load has been issued (a use right behind its load makes hipcc wait per load)
+            if (MASK) {
+#pragma unroll
+                for (int i = 0; i < ITS; ++i) vmask(val[i], ymv[i], P.alpha, P.vmax);
+            }
+#pragma unroll
+            for (int i = 0; i < ITS; ++i) {
+                const int e = ptid + i * NCT;
+                if (e < gc.nitems) *reinterpret_cast<V *>(buf + (e / Q) * RB + qv * ES) = vsel(((okm >> i) & 1u) != 0, val[i]);
+            }
+            PL_MARK();
+            __syncthreads();            // B_g: chunk g is in LDS
+            ++g;
+        };
+
+        // (Measured negative: issuing the loads of chunk g+1 BEFORE chunk g is written to LDS -- two register sets, one chunk
+        // ahead -- hides the 1.2-1.9 k cycles a producer waits for its loads, but its LDS writes then land in the consumers'
+        // MFMA phase, whose fragment reads slow down by more than was gained: 2.2 k -> 3.0 k cycles per tile at 32 -> 32
+        // channels, 0.936 -> 1.02 ms per training step.)
+        int cur_combo = -1;
+        V val[ITS], ymv[MASK ? ITS : 1];
+        uint32_t okm = 0;
+        // (Measured negative: requesting the first two chunks' weight fragments before the first tile's halo-table lookup and
+        // its input vectors before the weight stores -- two dependent round trips instead of three at the start of the kernel
+        // -- made the training step 3 % SLOWER; the first chunk's fragments alone before the lookup: 1 % slower.  The loads of a
+        // wave return in order: whatever is requested ahead of the table entries delays them.)
+        for (int t = t_first; t < t_last; ++t) {
+            const Geo gq = geo_of(t);
+            if (gq.combo != cur_combo) { lookup(gq); cur_combo = gq.combo; }        // uniform; a few times per workgroup
+            for (int ch = 0; ch < nchunks; ++ch) {
+                issue(gq, ch, val, ymv, okm);
+                commit(gq, ch, val, ymv, okm);
+            }
+        }
+        if (P.tune & TUNE_CONV_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(0);
+        return;
+    }
+
+    // ============================================= consumers =============================================
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    // NOTE: no s_setprio(1) here: a prioritised wave waiting for the busy matrix pipe still wins its SIMD's issue
+    // arbitration and starves the co-resident producer wave's address arithmetic.
+
+    // pixel `loc` (0 .. 32 * MT - 1) of this wave -> its index in the tile (row-major, rows of No pixels).  Normally the wave owns
+    // 32 * MT consecutive tile pixels.  P.colsplit (pooled second output on faces whose ROW is 32 * MT pixels, tile = 4 rows, 4
+    // consumer waves): wave wm owns the half-rows [ (wm & 1) * No/2, + No/2 ) of tile rows 2 * (wm >> 1) and + 1 -- whole
+    // 2 x 2 pooling blocks again.
+    auto tile_pix = [&](int loc) __attribute__((always_inline)) {
+        const int lin = wm * MT * 32 + loc;
+        const int hN = P.No >> 1;
+        const int r = loc >= hN ? 1 : 0;
+        const int cs = (2 * (wm >> 1) + r) * P.No + (wm & 1) * hN + (loc - r * hN);
+        return P.colsplit ? cs : lin;
+    };
+    f32x16 acc[MT][NT];
+    constexpr int LPP = 32 * ES / 16;           // epilogue: lanes per pixel on the way out (16 B each): 8 fp32 / 4 bf16
+    constexpr int PPP = 64 / LPP;               // pixels per store pass
+    constexpr int NPS = 32 / PPP;               // store passes per M tile
+    constexpr bool DIRECT = MODE == MODE_ZERO && KS == 3;   // data gradient: interior cells go straight to the sources
+    int g = 0;
+#ifdef DLWPCS_TIMELINE
+    int tli = 0;
+    long long *tlp = (P.dbg && tid == 0 && by == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
+#endif
+    TL_MARK();
+    int abase[MT];
+    int cur_combo = -1, cur_v = -1;
+    float4 bq[NT][4];
+    // store pass (nt, mt, ps) of this lane: byte offset of its 16 B inside ONE sample of the destination (ST_SKIP: nothing to
+    // store) and, data gradient in direct mode, which destination (2 bits each: 0 = out, 1 = d0, 2 = d1).  Like the LDS
+    // addresses they depend on the (face, band) only, not on the sample.
+    // (SOFF: kept in registers when there are at most 12 passes; the MT = 5 tilings recompute them per store)
+    constexpr bool SOFF = NT * MT * NPS <= 12;
+    uint32_t soff[SOFF ? NT : 1][SOFF ? MT : 1][SOFF ? NPS : 1];      // BYTE offsets, ST_SKIP = nothing to store
+    uint32_t ssel = 0;
+    auto store_off = [&](const Geo &gq, int nt, int mt, int ps, uint32_t &sel) __attribute__((always_inline)) {
+        const int px = ps * PPP + lane / LPP, q = lane % LPP;
+        const int mm = tile_pix(mt * 32 + px);
+        const int c = (nt0 + wn * NT + nt) * 32 + q * (16 / ES);
+        const int gm = gq.m0 + mm;
+        int off = (gq.f * face_pix + gm) * P.Cout + c;
+        sel = 0;
+        if constexpr (DIRECT) {
+            // direct mode: an interior cell of the padded gradient IS cell (oy-1, ox-1) of the source
+            const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
+            const int Ns = P.No - 2;
+            const bool in0 = c < P.dsplit;
+            const bool have = (in0 ? P.d0 : P.d1) != nullptr;
+            const int cs = in0 ? c : c - P.dsplit, CS = in0 ? P.dsplit : P.Cout - P.dsplit;
+            const bool interior = ((uint32_t)(oy - 1) < (uint32_t)Ns) & ((uint32_t)(ox - 1) < (uint32_t)Ns);
+            if (interior && have) {
+                off = ((gq.f * Ns + (oy - 1)) * Ns + (ox - 1)) * CS + cs;
+                sel = in0 ? 1u : 2u;
+            }
+        }
+        return (mm < gq.npix && c < P.Cout) ? (uint32_t)off * ES : ST_SKIP;
+    };
+
+    constexpr int PROW = 32 * ES + 16;          // patch row: one pixel's 32 channels + pad
+    // pooling as a second output: one patch per M tile of the wave (all of them are read back once the wave's rows are complete)
+    const bool pooling = MODE != MODE_ZERO && P.pool_out != nullptr;
+    char *const patch0 = smem + patch_base + wave * (32 * PROW) * (pooling ? MT : 1);
+    const int patch_step = pooling ? 32 * PROW : 0;
+    // ---- pooled second output.  The wave's MT * 32 pixels are whole pairs of tile rows: pooled pixel pp of the wave is the
+    // mean of local pixels i00 = 2 * (pp / (No/2)) * No + 2 * (pp % (No/2)), i00 + 1, i00 + No, i00 + No + 1, read from the
+    // wave's MT patches (bf16 / fp32 values exactly as stored to `out`), summed like avgpool2_fwd_kernel: (a + b) + (c + d),
+    // x 0.25, rounded once -- the same bits as the separate launch.
+    constexpr int PITEMS = MT * 8 * LPP;            // 16-B vectors of the wave's pooled pixels
+    constexpr int PNP = (PITEMS + 63) / 64;         // passes
+    uint32_t plds0[PNP], plds1[PNP], pgo[NT][PNP];  // LDS offsets of i00 / i00 + No, byte offset in one sample of pool_out
+    auto pool_setup = [&](const Geo &gq) {
+        const int hN = P.No >> 1;
+        const int Wl = P.colsplit ? hN : P.No, hW = Wl >> 1;        // the wave's pixels as rows of Wl (local, row-major)
+#pragma unroll
+        for (int ps = 0; ps < PNP; ++ps) {
+            const int item = ps * 64 + lane;
+            const int pp = min(item / LPP, MT * 8 - 1), q = item % LPP;
+            const int prow = pp / hW, pcol = pp - prow * hW;
+            const int i00 = 2 * prow * Wl + 2 * pcol, i10 = i00 + Wl;
+            plds0[ps] = (uint32_t)((i00 >> 5) * (32 * PROW) + (i00 & 31) * PROW + q * 16);
+            plds1[ps] = (uint32_t)((i10 >> 5) * (32 * PROW) + (i10 & 31) * PROW + q * 16);
+            const int gm = gq.m0 + tile_pix(i00);
+            const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = (nt0 + wn * NT + nt) * 32 + q * (16 / ES);
+                const bool ok = item / LPP < MT * 8 && tile_pix(i00) < gq.npix && c < P.Cout;
+                pgo[nt][ps] = ok ? (uint32_t)((((gq.f * hN + (oy >> 1)) * hN + (ox >> 1)) * P.Cout + c) * ES) : ST_SKIP;
+            }
+        }
+    };
+    // ---- per-tile set-up: LDS addresses and store offsets (rebuilt at (face, band) changes), bias quads (reloaded at face
+    // variant changes), accumulators = bias
+    auto setup = [&](const Geo &gq) {
+        if (gq.combo != cur_combo) {            // uniform; the same for every sample of a combo
+            cur_combo = gq.combo;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = tile_pix(mt * 32 + l31);
+                int base = 0;
+                if (m < gq.npix) {
+                    const int gm = gq.m0 + m;
+                    const int oy = __umulhi((uint32_t)gm, P.magicNo);
+                    const int ox = gm - oy * P.No;
+                    base = ((oy - gq.y0) * P.W2 + ox) * RB;
+                }
+                abase[mt] = base + half * 16;
+            }
+            if constexpr (MODE != MODE_ZERO) {
+                if (pooling) pool_setup(gq);
+            }
+            if constexpr (SOFF) {
+                ssel = 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int ps = 0; ps < NPS; ++ps) {
+                            uint32_t sel;
+                            soff[nt][mt][ps] = store_off(gq, nt, mt, ps, sel);
+                            ssel |= sel << (2 * ((nt * MT + mt) * NPS + ps));
+                        }
+            }
+        }
+        // the bias quads of the face variant (the packed bias vector is zero-padded to NTtot*32 floats, so every quad is
+        // readable; an N tile beyond C_out -- NTtot not a multiple of the workgroup's N tiles -- re-reads the last tile's)
+        if (gq.v != cur_v) {
+            cur_v = gq.v;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq)
+                    bq[nt][jq] = P.bias ? *reinterpret_cast<const float4 *>(P.bias + (size_t)gq.v * P.NTtot * 32 +
+                                                                             min(nt0 + wn * NT + nt, P.NTtot - 1) * 32 + 8 * jq + 4 * half)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            // The quads are waited for HERE, inside the (rare) branch: the empty asm redefines the registers, so nothing is
+            // pending on them at the join.  Otherwise the accumulator set-up below -- every tile -- sits behind a
+            // s_waitcnt vmcnt(0) (a load MAY be in flight; with the previous tile's stores in flight too the counter cannot be
+            // split), i.e. behind the acknowledgement of the previous epilogue's stores: ~1000 of a 5750-cycle tile period
+            // (s_memtime marks, 32 -> 32 at N = 48).
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq)
+                    asm volatile("" : "+v"(bq[nt][jq].x), "+v"(bq[nt][jq].y), "+v"(bq[nt][jq].z), "+v"(bq[nt][jq].w));
+        }
+        // the accumulators start at the bias (row = output channel in the MFMA's D[co][pixel] layout): no add in the epilogue
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq) {
+                    acc[mt][nt][4 * jq] = bq[nt][jq].x; acc[mt][nt][4 * jq + 1] = bq[nt][jq].y;
+                    acc[mt][nt][4 * jq + 2] = bq[nt][jq].z; acc[mt][nt][4 * jq + 3] = bq[nt][jq].w;
+                }
+    };
+
+    // ---- tile epilogue: bias + activation + stores.  The MFMA ran as D[co][pixel] (weights as the A operand), so in
+    // the C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) a lane owns ONE pixel and, per r>>2, FOUR
+    // CONSECUTIVE output channels.  Storing those quads directly costs one L2 write request per lane and quad (8 per
+    // 64-B line; measured: ~1 request/clk/CU, 3 k of a 5 k-cycle epilogue), so each M tile goes through a wave-private
+    // LDS patch [32 pixels][32 channels + 16 B pad] instead: 4 quad writes per lane in, 16 B per lane out with the
+    // lanes of a pixel contiguous -> every store instruction writes whole lines.  No fence: the LDS executes one wave's
+    // instructions in order; wave_barrier only pins the compiler's schedule (a release fence here waits vmcnt(0),
+    // i.e. for the previous stores to land -- that was the cost of the first LDS epilogue).
+    //
+    // Per (n tile, m tile) pair: 4 x "one quad -> patch" then NPS x "one store pass out of the patch" (epi_slice, called
+    // with compile-time-constant i from a fully unrolled loop).
+    constexpr int SPP = 4 + NPS;                // slices per (n tile, m tile) pair
+    constexpr int NSLICE = NT * MT * SPP;
+    // no activation == ReLU(alpha = 1, max = +inf): the epilogue applies the activation unconditionally and stays
+    // straight-line (a branch per quad chops it into 5-instruction blocks whose dependent chains cannot interleave).
+    // FAST (0 <= alpha <= 1, max >= 0, i.e. every activation of the reference's models and "none"): the activation is
+    // min(max(x, alpha*x), max) -- 2.5 VALU instructions per value (v_max_f32, v_min_f32, half a packed multiply) instead of 4.5
+    // (canonicalise, min, compare, select, half a multiply); the consumers' epilogue is VALU-issue bound.  (NOT med3(x, alpha*x, max): that is alpha*x,
+    // not max, once alpha*x itself exceeds max.)  NaN: keras' ReLU (Azure/train_cs.py:199) propagates it.  v_max_f32(NaN, alpha * NaN)
+    // is NaN (both operands), but v_min_f32 is IEEE minNum and would turn it into `max`; gfx950's v_minimum3_f32 is the IEEE-754-2019
+    // minimum (NaN if any operand is), same issue cost: a NaN pre-activation leaves the layer as NaN.
+    const float e_alpha = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.alpha : 1.f;
+    const float e_vmax = P.act == DLWPCS_ACT_LEAKY_CLIP ? P.vmax : __builtin_inff();
+    const bool fast_act = e_alpha >= 0.f && e_alpha <= 1.f && e_vmax >= 0.f;
+    auto quad = [&](auto fast_tag, const f32x16 &a, int jq) {
+        float4 v4 = make_float4(a[4 * jq], a[4 * jq + 1], a[4 * jq + 2], a[4 * jq + 3]);
+        if constexpr (MODE == MODE_ZERO) return v4;         // data gradient: never an activation (2.5 instructions per value)
+        if constexpr (decltype(fast_tag)::value == 2) return v4;    // no activation: identity (a NaN stays a NaN)
+        if constexpr (decltype(fast_tag)::value == 1) {
+            // v_max_f32 / v_min_f32 as (pure) asm: fmaxf / fminf -- and v_med3_f32 with an infinite operand, which LLVM folds
+            // back into them -- put a canonicalising `v_max x, x` in front of every value that comes out of an accumulator
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            auto lc = [&](float x, float ax) {
+                float t, y;
+                asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(ax));
+                asm("v_minimum3_f32 %0, %1, %2, %2" : "=v"(y) : "v"(t), "v"(e_vmax));
+                return y;
+            };
+            const f32x2 a01 = f32x2{v4.x, v4.y} * e_alpha, a23 = f32x2{v4.z, v4.w} * e_alpha;     // v_pk_mul_f32
+            v4.x = lc(v4.x, a01.x); v4.y = lc(v4.y, a01.y); v4.z = lc(v4.z, a23.x); v4.w = lc(v4.w, a23.y);
+        } else {
+            v4.x = act_leaky_clip(v4.x, e_alpha, e_vmax); v4.y = act_leaky_clip(v4.y, e_alpha, e_vmax);
+            v4.z = act_leaky_clip(v4.z, e_alpha, e_vmax); v4.w = act_leaky_clip(v4.w, e_alpha, e_vmax);
+        }
+        return v4;
+    };
+    // per-sample buffer descriptors of the destinations (uniform): write-through stores, see common.h
+    auto out_of = [&](const Geo &gq) {
+        return make_rsrc(reinterpret_cast<T *>(P.out) + (size_t)gq.b * 6 * face_pix * P.Cout, (uint32_t)(6 * face_pix * P.Cout * ES));
+    };
+    auto d0_of = [&](const Geo &gq) {
+        const int spix = 6 * (P.No - 2) * (P.No - 2);
+        return make_rsrc(P.d0 ? reinterpret_cast<T *>(P.d0) + (size_t)gq.b * spix * P.dsplit : nullptr, (uint32_t)(spix * P.dsplit * ES));
+    };
+    auto d1_of = [&](const Geo &gq) {
+        const int spix = 6 * (P.No - 2) * (P.No - 2), c1 = P.Cout - P.dsplit;
+        return make_rsrc(P.d1 ? reinterpret_cast<T *>(P.d1) + (size_t)gq.b * spix * c1 : nullptr, (uint32_t)(spix * c1 * ES));
+    };
+    // MOUT: the sources' own values at the cells this lane will store to d0 / d1, requested at the start of the tile (they land
+    // during its matrix phase) with the store offsets of the (face, band)
+    static_assert(!MOUT || SOFF, "MOUT needs the per-band store offsets in registers");
+    uint4 ymq[MOUT ? NT : 1][MOUT ? MT : 1][MOUT ? NPS : 1];
+    auto mask_load = [&](const Geo &gq) {
+        if constexpr (MOUT) {
+            const int spix = 6 * (P.No - 2) * (P.No - 2), c1 = P.Cout - P.dsplit;
+            const rsrc_t r0 = make_rsrc(P.m0 ? reinterpret_cast<const T *>(P.m0) + (size_t)gq.b * spix * P.dsplit : nullptr,
+                                        (uint32_t)(spix * P.dsplit * ES));
+            const rsrc_t r1 = make_rsrc(P.m1 ? reinterpret_cast<const T *>(P.m1) + (size_t)gq.b * spix * c1 : nullptr,
+                                        (uint32_t)(spix * c1 * ES));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int ps = 0; ps < NPS; ++ps) {
+                        const uint32_t boff = soff[nt][mt][ps], sel = (ssel >> (2 * ((nt * MT + mt) * NPS + ps))) & 3u;
+                        u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r0, sel == 1 ? boff : ST_SKIP, 0, 0);
+                        if (P.m1 != nullptr) {      // (uniform; a skip connection that is masked directly -- not in the U-Nets)
+                            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r1, sel == 2 ? boff : ST_SKIP, 0, 0);
+                            a = a | b;
+                        }
+                        ymq[nt][mt][ps] = make_uint4(a.x, a.y, a.z, a.w);
+                    }
+        }
+    };
+    auto pool_pass = [&](int nt, rsrc_t d_pool) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < PNP; ++ps) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(patch0 + plds0[ps]);
+            const uint4 b = *reinterpret_cast<const uint4 *>(patch0 + plds0[ps] + PROW);
+            const uint4 c = *reinterpret_cast<const uint4 *>(patch0 + plds1[ps]);
+            const uint4 d = *reinterpret_cast<const uint4 *>(patch0 + plds1[ps] + PROW);
+            uint4 o;
+            if constexpr (ES == 4) {
+                auto avg = [](uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+                    return __float_as_uint(((__uint_as_float(x) + __uint_as_float(y)) + (__uint_as_float(z) + __uint_as_float(w))) * 0.25f);
+                };
+                o = make_uint4(avg(a.x, b.x, c.x, d.x), avg(a.y, b.y, c.y, d.y), avg(a.z, b.z, c.z, d.z), avg(a.w, b.w, c.w, d.w));
+            } else {
+                auto avg2 = [](uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+                    const float lo = ((bf_lo(x) + bf_lo(y)) + (bf_lo(z) + bf_lo(w))) * 0.25f;
+                    const float hi = ((bf_hi(x) + bf_hi(y)) + (bf_hi(z) + bf_hi(w))) * 0.25f;
+                    return f2bf2(lo, hi);
+                };
+                o = make_uint4(avg2(a.x, b.x, c.x, d.x), avg2(a.y, b.y, c.y, d.y), avg2(a.z, b.z, c.z, d.z), avg2(a.w, b.w, c.w, d.w));
+            }
+            bst128(o, d_pool, pgo[nt][ps]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto epi_slice = [&](auto fast_tag, int i, const Geo &gq, rsrc_t d_out, rsrc_t d_0, rsrc_t d_1, const auto &A) {
+        const int pr = i / SPP, k = i % SPP;
+        const int nt = pr / MT, mt = pr % MT;
+        char *const patch = patch0 + mt * patch_step;
+        if (k < 4) {
+            const float4 v4 = quad(fast_tag, A[mt][nt], k);
+            char *pp = patch + l31 * PROW + (8 * k + 4 * half) * ES;
+            if constexpr (ES == 4) *reinterpret_cast<float4 *>(pp) = v4;
+            else *reinterpret_cast<uint2 *>(pp) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
+            if (k == 3) __builtin_amdgcn_wave_barrier();
+        } else {
+            const int ps = k - 4;
+            const int px = ps * PPP + lane / LPP, q = lane % LPP;
+            uint4 v = *reinterpret_cast<const uint4 *>(patch + px * PROW + q * 16);
+            uint32_t boff, sel;
+            if constexpr (SOFF) { boff = soff[nt][mt][ps]; sel = (ssel >> (2 * ((nt * MT + mt) * NPS + ps))) & 3u; }
+            else boff = store_off(gq, nt, mt, ps, sel);
+            if constexpr (MOUT) {
+                // (measured: the whole masking -- these ~11 instructions per bf16 pair and the six 16-B loads per tile -- costs
+                // the training step ~14 us over four layers; the loads alone nothing.  Branch-free on purpose: a uniform branch
+                // around this block made the step 25 us SLOWER.)
+                uint4 vm = v;
+                vmask_pk(vm, ymq[nt][mt][ps], P.m_alpha, P.m_thr1);
+                const bool on = (sel == 1 && P.m0 != nullptr) || (sel == 2 && P.m1 != nullptr);
+                // component by component: `v = on ? vm : v` on the uint4 becomes a select of two STACK ADDRESSES in LLVM -- both
+                // values went to scratch memory and came back through a scratch load behind s_waitcnt vmcnt(0), which also
+                // waited for the stores of the previous slice (measured: 43.8 us against 26.1 us unmasked, 32 -> 32 at N = 48)
+                v.x = on ? vm.x : v.x; v.y = on ? vm.y : v.y; v.z = on ? vm.z : v.z; v.w = on ? vm.w : v.w;
+            }
+#ifdef DLWPCS_TIMELINE
+            if (P.abl & 1) boff = ST_SKIP;          // ablation: no global stores
+#endif
+            if constexpr (DIRECT) {
+                // three possible destinations: one store each, the lanes of the other two skip
+                bst128(v, d_out, sel == 0 ? boff : ST_SKIP);
+                bst128(v, d_0, sel == 1 ? boff : ST_SKIP);
+                bst128(v, d_1, sel == 2 ? boff : ST_SKIP);
+            } else {
+                bst128(v, d_out, boff);
+            }
+            if (ps == NPS - 1) __builtin_amdgcn_wave_barrier();
+        }
+    };
+    auto pool_of = [&](const Geo &gq) {
+        const int ppix = 6 * (P.No >> 1) * (P.No >> 1);
+        return make_rsrc(pooling ? reinterpret_cast<T *>(P.pool_out) + (size_t)gq.b * ppix * P.Cout : nullptr,
+                         (uint32_t)(ppix * P.Cout * ES));
+    };
+    auto epilogue_lines = [&](const Geo &gq, const auto &A) {
+        TL_MARK();
+        if constexpr (MOUT) {
+            // Every mask value is waited for HERE, before the first store of the epilogue: with loads and stores both in flight
+            // hipcc cannot count (gfx9 has one vmcnt for both and they complete out of order), so each later use of a mask
+            // register became s_waitcnt vmcnt(0) -- one store round trip per slice, six per tile (measured: 43.8 us against
+            // 26.1 us unmasked on the 32 -> 32 layer at N = 48).  The empty asm redefines the registers: nothing pending on them.
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int ps = 0; ps < NPS; ++ps)
+                        asm volatile("" : "+v"(ymq[nt][mt][ps].x), "+v"(ymq[nt][mt][ps].y), "+v"(ymq[nt][mt][ps].z), "+v"(ymq[nt][mt][ps].w));
+        }
+        const rsrc_t d_out = out_of(gq);
+        const rsrc_t d_0 = DIRECT ? d0_of(gq) : d_out, d_1 = DIRECT ? d1_of(gq) : d_out;
+        const rsrc_t d_pool = pool_of(gq);
+        // (the pooled output is written when the slices of an n tile are through: its patches are complete then)
+        auto run = [&](auto tag) {
+#pragma unroll
+            for (int i = 0; i < NSLICE; ++i) {
+                epi_slice(tag, i, gq, d_out, d_0, d_1, A);
+                if constexpr (MODE != MODE_ZERO) {
+                    if ((i + 1) % (MT * SPP) == 0 && pooling) pool_pass(i / (MT * SPP), d_pool);
+                }
+            }
+        };
+        if (P.act != DLWPCS_ACT_LEAKY_CLIP) run(std::integral_constant<int, 2>{});
+        else if (fast_act) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 0>{});
+        TL_MARK();
+    };
+    // fallback (odd channel counts, or no LDS room for the patches): quads / scalars straight from the accumulators
+    auto epilogue_plain = [&](const Geo &gq) {
+        TL_MARK();
+        T *outp = reinterpret_cast<T *>(P.out) + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
+        const bool wide = (P.Cout & 3) == 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cot = (nt0 + wn * NT + nt) * 32;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = (wm * MT + mt) * 32 + l31;
+                T *dst = outp + (size_t)(gq.m0 + m) * P.Cout + cot + 4 * half;
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq) {
+                    const int co = cot + 8 * jq + 4 * half;
+                    const float4 v4 = quad(std::integral_constant<int, 0>{}, acc[mt][nt], jq);
+                    if (m >= gq.npix) continue;
+                    if (wide) {
+                        if (co < P.Cout) {
+                            if constexpr (ES == 4) *reinterpret_cast<float4 *>(dst + 8 * jq) = v4;
+                            else *reinterpret_cast<uint2 *>(dst + 8 * jq) = make_uint2(f2bf2(v4.x, v4.y), f2bf2(v4.z, v4.w));
+                        }
+                    } else {
+                        const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (co + u < P.Cout) {
+                                if constexpr (ES == 4) dst[8 * jq + u] = vs[u];
+                                else dst[8 * jq + u] = f2bf(vs[u]);
+                            }
+                    }
+                }
+            }
+        }
+        TL_MARK();
+    };
+
+    // ---- one chunk of MFMAs out of LDS buffer g & 1 (between two barriers: fragment reads + MFMAs only)
+    // Explicit two-register-set pipeline over the (channel group, tap) steps: the fragments of step s+1 are read from LDS
+    // BEFORE the MFMAs of step s are issued (left alone, the compiler reuses one register set and stalls on lgkmcnt after
+    // every step).
+    constexpr int NSTEP = KCG * TAPS;
+    auto mma_chunk = [&](int ch) {
+        const char *lds_in = smem + (g & 1) * in_step, *lds_w = smem + w_base + (P.wstat ? ch : (g & 1)) * w_step;
+        uint4 fa[2][MT], fb[2][NT];
+        auto load_frag = [&](int step, uint4 (&a)[MT], uint4 (&bw)[NT]) {
+            const int cgl = step / TAPS, tap = step % TAPS;
+            const int dy = tap / KS, dx = tap % KS;
+            const int tapoff = (dy * P.W2 + dx) * RB + cgl * 32;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const uint4 *>(lds_in + abase[mt] + tapoff);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bw[nt] = *reinterpret_cast<const uint4 *>(
+                    lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 512 + l31 * 16);
+        };
+        load_frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < NSTEP) load_frag(step + 1, fa[cur ^ 1], fb[cur ^ 1]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) frag_mma<T>(acc[mt][nt], fb[cur][nt], fa[cur][mt]);   // D[co][pixel]
+            // (round 3: spreading the reads behind the individual MFMAs -- (MFMA, 2 reads), (MFMA, 1), (MFMA, 1) -- as in the batched
+            // weight-gradient kernel measured +-0 here: three MFMAs already hide four reads.  Keeping the 18 weight fragments of a
+            // one-chunk layer in 72 VGPRs (3 reads per 3 MFMAs instead of 4; a template variant of its own): the 32 -> 32 data
+            // gradient at N = 48 alone 28.5 -> 27.8 us, the whole training step +6 us -- dropped.)
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);                          // DS reads of step s+1 first
+            __builtin_amdgcn_sched_group_barrier(0x008, MmaPerFrag<T>::N * MT * NT, 0);       // then the MFMAs of step s
+        }
+    };
+
+    const bool lines = P.patches && (P.Cout % (16 / ES)) == 0;
+    for (int t = t_first; t < t_last; ++t) {
+        const Geo gq = geo_of(t);
+        setup(gq);
+        mask_load(gq);
+        for (int ch = 0; ch < nchunks; ++ch, ++g) {
+            TL_MARK();
+            // B_g: chunk g has been written by the producers.  A RAW barrier behind an explicit LDS wait: __syncthreads() makes
+            // hipcc drain vmcnt(0) first, i.e. wait for the previous tile's epilogue stores to be acknowledged and -- MOUT -- for
+            // the mask values requested a moment ago (measured on the 32 -> 32 data gradient at N = 48: 43.8 us masked against
+            // 26.1 plain, nearly all of it this wait).  The consumers only owe the producers their LDS reads.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            TL_MARK();
+            mma_chunk(ch);
+        }
+        if (lines) epilogue_lines(gq, acc);
+        else epilogue_plain(gq);
+    }
+}
+
+// the per-layer launch: one workgroup per CU, workers laid out XCD-aware over the tile list
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false, bool MOUT = false>
+__global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_ws_body<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8, MOUT, false>(P, smem, xcd_remap(blockIdx.x, gridDim.x), (int)gridDim.x,
+                                                                              (int)blockIdx.y);
+}
+
+}  // namespace dlwpcs
