@@ -249,8 +249,7 @@ class CubeSphereConv2D(Layer):
 
     def can_fuse_halo(self, pad_width):
         """True if a preceding CubeSpherePadding2D(pad_width) can be folded into this layer's load."""
-        return (self._is_mfma_config() and self.kernel_size[0] == 3 and pad_width == 1
-                and self.data_format == 'channels_last' and self.activation is None)
+        return (self._is_mfma_config() and self.kernel_size[0] == 3 and pad_width == 1 and self.activation is None)
 
     def fused_call(self, src0, src1=None, up0=False, halo=True, act=ACT_NONE, alpha=0.0, vmax=0.0, premask0=None,
                    premask1=None, dy_premasked=False, defer_ring0=False, want_pool=False, out_padded=False):
@@ -262,8 +261,10 @@ class CubeSphereConv2D(Layer):
                            act=act, alpha=alpha, vmax=vmax, premask0=premask0, premask1=premask1,
                            dy_premasked=dy_premasked, defer_ring0=defer_ring0, want_pool=want_pool, out_padded=out_padded)
 
-    def call(self, inputs, **kwargs):
-        channels_first = self.data_format == 'channels_first'
+    def call(self, inputs, channels_last_io=False, **kwargs):
+        """channels_last_io (DLWP.keras.Model running a channels_first graph channels_last inside): the tensor arrives and
+        leaves channels_last whatever the layer's data_format says."""
+        channels_first = self.data_format == 'channels_first' and not channels_last_io
         x = ops.channels_first_to_last(inputs) if channels_first else inputs
         if self._is_mfma_config():
             outputs = ops.cs_conv(x, self.equatorial_kernel, self.polar_kernel, self.north_pole_kernel,

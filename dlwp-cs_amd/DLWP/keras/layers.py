@@ -73,13 +73,25 @@ class _FacePlane3D(Layer):
     """shared argument handling of the (1,2,2) pooling / upsampling layers on (B, 6, H, W, C) tensors."""
 
     def _check(self, size, data_format, what):
-        if data_format not in (None, 'channels_last'):
-            raise NotImplementedError('%s: the engine serves data_format="channels_last" (reference '
-                                      'Azure/train_cs.py:197-198); got %r' % (what, data_format))
+        if data_format not in (None, 'channels_last', 'channels_first'):
+            raise ValueError('The `data_format` argument must be one of "channels_first", "channels_last". Received: %r'
+                             % (data_format,))
         if tuple(size) != (1, 2, 2):
             raise NotImplementedError('%s: only size (1, 2, 2) -- per-face 2x2 -- is built (reference '
                                       'Azure/train_cs.py:197-198); got %r' % (what, tuple(size)))
-        self.data_format = 'channels_last'
+        # channels_first (B, C, 6, H, W): a layer called on its own transposes in and out; inside a uniformly channels_first
+        # DLWP.keras.Model the whole graph runs channels_last between ONE transpose at the inputs and one at the outputs
+        self.data_format = data_format or 'channels_last'
+
+    def _plane_shape(self, s, f):
+        if self.data_format == 'channels_first':
+            return (s[0], s[1], s[2], None if s[3] is None else f(s[3]), None if s[4] is None else f(s[4]))
+        return (s[0], s[1], None if s[2] is None else f(s[2]), None if s[3] is None else f(s[3]), s[4])
+
+    def _run(self, op, inputs):
+        if self.data_format == 'channels_first':
+            return ops.channels_last_to_first(op(ops.channels_first_to_last(inputs)))
+        return op(inputs)
 
 
 class AveragePooling3D(_FacePlane3D):
@@ -93,10 +105,10 @@ class AveragePooling3D(_FacePlane3D):
         self._check(self.pool_size, data_format, 'AveragePooling3D')
 
     def compute_output_shape(self, s):
-        return (s[0], s[1], None if s[2] is None else s[2] // 2, None if s[3] is None else s[3] // 2, s[4])
+        return self._plane_shape(s, lambda n: n // 2)
 
     def call(self, inputs):
-        return ops.avgpool2(inputs)
+        return self._run(ops.avgpool2, inputs)
 
     def get_config(self):
         cfg = super().get_config()
@@ -112,10 +124,10 @@ class UpSampling3D(_FacePlane3D):
         self._check(self.size, data_format, 'UpSampling3D')
 
     def compute_output_shape(self, s):
-        return (s[0], s[1], None if s[2] is None else s[2] * 2, None if s[3] is None else s[3] * 2, s[4])
+        return self._plane_shape(s, lambda n: n * 2)
 
     def call(self, inputs):
-        return ops.upsample2(inputs)
+        return self._run(ops.upsample2, inputs)
 
     def get_config(self):
         cfg = super().get_config()

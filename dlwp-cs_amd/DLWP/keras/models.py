@@ -147,6 +147,22 @@ class Model(object):
             return c[0] if (len(c) == 1 and t.uid not in out_uids) else None
 
         from ..custom import CubeSphereConv2D, CubeSpherePadding2D
+        # A graph whose every layer is channels_first (reference DLWP/custom.py:1085-1196: the layers' default) runs
+        # channels_last INSIDE the plan -- the layout of the kernels -- between one transpose at the inputs and one at the
+        # outputs, instead of two transposes around every layer.  Conditions: rank-5 tensors, only layer kinds whose
+        # channels_last twin the plan knows, concatenation along the channel axis (1).
+        def cf_layer(t):
+            lay = t.layer
+            if isinstance(lay, InputLayer):
+                return len(t.shape) == 5
+            if isinstance(lay, (CubeSpherePadding2D, CubeSphereConv2D, AveragePooling3D, UpSampling3D)):
+                return lay.data_format == 'channels_first'
+            if isinstance(lay, Concatenate):
+                return lay._axis(len(t.shape)) == 1
+            return isinstance(lay, ReLU)
+        self._cf_model = (os.environ.get('DLWPCS_CF_MODEL', '1') == '1' and all(cf_layer(t) for t in self._nodes)
+                          and any(isinstance(t.layer, (CubeSphereConv2D, CubeSpherePadding2D)) for t in self._nodes))
+        fmt = 'channels_first' if self._cf_model else 'channels_last'
         virtual = set()          # tensors never materialised
         fused = {}               # uid of the tensor a fused step produces -> step description
         for t in self._nodes:
@@ -156,7 +172,7 @@ class Model(object):
             padt = t.node_inputs[0]
             if not isinstance(padt.layer, CubeSpherePadding2D) or sole_consumer(padt) is not t:
                 continue
-            if padt.layer.data_format != 'channels_last' or not lay.can_fuse_halo(padt.layer.padding[1][0]):
+            if padt.layer.data_format != fmt or lay.data_format != fmt or not lay.can_fuse_halo(padt.layer.padding[1][0]):
                 continue
             if padt.layer.padding[1] != padt.layer.padding[2] or padt.layer.padding[1][0] != padt.layer.padding[1][1]:
                 continue
@@ -164,7 +180,7 @@ class Model(object):
             src0, src1, up0 = x, None, False
             chain = [padt]
             if isinstance(x.layer, Concatenate) and len(x.node_inputs) == 2 and sole_consumer(x) is padt \
-                    and x.layer._axis(len(x.shape)) == len(x.shape) - 1:
+                    and x.layer._axis(len(x.shape)) == (1 if self._cf_model else len(x.shape) - 1):
                 src0, src1 = x.node_inputs
                 chain.append(x)
             if isinstance(src0.layer, UpSampling3D) and sole_consumer(src0) is (chain[-1]) \
@@ -189,7 +205,7 @@ class Model(object):
                 continue
             if t.uid in fused:
                 steps.append(fused[t.uid])
-            elif isinstance(t.layer, AveragePooling3D) and len(t.node_inputs) == 1 and (
+            elif isinstance(t.layer, AveragePooling3D) and len(t.node_inputs) == 1 and self._runs_channels_last(t.layer) and (
                     len(consumers.get(t.node_inputs[0].uid, [])) > 1 or t.node_inputs[0].uid in out_uids):
                 # the pooled tensor has other consumers (U-Net skip connection): they are re-routed through an alias so
                 # that both gradients reach ONE backward kernel (ops.avgpool2_skip)
@@ -208,7 +224,7 @@ class Model(object):
                   if (st[0] == 'fused_conv' and u in (st[3], st[4])) or (st[0] == 'pool_skip' and st[3] == u)
                   or (st[0] == 'layer' and u in st[3])]
             self._padded_io_ok = (len(rd) == 1 and rd[0][0] == 'fused_conv' and rd[0][3] == u and rd[0][4] is None
-                                  and not rd[0][5] and u not in out_uids)
+                                  and not rd[0][5] and u not in out_uids and not self._cf_model)
         self._plan_premask(steps, out_uids)
         # model outputs that no other node consumes (candidates for the fused head + loss step) and appear once
         uids = [o.uid for o in self.outputs]
@@ -249,7 +265,7 @@ class Model(object):
             else:
                 _, out_uid, lay, in_uids, _ = st
                 head = (isinstance(lay, CubeSphereConv2D) and len(in_uids) == 1 and lay._is_mfma_config()
-                        and lay.data_format == 'channels_last' and lay.activation is None)
+                        and self._runs_channels_last(lay) and lay.activation is None)
                 src_mask[i] = bool(head and in_uids[0] in produced and in_uids[0] not in aliased)
                 for u in in_uids:
                     if u in produced and u not in aliased and not head:
@@ -280,6 +296,9 @@ class Model(object):
             if len(r) == 1 and st[1] not in out_uids and steps[r[0]][0] == 'fused_conv' and steps[r[0]][3] == st[1] \
                     and steps[r[0]][4] != st[1] and not steps[r[0]][5]:
                 self._defer_ring.add(r[0])
+
+    def _runs_channels_last(self, lay):
+        return lay.data_format == 'channels_last' or self._cf_model
 
     def _plan_exchange(self):
         """Two-bucket exchange: (first step of bucket A, element offset of bucket A in the flat gradient buffer) or None.
@@ -381,7 +400,10 @@ class Model(object):
         CubeSphereConv2D that nothing else consumes is then computed together with its loss, its loss gradient and the layer's
         data gradient by ONE launch (ops.head_mse); the entry of the returned list is the (2,) stats tensor instead of the
         prediction."""
-        from ..custom import CubeSphereConv2D
+        from ..custom import CubeSphereConv2D, CubeSpherePadding2D
+        cf = self._cf_model
+        if cf:
+            inputs = [ops.channels_first_to_last(v) for v in inputs]        # ONE transpose per input (and per output, below)
         values = {t.uid: v for t, v in zip(self.inputs, inputs)}
         self._fused_outputs = set()         # uids whose entry of the returned list is the (2,) stats tensor of ops.head_mse
         pm = self._premask if self._premask_on() else {}
@@ -423,7 +445,7 @@ class Model(object):
                 head_pm = pm.get(in_uids[0]) if (self._src_mask[i] and in_uids) else None
                 if (fuse_targets is not None and out_uid in fuse_targets and out_uid in self._sole_outputs
                         and isinstance(lay, CubeSphereConv2D) and len(args) == 1 and lay._is_mfma_config()
-                        and lay.data_format == 'channels_last' and lay.activation is None and lay.north_pole_kernel is None
+                        and self._runs_channels_last(lay) and lay.activation is None and lay.north_pole_kernel is None
                         and ops.head_mse_applicable(args[0], lay.equatorial_kernel, lay.kernel_size[0], ACT_NONE,
                                                     fuse_targets[out_uid][0])):
                     tgt, wgt = fuse_targets[out_uid]
@@ -436,14 +458,33 @@ class Model(object):
                     values[out_uid] = lay.fused_call(args[0], halo=False, premask0=head_pm)
                     continue
                 if (getattr(self, '_padded_io', False) and out_uid in self._sole_outputs and isinstance(lay, CubeSphereConv2D)
-                        and len(args) == 1 and lay._is_mfma_config() and lay.data_format == 'channels_last'
+                        and len(args) == 1 and lay._is_mfma_config() and self._runs_channels_last(lay)
                         and lay.activation is None and lay.kernel_size[0] == 1 and args[0].dtype == torch.bfloat16
                         and args[0].shape[-1] == 32 and 8 <= lay.filters <= 32 and lay.filters % 2 == 0
                         and (args[0].shape[2] * args[0].shape[3]) % 16 == 0):
                     # rollout: the output layer writes its rows padded to the 16-B vector, the layout the first layer reads fastest
                     values[out_uid] = lay.fused_call(args[0], halo=False, out_padded=True)
                     continue
+                if cf:
+                    # the channels_last twin of the layer (the graph was checked in _build_plan)
+                    if isinstance(lay, CubeSphereConv2D):
+                        values[out_uid] = lay.call(args[0], channels_last_io=True)
+                    elif isinstance(lay, CubeSpherePadding2D):
+                        values[out_uid] = ops.cs_pad(args[0], lay.padding[1][0])
+                    elif isinstance(lay, AveragePooling3D):
+                        values[out_uid] = ops.avgpool2(args[0])
+                    elif isinstance(lay, UpSampling3D):
+                        values[out_uid] = ops.upsample2(args[0])
+                    elif isinstance(lay, Concatenate):
+                        values[out_uid] = ops.concat_channels(list(args))
+                    else:
+                        values[out_uid] = lay.call(args[0])              # ReLU: layout-agnostic
+                    continue
                 values[out_uid] = lay.call(args if (takes_list or len(args) > 1) else args[0])
+        if cf and not getattr(self, '_loss_in_cl', False):
+            ops.chain_flush()
+            return [values[o.uid] if o.uid in self._fused_outputs else ops.channels_last_to_first(values[o.uid])
+                    for o in self.outputs]
         return [values[o.uid] for o in self.outputs]
 
     def __call__(self, inputs):
@@ -644,6 +685,9 @@ class Model(object):
         if len(targets) != len(self.outputs):
             raise ValueError('Error when checking model target: expected %d target arrays, got %d'
                              % (len(self.outputs), len(targets)))
+        if self._cf_model:
+            # (mse / mae do not depend on the layout: the loss is formed channels_last, the fused head's layout)
+            targets = [ops.channels_first_to_last(t) if t.dim() == 5 else t for t in targets]
         fuse = None
         if train and self.fuse_head_loss:
             fuse = {o.uid: (t, w) for o, t, w in zip(self.outputs, targets, self.loss_weights)}
@@ -656,10 +700,12 @@ class Model(object):
         ops.DEFER_LOSS_TAIL = bool(train and fuse_update is not None and self.fuse_adam and self.batch_wgrad and self.fold_loss_tail
                                    and self.optimizer is not None and (self._world == 1 or dp_fused) and not cutplan)
         self._pack_done = False
+        self._loss_in_cl = self._cf_model       # (the predictions stay channels_last for the loss)
         try:
             # skip_pack: the packed operands are current (_ensure_packed) and this step's own last launch keeps them so
             outs = self._forward(inputs, repack=not skip_pack, fuse_targets=fuse)
         finally:
+            self._loss_in_cl = False
             self._record_cut = None
             ops.DEFER_LOSS_TAIL = False
             if not train:

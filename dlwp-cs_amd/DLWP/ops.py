@@ -331,7 +331,7 @@ def _chain_key(d, pooled):
 
 def chain_supported(layers):
     """layers = [(ConvDesc, pooled second output?)]: can these layers (pre-packed operands), in this order, be ONE chain launch?
-    (every layer needs a chain phase, and all of them the same instantiation of the kernel body)"""
+    (every layer needs a chain phase)"""
     key = tuple(_chain_key(d, p) for d, p in layers)
     ok = _chain_ok.get(key)
     if ok is None:
@@ -669,7 +669,7 @@ class _CSConv(torch.autograd.Function):
         chainable = (CHAIN is not None and packed is not None and d.dtype == nat.BF16 and ksize == 3 and halo and not out_padded
                      and B > 0 and chain_supported([(d, yp is not None)]))
         if chainable and CHAIN and not chain_supported([(r[0], r[6] is not None) for r in CHAIN] + [(d, yp is not None)]):
-            chain_flush()                       # (another tiling than the recorded run: that run is launched, a new one starts)
+            chain_flush()                       # (the recorded run cannot take this layer too: it is launched, a new one starts)
         if chainable:
             CHAIN.append((ConvDesc.from_buffer_copy(d), src0, src1, packed[1], packed[2] if b_eq is not None else None, y, yp, table, ws))
             if yp is not None:

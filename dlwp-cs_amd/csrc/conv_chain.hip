@@ -71,34 +71,49 @@ __device__ __forceinline__ bool chain_group_barrier(const ChainArgs &A, int grp,
     return *s_flag != 0;
 }
 
-// ONE instantiation of the convolution body per chain kernel (conv_chain_kernel<cfg>): a chain is a run of consecutive layers that
-// take the same instantiation; the phase's parameter block is read where it lives -- in the kernel-argument segment, through a
-// block-uniform index, i.e. scalar loads on demand exactly like the per-layer kernel reads its arguments -- and the sample group's
-// first sample is passed separately (b0): the code of a phase IS the per-layer kernel's.  (Measured before this form, all
-// instantiations in one kernel behind a switch: inlined -> 256 VGPRs with 165-207 spilled; as noinline functions with a copy of
-// the block adjusted to the group -> no vector spills, but every phase ~7 us slower than the per-layer LAUNCH of the same layer:
-// the block lived in spilled SGPRs, each call saved / restored ~60 VGPRs through scratch memory.)
-template <int CFG> struct ChainBody;
-template <> struct ChainBody<CHAIN_CFG_3_32_3141> { static constexpr int KC = 32, MT = 3, WM = 4, WN = 1; static constexpr bool T8 = false; };
-template <> struct ChainBody<CHAIN_CFG_3_32_3122> { static constexpr int KC = 32, MT = 3, WM = 2, WN = 2; static constexpr bool T8 = false; };
-template <> struct ChainBody<CHAIN_CFG_3_16_5114> { static constexpr int KC = 16, MT = 5, WM = 1, WN = 4; static constexpr bool T8 = false; };
-template <> struct ChainBody<CHAIN_CFG_3_16_3141_T8> { static constexpr int KC = 16, MT = 3, WM = 4, WN = 1; static constexpr bool T8 = true; };
-template <> struct ChainBody<CHAIN_CFG_3_32_3141_T8> { static constexpr int KC = 32, MT = 3, WM = 4, WN = 1; static constexpr bool T8 = true; };
+// One phase = one instantiation of the convolution body as a noinline function.  What was measured on the way here (MI355X):
+//   * every instantiation INLINED in one kernel behind a switch: 256 VGPRs with 165-207 spilled;
+//   * one kernel per instantiation, the body inlined inside the phase loop: no spills -- but the compiler no longer unswitches the
+//     tile loop on the (uniform) layer options: 54 MFMA instructions in the kernel where the per-layer kernel has 267 (five
+//     specialised copies of its loop nest), 40 % more branches in the hot path; every phase ran ~20 % slower than the per-layer
+//     kernel of the same layer (C96 rollout 13.5 ms against 11.1);
+//   * noinline functions receiving a COPY of the parameter block: the copy lived in spilled SGPRs, ~7 us per phase lost.
+// Here the function reads the block where it lives -- in the kernel-argument segment, through a constant-address-space pointer made
+// uniform with readfirstlane: scalar loads on demand, like the per-layer kernel's own arguments -- and the tile loop is the top-level
+// loop of its function again.  The price is the calling convention: each call saves / restores its callee-saved VGPRs through
+// scratch memory (~0.3 us per phase and workgroup).
+typedef const __attribute__((address_space(4))) ConvKParams *ConvKParamsK;
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int CFG>
-__global__ void __launch_bounds__(512) conv_chain_kernel(const ChainArgs A) {
-    typedef ChainBody<CFG> Bd;
+template <int KC, int MT, int WM, int WN, bool TAIL8>
+__device__ __attribute__((noinline)) void chain_phase(ConvKParamsK pk, int b0v, int lwv, int Gv, int byv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint64_t a = (uint64_t)(uintptr_t)pk;
+    pk = (ConvKParamsK)(uintptr_t)(((uint64_t)(uint32_t)uni((int)(a >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)a));
+    const int b0 = uni(b0v), lw = uni(lwv), G = uni(Gv), by = uni(byv);
+    const ConvKParams &P = *(const ConvKParams *)pk;        // (the address space is recovered from the cast: scalar loads)
+    conv_ws_body<bf16_t, 3, KC, MT, 1, WM, WN, 8, MODE_HALO, false, TAIL8, false, true>(P, smem, (uint32_t)lw, G, by, b0);
+}
+
+__global__ void __launch_bounds__(512) conv_chain_kernel(const ChainArgs A) {
     __shared__ int s_flag;
     const int grp = (int)(blockIdx.x % (uint32_t)A.ngroups), w = (int)(blockIdx.x / (uint32_t)A.ngroups);
     const int Gw = (int)(gridDim.x / (uint32_t)A.ngroups);
     const int b0 = grp * A.Bg;
 #pragma unroll 1
     for (int ph = 0; ph < A.nph; ++ph) {
-        const ConvKParams &P = A.ph[ph];
+        // (taking &A.ph[ph] instead would make the compiler copy all of A to scratch memory first)
+        ConvKParamsK pk = (ConvKParamsK)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() +
+                                         offsetof(ChainArgs, ph) + (size_t)ph * sizeof(ConvKParams));
         const int gy = A.gy[ph];
         const int G = Gw / gy, lw = w % G, by = w / G;
-        conv_ws_body<bf16_t, 3, Bd::KC, Bd::MT, 1, Bd::WM, Bd::WN, 8, MODE_HALO, false, Bd::T8, false, true>(P, smem, (uint32_t)lw, G, by, b0);
+        switch (A.cfg[ph]) {
+            case CHAIN_CFG_3_32_3141:    chain_phase<32, 3, 4, 1, false>(pk, b0, lw, G, by); break;
+            case CHAIN_CFG_3_32_3122:    chain_phase<32, 3, 2, 2, false>(pk, b0, lw, G, by); break;
+            case CHAIN_CFG_3_16_5114:    chain_phase<16, 5, 1, 4, false>(pk, b0, lw, G, by); break;
+            case CHAIN_CFG_3_16_3141_T8: chain_phase<16, 3, 4, 1, true>(pk, b0, lw, G, by); break;
+            default:                     chain_phase<32, 3, 4, 1, true>(pk, b0, lw, G, by); break;
+        }
         if (!chain_group_barrier(A, grp, Gw, ph, &s_flag)) return;
     }
 }
@@ -143,9 +158,6 @@ static int chain_build(const dlwpcs_chain_item *items, int n_items, ChainArgs &A
             return fail(DLWPCS_E_UNSUPPORTED, "conv_chain: item %d (N=%d C0=%d C1=%d Cout=%d k=%d) has no chain phase", i, it.d.N, it.d.C0,
                         it.d.C1, it.d.Cout, it.d.ksize);
         if (256 / A.ngroups % po.gy != 0) return fail(DLWPCS_E_UNSUPPORTED, "conv_chain: item %d: %d N-tile groups do not divide a sample group's workers", i, po.gy);
-        if (i > 0 && po.cfg != A.cfg[0])
-            return fail(DLWPCS_E_UNSUPPORTED, "conv_chain: item %d takes another instantiation of the kernel body than item 0 (a chain is a "
-                                             "run of layers with the same tiling)", i);
         A.ph[i] = po.P;
         A.cfg[i] = (int16_t)po.cfg; A.gy[i] = (int16_t)po.gy;
         if (po.lds + 64 > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "conv_chain: item %d fills the LDS (%zu bytes): no room for the barrier word", i, po.lds);
@@ -183,14 +195,7 @@ extern "C" int dlwpcs_conv_chain_fwd(const dlwpcs_chain_item *items, int n_items
     if (!spin) { const char *e = getenv("DLWPCS_CHAIN_SPIN"); spin = e ? (uint32_t)strtoul(e, nullptr, 0) : 400000u; if (!spin) spin = 1; }
     A.spin_limit = spin;
     hipStream_t s = (hipStream_t)stream;
-    const void *kern = nullptr;
-    switch (A.cfg[0]) {
-        case CHAIN_CFG_3_32_3141: kern = (const void *)conv_chain_kernel<CHAIN_CFG_3_32_3141>; break;
-        case CHAIN_CFG_3_32_3122: kern = (const void *)conv_chain_kernel<CHAIN_CFG_3_32_3122>; break;
-        case CHAIN_CFG_3_16_5114: kern = (const void *)conv_chain_kernel<CHAIN_CFG_3_16_5114>; break;
-        case CHAIN_CFG_3_16_3141_T8: kern = (const void *)conv_chain_kernel<CHAIN_CFG_3_16_3141_T8>; break;
-        default: kern = (const void *)conv_chain_kernel<CHAIN_CFG_3_32_3141_T8>; break;
-    }
+    const void *kern = (const void *)conv_chain_kernel;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "conv_chain: hipFuncSetAttribute: %s", hipGetErrorString(e));

@@ -79,13 +79,12 @@ def test_forward_chain_is_bit_identical_to_the_layer_by_layer_path(B, N, cin, ba
     model = _build(N, cin, cin, base, chain=True)
     model.set_weights(w0)
     tags = _launch_tags(lambda: model.predict_on_device(x))
-    # a chain = a run of consecutive layers with the same tiling: unet2 at the config-3 geometry is conv1 | conv1_2 | conv2 conv2_2 |
-    # conv5_2 | conv5 | conv6_2 conv6 conv7 conv7_2 -> two chain launches (2 + 4 phases) and four single layers
+    # (narrow test models: a pooled second output needs 32-channel output tiles, such layers keep their own launch)
     n_chain = tags.count('conv_chain_kernel')
     left = [t for t in tags if t.startswith('conv_mfma_ws_kernel<unsigned short, 3,')]
     assert n_chain >= 1 and n_chain + len(left) < 10, tags
     if (N, cin, base) == (48, 14, 32):
-        assert n_chain == 2 and len(left) == 4, tags
+        assert n_chain == 1 and len(left) == 0, tags          # all ten 3x3 layers: one launch
     y = model.predict_on_device(x).float().cpu().numpy()
     ops.chain_check()
     assert np.isfinite(y_ref).all() and np.abs(y_ref).max() > 0

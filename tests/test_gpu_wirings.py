@@ -137,3 +137,88 @@ def test_layer_options_in_bf16_through_the_layer_class():
     t = rng.standard_normal((3, 6, 6, 6, 4)).astype(np.float32)
     hist = model.fit(x, t, batch_size=3, epochs=3, verbose=0)
     assert np.isfinite(hist.history['loss']).all() and hist.history['loss'][-1] < hist.history['loss'][0]
+
+
+def test_channels_first_unet2_runs_channels_last_inside():
+    """A uniformly channels_first graph (the layers' default data_format, reference DLWP/custom.py:1085-1196) is converted ONCE
+    at the inputs and once at the outputs: the same fused launch list as its channels_last twin plus two transposes, the same
+    numbers (bitwise: the arithmetic is the channels_last kernels'), training included."""
+    import ctypes
+    from DLWP import _native as nat, ops
+    from DLWP.custom import CubeSphereConv2D, CubeSpherePadding2D
+    from DLWP.keras.layers import AveragePooling3D, Input, ReLU, UpSampling3D, concatenate
+    from DLWP.keras.models import Model
+
+    def build(fmt, N, cin, cout, base):
+        np.random.seed(5)
+        cl = fmt == 'channels_last'
+        kw = dict(dilation_rate=1, padding='valid', activation='linear', data_format=fmt)
+        inp = Input(shape=(6, N, N, cin) if cl else (cin, 6, N, N), name='main_input')
+        pad = CubeSpherePadding2D(1, data_format=fmt)
+        pool = AveragePooling3D((1, 2, 2), data_format=fmt)
+        up = UpSampling3D((1, 2, 2), data_format=fmt)
+        relu = ReLU(negative_slope=0.1, max_value=10.)
+        ax = -1 if cl else 1
+        x0 = relu(CubeSphereConv2D(base, 3, **kw)(pad(inp)))
+        x0 = relu(CubeSphereConv2D(base, 3, **kw)(pad(x0)))
+        x1 = pool(x0)
+        x1 = relu(CubeSphereConv2D(2 * base, 3, **kw)(pad(x1)))
+        x = concatenate([up(x1), x0], axis=ax)
+        x = relu(CubeSphereConv2D(base, 3, **kw)(pad(x)))
+        y = CubeSphereConv2D(cout, 1, **kw)(x)
+        m = Model(inputs=inp, outputs=y)
+        m.compile(optimizer='adam', loss='mse', metrics=['mae'])
+        return m
+
+    def tags_of(fn):
+        lib = nat.lib()
+        lib.dlwpcs_prof_reset()
+        lib.dlwpcs_prof_enable(1)
+        try:
+            fn()
+            torch.cuda.synchronize()
+        finally:
+            lib.dlwpcs_prof_enable(0)
+        out, tag = [], ctypes.create_string_buffer(160)
+        ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        for i in range(lib.dlwpcs_prof_count()):
+            nat.check(lib.dlwpcs_prof_get(i, tag, 160, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)), 'prof_get')
+            out.append(tag.value.decode())
+        lib.dlwpcs_prof_reset()
+        return out
+
+    N, cin, cout, base = 8, 4, 4, 8
+    rng = np.random.default_rng(12)
+    x_cl = rng.standard_normal((4, 6, N, N, cin)).astype(np.float32)
+    t_cl = rng.standard_normal((4, 6, N, N, cout)).astype(np.float32)
+    x_cf = np.ascontiguousarray(np.transpose(x_cl, (0, 4, 1, 2, 3)))
+    t_cf = np.ascontiguousarray(np.transpose(t_cl, (0, 4, 1, 2, 3)))
+    m_cl, m_cf = build('channels_last', N, cin, cout, base), build('channels_first', N, cin, cout, base)
+    assert m_cf._cf_model and not m_cl._cf_model and m_cf.n_fused == m_cl.n_fused == 4
+    m_cf.set_weights(m_cl.get_weights())
+    y_cl = m_cl.predict(x_cl)
+    y_cf = m_cf.predict(x_cf)
+    assert y_cf.shape == (4, cout, 6, N, N)
+    assert np.array_equal(np.transpose(y_cf, (0, 2, 3, 4, 1)), y_cl)
+    # the launch lists: the same convolution launches, plus one transpose in and one out
+    d_cl = torch.tensor(x_cl, device='cuda')
+    d_cf = torch.tensor(x_cf, device='cuda')
+    l_cl = tags_of(lambda: m_cl.predict_on_device(d_cl))
+    l_cf = tags_of(lambda: m_cf.predict_on_device(d_cf))
+    assert [t for t in l_cf if t.startswith('conv')] == [t for t in l_cl if t.startswith('conv')]
+    # training: same losses, same parameters
+    h_cl = m_cl.fit(x_cl, t_cl, batch_size=4, epochs=3, verbose=0, shuffle=False)
+    h_cf = m_cf.fit(x_cf, t_cf, batch_size=4, epochs=3, verbose=0, shuffle=False)
+    assert np.array_equal(np.array(h_cl.history['loss']), np.array(h_cf.history['loss']))
+    assert np.array_equal(np.array(h_cl.history['mean_absolute_error']), np.array(h_cf.history['mean_absolute_error']))
+    for a, b in zip(m_cl.get_weights(), m_cf.get_weights()):
+        assert np.array_equal(a, b)
+    # DLWPCS_CF_MODEL=0 semantics (per-layer transposes) stay available: same numbers
+    os.environ['DLWPCS_CF_MODEL'] = '0'
+    try:
+        m_old = build('channels_first', N, cin, cout, base)
+    finally:
+        os.environ.pop('DLWPCS_CF_MODEL', None)
+    assert not m_old._cf_model
+    m_old.set_weights(m_cf.get_weights())
+    assert np.array_equal(m_old.predict(x_cf), m_cf.predict(x_cf))
