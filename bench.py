@@ -685,6 +685,9 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
     return result
 
 
+_REAL_STDOUT = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -723,6 +726,14 @@ def main():
     if args.channels is None:
         args.channels = 26 if args.workload == 'rollout' else 14
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner through C stdio when
+    # a communicator is created, flushed at process exit): file descriptor 1 is pointed at stderr for the life of the process and
+    # the JSON line goes to the ORIGINAL stdout at the very end.
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None and not args.pmc_child:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -738,7 +749,7 @@ def main():
             port = sk.getsockname()[1]
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.run(cmd).returncode)
+        sys.exit(subprocess.run(cmd, stdout=_REAL_STDOUT if _REAL_STDOUT is not None else None).returncode)
     if world != args.gpus:
         if rank == 0:
             sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
@@ -799,7 +810,12 @@ def main():
     if rank == 0 and single and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args.workload, args.face, args.channels, args.channels, args.base, args.batch)
     if rank == 0:
-        print(json.dumps(result))
+        line = json.dumps(result) + '\n'
+        if _REAL_STDOUT is not None:
+            os.write(_REAL_STDOUT, line.encode())
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
