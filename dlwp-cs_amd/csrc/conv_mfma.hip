@@ -1403,6 +1403,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     P.magicNblk = P.nblk_face > 1 ? div_magic(P.nblk_face) : 0;
     P.tile_rows_max = tile_rows_for(pix, P.No) + (KS - 1);
     P.ntiles = P.B * 6 * P.nblk_face;
+    P.split_gb = P.split_fb = 0;
     P.tune = tune_bits();
     P.dbg = nullptr;
 #ifdef DLWPCS_TIMELINE
@@ -1466,6 +1467,31 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     if (gx < 1) gx = 1;
     if (gx > P.ntiles) gx = P.ntiles;
     dim3 grid((unsigned)gx, (unsigned)gy);
+    // ILV cost split (conv_ws.h): data gradient, MT = 3, the last band of a face shorter than the others.  Tile cost = 2 x rounds of
+    // M tiles per consumer wave + 1.  Choose how many workers (GB) take the short tiles + FB full ones so that the most expensive
+    // list is as cheap as possible; keep the plain split unless that beats it.
+    if (MODE == MODE_ZERO && MT == 3 && sizeof(T) == 4 && (P.tune & TUNE_CONV_ILV) && P.nblk_face > 1 && gx > 1) {
+        auto cost = [&](int npix) { const int mn = (npix + 31) / 32; return 2 * ceil_div(mn, WM) + 1; };
+        const int nbl = P.nblk_face, cF = cost(pix), cL = cost(face_pix - (nbl - 1) * pix);
+        if (cL < cF) {
+            const long F = 6l * (nbl - 1) * P.B, S = 6l * P.B;
+            const long plain = (long)ceil_div(P.ntiles, gx) * cF;       // (some workgroup has that many tiles, full ones in general)
+            long best = plain;
+            int best_gb = 0, best_fb = 0;
+            for (int GB = 1; GB < gx; ++GB) {
+                const int GA = gx - GB;
+                // FB full tiles for the B group: as many as keep a B list (ceil(FB / GB) full + ceil(S / GB) short) under the A lists
+                const long sB = ceil_div((int)S, GB) * (long)cL;
+                for (long mB = 0; mB <= ceil_div((int)F, gx) + 1; ++mB) {
+                    const long FB = mB * GB < F ? mB * GB : F, FA = F - FB;
+                    const long cA = (long)ceil_div((int)FA, GA) * cF, cB = mB * cF + sB;
+                    const long mx = cA > cB ? cA : cB;
+                    if (mx < best) { best = mx; best_gb = GB; best_fb = (int)FB; }
+                }
+            }
+            P.split_gb = best_gb; P.split_fb = best_fb;
+        }
+    }
     if (P.dry_run) {
         if (P.plan) {
             ConvPlanOut *po = P.plan;

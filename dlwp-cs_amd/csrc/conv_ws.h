@@ -57,6 +57,8 @@ struct ConvKParams {
     int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
     int tile_rows_max;          // rows reserved in LDS
     int ntiles;                 // B * 6 * nblk_face (persistent kernel)
+    int split_gb, split_fb;     // ILV cost split (launch_conv_cfg): the LAST split_gb workers take all the short tiles (the last band
+                                // of every face) and split_fb of the full ones, the others the remaining full tiles; 0: plain split
     long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
 };
 
@@ -92,12 +94,14 @@ int conv_fwd_plan(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
 //  64: 3-4 channel chunks per tile: one resident LDS weight area per chunk (P.wstat), with the tiling that makes them fit
 // 256: forward / data-gradient kernel: late start of the workgroups with the shorter tile list, bits 12..17 = how late (see the
 //      kernel; default 3)
+// 512: data-gradient kernel: M tiles of a tile dealt to the consumer waves round-robin, short tiles skip the M tiles they do not
+//      have, tile list split by cost (see ILV in the kernel)
 enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_SPLIT_N = 16,
-       TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64, TUNE_CONV_STAGGER = 256 };
+       TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64, TUNE_CONV_STAGGER = 256, TUNE_CONV_ILV = 512 };
 static int tune_bits() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_WG_PRODUCER_PRIO | TUNE_CONV_PRODUCER_PRIO | TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT |
-                               TUNE_CONV_STAGGER | (3 << 12)); }
+                               TUNE_CONV_STAGGER | TUNE_CONV_ILV | (3 << 12)); }
     return v;
 }
 
@@ -235,13 +239,56 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // are laid out XCD-aware: neighbouring ranges on the same XCD's L2).  Consecutive tiles of a workgroup are then the same
     // tile position in consecutive samples: gather offsets, validity flags and LDS addresses stay put, only a scalar sample
     // base moves; they are rebuilt at the few (face, band) changes.
-    const int t_first = (int)(((long)P.ntiles * lw) / G), t_last = (int)(((long)P.ntiles * (lw + 1)) / G);
+    // ILV (data gradient, MT = 3; round 4).  The data gradient is computed on the padded grid: (N + 2)^2 = 2500 pixels per face at
+    // N = 48 are 6 tiles of 384 pixels and one of 196 -- and with a wave owning 96 CONSECUTIVE pixels that short tile costs what a
+    // full one does (wave 0 has its three M tiles either way), the 42 tiles per sample run as 6 rounds per CU where their pixels
+    // are worth 4.9.  With ILV the M tiles of a tile are dealt to the consumer waves round-robin (M tile j -> wave j % WM), a wave
+    // runs the MFMA loop and the epilogue instantiated for the number of M tiles it actually has (1, 2 or 3), and the tile list
+    // is cut by COST (2 x rounds of M tiles + 1 per tile) instead of by count.  Which wave computes a pixel changes, what is
+    // computed for it does not: same bits (tests/test_gpu_parity.py::test_data_gradient_tile_interleave_is_bitwise_neutral).
+    // fp32 only: there a tile's time is its MFMA work and the cost split pays (unet2 fp32 step 3.278 -> 3.189 ms, same box); the bf16
+    // kernels are bandwidth-bound in steady state -- their launch time did not move with the split (25.2 -> 25.0 us) and the step lost
+    // the staggered start's 2-3 us -- so they keep the plain map.
+    constexpr bool ILV_OK = MODE == MODE_ZERO && MT == 3 && sizeof(T) == 4;
+    const bool ilv = ILV_OK && (P.tune & TUNE_CONV_ILV) != 0;
+    // The tile list of this worker: n_my tiles, tile_of(q) = the q-th.  Plain split: one contiguous range of the (face, band)-major,
+    // sample-minor list.  Cost split (P.split_gb > 0; the host found it worthwhile): per face the list is (nbl - 1) * B FULL tiles and
+    // then B SHORT ones (the last band).  Workers [0, GA) share the full tiles [0, F - split_fb) of the "full list" evenly, workers
+    // [GA, G) the remaining split_fb full tiles and ALL short ones -- at N = 48, batch 32: 192 workers x 5 full tiles (cost 35) and
+    // 64 workers x (3 full + 3 short) (cost 36) where the plain split has workgroups with 6 full tiles (42).
+    const int nbl = P.nblk_face;
+    const bool csplit = ilv && P.split_gb > 0;
+    int t_first = 0, t_last = 0;            // plain split
+    int f0 = 0, f1 = 0, s0 = 0, s1 = 0;     // cost split: ranges in the full list / in the short list
+    if (csplit) {
+        const int GB = P.split_gb, GA = G - GB;
+        const int Ftot = 6 * (nbl - 1) * P.B, Stot = 6 * P.B, FA = Ftot - P.split_fb;
+        if ((int)lw < GA) {
+            f0 = (int)(((long)FA * lw) / GA); f1 = (int)(((long)FA * (lw + 1)) / GA);
+        } else {
+            const int u = (int)lw - GA;
+            f0 = FA + (int)(((long)P.split_fb * u) / GB); f1 = FA + (int)(((long)P.split_fb * (u + 1)) / GB);
+            s0 = (int)(((long)Stot * u) / GB); s1 = (int)(((long)Stot * (u + 1)) / GB);
+        }
+    } else {
+        t_first = (int)(((long)P.ntiles * lw) / G);
+        t_last = (int)(((long)P.ntiles * (lw + 1)) / G);
+    }
+    const int n_my = csplit ? (f1 - f0) + (s1 - s0) : t_last - t_first;
+    auto tile_of = [&](int q) __attribute__((always_inline)) {
+        if (!csplit) return t_first + q;
+        const int nf = f1 - f0, perF = (nbl - 1) * P.B;
+        if (q < nf) { const int i = f0 + q, f = i / perF; return f * nbl * P.B + (i - f * perF); }
+        const int i = s0 + (q - nf), f = i / P.B;
+        return f * nbl * P.B + perF + (i - f * P.B);
+    };
     // TUNE_CONV_STAGGER: the workgroups whose tile list is one shorter than the longest (4 against 5 tiles at N = 48: half of
     // them) start ~1.3 us late -- (tune >> 12) & 63 sleeps of 1024 cycles.  They have a tile's worth of slack, and the chip's 256
     // workgroups no longer hit memory and the matrix cores in lockstep at the start of the kernel (the first tile of a workgroup
     // costs twice a later one).  Measured on the bf16 training step, 0 / 1 / 2 / 3 / 4 / 6 / 8 sleeps: 0.6842 / 0.6795 / 0.6781 /
     // 0.6768 / 0.6775 / 0.6786 / 0.6797 ms; 16 sleeps +24 us.
-    if ((P.tune & TUNE_CONV_STAGGER) && (t_last - t_first) * G < P.ntiles) {
+    // (not with the cost split: there every workgroup's list is as expensive as the next one's, whatever its length)
+    if ((P.tune & TUNE_CONV_STAGGER) && !csplit && (t_last - t_first) * G < P.ntiles) {
 #pragma unroll 1
         for (int i = 0; i < ((P.tune >> 12) & 63); ++i) __builtin_amdgcn_s_sleep(16);
     }
@@ -443,8 +490,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         // its input vectors before the weight stores -- two dependent round trips instead of three at the start of the kernel
         // -- made the training step 3 % SLOWER; the first chunk's fragments alone before the lookup: 1 % slower.  The loads of a
         // wave return in order: whatever is requested ahead of the table entries delays them.)
-        for (int t = t_first; t < t_last; ++t) {
-            const Geo gq = geo_of(t);
+        for (int q = 0; q < n_my; ++q) {
+            const Geo gq = geo_of(tile_of(q));
             if (gq.combo != cur_combo) { lookup(gq); cur_combo = gq.combo; }        // uniform; a few times per workgroup
             for (int ch = 0; ch < nchunks; ++ch) {
                 issue(gq, ch, val, ymv, okm);
@@ -467,7 +514,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // consumer waves): wave wm owns the half-rows [ (wm & 1) * No/2, + No/2 ) of tile rows 2 * (wm >> 1) and + 1 -- whole
     // 2 x 2 pooling blocks again.
     auto tile_pix = [&](int loc) __attribute__((always_inline)) {
-        const int lin = wm * MT * 32 + loc;
+        const int lin = ilv ? (((loc >> 5) * WM + wm) * 32 + (loc & 31)) : wm * MT * 32 + loc;
         const int hN = P.No >> 1;
         const int r = loc >= hN ? 1 : 0;
         const int cs = (2 * (wm >> 1) + r) * P.No + (wm & 1) * hN + (loc - r * hN);
@@ -777,7 +824,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         return make_rsrc(pooling ? reinterpret_cast<T *>(P.pool_out) + (size_t)gq.b * ppix * P.Cout : nullptr,
                          (uint32_t)(ppix * P.Cout * ES));
     };
-    auto epilogue_lines = [&](const Geo &gq, const auto &A) {
+    auto epilogue_lines = [&](const Geo &gq, const auto &A, auto mta_tag) {
+        constexpr int MTA = decltype(mta_tag)::value;       // M tiles this wave has in this tile (ILV), else MT
         TL_MARK();
         if constexpr (MOUT) {
             // Every mask value is waited for HERE, before the first store of the epilogue: with loads and stores both in flight
@@ -799,7 +847,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         auto run = [&](auto tag) {
 #pragma unroll
             for (int i = 0; i < NSLICE; ++i) {
-                epi_slice(tag, i, gq, d_out, d_0, d_1, A);
+                if ((i / SPP) % MT < MTA) epi_slice(tag, i, gq, d_out, d_0, d_1, A);        // (compile-time: the loop is unrolled)
                 if constexpr (MODE != MODE_ZERO) {
                     if ((i + 1) % (MT * SPP) == 0 && pooling) pool_pass(i / (MT * SPP), d_pool);
                 }
@@ -820,7 +868,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             const int cot = (nt0 + wn * NT + nt) * 32;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int m = (wm * MT + mt) * 32 + l31;
+                const int m = tile_pix(mt * 32 + l31);
                 T *dst = outp + (size_t)(gq.m0 + m) * P.Cout + cot + 4 * half;
 #pragma unroll
                 for (int jq = 0; jq < 4; ++jq) {
@@ -852,7 +900,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // BEFORE the MFMAs of step s are issued (left alone, the compiler reuses one register set and stalls on lgkmcnt after
     // every step).
     constexpr int NSTEP = KCG * TAPS;
-    auto mma_chunk = [&](int ch) {
+    auto mma_chunk = [&](int ch, auto mta_tag) {
+        constexpr int MTA = decltype(mta_tag)::value;       // M tiles this wave has in this tile (ILV), else MT
         const char *lds_in = smem + (g & 1) * in_step, *lds_w = smem + w_base + (P.wstat ? ch : (g & 1)) * w_step;
         uint4 fa[2][MT], fb[2][NT];
         auto load_frag = [&](int step, uint4 (&a)[MT], uint4 (&bw)[NT]) {
@@ -860,7 +909,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             const int dy = tap / KS, dx = tap % KS;
             const int tapoff = (dy * P.W2 + dx) * RB + cgl * 32;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const uint4 *>(lds_in + abase[mt] + tapoff);
+            for (int mt = 0; mt < MTA; ++mt) a[mt] = *reinterpret_cast<const uint4 *>(lds_in + abase[mt] + tapoff);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 bw[nt] = *reinterpret_cast<const uint4 *>(
@@ -872,23 +921,25 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             const int cur = step & 1;
             if (step + 1 < NSTEP) load_frag(step + 1, fa[cur ^ 1], fb[cur ^ 1]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTA; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) frag_mma<T>(acc[mt][nt], fb[cur][nt], fa[cur][mt]);   // D[co][pixel]
             // (round 3: spreading the reads behind the individual MFMAs -- (MFMA, 2 reads), (MFMA, 1), (MFMA, 1) -- as in the batched
             // weight-gradient kernel measured +-0 here: three MFMAs already hide four reads.  Keeping the 18 weight fragments of a
             // one-chunk layer in 72 VGPRs (3 reads per 3 MFMAs instead of 4; a template variant of its own): the 32 -> 32 data
             // gradient at N = 48 alone 28.5 -> 27.8 us, the whole training step +6 us -- dropped.)
-            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);                          // DS reads of step s+1 first
-            __builtin_amdgcn_sched_group_barrier(0x008, MmaPerFrag<T>::N * MT * NT, 0);       // then the MFMAs of step s
+            __builtin_amdgcn_sched_group_barrier(0x100, MTA + NT, 0);                         // DS reads of step s+1 first
+            __builtin_amdgcn_sched_group_barrier(0x008, MmaPerFrag<T>::N * MTA * NT, 0);      // then the MFMAs of step s
         }
     };
 
     const bool lines = P.patches && (P.Cout % (16 / ES)) == 0;
-    for (int t = t_first; t < t_last; ++t) {
-        const Geo gq = geo_of(t);
+    for (int q = 0; q < n_my; ++q) {
+        const Geo gq = geo_of(tile_of(q));
         setup(gq);
         mask_load(gq);
+        // (ILV: how many of its M tiles this wave has in this tile: M tile j of the tile's ceil(npix / 32) belongs to wave j % WM)
+        const int my_mt = ilv ? max(0, min(MT, (((gq.npix + 31) >> 5) - wm + WM - 1) / WM)) : MT;
         for (int ch = 0; ch < nchunks; ++ch, ++g) {
             TL_MARK();
             // B_g: chunk g has been written by the producers.  A RAW barrier behind an explicit LDS wait: __syncthreads() makes
@@ -898,10 +949,25 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             TL_MARK();
-            mma_chunk(ch);
+            if constexpr (ILV_OK) {
+                if (my_mt >= MT) mma_chunk(ch, std::integral_constant<int, MT>{});
+                else if (my_mt == 2) mma_chunk(ch, std::integral_constant<int, 2>{});
+                else if (my_mt == 1) mma_chunk(ch, std::integral_constant<int, 1>{});
+            } else {
+                mma_chunk(ch, std::integral_constant<int, MT>{});
+            }
         }
-        if (lines) epilogue_lines(gq, acc);
-        else epilogue_plain(gq);
+        if (lines) {
+            if constexpr (ILV_OK) {
+                if (my_mt >= MT) epilogue_lines(gq, acc, std::integral_constant<int, MT>{});
+                else if (my_mt == 2) epilogue_lines(gq, acc, std::integral_constant<int, 2>{});
+                else if (my_mt == 1) epilogue_lines(gq, acc, std::integral_constant<int, 1>{});
+            } else {
+                epilogue_lines(gq, acc, std::integral_constant<int, MT>{});
+            }
+        } else {
+            epilogue_plain(gq);
+        }
     }
 }
 

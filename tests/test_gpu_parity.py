@@ -276,6 +276,51 @@ def test_nan_propagates_like_keras_relu(dtype):
         mixed_precision.set_policy('float32')
 
 
+def test_data_gradient_tile_interleave_is_bitwise_neutral(tmp_path):
+    """Round 4 (TUNE_CONV_ILV, csrc/conv_ws.h): in the data-gradient kernel the M tiles of a tile are dealt to the consumer waves
+    round-robin, short tiles skip the M tiles they do not have and the tile list is cut by cost.  Which wave computes a pixel
+    changes, the arithmetic per pixel does not: input gradients bitwise equal with the bit on (default) and off, fp32 and bf16,
+    face sizes whose padded grid ends in a short tile (N = 48: 2500 = 6 x 384 + 196) and others, one and two sources."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%r, 'dlwp-cs_amd'))
+import numpy as np, torch
+from DLWP import ops
+from DLWP._native import ACT_LEAKY_CLIP
+dev = torch.device('cuda', 0)
+out = {}
+for name, (B, N, C0, C1, Cout, dt) in {'a': (5, 48, 32, 0, 32, torch.bfloat16), 'b': (3, 48, 32, 0, 64, torch.float32),
+                                        'c': (4, 24, 64, 0, 64, torch.bfloat16), 'd': (2, 48, 16, 16, 32, torch.bfloat16),
+                                        'e': (7, 12, 64, 0, 128, torch.bfloat16), 'f': (2, 96, 32, 0, 32, torch.bfloat16)}.items():
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + N)
+    x0 = torch.randn(B, 6, N, N, C0, device=dev, generator=g).to(dt).requires_grad_(True)
+    x1 = torch.randn(B, 6, N, N, C1, device=dev, generator=g).to(dt).requires_grad_(True) if C1 else None
+    w = [torch.randn(3, 3, C0 + C1, Cout, device=dev, generator=g) * 0.1 for _ in range(2)]
+    b = [torch.randn(Cout, device=dev, generator=g) * 0.1 for _ in range(2)]
+    y = ops.cs_conv(x0, w[0], w[1], None, b[0], b[1], None, src1=x1, ksize=3, halo=True, act=ACT_LEAKY_CLIP, alpha=0.1, vmax=10.0)
+    gy = torch.randn(y.shape, device=dev, generator=g).to(dt)
+    y.backward(gy)
+    out[name + '0'] = x0.grad.float().cpu().numpy()
+    if x1 is not None:
+        out[name + '1'] = x1.grad.float().cpu().numpy()
+np.savez(sys.argv[1], **out)
+''' % root
+    res = []
+    for tune in ('13175', '12663'):          # default bits with / without TUNE_CONV_ILV (512)
+        f = str(tmp_path / ('dx_%s.npz' % tune))
+        r = subprocess.run([sys.executable, '-c', code, f], cwd=root, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, DLWPCS_TUNE=tune))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(f))
+    assert sorted(res[0].files) == sorted(res[1].files) and len(res[0].files) == 7
+    for k in res[0].files:
+        assert np.isfinite(res[0][k]).all() and np.abs(res[0][k]).max() > 0
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
 def test_conv_cfg1_golden(golden_dir):
     """BASELINE config 1 against the vector produced by the reference layers."""
     from DLWP import ops
