@@ -75,7 +75,7 @@ class ChainItem(ctypes.Structure):
     _fields_ = [('d', ConvDesc)] + [(n, ctypes.c_void_p) for n in ('src0', 'src1', 'wpk_fwd', 'bias_pk', 'y', 'y_pooled', 'table_dev')]
 
 
-CHAIN_MAX = 12              # DLWPCS_CHAIN_MAX
+CHAIN_MAX = 11              # DLWPCS_CHAIN_MAX
 
 
 class LossTail(ctypes.Structure):

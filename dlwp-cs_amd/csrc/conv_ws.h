@@ -57,6 +57,14 @@ struct ConvKParams {
     int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
     int tile_rows_max;          // rows reserved in LDS
     int ntiles;                 // B * 6 * nblk_face (persistent kernel)
+    // FLOW (chain launch without barriers, conv_chain.hip): per-(phase, sample) completion counters.  flow_done != nullptr: this
+    // call is phase flow_phase of a flow launch -- its tile list is dealt sample-MAJOR and round-robin (tile w + q * G of the list
+    // ordered (sample, face, band), rotated by flow_rot workers), a tile of sample s starts when flow_done[(flow_phase - 1) * flow_bmax
+    // + s] has reached flow_need (every consumer wave of every tile of the previous phase has arrived), and every consumer wave
+    // adds 1 to flow_done[flow_phase * flow_bmax + s] when its stores of a tile of sample s have left.
+    uint32_t *flow_done, *flow_abort;
+    int flow_phase, flow_bmax, flow_need, flow_rot;
+    uint32_t flow_spin;
     int split_gb, split_fb;     // ILV cost split (launch_conv_cfg): the LAST split_gb workers take all the short tiles (the last band
                                 // of every face) and split_fb of the full ones, the others the remaining full tiles; 0: plain split
     long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
@@ -274,8 +282,16 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         t_first = (int)(((long)P.ntiles * lw) / G);
         t_last = (int)(((long)P.ntiles * (lw + 1)) / G);
     }
-    const int n_my = csplit ? (f1 - f0) + (s1 - s0) : t_last - t_first;
+    // FLOW: tile w' + q * G of the SAMPLE-major list (w' = the worker rotated by flow_rot: who gets the longer list alternates
+    // from phase to phase)
+    const bool flow = CHAIN && P.flow_done != nullptr;
+    const int ncombo = 6 * nbl;
+    const bool fdeal = flow && P.flow_rot >= 0;     // (flow_rot < 0, experiments: dependencies only, the plain contiguous tile ranges)
+    const int lwr = fdeal ? (int)((lw + (uint32_t)P.flow_rot) % (uint32_t)G) : 0;
+    const int n_my = fdeal ? (P.ntiles > lwr ? (P.ntiles - lwr + G - 1) / G : 0)
+                           : (csplit ? (f1 - f0) + (s1 - s0) : t_last - t_first);
     auto tile_of = [&](int q) __attribute__((always_inline)) {
+        if (fdeal) { const int idx = lwr + q * G, sm = idx / ncombo; return (idx - sm * ncombo) * P.B + sm; }
         if (!csplit) return t_first + q;
         const int nf = f1 - f0, perF = (nbl - 1) * P.B;
         if (q < nf) { const int i = f0 + q, f = i / perF; return f * nbl * P.B + (i - f * perF); }
@@ -288,7 +304,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // costs twice a later one).  Measured on the bf16 training step, 0 / 1 / 2 / 3 / 4 / 6 / 8 sleeps: 0.6842 / 0.6795 / 0.6781 /
     // 0.6768 / 0.6775 / 0.6786 / 0.6797 ms; 16 sleeps +24 us.
     // (not with the cost split: there every workgroup's list is as expensive as the next one's, whatever its length)
-    if ((P.tune & TUNE_CONV_STAGGER) && !csplit && (t_last - t_first) * G < P.ntiles) {
+    if ((P.tune & TUNE_CONV_STAGGER) && !csplit && !flow && (t_last - t_first) * G < P.ntiles) {
 #pragma unroll 1
         for (int i = 0; i < ((P.tune >> 12) & 63); ++i) __builtin_amdgcn_s_sleep(16);
     }
@@ -446,9 +462,14 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 int pix = ok ? idx : 0;
                 if constexpr (!SUP) pix = up ? upmap(pix) : pix;
                 const size_t oo = ok ? (size_t)pix * cstride + cs_ld : 0;
-                if constexpr (TAIL8) val[i] = ld_act<CHAIN, uint4_a4>(sb + oo);
-                else val[i] = ld_act<CHAIN, V>(sb + oo);
-                if (MASK) ymv[i] = ld_act<CHAIN, V>(ymb + oo);
+                if constexpr (CHAIN && CHAIN_NT_LOADS) {
+                    // sc1: served by the L2, never by this CU's L1 (measured: the forward pass +35 us; see ld_act)
+                    static_assert(!CHAIN || (VW * ES == 16 && !MASK), "chain phases: 16-B activation vectors");
+                    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(sb, 0x7ffffff0u), (uint32_t)oo * ES, 0, 16);
+                    val[i] = V{r.x, r.y, r.z, r.w};
+                } else if constexpr (TAIL8) val[i] = ld_act<false, uint4_a4>(sb + oo);
+                else val[i] = ld_act<false, V>(sb + oo);
+                if (MASK) ymv[i] = ld_act<false, V>(ymb + oo);
                 okm |= (uint32_t)ok << i;
             }
             PL_MARK();
@@ -490,9 +511,74 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         // its input vectors before the weight stores -- two dependent round trips instead of three at the start of the kernel
         // -- made the training step 3 % SLOWER; the first chunk's fragments alone before the lookup: 1 % slower.  The loads of a
         // wave return in order: whatever is requested ahead of the table entries delays them.)
+        if constexpr (CHAIN && MODE == MODE_HALO) {
+            if (flow) {
+                // FLOW: consecutive tiles of a workgroup are different (face, band)s of different samples, so every tile needs its
+                // halo-table entries and its dependency checked.  Both are requested ONE TILE AHEAD, behind the current tile's
+                // input loads (loads return in order: they arrive while the wave waits for its data anyway): the serial chain of
+                // round trips per tile stays one (table -> inputs would be two, a polled flag three: measured 3 x the tile time).
+                int tv[ITS];
+                uint32_t fv = 0xffffffffu;
+                const int tbase0 = -OFF;
+                auto table_issue = [&](const Geo &gn) __attribute__((always_inline)) {
+                    const int base = (gn.f * rstride + gn.y0) * rstride + tbase0;
+#pragma unroll
+                    for (int i = 0; i < ITS; ++i) {
+                        const bool live = ptid + i * NCT < gn.nitems;
+                        tv[i] = P.table[live ? base + (slot_c[i] >> 6) : 0];
+                    }
+                    fv = P.flow_phase > 0 ? __hip_atomic_load(P.flow_done + (size_t)(P.flow_phase - 1) * P.flow_bmax + gn.b,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                };
+                if (n_my > 0) table_issue(geo_of(tile_of(0)));
+                for (int q = 0; q < n_my; ++q) {
+                    const Geo gq = geo_of(tile_of(q));
+#pragma unroll
+                    for (int i = 0; i < ITS; ++i) sidx[i] = (ptid + i * NCT < gq.nitems) ? tv[i] : -1;
+                    if constexpr (SUP) {
+#pragma unroll
+                        for (int i = 0; i < ITS; ++i) sup[i] = sidx[i] >= 0 ? upmap(sidx[i]) - sidx[i] : 0;
+                    }
+                    // the previous phase must be complete for this tile's sample (normally long since: the value fetched a tile ago
+                    // says so); else poll, bounded: a wait that does not end sets the abort word, later waits give up at once
+                    if (P.flow_phase > 0 && fv < (uint32_t)P.flow_need) {
+                        const uint32_t *cnt = P.flow_done + (size_t)(P.flow_phase - 1) * P.flow_bmax + gq.b;
+                        uint32_t n = 0;
+                        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)P.flow_need) {
+                            __builtin_amdgcn_s_sleep(4);
+                            if ((++n & 31u) == 0 && __hip_atomic_load(P.flow_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                            if (n > P.flow_spin) { __hip_atomic_store(P.flow_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
+                    }
+                    const bool more = q + 1 < n_my;
+                    const Geo gn = geo_of(tile_of(more ? q + 1 : q));
+                    for (int ch = 0; ch < nchunks; ++ch) {
+                        issue(gq, ch, val, ymv, okm);
+                        if (ch == 0 && more) table_issue(gn);          // (behind this tile's loads; used one tile later)
+                        commit(gq, ch, val, ymv, okm);
+                    }
+                }
+                if (P.tune & TUNE_CONV_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(0);
+                return;
+            }
+        }
         for (int q = 0; q < n_my; ++q) {
             const Geo gq = geo_of(tile_of(q));
             if (gq.combo != cur_combo) { lookup(gq); cur_combo = gq.combo; }        // uniform; a few times per workgroup
+            if constexpr (false) {
+                // FLOW: the previous phase must be complete for this tile's sample before its activations are fetched (the table
+                // look-up above does not depend on it).  One lane polls (relaxed device-scope load + s_sleep), bounded: a wait
+                // that does not end sets the abort word and every later wait gives up at once.
+                if (flow && P.flow_phase > 0) {
+                    const uint32_t *cnt = P.flow_done + (size_t)(P.flow_phase - 1) * P.flow_bmax + gq.b;
+                    uint32_t n = 0;
+                    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)P.flow_need) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if ((++n & 31u) == 0 && __hip_atomic_load(P.flow_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        if (n > P.flow_spin) { __hip_atomic_store(P.flow_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                }
+            }
             for (int ch = 0; ch < nchunks; ++ch) {
                 issue(gq, ch, val, ymv, okm);
                 commit(gq, ch, val, ymv, okm);
@@ -934,6 +1020,22 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     };
 
     const bool lines = P.patches && (P.Cout % (16 / ES)) == 0;
+    // FLOW: this wave's arrival for the PREVIOUS tile is posted behind the matrix phase of the current one: its stores have long
+    // left by then, the wait costs nothing (posting right behind the epilogue would put a store round trip into every tile)
+    int arrive_b = -1;
+    auto flow_arrive = [&]() __attribute__((always_inline)) {
+        if constexpr (CHAIN) {
+            if (flow && arrive_b >= 0) {
+#ifndef DLWPCS_FLOW_NOWAIT          // (timing experiment only: arrivals without waiting for the stores -- results are then unordered)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                if (lane == 0)
+                    __hip_atomic_fetch_add(P.flow_done + (size_t)P.flow_phase * P.flow_bmax + arrive_b, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                arrive_b = -1;
+            }
+        }
+    };
     for (int q = 0; q < n_my; ++q) {
         const Geo gq = geo_of(tile_of(q));
         setup(gq);
@@ -957,6 +1059,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 mma_chunk(ch, std::integral_constant<int, MT>{});
             }
         }
+        flow_arrive();
         if (lines) {
             if constexpr (ILV_OK) {
                 if (my_mt >= MT) epilogue_lines(gq, acc, std::integral_constant<int, MT>{});
@@ -968,7 +1071,9 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         } else {
             epilogue_plain(gq);
         }
+        arrive_b = gq.b;
     }
+    flow_arrive();
 }
 
 // the per-layer launch: one workgroup per CU, workers laid out XCD-aware over the tile list

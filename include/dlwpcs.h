@@ -329,8 +329,8 @@ int dlwpcs_wgrad_batch_apply(const dlwpcs_wgrad_item *items, int n_items, const 
  * shared with another process) ABORTS the launch: every workgroup leaves and word [8 * 64] of sync_dev is set --
  * dlwpcs_conv_chain_status reports it (blocking copy); results of that launch are undefined, and the buffer must be zeroed again.
  * ------------------------------------------------------------------------------------------------------------- */
-#define DLWPCS_CHAIN_MAX 12
-#define DLWPCS_CHAIN_SYNC_BYTES 4096
+#define DLWPCS_CHAIN_MAX 11
+#define DLWPCS_CHAIN_SYNC_BYTES 65536
 typedef struct dlwpcs_chain_item {
     dlwpcs_conv_desc d;
     const void *src0, *src1;        /* as for dlwpcs_conv_fwd */

@@ -218,3 +218,32 @@ print('DONE ok=%%d timed_out=%%d' %% (ok, bad))
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0 and 'DONE' in so, (so[-300:], se[-2000:])
     print(' | '.join(o[0].strip().splitlines()[-1] for o in outs))
+
+
+def test_barrier_free_flow_form_is_bit_identical():
+    """DLWPCS_CHAIN_FLOW=1: the chain without barriers -- per-(phase, sample) completion counters, tiles dealt sample-major, table
+    entries and dependency flags fetched one tile ahead.  Slower than everything else but the same bits."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%r, 'dlwp-cs_amd'))
+sys.path.insert(0, %r)
+import numpy as np, torch
+sys.path.insert(0, os.path.join(%r, 'tests')); from test_gpu_chain import _build
+from DLWP import ops
+dev = torch.device('cuda', 0)
+rng = np.random.default_rng(3)
+for B, N, cin, base in ((8, 48, 14, 32), (6, 24, 8, 16)):
+    x = torch.tensor(rng.standard_normal((B, 6, N, N, cin)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    ref = _build(N, cin, cin, base, False)
+    y_ref = ref.predict_on_device(x).float().cpu().numpy()
+    m = _build(N, cin, cin, base, True)
+    m.set_weights(ref.get_weights())
+    for _ in range(3):
+        y = m.predict_on_device(x).float().cpu().numpy()
+        ops.chain_check()
+        assert np.array_equal(y, y_ref)
+print('FLOW_OK')
+''' % (ROOT, ROOT, ROOT)
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, DLWPCS_CHAIN_FLOW='1'))
+    assert out.returncode == 0 and 'FLOW_OK' in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
