@@ -100,6 +100,7 @@ __device__ __attribute__((noinline)) void chain_phase(ConvKParamsK pk, int b0v, 
 
 __global__ void __launch_bounds__(512) conv_chain_kernel(const ChainArgs A) {
     __shared__ int s_flag;
+    // (flow form: one group of all workers.  Laying its workers out XCD-aware like the per-layer launch's made it slower still.)
     const int grp = (int)(blockIdx.x % (uint32_t)A.ngroups), w = (int)(blockIdx.x / (uint32_t)A.ngroups);
     const int Gw = (int)(gridDim.x / (uint32_t)A.ngroups);
     const int b0 = grp * A.Bg;
@@ -167,9 +168,10 @@ static int chain_build(const dlwpcs_chain_item *items, int n_items, ChainArgs &A
     memset(&A, 0, sizeof(A));
     static int flow_on = -1;
     // DLWPCS_CHAIN_FLOW: 0 (default) group barriers between the phases; 1: the barrier-free form -- per-(phase, sample) completion
-    // counters, tiles dealt sample-major so that nobody waits; 2: the counters with the plain contiguous tile ranges.  Measured on the
-    // unet2 step (0.680 ms with per-layer launches): 0.744 (barriers) / 1.139 (flow) / 0.885 (counters only) -- every tile of a flow
-    // launch pays the halo-table gather and the store-offset set-up that the plain order pays once per (face, band).
+    // counters, a worker owns one (face, band) and every M-th sample so that whole samples complete rounds before they are needed;
+    // 2: the counters with the plain contiguous tile ranges.  Measured on the unet2 step (0.680 ms with per-layer launches):
+    // 0.744 (barriers) / 1.07-1.09 (flow) / 0.865 (counters only); an earlier flow form that dealt single tiles sample-major (table
+    // gather per tile) 1.139.  Not understood beyond "the dependencies couple the workgroups more tightly than a barrier does".
     if (flow_on < 0) { const char *e = getenv("DLWPCS_CHAIN_FLOW"); flow_on = e ? atoi(e) : 0; }
     A.flow = flow_on && (size_t)(CHAIN_FLOW_OFF + n_items * B) * 4 <= DLWPCS_CHAIN_SYNC_BYTES ? 1 : 0;
     A.ngroups = A.flow ? 1 : chain_groups(B);

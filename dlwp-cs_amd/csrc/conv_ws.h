@@ -286,12 +286,19 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // from phase to phase)
     const bool flow = CHAIN && P.flow_done != nullptr;
     const int ncombo = 6 * nbl;
-    const bool fdeal = flow && P.flow_rot >= 0;     // (flow_rot < 0, experiments: dependencies only, the plain contiguous tile ranges)
-    const int lwr = fdeal ? (int)((lw + (uint32_t)P.flow_rot) % (uint32_t)G) : 0;
-    const int n_my = fdeal ? (P.ntiles > lwr ? (P.ntiles - lwr + G - 1) / G : 0)
+    // FLOW dealing (flow_rot >= 0): a worker OWNS one (face, band) and a share of its samples -- M = G / (faces x bands) workers
+    // per (face, band), worker i of them takes samples i, i + M, i + 2 M, ... (i rotated by flow_rot from phase to phase: who gets
+    // the longer list changes).  Consecutive tiles of a worker stay the same (face, band) -- the halo-table gather and the store
+    // offsets are set up once per phase, as in the plain order -- and every round of the chip covers ALL (face, band)s of M
+    // samples, so a sample is complete M-samples-at-a-time, rounds before the next phase needs it: nobody waits.
+    // (flow_rot < 0, or more (face, band)s than workers: the plain contiguous ranges; dependencies then act like a barrier.)
+    const int fM = flow && P.flow_rot >= 0 ? G / ncombo : 0;
+    const bool fdeal = fM >= 1;
+    const int fc = fdeal ? (int)lw / fM : 0, fi = fdeal ? (int)(((int)lw % fM + P.flow_rot) % fM) : 0;
+    const int n_my = fdeal ? ((fc < ncombo && fi < P.B) ? (P.B - fi + fM - 1) / fM : 0)
                            : (csplit ? (f1 - f0) + (s1 - s0) : t_last - t_first);
     auto tile_of = [&](int q) __attribute__((always_inline)) {
-        if (fdeal) { const int idx = lwr + q * G, sm = idx / ncombo; return (idx - sm * ncombo) * P.B + sm; }
+        if (fdeal) return fc * P.B + fi + q * fM;
         if (!csplit) return t_first + q;
         const int nf = f1 - f0, perF = (nbl - 1) * P.B;
         if (q < nf) { const int i = f0 + q, f = i / perF; return f * nbl * P.B + (i - f * perF); }
@@ -511,76 +518,36 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         // its input vectors before the weight stores -- two dependent round trips instead of three at the start of the kernel
         // -- made the training step 3 % SLOWER; the first chunk's fragments alone before the lookup: 1 % slower.  The loads of a
         // wave return in order: whatever is requested ahead of the table entries delays them.)
-        if constexpr (CHAIN && MODE == MODE_HALO) {
-            if (flow) {
-                // FLOW: consecutive tiles of a workgroup are different (face, band)s of different samples, so every tile needs its
-                // halo-table entries and its dependency checked.  Both are requested ONE TILE AHEAD, behind the current tile's
-                // input loads (loads return in order: they arrive while the wave waits for its data anyway): the serial chain of
-                // round trips per tile stays one (table -> inputs would be two, a polled flag three: measured 3 x the tile time).
-                int tv[ITS];
-                uint32_t fv = 0xffffffffu;
-                const int tbase0 = -OFF;
-                auto table_issue = [&](const Geo &gn) __attribute__((always_inline)) {
-                    const int base = (gn.f * rstride + gn.y0) * rstride + tbase0;
-#pragma unroll
-                    for (int i = 0; i < ITS; ++i) {
-                        const bool live = ptid + i * NCT < gn.nitems;
-                        tv[i] = P.table[live ? base + (slot_c[i] >> 6) : 0];
-                    }
-                    fv = P.flow_phase > 0 ? __hip_atomic_load(P.flow_done + (size_t)(P.flow_phase - 1) * P.flow_bmax + gn.b,
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-                };
-                if (n_my > 0) table_issue(geo_of(tile_of(0)));
-                for (int q = 0; q < n_my; ++q) {
-                    const Geo gq = geo_of(tile_of(q));
-#pragma unroll
-                    for (int i = 0; i < ITS; ++i) sidx[i] = (ptid + i * NCT < gq.nitems) ? tv[i] : -1;
-                    if constexpr (SUP) {
-#pragma unroll
-                        for (int i = 0; i < ITS; ++i) sup[i] = sidx[i] >= 0 ? upmap(sidx[i]) - sidx[i] : 0;
-                    }
-                    // the previous phase must be complete for this tile's sample (normally long since: the value fetched a tile ago
-                    // says so); else poll, bounded: a wait that does not end sets the abort word, later waits give up at once
-                    if (P.flow_phase > 0 && fv < (uint32_t)P.flow_need) {
-                        const uint32_t *cnt = P.flow_done + (size_t)(P.flow_phase - 1) * P.flow_bmax + gq.b;
-                        uint32_t n = 0;
-                        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)P.flow_need) {
-                            __builtin_amdgcn_s_sleep(4);
-                            if ((++n & 31u) == 0 && __hip_atomic_load(P.flow_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                            if (n > P.flow_spin) { __hip_atomic_store(P.flow_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        }
-                    }
-                    const bool more = q + 1 < n_my;
-                    const Geo gn = geo_of(tile_of(more ? q + 1 : q));
-                    for (int ch = 0; ch < nchunks; ++ch) {
-                        issue(gq, ch, val, ymv, okm);
-                        if (ch == 0 && more) table_issue(gn);          // (behind this tile's loads; used one tile later)
-                        commit(gq, ch, val, ymv, okm);
-                    }
-                }
-                if (P.tune & TUNE_CONV_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(0);
-                return;
-            }
-        }
+        // FLOW: the dependency flag of a tile's sample ((phase - 1, sample) complete?) is fetched one tile ahead, behind the
+        // current tile's loads; normally it says "long since".  Else poll, bounded: a wait that does not end sets the abort word,
+        // every later wait gives up at once.
+        uint32_t fv = 0xffffffffu;
+        auto flag_of = [&](int b) __attribute__((always_inline)) {
+            return __hip_atomic_load(P.flow_done + (size_t)(P.flow_phase - 1) * P.flow_bmax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        const bool fdep = flow && P.flow_phase > 0;
+        if constexpr (CHAIN) { if (fdep && n_my > 0) fv = flag_of(geo_of(tile_of(0)).b); }
         for (int q = 0; q < n_my; ++q) {
             const Geo gq = geo_of(tile_of(q));
             if (gq.combo != cur_combo) { lookup(gq); cur_combo = gq.combo; }        // uniform; a few times per workgroup
-            if constexpr (false) {
-                // FLOW: the previous phase must be complete for this tile's sample before its activations are fetched (the table
-                // look-up above does not depend on it).  One lane polls (relaxed device-scope load + s_sleep), bounded: a wait
-                // that does not end sets the abort word and every later wait gives up at once.
-                if (flow && P.flow_phase > 0) {
-                    const uint32_t *cnt = P.flow_done + (size_t)(P.flow_phase - 1) * P.flow_bmax + gq.b;
+            if constexpr (CHAIN) {
+                if (fdep && fv < (uint32_t)P.flow_need) {
+                    // (ONE lane per wave polls, with a long sleep: 256 workgroups x 4 waves x 64 lanes re-reading flags is memory
+                    // traffic of its own -- MI355X_MICROARCH.md "polling-cost")
                     uint32_t n = 0;
-                    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)P.flow_need) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if ((++n & 31u) == 0 && __hip_atomic_load(P.flow_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                        if (n > P.flow_spin) { __hip_atomic_store(P.flow_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if ((ptid & 63) == 0) {
+                        while (flag_of(gq.b) < (uint32_t)P.flow_need) {
+                            __builtin_amdgcn_s_sleep(32);
+                            if ((++n & 15u) == 0 && __hip_atomic_load(P.flow_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                            if (n > P.flow_spin) { __hip_atomic_store(P.flow_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
             for (int ch = 0; ch < nchunks; ++ch) {
                 issue(gq, ch, val, ymv, okm);
+                if constexpr (CHAIN) { if (ch == 0 && fdep && q + 1 < n_my) fv = flag_of(geo_of(tile_of(q + 1)).b); }
                 commit(gq, ch, val, ymv, okm);
             }
         }
