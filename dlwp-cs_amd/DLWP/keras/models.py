@@ -958,6 +958,9 @@ class Model(object):
                         stats = self._loss_and_backward(static_in, static_tg, True, fuse_update=None)
             if g2 is not None:
                 dev = static_in[0].device
+                if getattr(self, '_wb_done', None) and self.fuse_adam and self.batch_wgrad:
+                    # (the union of the two buckets' layers: its plan has not been uploaded yet)
+                    ops.prepare_wgrad_plan(self._wb_done, sum(w.numel() for w in self.weights))
                 with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
                     self._apply_update(grad_scale, dev)
         finally:

@@ -227,6 +227,17 @@ def apply_wgrad_batch(adam, pack_lookup=None, entries=None):
     return True
 
 
+def prepare_wgrad_plan(entries, n_elems):
+    """Build (and upload) the plan of an item list outside a graph capture, so that a captured apply_wgrad_batch() of the same
+    layers finds it (the two-bucket step flushes its halves separately: their union is first needed by the captured update)."""
+    entries = list(entries)
+    if not entries or len(entries) > nat.WGRAD_BATCH_MAX or not _wb_covers(entries, n_elems):
+        return
+    dev = entries[0][3].device
+    arr, key = _wb_items(entries)
+    _wb_plan(arr, len(entries), (str(dev), key), dev)
+
+
 def _pack_array(packs):
     pk_arr = (nat.PackItem * len(packs))()
     for it, (we, wp, wn, be, bp, bn, bufs, ksize, flip, tag) in zip(pk_arr, packs):
@@ -753,13 +764,16 @@ class _CSConv(torch.autograd.Function):
                 dn, src0, src1, dz, None, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp)
             return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 14
         no_dgrad = dsrc0 is None and dsrc1 is None        # (first layer: the batched kernel applies act' itself)
+        # (exact-fp32 mode: the batched kernel forms dz = dy * act'(y) on load in every 3x3 layer -- exact in fp32, so the
+        #  data-gradient kernel forming its own copy changes no bits -- and no dz hand-over is written at all)
+        mask_on_load = d.ksize == 3 and (no_dgrad or d.dtype == nat.F32)
         batching = (direct and WGRAD_BATCH and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(d)
-                    and (d.act == nat.ACT_NONE or (no_dgrad and d.ksize == 3)))
+                    and (d.act == nat.ACT_NONE or mask_on_load))
         defer = direct and DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM and d.B > 0 and not batching
         # deferred reduction: the partials (and the dz hand-over next to them) live in this node's own workspace
         ws = _workspace(nbytes, dev, 'defer%d' % len(_deferred)) if defer else _workspace(nbytes, dev)
         reuse_dz = ((dsrc0 is not None or dsrc1 is not None) and want_w and d.act != nat.ACT_NONE
-                    and not WGRAD_SIDE_STREAM)
+                    and not WGRAD_SIDE_STREAM and not batching)
         if reuse_dz:
             # the weight-gradient kernel computes dz = dy * act'(y) anyway: launched FIRST, it leaves dz in the workspace
             # for the data-gradient kernel right behind it (which then reads neither y nor does the act' arithmetic)
@@ -776,7 +790,7 @@ class _CSConv(torch.autograd.Function):
             run_bwd_data()
         dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np = _weight_gradients(
             d, src0, src1, dy, y, ctx.params, table, ws, nbytes, direct, defer, need[2:8], has_np, has_bias, has_bnp,
-            batch_mask_ok=no_dgrad)
+            batch_mask_ok=mask_on_load)
         if reuse_dz:
             run_bwd_data()
         return (dsrc0, dsrc1, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np) + (None,) * 14

@@ -41,6 +41,11 @@ enum {
     WB_V_3_2_16,        // 4-B X vectors, <= 32 input channels (26 = 13 x 2)
     WB_V_1_8_11,        // 1x1, C_out % 8 == 0
     WB_V_1_8_D2,        // 1x1, even C_out <= 16 (the 14-channel head): 4-B dZ vectors
+    WB_V_F32_3,         // exact-fp32 mode (round 4): 3x3, 16-B vectors of 4 channels, 32 ci x 32 co per worker, fp32 MFMA (K = 2 pixels)
+    WB_V_F32_1,         // ... 1x1
+    WB_V_F32_3_X2,      // ... 3x3, even input channel counts that are no multiples of 4 (the 14-channel input): 8-B X loads
+    WB_V_F32_3_H2,      // ... 3x3, the output channel count too: 8-B X and dZ loads
+    WB_V_F32_1_D2,      // ... 1x1, even output channel count that is no multiple of 4 (the 14-channel head): 8-B dZ loads
     WB_NVARIANTS
 };
 
@@ -90,7 +95,7 @@ struct WbAdam {
 struct WbRedLayer { int32_t KS, Cin, Cout, want_bias, TC, TN, ncot, group_base, flip; };
 // optimizer fused in + weight packing fused in: where the layer's packed bf16 operands (dlwpcs_pack_batch outputs) live; the
 // reduction writes the updated values into them in place, so the next pass starts without a packing launch
-struct WbRedPack { bf16_t *wf, *wb; float *bp; int32_t CGf, NTf, CGb, NTb; };
+struct WbRedPack { bf16_t *wf, *wb; float *bp; int32_t CGf, NTf, CGb, NTb, f32; };     // (f32: fp32 operands, 4 values per 16-B entry)
 struct WbPackArgs { WbRedPack l[WB_MAX_LAYERS]; };
 struct WbRedPtrs {
     float *dw_eq[WB_MAX_LAYERS], *dw_pol[WB_MAX_LAYERS], *dw_np[WB_MAX_LAYERS];
@@ -504,6 +509,299 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One segment in the exact-fp32 mode (round 4): the main loop of wgrad_mfma_kernel<float, KS, 4, MASK> (conv_mfma.hip) --
+// D[ci][co] += sum over pixel pairs of Xpad[pixel + tap][ci] * dZ[pixel][co] on v_mfma_f32_32x32x2_f32, four consumer waves
+// splitting the pixel pairs of an item of <= 192 pixels, four producer waves staging the X tile (band + halo rows, 32 input
+// channels, fp32: 128 B per pixel) and the dZ tile through two LDS buffers, dZ = dy * act'(y) formed on load where the item carries
+// y -- run over the segment's range of work items, one partial sum per segment in the layout wb_reduce_kernel expects.
+// Called by all 512 threads; both halves execute n_items + 2 * ceil(TAPS / 3) + 3 workgroup barriers.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef DLWPCS_WB_F32_SCHED
+#define DLWPCS_WB_F32_SCHED 1
+#endif
+#if DLWPCS_WB_F32_SCHED == 1
+#define WB_F32_SCHED() do {                                                                                  \
+        _Pragma("unroll") for (int t_ = 0; t_ < TAPS; ++t_) {                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      /* one LDS read of the next step */       \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      /* address arithmetic of the step after */ \
+        }                                                                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                    \
+    } while (0)
+#else
+#define WB_F32_SCHED() do {                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, TAPS + 1, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);                                                 \
+    } while (0)
+#endif
+template <int KS, bool MASK, bool X2 = false, bool D2 = false>
+__device__ __attribute__((noinline)) void wb_segment_f32(const WbLayer &Lg, const WbSeg &sgg, const void *src0, const void *src1,
+                                                       const void *dzp, const void *yp, const int32_t *table, float *ws, char *smem_raw) {
+    const WbLayer L = load_uniform(Lg);
+    const WbSeg sg = load_uniform(sgg);
+    constexpr int TAPS = KS * KS;
+    constexpr int XS = 32;                  // floats per X tile pixel (the 32 input channels of this ci tile)
+    constexpr int NCT = 256;
+    constexpr int IT_X = 14;                // X vectors per producer thread per item: capacity 448 tile pixels
+    constexpr int IT_DY = 6;                // dZ quads per producer thread per item: capacity 192 pixels
+    constexpr int TG = TAPS >= 3 ? 3 : 1;   // taps summed across the consumer waves per LDS round of the epilogue
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int pix_cap = (L.pix + 1) & ~1;
+    const int x_floats = L.tile_rows_max * L.W2 * XS;
+    const int buf_floats = x_floats + pix_cap * 32;
+    const int fbase = sg.cls == 0 ? 0 : (sg.cls == 1 ? 4 : 5);
+    const int n_my = sg.t_last - sg.t_first;
+    const int face_pix = L.No * L.No;
+    const int tid = threadIdx.x;
+    // 16-B vectors per staged pixel, rounded up to a power of two: a 14-channel input takes 4 lanes per pixel, not 8 (the
+    // channels above them keep whatever the LDS held: they only reach rows / columns of the product nobody reads)
+    const int cin_grp = min(32, L.Cin - sg.cit * 32), cout_grp = min(32, L.Cout - sg.cot * 32);
+    const int lqx = cin_grp > 16 ? 3 : (cin_grp > 8 ? 2 : (cin_grp > 4 ? 1 : 0));
+    const int lqd = cout_grp > 16 ? 3 : (cout_grp > 8 ? 2 : (cout_grp > 4 ? 1 : 0));
+    struct Item { int b, f, combo, m0, npix, y0, nitems; };
+    auto item_of = [&](int k) {
+        Item it;
+        const int t = sg.t_first + max(min(k, n_my - 1), 0);
+        it.combo = L.magicB ? __umulhi((uint32_t)t, L.magicB) : t;
+        it.b = t - it.combo * L.B;
+        const int fl = L.magicNb ? __umulhi((uint32_t)it.combo, L.magicNb) : it.combo;
+        const int band = it.combo - fl * L.nbands;
+        it.f = fbase + fl;
+        it.m0 = band * L.pix;
+        it.npix = min(L.pix, face_pix - it.m0);
+        it.y0 = __umulhi((uint32_t)it.m0, L.magicNo);
+        const int ylast = __umulhi((uint32_t)(it.m0 + it.npix - 1), L.magicNo);
+        it.nitems = ((ylast - it.y0 + KS) * L.W2) << lqx;
+        return it;
+    };
+    float *slot = ws + sg.slot_off;
+
+    if (tid >= NCT) {
+        // =========================================== producers ===========================================
+        const int ptid = tid - NCT;
+        const int qx = ptid & ((1 << lqx) - 1), qd = ptid & ((1 << lqd) - 1);
+        const int nit_x = (((L.tile_rows_max * L.W2) << lqx) + NCT - 1) / NCT;         // (uniform: iterations that carry work)
+        const int nit_d = ((pix_cap << lqd) + NCT - 1) / NCT;
+        const int cx = sg.cit * 32 + qx * 4;
+        const bool cx_ok = cx < L.Cin;
+        const bool hi_ok = cx + 2 < L.Cin;      // (H2: the vector is two 8-B halves, the upper one may lie past the last channel)
+        const bool from0 = cx < L.C0;
+        const int g0 = L.up0 ? (L.Nin >> 1) : L.Nin;
+        const int cs = from0 ? cx : cx - L.C0;
+        const int cstride = from0 ? L.C0 : L.C1;
+        const bool up = from0 && L.up0;
+        const int M = L.Nin + KS - 1;
+        const bool want_bias = sg.bias != 0;
+        float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+        int xoff[IT_X];
+        int cur_combo = -1;
+        auto rebuild = [&](const Item &it) {
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                if (i >= nit_x) { xoff[i] = -1; continue; }
+                const int e = min(ptid + i * NCT, it.nitems - 1);
+                const int pix = e >> lqx;
+                const int ty = __umulhi((uint32_t)pix, L.magicW2);
+                const int tx = pix - ty * L.W2;
+                const int iy = it.y0 + ty;
+                int ii;
+                if (L.halo) ii = table[(it.f * M + iy) * M + tx];
+                else ii = (it.f * L.Nin + iy) * L.Nin + tx;
+                const int r = __umulhi((uint32_t)ii, L.magicN);
+                const int pix_up = (r >> 1) * g0 + ((ii - r * L.Nin) >> 1);
+                const int spix = up ? pix_up : ii;
+                xoff[i] = (cx_ok && ptid + i * NCT < it.nitems) ? spix * cstride + cs : -1;
+            }
+            cur_combo = it.combo;
+        };
+        const size_t sample_elems = from0 ? (size_t)6 * g0 * g0 * L.C0 : (size_t)6 * L.Nin * L.Nin * L.C1;
+        const float *src_base = reinterpret_cast<const float *>(from0 ? src0 : src1);
+        Item cur = item_of(0);
+        for (int k = 0; k < n_my; ++k) {
+            float *buf = smem + (k & 1) * buf_floats;
+            const Item nxt = item_of(k + 1);
+            if (cur.combo != cur_combo) rebuild(cur);
+            const float *sb = src_base + (size_t)cur.b * sample_elems;
+            float4 xv[IT_X];
+            bool xok[IT_X];
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+#ifdef WB_F32_ABL
+                if (WB_F32_ABL & 2) { xv[i] = make_float4(1.f, 2.f, 3.f, 4.f); xok[i] = true; continue; }
+#endif
+                const int o = xoff[i];
+                if (i >= nit_x) { xok[i] = false; continue; }
+                if constexpr (X2) {
+                    const float2 lo = *reinterpret_cast<const float2 *>(sb + (uint32_t)max(o, 0));
+                    const float2 hi = *reinterpret_cast<const float2 *>(sb + (uint32_t)(hi_ok ? max(o, 0) + 2 : 0));
+                    xv[i] = make_float4(lo.x, lo.y, hi_ok ? hi.x : 0.f, hi_ok ? hi.y : 0.f);
+                } else {
+                    xv[i] = *reinterpret_cast<const float4 *>(sb + (uint32_t)max(o, 0));
+                }
+                xok[i] = o >= 0;
+            }
+            const size_t rowbase = (((size_t)cur.b * 6 + cur.f) * face_pix + cur.m0) * L.Cout;
+            const float *dyb = reinterpret_cast<const float *>(dzp) + rowbase;
+            const float *yb = MASK ? reinterpret_cast<const float *>(yp) + rowbase : nullptr;
+            float4 dv[IT_DY], yv[MASK ? IT_DY : 1];
+            bool dok[IT_DY];
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) {
+                const int e = ptid + i * NCT;
+                const int kk = e >> lqd, co = sg.cot * 32 + qd * 4;
+                const bool ok = kk < cur.npix && co < L.Cout;
+                const size_t o = ok ? (size_t)kk * L.Cout + co : 0;
+                if (i >= nit_d) { dv[i] = make_float4(0.f, 0.f, 0.f, 0.f); if (MASK) yv[i] = dv[i]; dok[i] = false; continue; }
+#ifdef WB_F32_ABL
+                if (WB_F32_ABL & 2) { dv[i] = make_float4(1.f, 2.f, 3.f, 4.f); if (MASK) yv[i] = dv[i]; dok[i] = ok; continue; }
+#endif
+                if constexpr (D2) {
+                    const bool dhi = ok && co + 2 < L.Cout;
+                    const float2 lo = *reinterpret_cast<const float2 *>(dyb + o), hi = *reinterpret_cast<const float2 *>(dyb + (dhi ? o + 2 : 0));
+                    dv[i] = make_float4(lo.x, lo.y, dhi ? hi.x : 0.f, dhi ? hi.y : 0.f);
+                    if (MASK) {
+                        const float2 ylo = *reinterpret_cast<const float2 *>(yb + o), yhi = *reinterpret_cast<const float2 *>(yb + (dhi ? o + 2 : 0));
+                        yv[i] = make_float4(ylo.x, ylo.y, yhi.x, yhi.y);
+                    }
+                } else {
+                    dv[i] = *reinterpret_cast<const float4 *>(dyb + o);
+                    if (MASK) yv[i] = *reinterpret_cast<const float4 *>(yb + o);
+                }
+                dok[i] = ok;
+            }
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) {
+                if (MASK) vmask(dv[i], yv[i], L.alpha, L.vmax);
+                dv[i] = vsel(dok[i], dv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < IT_X; ++i) {
+                const int e = ptid + i * NCT;
+                if (i < nit_x && e < cur.nitems) *reinterpret_cast<float4 *>(buf + (e >> lqx) * XS + qx * 4) = vsel(xok[i], xv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) {
+                const int e = ptid + i * NCT;
+                if (i < nit_d && (e >> lqd) < pix_cap) *reinterpret_cast<float4 *>(buf + x_floats + (e >> lqd) * 32 + qd * 4) = dv[i];
+                if (want_bias) { bsum.x += dv[i].x; bsum.y += dv[i].y; bsum.z += dv[i].z; bsum.w += dv[i].w; }
+            }
+            __syncthreads();            // B_k: item k is in LDS
+            cur = nxt;
+        }
+        __syncthreads();                // E1: consumers are done with the buffers
+        if (want_bias) {
+            float *red = smem + TG * 4096;          // behind the consumers' reduction scratch
+            red[ptid * 4 + 0] = bsum.x; red[ptid * 4 + 1] = bsum.y; red[ptid * 4 + 2] = bsum.z; red[ptid * 4 + 3] = bsum.w;
+        }
+        __syncthreads();                // E2
+        if (want_bias && ptid < 32) {
+            float sum = 0.f;
+            const float *red = smem + TG * 4096;
+            // the threads that staged this channel's quad: ptid % (1 << lqd) == channel / 4
+            if ((ptid >> 2) < (1 << lqd))
+                for (int t = ptid >> 2; t < NCT; t += 1 << lqd) sum += red[t * 4 + (ptid & 3)];
+            slot[TAPS * 32 * 32 + ptid] = sum;
+        }
+#pragma unroll
+        for (int t0 = 0; t0 < TAPS; t0 += TG) { __syncthreads(); __syncthreads(); }
+        __syncthreads();                // E3: the next segment may overwrite the buffers
+        return;
+    }
+
+    // ============================================= consumers =============================================
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int nsteps = pix_cap / 2;
+    const int S = (((nsteps + 3) / 4) + 1) & ~1;
+    for (int k = 0; k < n_my; ++k) {
+        __syncthreads();                // B_k
+        const float *lds_x = smem + (k & 1) * buf_floats, *lds_dy = lds_x + x_floats;
+        const Item it = item_of(k);
+        // Pixel pair `si` of this wave: the LDS offset of its X value under tap (0, 0) and of its dZ value.  The addresses of
+        // step si + 2 are computed, and the 10 reads of step si + 1 issued, in the shadow of the 9 MFMAs of step si: an in-order
+        // wave that first issues all reads, then all MFMAs leaves the matrix pipe idle while it does the address arithmetic
+        // (measured, nine 3x3 layers of unet2 at B = 32: 816 us that way, ... us interleaved; 440 us is the pipe's own time).
+        struct Addr { int pb, db; bool on; };
+        auto addr = [&](int si) {
+            const int s = wave + 4 * si;
+            const int kk = min(2 * s + half, pix_cap - 1);
+            const int gm = it.m0 + min(kk, it.npix - 1);
+            const int oy = __umulhi((uint32_t)gm, L.magicNo);
+            Addr A;
+            A.pb = ((oy - it.y0) * L.W2 + (gm - oy * L.No)) * XS + l31;
+            A.db = kk * 32 + l31;
+            A.on = s < nsteps;
+            return A;
+        };
+        auto frag = [&](const Addr &A, float (&a)[TAPS], float &bq) {
+#ifdef WB_F32_ABL
+            if (WB_F32_ABL & 4) {
+                bq = __int_as_float(A.db);
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) a[tap] = __int_as_float(A.pb + tap);
+                return;
+            }
+#endif
+            const float bv = lds_dy[A.db];
+            bq = A.on ? bv : 0.f;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) a[tap] = lds_x[A.pb + ((tap / KS) * L.W2 + (tap % KS)) * XS];
+        };
+        float fa[2][TAPS], fb[2];
+        Addr A0 = addr(0), A1 = addr(1);
+        frag(A0, fa[0], fb[0]);
+#ifdef WB_F32_ABL
+        if (WB_F32_ABL & 1) continue;
+#endif
+        for (int si = 0; si < S; si += 2) {
+            frag(A1, fa[1], fb[1]);
+            A0 = addr(si + 2);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][tap], fb[0], acc[tap], 0, 0, 0);
+            WB_F32_SCHED();
+            frag(A0, fa[0], fb[0]);
+            A1 = addr(si + 3);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][tap], fb[1], acc[tap], 0, 0, 0);
+            WB_F32_SCHED();
+        }
+    }
+    __syncthreads();                    // E1
+    __syncthreads();                    // E2 (the producers stage their bias sums between these two)
+    float *red = smem;
+#pragma unroll
+    for (int t0 = 0; t0 < TAPS; t0 += TG) {
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt)
+            if (t0 + tt < TAPS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    red[(tt * 4 + wave) * 1024 + ci * 32 + l31] = acc[t0 + tt][r];
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt)
+            if (t0 + tt < TAPS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = tid + i * NCT;
+                    const float *rt = red + tt * 4096;
+                    slot[(size_t)(t0 + tt) * 1024 + e] = (rt[e] + rt[1024 + e]) + (rt[2048 + e] + rt[3072 + e]);
+                }
+            }
+        __syncthreads();
+    }
+    __syncthreads();                    // E3
+}
+
 __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict__ plan, const WbPtrs ptrs, float *__restrict__ ws,
                                                           long long *dbg, int32_t *adam_state) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -512,11 +810,35 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
     const WbSeg *segs = reinterpret_cast<const WbSeg *>(plan + H->off_segs);
     const int w = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int s0 = (int)H->seg_start[w], s1 = (int)H->seg_start[w + 1];
+#ifdef DLWPCS_WB_SEGTIME
+    long long seg_t = __builtin_amdgcn_s_memtime();      // development: dbg[segment] = constant-clock ticks the segment took
+#endif
     for (int s = s0; s < s1; ++s) {
+#ifdef DLWPCS_WB_SEGTIME
+        if (s > s0 && dbg && threadIdx.x == 0) { const long long t = __builtin_amdgcn_s_memtime(); dbg[s - 1] = t - seg_t; seg_t = t; }
+#endif
         const WbSeg &sg = segs[s];
         const WbLayer &L = layers[sg.layer];
         const void *a0 = ptrs.src0[sg.layer], *a1 = ptrs.src1[sg.layer], *dz = ptrs.dz[sg.layer], *yy = ptrs.y[sg.layer];
         const int32_t *tb = ptrs.table[sg.layer];
+        if (L.variant >= WB_V_F32_3) {
+            switch (L.variant) {
+            case WB_V_F32_1: wb_segment_f32<1, false>(L, sg, a0, a1, dz, yy, tb, ws, smem); break;
+            case WB_V_F32_1_D2: wb_segment_f32<1, false, false, true>(L, sg, a0, a1, dz, yy, tb, ws, smem); break;
+            case WB_V_F32_3_X2:
+                if (L.mask) wb_segment_f32<3, true, true>(L, sg, a0, a1, dz, yy, tb, ws, smem);
+                else wb_segment_f32<3, false, true>(L, sg, a0, a1, dz, yy, tb, ws, smem);
+                break;
+            case WB_V_F32_3_H2:
+                if (L.mask) wb_segment_f32<3, true, true, true>(L, sg, a0, a1, dz, yy, tb, ws, smem);
+                else wb_segment_f32<3, false, true, true>(L, sg, a0, a1, dz, yy, tb, ws, smem);
+                break;
+            default:
+                if (L.mask) wb_segment_f32<3, true>(L, sg, a0, a1, dz, yy, tb, ws, smem);
+                else wb_segment_f32<3, false>(L, sg, a0, a1, dz, yy, tb, ws, smem);
+            }
+            continue;
+        }
         if (L.mask) {
             switch (L.variant) {
                 case WB_V_3_8_22: wb_segment<3, 8, 4, 2, 2, 8, true>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
@@ -539,6 +861,9 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
             default:          wb_segment<1, 8, 4, 1, 1, 2>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
         }
     }
+#ifdef DLWPCS_WB_SEGTIME
+    if (s1 > s0 && dbg && threadIdx.x == 0) dbg[s1 - 1] = __builtin_amdgcn_s_memtime() - seg_t;
+#endif
     // optimizer fused into the reduction that follows: the step counter {t, ticket} moves on here (last worker to finish)
     if (adam_state != nullptr && threadIdx.x == 0) {
         const int done = atomicAdd(adam_state + 1, 1);
@@ -658,6 +983,25 @@ __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGrou
             if (is_w) {
                 const int TAPS2 = KS * KS;
                 const int tyv = (vv == 2 && L.flip) ? KS - 1 - w_ty : w_ty;
+                if (K.f32) {
+                    // exact-fp32 mode: the same fragment order with 4 fp32 values per 16-B entry (ci / co groups of 8)
+                    float *wf = reinterpret_cast<float *>(K.wf), *wb = reinterpret_cast<float *>(K.wb);
+                    {
+                        const int cg = w_ci >> 3, hf = (w_ci >> 2) & 1, j = w_ci & 3;
+                        const size_t base = (size_t)(((((vv * K.NTf + (w_co >> 5)) * K.CGf + cg) * TAPS2 + tyv * KS + w_tx) * 2 + hf) * 32);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) wf[(base + ((w_co + k) & 31)) * 4 + j] = pv[k];
+                    }
+                    {
+                        const int cg = w_co >> 3, hf = (w_co >> 2) & 1, j = w_co & 3;
+                        const int ey = KS - 1 - tyv, ex = KS - 1 - w_tx;
+                        float *q = wb + ((size_t)(((((vv * K.NTb + (w_ci >> 5)) * K.CGb + cg) * TAPS2 + ey * KS + ex) * 2 + hf) * 32) +
+                                         (w_ci & 31)) * 4 + j;
+                        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(q) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                        else q[0] = pv[0];
+                    }
+                    continue;
+                }
                 {   // forward fragments: VEC consecutive co of one 32-column tile, 16 B apart
                     const int cg = w_ci >> 4, hf = (w_ci >> 3) & 1, j = w_ci & 7;
                     const size_t base = (size_t)(((((vv * K.NTf + (w_co >> 5)) * K.CGf + cg) * TAPS2 + tyv * KS + w_tx) * 2 + hf) * 32);
@@ -740,6 +1084,18 @@ static inline int wb_out_size(const dlwpcs_conv_desc *d) { return d->halo ? d->N
 // -1: the layer cannot be an item of the batch
 static int wb_variant(const dlwpcs_conv_desc *d, int &CT, int &NT, int &cap_tile_px, int &cap_pix) {
     CT = NT = 1;
+    if (d->dtype == DLWPCS_F32) {
+        // exact-fp32 mode: 16-B vectors of 4 channels on both operands, one 32 x 32 tile pair per worker
+        if (d->B < 1 || (d->ksize != 1 && d->ksize != 3) || (d->halo && d->ksize != 3) || (d->up0 && (d->N % 2))) return -1;
+        if (!d->halo && d->N < d->ksize) return -1;
+        if ((long)d->N * d->N >= (1l << 16)) return -1;
+        if ((long)6 * d->N * d->N * (d->C0 > d->C1 ? d->C0 : d->C1) >= (1l << 31) || (long)6 * d->N * d->N * d->Cout >= (1l << 31)) return -1;
+        cap_tile_px = 448; cap_pix = 192;
+        if (d->C0 % 2 || d->C1 % 2 || d->Cout % 2 || (d->C1 > 0 && d->C0 % 4)) return -1;     // (a vector never straddles the sources)
+        const bool x2 = d->C0 % 4 || d->C1 % 4, d2 = d->Cout % 4 != 0;
+        if (d->ksize == 1) return x2 ? -1 : (d2 ? WB_V_F32_1_D2 : WB_V_F32_1);
+        return x2 ? (d2 ? WB_V_F32_3_H2 : WB_V_F32_3_X2) : (d2 ? WB_V_F32_3_H2 : WB_V_F32_3);
+    }
     if (d->dtype != DLWPCS_BF16 || d->B < 1 || (d->ksize != 1 && d->ksize != 3)) return -1;
     if (d->halo && d->ksize != 3) return -1;
     if (d->up0 && (d->N % 2)) return -1;
@@ -797,7 +1153,8 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
     memset(&L, 0, sizeof(L));
     L.B = d->B; L.Nin = d->N; L.No = No; L.C0 = d->C0; L.C1 = d->C1; L.Cin = d->C0 + d->C1; L.Cout = d->Cout; L.up0 = d->up0;
     L.halo = d->halo; L.KS = KS; L.W2 = W2; L.tile_rows_max = rows; L.pix = pix; L.nbands = ceil_div(face_pix, pix);
-    L.pix_cap = (pix + 15) & ~15; L.variant = variant;
+    const bool f32 = variant >= WB_V_F32_3;
+    L.pix_cap = f32 ? (pix + 1) & ~1 : (pix + 15) & ~15; L.variant = variant;
     if ((long)d->B * 4 * L.nbands >= (1l << 16))
         return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: %ld work items per face class exceed the 16-bit item arithmetic", (long)d->B * 4 * L.nbands);
     L.magicW2 = div_magic(W2); L.magicNo = div_magic(No); L.magicN = div_magic(d->N);
@@ -810,10 +1167,33 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
         if (KS != 3) return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: act' on load is built for the 3x3 kernels (pass a pre-masked dz)");
         if (d->act != DLWPCS_ACT_LEAKY_CLIP || !(d->alpha >= 0.f) || !(d->vmax >= 0.f))
             return fail(DLWPCS_E_INVALID, "wgrad_batch: item with y needs act = LEAKY_CLIP with negative_slope >= 0 and max_value >= 0");
-        L.mask = 1; L.alpha = d->alpha; L.vmax = d->vmax; L.pad0 = (int32_t)bf16_mask_threshold(d->vmax);
+        L.mask = 1; L.alpha = d->alpha; L.vmax = d->vmax; L.pad0 = f32 ? 0 : (int32_t)bf16_mask_threshold(d->vmax);
     }
     const int TAPS = KS * KS;
     L.slot_floats = (int)align_up((size_t)TAPS * 32 * CT * 32 * NT + 32 * NT, 64);
+    if (f32) {
+        // fp32 tiles: 128 B per X pixel and per dZ pixel, two buffers; the epilogue's scratch (3 taps x 4 waves x 4 KiB + the
+        // bias partials) aliases them.  The consumers set the period: 9 (1) v_mfma_f32_32x32x2 of 64 cycles per pixel pair.
+        const size_t buf = ((size_t)rows * W2 + L.pix_cap) * 128;
+        const size_t need = (size_t)(TAPS >= 3 ? 3 : 1) * 4 * 4096 + 4096;
+        G.lds = 2 * buf > need ? 2 * buf : need;
+        if (G.lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: LDS tile of %zu bytes exceeds 160 KiB", G.lds);
+        // Cost model (ticks per item), fitted to the per-segment s_memtime accounting of tools/wb_segtime.py on MI355X (the
+        // eleven layers of unet2 at B = 32, +-3 %): the consumers set the period -- ~85 per v_mfma_f32_32x32x2 (64 is the pipe's
+        // own time) plus ~3500 per item (barrier, first fragments), ~6300 for a 1x1 kernel whose few MFMAs no longer hide the
+        // producers; act' on load adds ~7.5 per pixel.  The chains are cut at equal cost: a layer whose items run x % over the
+        // model makes the whole launch x % longer.
+        static double cm[4] = {-1, 0, 0, 0};
+        if (cm[0] < 0) {
+            const char *e = getenv("DLWPCS_WB_COST_F32");
+            cm[0] = 85.0; cm[1] = 3500.0; cm[2] = 6300.0; cm[3] = 7.5;
+            if (e) sscanf(e, "%lf,%lf,%lf,%lf", &cm[0], &cm[1], &cm[2], &cm[3]);
+        }
+        const int nsteps = L.pix_cap / 2, S = (ceil_div(nsteps, 4) + 1) & ~1;
+        const double cost = (double)S * TAPS * cm[0] + (KS == 1 ? cm[2] : cm[1]) + (mask ? cm[3] * pix : 0.0);
+        G.cost_item[0] = G.cost_item[1] = cost;
+        return DLWPCS_OK;
+    }
     const size_t buf = (size_t)CT * rows * W2 * 64 + (size_t)NT * L.pix_cap * 64;
     const int nph = 4 / (CT * NT), rslots = TAPS - TAPS / nph;
     const size_t need = ((size_t)4 * rslots * 1024 + 2048) * 4;
@@ -1119,7 +1499,7 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
         R.db_eq[l] = (float *)it.db_eq; R.db_pol[l] = (float *)it.db_pol; R.db_np[l] = (float *)it.db_np;
         const double n0 = L.up0 ? L.Nin / 2 : L.Nin;
         flops += 2.0 * L.B * 6 * (double)L.No * L.No * L.KS * L.KS * L.cin_logical * L.Cout;
-        bytes += 2.0 * L.B * 6.0 * (n0 * n0 * L.C0 + (double)L.Nin * L.Nin * L.C1 + (double)L.No * L.No * L.Cout) +
+        bytes += (it.d.dtype == DLWPCS_F32 ? 4.0 : 2.0) * L.B * 6.0 * (n0 * n0 * L.C0 + (double)L.Nin * L.Nin * L.C1 + (double)L.No * L.No * L.Cout) +
                  4.0 * L.KS * L.KS * L.cin_logical * L.Cout;
     }
     memcpy(R.first, H->red_first, sizeof(R.first));
@@ -1140,7 +1520,7 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
     if (!apply_only) {
         if (prof_enabled()) pidx = prof_begin("wgrad_batch_kernel", flops, bytes, s);
         long long *dbg = nullptr;
-#ifdef DLWPCS_WB_TIMING
+#if defined(DLWPCS_WB_TIMING) || defined(DLWPCS_WB_SEGTIME)
         { const char *e = getenv("DLWPCS_DBG_PTR"); dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
         hipLaunchKernelGGL(wgrad_batch_kernel, dim3(H->n_workers), dim3(512), lds, s, (const char *)plan_dev, ptrs, (float *)workspace, dbg,
@@ -1173,14 +1553,17 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
                 const WbLayer &L = layers[l];
                 // the packed operands must belong to the parameters this item's gradients update
                 const float *pw = adam.p + ((const float *)items[l].dw_eq - adam.g);
-                if (pk.dtype != DLWPCS_BF16 || pk.ksize != L.KS || pk.Cin != L.cin_logical || pk.Cout != L.Cout ||
+                const bool pf32 = items[l].d.dtype == DLWPCS_F32;
+                if (pk.dtype != items[l].d.dtype || pk.ksize != L.KS || pk.Cin != L.cin_logical || pk.Cout != L.Cout ||
                     (const float *)pk.w_eq != pw || !pk.wpk_fwd || !pk.wpk_bwd || (pk.flip_north_pole != 0) != (L.flip != 0) ||
                     (L.want_bias && !pk.bias_pk))
                     return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: pack item %d does not describe the layer of gradient item %d", l, l);
                 WbRedPack &K = PK.l[l];
                 K.wf = (bf16_t *)pk.wpk_fwd; K.wb = (bf16_t *)pk.wpk_bwd; K.bp = (float *)pk.bias_pk;
-                K.CGf = (pk.Cin + 15) / 16; K.NTf = (pk.Cout + 31) / 32;
-                K.CGb = (pk.Cout + 15) / 16; K.NTb = (pk.Cin + 31) / 32;
+                const int cgw = pf32 ? 8 : 16;
+                K.CGf = (pk.Cin + cgw - 1) / cgw; K.NTf = (pk.Cout + 31) / 32;
+                K.CGb = (pk.Cout + cgw - 1) / cgw; K.NTb = (pk.Cin + 31) / 32;
+                K.f32 = pf32 ? 1 : 0;
             }
         }
         hipLaunchKernelGGL(wb_reduce_kernel, dim3(rb + (tail ? 1u : 0u)), dim3(tail ? 256 : WB_RED_THREADS), 0, s,

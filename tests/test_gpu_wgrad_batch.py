@@ -29,6 +29,10 @@ def _bf(a):
     return torch.tensor(np.asarray(a), dtype=torch.float32).to(torch.bfloat16).to(_dev())
 
 
+def _f32(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float32).to(_dev())
+
+
 def _f64(t):
     return t.detach().to(torch.float64).cpu()
 
@@ -43,8 +47,9 @@ def rel_err(a, ref):
 class Layer(object):
     """one item: device tensors + the oracle's gradients"""
 
-    def __init__(self, rng, B, N, C0, C1, up0, Cout, k, halo, flip=True, indep=False, bias=True, c0_valid=0):
+    def __init__(self, rng, B, N, C0, C1, up0, Cout, k, halo, flip=True, indep=False, bias=True, c0_valid=0, f32=False):
         from DLWP import _native as nat
+        _bf = _f32 if f32 else globals()['_bf']
         self.cfg = (B, N, C0, C1, up0, Cout, k, halo, flip, indep, bias, c0_valid)
         n0 = N // 2 if up0 else N
         x0 = rng.standard_normal((B, 6, n0, n0, C0)) * 2.0
@@ -59,7 +64,8 @@ class Layer(object):
         self.dw = {n: torch.zeros((k, k, cin, Cout), dtype=torch.float32, device=_dev()) for n in names}
         self.db = {n: torch.zeros((Cout,), dtype=torch.float32, device=_dev()) for n in names} if bias else {}
         self.d = nat.ConvDesc(B=B, N=N, C0=C0, C1=C1, Cout=Cout, ksize=k, halo=int(halo), up0=int(up0),
-                              flip_north_pole=int(flip), act=0, alpha=0., vmax=0., dtype=nat.BF16, flags=0, c0_valid=c0_valid)
+                              flip_north_pole=int(flip), act=0, alpha=0., vmax=0., dtype=nat.F32 if f32 else nat.BF16, flags=0,
+                              c0_valid=c0_valid)
         self.table = nat.halo_tables(N, 1, _dev())[0] if halo else None
 
     def entry(self):
@@ -161,6 +167,90 @@ def test_mask_on_load(case):
     e = lay.entry()
     ops.wgrad_batch([(d, e[1], e[2], dy, e[4], e[5], y)])
     lay.check()
+
+
+# exact-fp32 mode (round 4): 16-B vectors of 4 channels, one 32 x 32 tile pair per worker, v_mfma_f32_32x32x2_f32
+F32_CASES = [
+    (2, 48, 32, 0, 0, 32, 3, 1),      # 192-pixel items (4 rows of 48)
+    (2, 24, 64, 0, 0, 64, 3, 1),      # two ci x two co groups
+    (2, 24, 64, 64, 1, 64, 3, 1),     # decoder: upsampled source + skip source
+    (3, 12, 64, 0, 0, 128, 3, 1),     # whole-face items
+    (2, 48, 16, 0, 0, 32, 3, 1),      # the padded 14-channel input (16 channels)
+    (3, 10, 20, 0, 0, 24, 3, 1),      # partial channel tiles, ragged bands
+    (2, 20, 40, 8, 0, 48, 3, 1),      # 48 input channels from two sources
+    (2, 16, 32, 0, 0, 32, 1, 0),      # 1x1
+    (2, 14, 32, 0, 0, 32, 3, 0),      # 3x3 'valid', no halo
+    (2, 48, 14, 0, 0, 32, 3, 1),      # 8-B loads: the 14-channel network input
+    (2, 48, 32, 0, 0, 14, 1, 0),      # ... the 1x1 head with 14 outputs
+    (2, 12, 8, 6, 0, 10, 3, 1),       # ... two sources, 10 outputs
+]
+
+
+@pytest.mark.parametrize('case', F32_CASES)
+def test_f32_single_layer_matches_oracle(case):
+    from DLWP import ops
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    lay = Layer(rng, *case, f32=True)
+    assert ops.wgrad_batch_supported(lay.d)
+    ops.wgrad_batch([lay.entry()])
+    lay.check()
+
+
+def test_f32_options_and_mask_on_load():
+    """fp32 items: independent north pole / no flip / no bias / 14 of 16 channels valid, and an item with y (act' formed on
+    load, exact in fp32 -- also through the 8-B loads); odd channel counts have no batched fp32 kernel"""
+    from DLWP import _native as nat
+    from DLWP import ops
+    rng = np.random.default_rng(23)
+    lays = [Layer(rng, 2, 12, 32, 0, 0, 32, 3, 1, flip=True, indep=True, f32=True),
+            Layer(rng, 2, 12, 64, 0, 0, 64, 3, 1, flip=False, indep=True, bias=False, f32=True),
+            Layer(rng, 3, 48, 16, 0, 0, 32, 3, 1, c0_valid=14, f32=True),
+            Layer(rng, 2, 24, 32, 0, 0, 64, 3, 1, f32=True),
+            Layer(rng, 2, 24, 14, 0, 0, 30, 3, 1, f32=True)]
+    entries = [l.entry() for l in lays]
+    for k in (3, 4):
+        m = lays[k]
+        y = _f32(rng.standard_normal(tuple(m.dz.shape)) * 6.0)
+        dy = m.dz
+        yf, gf = y.cpu().numpy(), dy.cpu().numpy()
+        sl = np.where(yf < 0, np.float32(0.1), np.where((yf > 0) & (yf < 10.0), np.float32(1.0), np.float32(0.0)))
+        m.dz = _f32(gf * sl)
+        d = nat.ConvDesc.from_buffer_copy(m.d)
+        d.act, d.alpha, d.vmax = nat.ACT_LEAKY_CLIP, 0.1, 10.0
+        e = entries[k]
+        entries[k] = (d, e[1], e[2], dy, e[4], e[5], y)
+    ops.wgrad_batch(entries)
+    for l in lays:
+        l.check()
+    odd = Layer(rng, 1, 12, 32, 0, 0, 7, 1, 0, f32=True)
+    assert not ops.wgrad_batch_supported(odd.d)
+
+
+def test_f32_layer_list_is_reproducible_and_matches_the_per_layer_kernel():
+    from DLWP import _native as nat
+    from DLWP import ops
+    rng = np.random.default_rng(29)
+    lays = [Layer(rng, 2, *cfg, f32=True) for cfg in UNET2]
+    ops.wgrad_batch([l.entry() for l in lays])
+    first = [[g.clone() for g in list(l.dw.values()) + list(l.db.values())] for l in lays]
+    for l in lays:
+        l.check()
+    ops.wgrad_batch([l.entry() for l in lays])
+    for l, f in zip(lays, first):
+        for g, g1 in zip(list(l.dw.values()) + list(l.db.values()), f):
+            assert torch.equal(g, g1 + g1)
+    lay = lays[3]
+    d = lay.d
+    nbytes = nat.lib().dlwpcs_conv_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=_dev())
+    ref = {n: torch.empty_like(v) for n, v in lay.dw.items()}
+    rb = {n: torch.empty_like(v) for n, v in lay.db.items()}
+    nat.check(nat.lib().dlwpcs_conv_bwd_weights(ctypes.byref(d), nat.ptr(lay.x0), 0, nat.ptr(lay.dz), 0, nat.ptr(ref['eq']),
+                                                nat.ptr(ref['pol']), 0, nat.ptr(rb['eq']), nat.ptr(rb['pol']), 0,
+                                                nat.ptr(lay.table), nat.ptr(ws), nbytes, nat.stream_ptr()), 'conv_bwd_weights')
+    for n in ref:
+        assert rel_err(_f64(lay.dw[n]).numpy(), 2.0 * _f64(ref[n]).numpy()) <= TOL
+        assert rel_err(_f64(lay.db[n]).numpy(), 2.0 * _f64(rb[n]).numpy()) <= TOL
 
 
 def test_unet2_layer_list_accumulates_and_is_reproducible():

@@ -114,7 +114,10 @@ def test_plan_is_balanced_and_small():
 def test_unsupported_layers_are_reported():
     lib = nat.lib()
     assert lib.dlwpcs_wgrad_batch_supported(ctypes.byref(_desc(4, 24, 32, 0, 0, 64, 3, 1))) == 1
-    assert lib.dlwpcs_wgrad_batch_supported(ctypes.byref(_desc(4, 24, 32, 0, 0, 64, 3, 1, dtype=nat.F32))) == 0
+    assert lib.dlwpcs_wgrad_batch_supported(ctypes.byref(_desc(4, 24, 32, 0, 0, 64, 3, 1, dtype=nat.F32))) == 1   # (round 4)
+    assert lib.dlwpcs_wgrad_batch_supported(ctypes.byref(_desc(4, 48, 14, 0, 0, 32, 3, 1, dtype=nat.F32))) == 1   # 8-B loads
+    assert lib.dlwpcs_wgrad_batch_supported(ctypes.byref(_desc(4, 24, 14, 16, 0, 32, 3, 1, dtype=nat.F32))) == 0  # a vector would straddle
+    assert lib.dlwpcs_wgrad_batch_supported(ctypes.byref(_desc(4, 24, 7, 0, 0, 64, 3, 1, dtype=nat.F32))) == 0
     assert lib.dlwpcs_wgrad_batch_supported(ctypes.byref(_desc(4, 24, 7, 0, 0, 64, 3, 1))) == 0          # odd channel count
     assert lib.dlwpcs_wgrad_batch_supported(ctypes.byref(_desc(4, 24, 8, 0, 0, 64, 3, 1, c0_valid=7))) == 1
     arr = _items(2, [(24, 7, 0, 0, 64, 3, 1)])
