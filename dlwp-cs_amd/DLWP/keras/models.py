@@ -920,7 +920,7 @@ class Model(object):
                 if one:
                     try:
                         no_pack = (self.fuse_pack and self.fuse_adam and self.batch_wgrad and self.prepack_weights
-                                   and self.compute_dtype == 'bfloat16' and static_in[0].is_cuda)
+                                   and static_in[0].is_cuda)
                         if no_pack:
                             self._ensure_packed(static_in[0].device)
                             gtry = _new_graph()

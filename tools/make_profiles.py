@@ -61,7 +61,7 @@ def step_summaries(pdir, modes):
     steps = []
     for a, b in zip(idx[:-1], idx[1:]):
         seg = rows[a:b]
-        bf = any('unsigned short' in r['Kernel_Name'] or 'wgrad_b' in r['Kernel_Name'] or 'pw_' in r['Kernel_Name'] for r in seg)
+        bf = any('unsigned short' in r['Kernel_Name'] or 'pw_' in r['Kernel_Name'] for r in seg)      # (both modes batch their weight gradients)
         steps.append((a, b, bf))
     txt = []
     for want, title in modes:
