@@ -518,7 +518,7 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
 // Called by all 512 threads; both halves execute n_items + 2 * ceil(TAPS / 3) + 3 workgroup barriers.
 // ------------------------------------------------------------------------------------------------------------------
 #ifndef DLWPCS_WB_F32_SCHED
-#define DLWPCS_WB_F32_SCHED 1
+#define DLWPCS_WB_F32_SCHED 2
 #endif
 #if DLWPCS_WB_F32_SCHED == 1
 #define WB_F32_SCHED() do {                                                                                  \
@@ -528,6 +528,21 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      /* address arithmetic of the step after */ \
         }                                                                                                     \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                    \
+    } while (0)
+#elif DLWPCS_WB_F32_SCHED == 2
+// the reads front-loaded, two behind each of the first MFMAs: the last one has four MFMAs to land before the next step needs it
+#define WB_F32_G(nread) do {                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
+        if (nread) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);                                     \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                    \
+    } while (0)
+#define WB_F32_SCHED() do {                                                                                  \
+        if constexpr (TAPS == 9) {                                                                            \
+            WB_F32_G(2); WB_F32_G(2); WB_F32_G(2); WB_F32_G(2); WB_F32_G(2);                                  \
+            WB_F32_G(0); WB_F32_G(0); WB_F32_G(0); WB_F32_G(0);                                               \
+        } else {                                                                                              \
+            WB_F32_G(2);                                                                                      \
+        }                                                                                                     \
     } while (0)
 #else
 #define WB_F32_SCHED() do {                                                                                  \
@@ -1179,14 +1194,15 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
         G.lds = 2 * buf > need ? 2 * buf : need;
         if (G.lds > 160 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch: LDS tile of %zu bytes exceeds 160 KiB", G.lds);
         // Cost model (ticks per item), fitted to the per-segment s_memtime accounting of tools/wb_segtime.py on MI355X (the
-        // eleven layers of unet2 at B = 32, +-3 %): the consumers set the period -- ~85 per v_mfma_f32_32x32x2 (64 is the pipe's
-        // own time) plus ~3500 per item (barrier, first fragments), ~6300 for a 1x1 kernel whose few MFMAs no longer hide the
-        // producers; act' on load adds ~7.5 per pixel.  The chains are cut at equal cost: a layer whose items run x % over the
+        // eleven layers of unet2 at B = 32, +-3 %): the consumers set the period -- ~73 per v_mfma_f32_32x32x2 (64 is the pipe's
+        // own time; 85 before the LDS reads of a step were front-loaded behind its first five MFMAs) plus ~4300 per item
+        // (barrier, first fragments), ~6500 for a 1x1 kernel whose few MFMAs no longer hide the producers; act' on load adds
+        // ~7.5 per pixel.  The chains are cut at equal cost: a layer whose items run x % over the
         // model makes the whole launch x % longer.
         static double cm[4] = {-1, 0, 0, 0};
         if (cm[0] < 0) {
             const char *e = getenv("DLWPCS_WB_COST_F32");
-            cm[0] = 85.0; cm[1] = 3500.0; cm[2] = 6300.0; cm[3] = 7.5;
+            cm[0] = 73.0; cm[1] = 4300.0; cm[2] = 6500.0; cm[3] = 7.5;
             if (e) sscanf(e, "%lf,%lf,%lf,%lf", &cm[0], &cm[1], &cm[2], &cm[3]);
         }
         const int nsteps = L.pix_cap / 2, S = (ceil_div(nsteps, 4) + 1) & ~1;
