@@ -594,8 +594,6 @@ class _Writer(object):
         for name in sorted(g.children, key=lambda s: s.encode('utf8')):             # symbol nodes are sorted by name (strcmp)
             child = g.children[name]
             links.append((name, self.group(child)[0] if isinstance(child, _WGroup) else self.dataset(child)))
-        if len(links) > 2 * self.leaf_k:
-            raise HDF5Error('writer: %d links in one group exceed the symbol-node capacity' % len(links))
         # local heap: the link names, 8-byte aligned, the empty string at offset 0; the tail is one free block
         heap, offs = bytearray(8), []
         for name, _ in links:
@@ -605,17 +603,43 @@ class _Writer(object):
         heap += struct.pack('<QQ', 1, 32) + b'\x00' * 16                            # free block: next = 1 (none), size 32
         heap_hdr_addr = self.alloc(b'')
         heap_addr = self.alloc(b'HEAP' + struct.pack('<B3xQQQ', 0, len(heap), free_off, heap_hdr_addr + 32) + bytes(heap))
-        # one symbol node with every link, one leaf B-tree node pointing at it
-        snod = b'SNOD' + struct.pack('<BBH', 1, 0, len(links))
-        for (name, addr), off in zip(links, offs):
-            snod += struct.pack('<QQII16x', off, addr, 0, 0)
-        snod += b'\x00' * (8 + 2 * self.leaf_k * 40 - len(snod))
-        snod_addr = self.alloc(snod)
-        tree = b'TREE' + struct.pack('<BBHQQ', 0, 0, 1 if links else 0, UNDEF, UNDEF)
-        if links:
-            tree += struct.pack('<QQQ', 0, snod_addr, offs[-1])
-        tree += b'\x00' * (24 + (4 * self.internal_k + 1) * 8 - len(tree))
-        tree_addr = self.alloc(tree)
+        # Symbol nodes of <= 2 * leaf_k links each under a v1 B-tree (node type 0) whose nodes hold <= 2 * internal_k children:
+        # key i of a node is the heap offset of the LAST name below child i - 1 (key 0 of the leftmost node: the empty string at
+        # offset 0), so a group of any size costs its own links only (the first version raised the file-wide leaf K to the
+        # largest group and padded every group's node to it: O(groups x max_links) bytes).
+        cap = 2 * self.leaf_k
+        snod_size = 8 + cap * 40
+        level = []                                                                  # [(address, heap offset of the last name)]
+        for lo in range(0, len(links), cap):
+            part = list(zip(links[lo:lo + cap], offs[lo:lo + cap]))
+            snod = b'SNOD' + struct.pack('<BBH', 1, 0, len(part))
+            for (name, addr), off in part:
+                snod += struct.pack('<QQII16x', off, addr, 0, 0)
+            snod += b'\x00' * (snod_size - len(snod))
+            level.append((self.alloc(snod), part[-1][1]))
+        fan = 2 * self.internal_k
+        node_size = 24 + (2 * fan + 1) * 8
+        depth = 0
+        while True:
+            groups_ = [level[lo:lo + fan] for lo in range(0, len(level), fan)] or [[]]
+            base = self.alloc(b'\x00' * (node_size * len(groups_)))                 # the nodes of a level are contiguous
+            nxt = []
+            for i, kids in enumerate(groups_):
+                left = base + (i - 1) * node_size if i > 0 else UNDEF
+                right = base + (i + 1) * node_size if i + 1 < len(groups_) else UNDEF
+                node = b'TREE' + struct.pack('<BBHQQ', 0, depth, len(kids), left, right)
+                first_key = groups_[i - 1][-1][1] if i > 0 else 0
+                node += struct.pack('<Q', first_key)
+                for addr, last in kids:
+                    node += struct.pack('<QQ', addr, last)
+                node += b'\x00' * (node_size - len(node))
+                self.buf[base + i * node_size:base + (i + 1) * node_size] = node
+                nxt.append((base + i * node_size, kids[-1][1] if kids else 0))
+            level = nxt
+            depth += 1
+            if len(level) == 1:
+                break
+        tree_addr = level[0][0]
         msgs = [(0x11, struct.pack('<QQ', tree_addr, heap_addr))]
         for name, value in g.attrs:
             for n2, v2 in _split_attr(name, value):
@@ -633,21 +657,10 @@ class _Writer(object):
         return bytes(self.buf)
 
 
-def _max_links(g):
-    n = len(g.children)
-    for c in g.children.values():
-        if isinstance(c, _WGroup):
-            n = max(n, _max_links(c))
-    return n
-
-
 def write_tree(path, root):
     """root: _WGroup.  Atomic (temporary file + rename)."""
     import os
-    k = 4
-    while 2 * k < _max_links(root):
-        k *= 2
-    data = _Writer(k).finish(root)
+    data = _Writer(4).finish(root)          # libhdf5's defaults: group leaf K = 4, internal K = 16
     tmp = '%s.tmp%d' % (path, os.getpid())
     with open(tmp, 'wb') as f:
         f.write(data)

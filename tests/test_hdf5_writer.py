@@ -54,6 +54,42 @@ def test_weights_and_model_files_round_trip_through_the_reader(tmp_path):
     assert json.dumps(loaded.to_keras_config(), sort_keys=True) == json.dumps(model.to_keras_config(), sort_keys=True)
 
 
+@pytest.mark.parametrize('n_links', [0, 1, 8, 9, 256, 257, 2500])
+def test_groups_of_any_size_cost_their_own_links_only(tmp_path, n_links):
+    """symbol nodes of <= 8 links under a multi-level v1 B-tree (libhdf5's default K): a 2500-layer file is ~4 MB, not 600"""
+    from DLWP.keras import hdf5_lite as h5
+    root = h5._WGroup()
+    big = root.group('big')
+    names = ['layer_%04d' % i for i in range(n_links)]
+    rng = np.random.default_rng(n_links)
+    for n in rng.permutation(names) if names else []:
+        big.group(str(n)).children['w'] = np.full((3,), float(str(n)[-4:]), dtype=np.float32)
+    root.group('small').children['x'] = np.arange(5, dtype=np.int64)
+    path = str(tmp_path / 'big.h5')
+    h5.write_tree(path, root)
+    assert os.path.getsize(path) < 8192 + 1700 * n_links          # (each link here is a group of its own: ~1.3 KB)
+    with h5.File(path) as f:
+        assert sorted(f['big'].keys()) == names
+        for n in names[::97]:
+            assert np.array_equal(f['big'][n]['w'].read(), np.full((3,), float(n[-4:]), dtype=np.float32))
+        assert np.array_equal(f['small']['x'].read(), np.arange(5))
+    if _has_h5py():
+        script = ('import h5py, sys\n'
+                  'with h5py.File(sys.argv[1], "r") as f:\n'
+                  '    ks = sorted(f["big"].keys())\n'
+                  '    assert len(ks) == int(sys.argv[2]), len(ks)\n'
+                  '    assert all(float(f["big"][k]["w"][0]) == float(k[-4:]) for k in ks)\n'
+                  '    assert list(f["small"]["x"][:]) == [0, 1, 2, 3, 4]\n'
+                  'with h5py.File(sys.argv[1], "a") as f:\n'
+                  '    f["big"].create_group("zz_added")\n'
+                  'with h5py.File(sys.argv[1], "r") as f:\n'
+                  '    assert len(f["big"].keys()) == int(sys.argv[2]) + 1\n')
+        r = subprocess.run([H5PY_PYTHON, '-c', script, path, str(n_links)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        with h5.File(path) as f:
+            assert len(f['big'].keys()) == n_links + 1
+
+
 def test_long_attributes_are_split_like_keras(tmp_path):
     from DLWP.keras import hdf5_lite
     names = ['layer_with_a_rather_long_name_%04d' % i for i in range(2500)]          # > 64 KB of layer names
