@@ -32,6 +32,7 @@ CONV_REUSE_DZ = 4
 CONV_DEFER_REDUCE = 8
 CONV_DEFER_RING0 = 16
 CONV_OUT_PADDED = 32
+CONV_DGRAD_GATHER = 64
 PACK_FWD, PACK_BWD, PACK_BIAS = 0, 1, 2
 WGRAD_BATCH_MAX = 24
 
@@ -97,6 +98,8 @@ PROTOTYPES = {
     'dlwpcs_last_error': (ctypes.c_char_p, []),
     'dlwpcs_halo_table': (c_int, [c_int, c_int, c_void_p]),
     'dlwpcs_halo_inverse_table': (c_int, [c_int, c_int, c_void_p]),
+    'dlwpcs_dgrad_gather_plan_ints': (c_size_t, [c_int]),
+    'dlwpcs_dgrad_gather_plan': (c_int, [c_int, c_void_p]),
     'dlwpcs_pad_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dlwpcs_pad_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dlwpcs_conv_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvDesc)]),
@@ -258,13 +261,38 @@ def halo_inverse_table_host(N, p):
     return out
 
 
+def dgrad_gather_plan_host(N):
+    """dlwpcs_dgrad_gather_plan(N): the inverse table followed by the gather-form data-gradient plan, or None (N < 8)."""
+    n = int(lib().dlwpcs_dgrad_gather_plan_ints(int(N)))
+    if n == 0:
+        return None
+    out = np.empty((n,), dtype=np.int32)
+    check(lib().dlwpcs_dgrad_gather_plan(int(N), out.ctypes.data), 'dlwpcs_dgrad_gather_plan')
+    return out
+
+
+_gather_ok = set()
+
+
+def dgrad_gather_ready(N, p, device):
+    """True when halo_tables(N, p, device)[1] is a dlwpcs_dgrad_gather_plan buffer (CONV_DGRAD_GATHER may be set)."""
+    halo_tables(N, p, device)
+    return (int(N), int(p), str(device)) in _gather_ok
+
+
 def halo_tables(N, p, device):
-    """(table, inverse_table) int32 device tensors, immutable, cached."""
+    """(table, inverse_table) int32 device tensors, immutable, cached.  p == 1, N >= 8: the inverse table is the head of a
+    dlwpcs_dgrad_gather_plan buffer (same pointer serves every call that takes inv_table_dev)."""
     key = (int(N), int(p), str(device))
     hit = _table_cache.get(key)
     if hit is None:
         t = torch.from_numpy(halo_table_host(N, p)).to(device)
-        inv = torch.from_numpy(halo_inverse_table_host(N, p)).to(device)
+        plan = dgrad_gather_plan_host(N) if int(p) == 1 else None
+        if plan is not None:
+            inv = torch.from_numpy(plan).to(device)
+            _gather_ok.add(key)
+        else:
+            inv = torch.from_numpy(halo_inverse_table_host(N, p)).to(device)
         hit = (t, inv)
         _table_cache[key] = hit
     return hit

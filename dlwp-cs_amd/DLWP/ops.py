@@ -5,6 +5,7 @@ are channels_last `(B, 6, H, W, C)` on a HIP device, float32 or bfloat16 (activa
 and the optimizer state are always float32 -- see the dtype note in include/dlwpcs.h).
 """
 import ctypes
+import os
 
 import torch
 
@@ -740,7 +741,7 @@ class _CSConv(torch.autograd.Function):
                                            nat.dtype_tag(dy), stream_ptr()), 'dlwpcs_act_bwd')
             dn = ConvDesc.from_buffer_copy(d)
             dn.act = nat.ACT_NONE
-            dn.flags = d.flags & nat.CONV_PREPACKED
+            dn.flags = (d.flags & nat.CONV_PREPACKED) | _gather_flag(d, dev)
             batching = (direct and WGRAD_BATCH and d.B > 0 and not WGRAD_SIDE_STREAM and wgrad_batch_supported(dn))
             defer = direct and DEFER_WGRAD_REDUCE and not WGRAD_SIDE_STREAM and d.B > 0 and not batching
             ws = _workspace(nbytes, dev, 'defer%d' % len(_deferred)) if defer else _workspace(nbytes, dev)
@@ -783,9 +784,11 @@ class _CSConv(torch.autograd.Function):
             if dsrc0 is not None or dsrc1 is not None:
                 # (d.flags carries CONV_PREPACKED from the forward when packed buffers were used)
                 wq = ctx.packed[3] if ctx.packed is not None else w_eq
+                d.flags |= _gather_flag(d, dev)         # (honoured where the gradient needs no mask on load: layers without activation)
                 check(lib().dlwpcs_conv_bwd_data(ctypes.byref(d), ptr(dy), ptr(y), ptr(wq), ptr(w_pol), ptr(w_np),
                                                  ptr(dsrc0), ptr(dsrc1), ptr(inv), ptr(ws), ws.numel(), stream_ptr()),
                       'dlwpcs_conv_bwd_data')
+                d.flags &= ~nat.CONV_DGRAD_GATHER
         if not reuse_dz:
             run_bwd_data()
         dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np = _weight_gradients(
@@ -798,11 +801,24 @@ class _CSConv(torch.autograd.Function):
 
 _ring_info_cache = {}
 
+# Data gradient in gather form (dlwpcs.h: DLWPCS_CONV_DGRAD_GATHER): bf16 3x3 halo layers whose gradient arrives as dz compute every
+# border cell completely inside the data-gradient kernel (no halo ring, no fix-up launch; window_src 2 x 2 sums for upsampled
+# sources).  Built and bit-checked in round 4 (tests/test_gpu_dgrad_gather.py: <= 1 bf16 ulp against the fp64 oracle), but NOT yet
+# faster than the padded-grid kernel + fix-up launches it replaces (0.766 against 0.684 ms per unet2 step): opt-in,
+# DLWPCS_DGRAD_GATHER=1.
+DGRAD_GATHER = os.environ.get('DLWPCS_DGRAD_GATHER', '0') == '1'
+
+
+def _gather_flag(d, dev):
+    if DGRAD_GATHER and d.halo and d.ksize == 3 and d.dtype == nat.BF16 and nat.dgrad_gather_ready(d.N, 1, dev):
+        return nat.CONV_DGRAD_GATHER
+    return 0
+
 
 def halo_ring_info(d):
     """(byte offset of the padded gradient in the workspace, its channel count) if a data-gradient call on `d` with
     CONV_DEFER_RING0 leaves the fix-up of source 0 to the caller, else None (dlwpcs_conv_ring_info)."""
-    key = (d.B, d.N, d.C0, d.C1, d.Cout, d.ksize, d.halo, d.up0, d.dtype, d.c0_valid)
+    key = (d.B, d.N, d.C0, d.C1, d.Cout, d.ksize, d.halo, d.up0, d.dtype, d.c0_valid, d.flags & nat.CONV_DGRAD_GATHER)
     if key not in _ring_info_cache:
         off, ch = ctypes.c_size_t(), ctypes.c_int()
         ok = lib().dlwpcs_conv_ring_info(ctypes.byref(d), ctypes.byref(off), ctypes.byref(ch))

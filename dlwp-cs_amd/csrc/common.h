@@ -24,6 +24,13 @@ bool prof_enabled();
 int prof_begin(const char *tag, double flops, double bytes, hipStream_t s);
 void prof_end(int idx, hipStream_t s);
 
+// dlwpcs_dgrad_gather_plan buffer (halo_table.cpp): [inverse table 6*N*N*4][header][T 6*M*M][border cells 6*(4N-4)*8][triples 6*2*3]
+constexpr int DGG_HEADER = 8;
+constexpr int DGG_CELL = 8;
+constexpr int32_t DGG_MAGIC = 0x44474731;
+size_t dgrad_gather_plan_ints(int N);
+int dgrad_gather_wids(int N, int32_t out[36]);
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

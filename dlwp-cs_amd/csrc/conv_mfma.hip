@@ -1383,11 +1383,16 @@ static int tile_pixels(int BM, int No) {
     return pix;
 }
 
+// the gather-form plan of the data-gradient launch in flight on this thread (conv_bwd_data_impl sets it around its dispatch_conv;
+// every other launch passes the empty record: the kernels that read it are the EDGE instantiations only)
+static thread_local ConvEdgeArgs g_edge_args{};
+
 template <typename T> struct TName;
 template <> struct TName<float> { static const char *str() { return "float"; } };
 template <> struct TName<bf16_t> { static const char *str() { return "unsigned short"; } };
 
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false, bool MOUT = false>
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false, bool MOUT = false,
+          bool EDGE = false>
 static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     constexpr int ES = sizeof(T), CGW = 32 / ES;
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
@@ -1434,10 +1439,35 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     if (!pool) P.pool_out = nullptr;
     P.colsplit = (pool && halfrows) ? 1 : 0;
     if (P.pool_done) *P.pool_done = pool ? 1 : 0;
-    if (MODE == MODE_ZERO && KS == 3 && P.patches && P.Cout % (16 / ES) == 0 && P.dsplit % (16 / ES) == 0) {
+    if ((MODE == MODE_ZERO || EDGE) && KS == 3 && P.patches && P.Cout % (16 / ES) == 0 && P.dsplit % (16 / ES) == 0) {
         if (P.direct_done) *P.direct_done = (P.d0 || P.d1) ? 1 : 0;             // the line-store epilogue honours d0 / d1
     } else {
         P.d0 = P.d1 = nullptr;
+    }
+    if (EDGE) {
+        // The kernel compacts a lane's border pixels (one pixel per M tile of its wave) into at most 4 levels -- a cube corner takes
+        // two -- and uses ONE weight-id triple per wave: a consumer wave must not hold cells of both edge rows of a face.  Checked
+        // here with the kernel's own pixel map (wave wm owns tile pixels [wm * 32 * MT, + 32 * MT)); a tiling that does not fit is
+        // refused and the caller keeps the padded-grid path (faces of <= 12 x 12 cells in the U-Nets).
+        if (P.No < 8) return fail(DLWPCS_E_UNSUPPORTED, "conv: gather-form data gradient needs N >= 8");
+        const int No = P.No;
+        for (int blk = 0; blk < P.nblk_face; ++blk)
+            for (int wm = 0; wm < WM; ++wm) {
+                bool top = false, bot = false;
+                for (int l = 0; l < 32; ++l) {
+                    int cnt = 0;
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int m = wm * MT * 32 + mt * 32 + l, gm = blk * pix + m;
+                        if (m >= pix || gm >= face_pix) continue;
+                        const int oy = gm / No, ox = gm % No;
+                        const bool ey = oy == 0 || oy == No - 1, ex = ox == 0 || ox == No - 1;
+                        top |= oy == 0; bot |= oy == No - 1;
+                        cnt += (ey || ex) ? ((ey && ex) ? 2 : 1) : 0;
+                    }
+                    if (cnt > 4) return fail(DLWPCS_E_UNSUPPORTED, "conv: gather-form data gradient: more than four edge levels per lane (N=%d)", No);
+                }
+                if (top && bot) return fail(DLWPCS_E_UNSUPPORTED, "conv: gather-form data gradient: a wave holds both edge rows (N=%d)", No);
+            }
     }
     if (lds > 160 * 1024)
         return fail(DLWPCS_E_UNSUPPORTED, "conv: LDS tile of %zu bytes exceeds 160 KiB (face size %d)", lds, P.No);
@@ -1450,7 +1480,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
                     (long)6 * face_pix * P.Cout * ES);
     if ((long)P.Nin * P.Nin * 6 >= (1l << 16) * 6 && (long)P.Nin * P.Nin >= (1l << 16))
         return fail(DLWPCS_E_UNSUPPORTED, "conv: face size %d too large for the 16-bit index arithmetic", P.Nin);
-    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8, MOUT>;
+    auto kern = conv_mfma_ws_kernel<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8, MOUT, EDGE>;
     if (!MOUT || !(P.d0 || P.d1)) {
         // the epilogue masks only what it stores directly: whoever routes the rest (ring fix-up, inverse gather) applies the rest
         if (!(P.d0)) P.m0 = nullptr;
@@ -1506,50 +1536,50 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     int pidx = -1;
     if (prof_enabled()) {
         char tag[160];
-        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s>", TName<T>::str(), KS, KC,
-                 MT, NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? "true" : "false", MOUT ? "true" : "false");
+        snprintf(tag, sizeof(tag), "conv_mfma_ws_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s%s>", TName<T>::str(), KS, KC,
+                 MT, NT, WM, WN, VW, MODE, MASK ? "true" : "false", TAIL8 ? "true" : "false", MOUT ? "true" : "false", EDGE ? ", true" : "");
         pidx = prof_begin(tag, W.flops, W.bytes, s);
     }
-    hipLaunchKernelGGL(kern, grid, dim3(2 * NTHREADS), lds, s, P);
+    hipLaunchKernelGGL(kern, grid, dim3(2 * NTHREADS), lds, s, P, g_edge_args);
     if (pidx >= 0) prof_end(pidx, s);
     return check_launch("conv_mfma");
 }
 
-template <typename T, int KS, int VW, int MODE, bool MASK, bool MOUT = false>
+template <typename T, int KS, int VW, int MODE, bool MASK, bool MOUT = false, bool EDGE = false>
 static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
     const int face_pix = P.No * P.No;
     constexpr int VWF = 16 / (int)sizeof(T);        // full 16-B vectors
     constexpr int K2 = 64 / (int)sizeof(T);         // channels in a 64-B chunk row (16 fp32 / 32 bf16)
     constexpr int K1 = K2 / 2;
-    if constexpr (KS == 1) return launch_conv_cfg<T, KS, K1, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT>(P, W, s);
-    else if constexpr (VW != VWF) return launch_conv_cfg<T, KS, K1, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT>(P, W, s);   // odd channel counts
+    if constexpr (KS == 1) return launch_conv_cfg<T, KS, K1, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
+    else if constexpr (VW != VWF) return launch_conv_cfg<T, KS, K1, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);   // odd channel counts
     else {
         // Measured (MI355X, batch 32): the smaller tiles (MT = 2 / MT = 1) that would even out the tile count per CU
         // lose more to halo re-staging (the producers become the bottleneck) than they gain -> fixed MT = 3 tilings.
-        if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT>(P, W, s);
+        if (P.NTtot == 1) return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
         // data gradient with 64 output channels: the padded grid (N + 2 columns) leaves a 192-pixel tile 3 rows at N = 48
         // (5 fetched per 3 computed, 150 of 192 pixels used); two 32-channel groups with 384-pixel tiles get 7 rows (9 per 7,
         // 350 of 384) and read the smaller operand (dz) twice.  bf16 step -0.7 % (fp32 -0.3 %); the same split for the forward pass
         // measured +-0.
-        if (P.NTtot == 2 && MODE == MODE_ZERO && (tune_bits() & TUNE_CONV_SPLIT2_BWD))
-            return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT>(P, W, s);
+        if (P.NTtot == 2 && (MODE == MODE_ZERO || EDGE) && (tune_bits() & TUNE_CONV_SPLIT2_BWD))
+            return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
         // bf16, 64 output channels from 65-128 input channels (3-4 chunks): 32 output channels per workgroup, whose 4 x 18 KB of
         // fragments fit as resident areas beside two 384-pixel input buffers (64 per workgroup would need 4 x 37 KB)
         // (faces of more than 320 pixels: at N = 12 a 384-pixel tile is 37 % full and the layer came out 6 us slower; the
         // 128 -> 64 forward at N = 24: 33.3 -> 28.5 us)
         if (P.NTtot == 2 && sizeof(T) == 2 && P.CG > 2 * (K2 / (32 / (int)sizeof(T))) && P.CG <= 4 * (K2 / (32 / (int)sizeof(T))) &&
             face_pix > 320 && (tune_bits() & TUNE_CONV_WSTAT))
-            return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT>(P, W, s);
-        if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK, false, MOUT>(P, W, s);
+            return launch_conv_cfg<T, KS, K2, 3, 1, 4, 1, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
+        if (P.NTtot == 2) return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
         // more than 64 output channels: 64 per workgroup (two 32-channel chunks whose weight fragments STAY in the two LDS
         // buffers) and the 256 workgroups split over the output-channel groups, instead of 128 channels per workgroup in four
         // 16-channel chunks whose 37 KB of fragments had to be re-fetched every chunk (the 128-channel data gradient at N = 24:
         // 43.9 us, producers weight-fetch-bound; whole bf16 step -1.9 %, fp32 -0.9 %)
         // (not the forward pass on faces of <= 320 pixels: 64 -> 128 at N = 12 measured 13.4 us with the 160-pixel tiling, 14.9 split)
         if ((tune_bits() & TUNE_CONV_SPLIT_N) && (face_pix > 320 || MODE == MODE_ZERO))
-            return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK, false, MOUT>(P, W, s);
-        if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK, false, MOUT>(P, W, s);
-        return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK, false, MOUT>(P, W, s);
+            return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
+        if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
+        return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
     }
 }
 
@@ -1569,6 +1599,16 @@ template <typename T>
 static int dispatch_conv_t(int KS, int vw, const ConvKParams &P, const Work &W, hipStream_t s) {
     const bool mask = P.ymask != nullptr;
     if (KS == 3) {
+        if (P.mode == MODE_HALO && P.edge) {
+            // data gradient in gather form (bf16, 16-B channel vectors; conv_bwd_data_impl checked)
+            if constexpr (sizeof(T) == 2) {
+                if (vw == 8) {
+                    if (P.m0 || P.m1) return launch_conv<T, 3, 8, MODE_HALO, false, true, true>(P, W, s);
+                    return launch_conv<T, 3, 8, MODE_HALO, false, false, true>(P, W, s);
+                }
+            }
+            return fail(DLWPCS_E_UNSUPPORTED, "conv: gather-form data gradient serves bf16 with 16-B channel vectors");
+        }
         if (P.mode == MODE_HALO) return dispatch_vw<T, 3, MODE_HALO, false>(vw, P, W, s);
         if (P.mode == MODE_DIRECT) return dispatch_vw<T, 3, MODE_DIRECT, false>(vw, P, W, s);
         if constexpr (sizeof(T) == 2) {
@@ -2067,6 +2107,52 @@ static int conv_bwd_data_impl(const dlwpcs_conv_desc *d, const void *dy, const v
     P.m0 = P.d0 ? m0 : nullptr; P.m1 = P.d1 ? m1 : nullptr;
     P.m_alpha = m_alpha; P.m_vmax = m_vmax; P.m_thr1 = bf16_mask_threshold(m_vmax);
     P.mask_done = &mask_done;
+    // ---- gather form (DLWPCS_CONV_DGRAD_GATHER; conv_ws.h EDGE): the gradient on the N x N grid, every cell complete when it is
+    // stored.  Sources that are not upsampled are written directly (masked where asked), an upsampled source 0 goes through the
+    // workspace and ONE 2 x 2 block-sum launch; no halo ring, no fix-up, no inverse gather.
+    if ((d->flags & DLWPCS_CONV_DGRAD_GATHER) && d->halo && d->ksize == 3 && d->dtype == DLWPCS_BF16 && !P.ymask && d->N >= 8 &&
+        vec_width(d->Cout, 0, d->dtype) == 8 && d->C0 % 8 == 0 && d->C1 % 8 == 0) {
+        ConvKParams G = P;
+        const int M = d->N + 2;
+        const int32_t *plan = inv_table_dev + (size_t)6 * d->N * d->N * 4 + DGG_HEADER;
+        G.table = plan; G.edge = 1;
+        G.mode = MODE_HALO; G.Nin = d->N; G.No = d->N;
+        ConvEdgeArgs EA{};
+        EA.src = plan + (size_t)6 * M * M;
+        int32_t wids[36];
+        int grc = dgrad_gather_wids(d->N, wids);
+        for (int k = 0; k < 36; ++k) EA.wids[k] = (int8_t)wids[k];
+        g_edge_args = EA;
+        G.d0 = (dsrc0 && !d->up0) ? dsrc0 : nullptr;
+        G.d1 = (dsrc1 && d->C1 > 0) ? dsrc1 : nullptr;
+        G.m0 = G.d0 ? m0 : nullptr; G.m1 = G.d1 ? m1 : nullptr;
+        int g_direct = 0, g_mask = 0;
+        G.direct_done = &g_direct; G.mask_done = &g_mask;
+        G.dry_run = 1;
+        const bool need_direct = G.d0 || G.d1;
+        if (!grc) grc = dispatch_conv(d->dtype, d->ksize, 8, G, conv_work(d), s);
+        if (!grc && (g_direct || !need_direct)) {
+            if (ring_query) { *ring_query = 0; return DLWPCS_OK; }      // nothing is deferred: there is no ring
+            G.dry_run = 0;
+            grc = dispatch_conv(d->dtype, d->ksize, 8, G, conv_work(d), s);
+            if (grc) return grc;
+            bool todo0 = m0 != nullptr && !(G.d0 && (g_mask & 1)), todo1 = m1 != nullptr && !(G.d1 && (g_mask & 2));
+            if (dsrc0 && !G.d0) {
+                int masked = 0;
+                grc = launch_src_grad(dxv, dsrc0, nullptr, d->B, d->N, Cin, 0, d->C0, d->up0, 0, d->dtype, s, m0, m_alpha, m_vmax, &masked);
+                if (grc) return grc;
+                if (masked) todo0 = false;
+            }
+            if (dsrc1 && d->C1 > 0 && !G.d1) {
+                int masked = 0;
+                grc = launch_src_grad(dxv, dsrc1, nullptr, d->B, d->N, Cin, d->C0, d->C1, 0, 0, d->dtype, s, m1, m_alpha, m_vmax, &masked);
+                if (grc) return grc;
+                if (masked) todo1 = false;
+            }
+            return finish_masks(todo0, todo1);
+        }
+        // (a tiling without the line-store epilogue: the padded-grid path below)
+    }
     // no halo, no upsample, one source: the virtual input IS the source -> write its gradient in place (no routing pass)
     const bool whole = !d->halo && !d->up0 && d->C1 == 0 && dsrc0;
     if (whole) P.out = dsrc0;

@@ -17,6 +17,7 @@ struct ConvKParams {
     const float *bias;          // packed bias [3][NTtot*32] fp32 or nullptr
     void *out;                  // (B,6,No,No,Cout), element type T
     const int32_t *table;       // (6, Nin+2, Nin+2) halo table (MODE_HALO, k=3)
+    int edge;                   // EDGE instantiations (data gradient in gather form, see conv_ws_body and ConvEdgeArgs): requested
     int B, Nin, No;             // face size of V, face size of the output
     int C0, C1, Cin, Cout;      // Cin = C0 + C1
     int CG, NTtot;              // ceil(Cin/CGW) (CGW = 8 fp32 / 16 bf16 channels per MFMA operand group), ceil(Cout/32)
@@ -70,6 +71,12 @@ struct ConvKParams {
     long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
 };
 
+// EDGE instantiations: `P.table` is the forward halo table inside a dlwpcs_dgrad_gather_plan buffer, `src` its border-cell records
+// [6][4 No - 4][8] (six window positions, the wrong-tap mask, 0), `wids` the two weight-id triples per face [6][2][3] BY VALUE (scalar
+// loads out of the kernel arguments: no memory round trip in front of the fragment loads that need them).  A kernel argument of
+// its own: the chain launch packs eight ConvKParams into the 4 KB argument segment.
+struct ConvEdgeArgs { const int32_t *src; int8_t wids[36]; };
+
 // What a chain launch needs of one layer: the parameter block launch_conv_cfg finished, which instantiation it chose (chain_cfg
 // below; -1 = none the chain kernel carries), its grid's y extent and its LDS bytes.
 struct ConvPlanOut { ConvKParams P; int cfg, gy; size_t lds; };
@@ -109,7 +116,8 @@ enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS
 static int tune_bits() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_WG_PRODUCER_PRIO | TUNE_CONV_PRODUCER_PRIO | TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT |
-                               TUNE_CONV_STAGGER | TUNE_CONV_ILV | (3 << 12)); }
+                               TUNE_CONV_STAGGER | TUNE_CONV_ILV | (3 << 12));
+                 const char *o = getenv("DLWPCS_TUNE_OR"); if (o) v |= atoi(o); }     // (A/B runs: extra bits on top of the defaults)
     return v;
 }
 
@@ -206,12 +214,23 @@ template <bool CHAIN, typename V, typename T> __device__ __forceinline__ V ld_ac
 // (no early exits: a chain launch meets at a workgroup barrier behind it).  CHAIN: the activations this call reads may have been
 // written EARLIER IN THE SAME LAUNCH by other workgroups (write-through stores): their loads bypass this CU's L1
 // (nontemporal: L2-served), see conv_chain.hip.
+// EDGE (round 4): the DATA GRADIENT IN GATHER FORM.  MODE_HALO on the N x N grid with the flipped operand pack: the main loop is the
+// plain correlation of the HALO-PADDED dz (the forward's own gather).  Taps that stay inside the face, and taps that cross an
+// equatorial-equatorial edge (same kernel, same orientation), are terms of the adjoint of DLWP/custom.py:1198-1308 as they are.  A
+// tap that crosses any other edge is WRONG: the adjoint wants the same halo cell's dz row times a tap of the NEIGHBOUR's kernel
+// (rotated into this face's frame).  Both corrections run per channel chunk right behind the chunk's MFMAs, out of the SAME LDS
+// tile, for the few border pixels of a wave compacted into "levels" (one edge M tile each): the wrong taps are cancelled (pixel
+// operand negated, the face's own fragments out of the LDS weight area), the true terms added (fragments of (variant, tap) out of the
+// packed operands, fetched from L2 while the chunk's main MFMAs run).  No global gathers, no memory latency in the consumers' path;
+// every cell is complete when it is stored: no halo ring, no fix-up launch, one rounding.  Stores go to d0 / d1 like the direct
+// mode's interior cells (all cells are interior here), masks (MOUT) included.
 template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false, bool MOUT = false,
-          bool CHAIN = false>
+          bool CHAIN = false, bool EDGE = false>
 __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, const uint32_t lw, const int G, const int by,
-                                             const int b0 = 0) {
+                                             const int b0 = 0, const ConvEdgeArgs &E = ConvEdgeArgs{}) {
     static_assert(!TAIL8 || (VW == 8 && sizeof(T) == 2 && !MASK), "TAIL8: bf16 16-B vectors, forward only");
-    static_assert(!MOUT || (MODE == MODE_ZERO && KS == 3 && sizeof(T) == 2 && !MASK), "MOUT: bf16 data gradient, direct mode");
+    static_assert(!MOUT || ((MODE == MODE_ZERO || EDGE) && KS == 3 && sizeof(T) == 2 && !MASK), "MOUT: bf16 data gradient, direct mode");
+    static_assert(!EDGE || (MODE == MODE_HALO && KS == 3 && !MASK && !TAIL8 && !CHAIN && VW * sizeof(T) == 16), "EDGE: gather-form data gradient");
     constexpr int ES = sizeof(T);
     constexpr int CGW = 32 / ES;                    // channels per MFMA operand group (two 16-B half fragments)
     constexpr int TAPS = KS * KS;
@@ -577,7 +596,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     constexpr int LPP = 32 * ES / 16;           // epilogue: lanes per pixel on the way out (16 B each): 8 fp32 / 4 bf16
     constexpr int PPP = 64 / LPP;               // pixels per store pass
     constexpr int NPS = 32 / PPP;               // store passes per M tile
-    constexpr bool DIRECT = MODE == MODE_ZERO && KS == 3;   // data gradient: interior cells go straight to the sources
+    constexpr bool DIRECT = (MODE == MODE_ZERO || EDGE) && KS == 3;   // data gradient: interior cells go straight to the sources
+    constexpr int RING = EDGE ? 0 : 1;          // width of the ring around the sources' cells on the output grid (gather form: none)
     int g = 0;
 #ifdef DLWPCS_TIMELINE
     int tli = 0;
@@ -586,6 +606,39 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     TL_MARK();
     int abase[MT];
     int cur_combo = -1, cur_v = -1;
+    // EDGE: per (face, band).  A lane owns pixel l31 of each of the wave's MT M tiles; the few of them that are border cells with
+    // corrections are compacted into LEVELS: level L of a lane = its L-th such pixel (a cube corner, with two terms per weight id,
+    // takes two): lvm = the M tile it belongs to (-1: none), lvb = the LDS offset of its window's first cell (abase), lvw = its
+    // wrong-tap mask, lvo = the LDS offsets of the halo cells its three true terms read (-1: none).  One level of the whole wave is
+    // ONE edge M tile whose scratch accumulator is added to the accumulator of the M tile each lane's pixel lives in.  Uniform:
+    // lv_any (bit L: some lane has a level L), wcls (the wave holds
+    // cells of the face's last row: second weight-id triple; launch_conv_cfg guarantees a wave never holds both edge rows).
+    // (register budget: two VGPRs per level -- lvb, and lvp = positions + 1 of the three slots (4 bits each, 0 = none) | wrong-tap mask
+    // << 12 | (M tile + 1) << 21; the uniform "does any lane ..." questions are asked with a ballot where they are needed)
+    constexpr int LV = 4;
+    int lvb[EDGE ? LV : 1];
+    uint32_t lvp[EDGE ? LV : 1];
+    uint32_t lv_any = 0, wcls = 0, lv_rows = 0;     // lv_rows: bit 3 * L + a = some lane of level L has a wrong tap in window row a
+    // the true terms' weight fragments (variant, tap) x operand groups of a chunk out of the packed operands: per (face, band) when the
+    // layer is one chunk (they stay in registers across the tiles of a combo), else fetched by every edge_chunk (an exposed L2 round trip)
+    uint4 wfk[EDGE ? 3 : 1][EDGE ? KCG : 1][EDGE ? NT : 1];
+    auto edge_wload = [&](int f, int ch) {
+        if constexpr (EDGE) {
+            const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.wpk);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int wid = max((int)E.wids[(f * 2 + (int)wcls) * 3 + k], 0);
+                const int wv = wid / 9, wtap = wid - wv * 9;
+#pragma unroll
+                for (int cgl = 0; cgl < KCG; ++cgl)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int ntile = min(nt0 + wn * NT + nt, P.NTtot - 1), cg = min(ch * KCG + cgl, P.CG - 1);
+                        wfk[k][cgl][nt] = wsrc[(((size_t)wv * P.NTtot + ntile) * P.CG + cg) * GF4 + wtap * 64 + lane];
+                    }
+            }
+        }
+    };
     float4 bq[NT][4];
     // store pass (nt, mt, ps) of this lane: byte offset of its 16 B inside ONE sample of the destination (ST_SKIP: nothing to
     // store) and, data gradient in direct mode, which destination (2 bits each: 0 = out, 1 = d0, 2 = d1).  Like the LDS
@@ -604,13 +657,13 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         if constexpr (DIRECT) {
             // direct mode: an interior cell of the padded gradient IS cell (oy-1, ox-1) of the source
             const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
-            const int Ns = P.No - 2;
+            const int Ns = P.No - 2 * RING;
             const bool in0 = c < P.dsplit;
             const bool have = (in0 ? P.d0 : P.d1) != nullptr;
             const int cs = in0 ? c : c - P.dsplit, CS = in0 ? P.dsplit : P.Cout - P.dsplit;
-            const bool interior = ((uint32_t)(oy - 1) < (uint32_t)Ns) & ((uint32_t)(ox - 1) < (uint32_t)Ns);
+            const bool interior = ((uint32_t)(oy - RING) < (uint32_t)Ns) & ((uint32_t)(ox - RING) < (uint32_t)Ns);
             if (interior && have) {
-                off = ((gq.f * Ns + (oy - 1)) * Ns + (ox - 1)) * CS + cs;
+                off = ((gq.f * Ns + (oy - RING)) * Ns + (ox - RING)) * CS + cs;
                 sel = in0 ? 1u : 2u;
             }
         }
@@ -666,6 +719,79 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                     base = ((oy - gq.y0) * P.W2 + ox) * RB;
                 }
                 abase[mt] = base + half * 16;
+            }
+            if constexpr (EDGE) {
+                // ONE memory round trip per (face, band): the weight fragments of the face's triple and the border-cell records are
+                // requested together (nothing here depends on a loaded value until both are waited for below).  Consumer waves do
+                // this while the producers' first loads are in flight -- a chain of dependent round trips here (records -> triple ->
+                // fragments) cost 12 us per launch, more than all corrections together.
+                bool last_row = false;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = tile_pix(mt * 32 + l31);
+                    const int oy = __umulhi((uint32_t)(gq.m0 + min(m, gq.npix - 1)), P.magicNo);
+                    last_row |= m < gq.npix && oy == P.No - 1;
+                }
+                wcls = __builtin_amdgcn_ballot_w64(last_row) != 0 ? 1u : 0u;
+                // (equatorial faces: only the bands that hold the first or the last row have corrections)
+                const int ylast = __umulhi((uint32_t)(gq.m0 + gq.npix - 1), P.magicNo);
+                const bool maybe = gq.f >= 4 || gq.y0 == 0 || ylast == P.No - 1;
+                if (maybe && nchunks == 1) edge_wload(gq.f, 0);
+                int cnt = 0;
+#pragma unroll
+                for (int L = 0; L < LV; ++L) { lvb[L] = 0; lvp[L] = 0; }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = tile_pix(mt * 32 + l31);
+                    const int gm = gq.m0 + min(m, gq.npix - 1);
+                    const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
+                    const bool border = maybe && m < gq.npix && ((oy == 0) | (oy == P.No - 1) | (ox == 0) | (ox == P.No - 1));
+                    const int ord = oy == 0 ? ox : (oy == P.No - 1 ? P.No + ox : 2 * P.No + 2 * (oy - 1) + (ox ? 1 : 0));
+                    int4 e0 = make_int4(-1, -1, -1, -1), e1 = make_int4(-1, -1, 0, 0);
+                    if (maybe) {
+                        const int4 *es = reinterpret_cast<const int4 *>(E.src + ((size_t)gq.f * (4 * P.No - 4) + (border ? ord : 0)) * 8);
+                        e0 = es[0]; e1 = es[1];
+                    }
+                    const uint32_t wrong = border ? (uint32_t)e1.z : 0u;
+                    // (slot values are -1 or 0..8: + 1 packs them as 0 = none)
+                    const uint32_t p0 = border ? (uint32_t)(e0.x + 1) | (uint32_t)(e0.y + 1) << 4 | (uint32_t)(e0.z + 1) << 8 : 0u;
+                    const uint32_t p1 = border ? (uint32_t)(e0.w + 1) | (uint32_t)(e1.x + 1) << 4 | (uint32_t)(e1.y + 1) << 8 : 0u;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {       // the first three slots (+ the cancellations), then the second terms of a cube corner
+                        const uint32_t rec = (h == 0 ? (p0 | wrong << 12) : p1);
+                        const bool have = rec != 0;
+#pragma unroll
+                        for (int L = 0; L < LV; ++L) {
+                            const bool here = have && cnt == L;
+                            lvb[L] = here ? abase[mt] : lvb[L];
+                            lvp[L] = here ? (rec | (uint32_t)(mt + 1) << 21) : lvp[L];
+                        }
+                        cnt += have ? 1 : 0;
+                    }
+                }
+                lv_any = 0; lv_rows = 0;
+#pragma unroll
+                for (int L = 0; L < LV; ++L) {
+                    if (__builtin_amdgcn_ballot_w64(lvp[L] != 0) != 0) lv_any |= 1u << L;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        if (__builtin_amdgcn_ballot_w64(((lvp[L] >> (12 + 3 * a)) & 7u) != 0) != 0) lv_rows |= 1u << (3 * L + a);
+                }
+                if (P.tune & (1 << 20)) lv_any = 0;         // (ablation, timing only: no corrections -- wrong border cells)
+                if (maybe && nchunks == 1) {
+                    // the fragments are waited for HERE, inside the (rare) branch (the empty asm redefines the registers: nothing is
+                    // pending on them at the join) -- else every tile's first use sits behind s_waitcnt vmcnt(0), i.e. behind the
+                    // acknowledgement of the previous tile's stores
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int cgl = 0; cgl < KCG; ++cgl)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                asm volatile("" : "+v"(wfk[k][cgl][nt].x), "+v"(wfk[k][cgl][nt].y), "+v"(wfk[k][cgl][nt].z), "+v"(wfk[k][cgl][nt].w));
+                }
+#pragma unroll
+                for (int L = 0; L < LV; ++L) asm volatile("" : "+v"(lvb[L]), "+v"(lvp[L]));
             }
             if constexpr (MODE != MODE_ZERO) {
                 if (pooling) pool_setup(gq);
@@ -769,11 +895,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         return make_rsrc(reinterpret_cast<T *>(P.out) + (size_t)gq.b * 6 * face_pix * P.Cout, (uint32_t)(6 * face_pix * P.Cout * ES));
     };
     auto d0_of = [&](const Geo &gq) {
-        const int spix = 6 * (P.No - 2) * (P.No - 2);
+        const int spix = 6 * (P.No - 2 * RING) * (P.No - 2 * RING);
         return make_rsrc(P.d0 ? reinterpret_cast<T *>(P.d0) + (size_t)gq.b * spix * P.dsplit : nullptr, (uint32_t)(spix * P.dsplit * ES));
     };
     auto d1_of = [&](const Geo &gq) {
-        const int spix = 6 * (P.No - 2) * (P.No - 2), c1 = P.Cout - P.dsplit;
+        const int spix = 6 * (P.No - 2 * RING) * (P.No - 2 * RING), c1 = P.Cout - P.dsplit;
         return make_rsrc(P.d1 ? reinterpret_cast<T *>(P.d1) + (size_t)gq.b * spix * c1 : nullptr, (uint32_t)(spix * c1 * ES));
     };
     // MOUT: the sources' own values at the cells this lane will store to d0 / d1, requested at the start of the tile (they land
@@ -782,7 +908,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     uint4 ymq[MOUT ? NT : 1][MOUT ? MT : 1][MOUT ? NPS : 1];
     auto mask_load = [&](const Geo &gq) {
         if constexpr (MOUT) {
-            const int spix = 6 * (P.No - 2) * (P.No - 2), c1 = P.Cout - P.dsplit;
+            const int spix = 6 * (P.No - 2 * RING) * (P.No - 2 * RING), c1 = P.Cout - P.dsplit;
             const rsrc_t r0 = make_rsrc(P.m0 ? reinterpret_cast<const T *>(P.m0) + (size_t)gq.b * spix * P.dsplit : nullptr,
                                         (uint32_t)(spix * P.dsplit * ES));
             const rsrc_t r1 = make_rsrc(P.m1 ? reinterpret_cast<const T *>(P.m1) + (size_t)gq.b * spix * c1 : nullptr,
@@ -986,6 +1112,106 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         }
     };
 
+    // ---- EDGE: the corrections of one channel chunk (see the head of the function).  edge_wload: the true terms' weight fragments
+    // (variant, tap) of the chunk's operand groups out of the packed operands, issued BEFORE the chunk's main MFMAs; edge_chunk: behind
+    // them, between the same two barriers (the chunk's LDS buffer is still this workgroup's).
+    constexpr uint32_t SIGN = ES == 2 ? 0x80008000u : 0x80000000u;
+    auto edge_chunk = [&](const Geo &gq, int ch) {
+      if constexpr (EDGE) {
+        const char *lds_in = smem + (g & 1) * in_step, *lds_w = smem + w_base + (P.wstat ? ch : (g & 1)) * w_step;
+        if (nchunks != 1) edge_wload(gq.f, ch);
+#pragma unroll 1
+        for (int L = 0; L < LV; ++L) {
+            if (!((lv_any >> L) & 1u)) break;           // (levels fill from 0: the first empty one ends the list)
+            if ((P.tune & (1 << 24)) && L > 0) break;   // (ablations, timing only: bits 21 / 22 / 23 / 24 = no cancel / no true terms / no merge / level 0 only)
+            // (runtime loop, static register indices: the level's two registers are selected, not indexed)
+            const int lb = L == 0 ? lvb[0] : (L == 1 ? lvb[1] : (L == 2 ? lvb[2] : lvb[3]));
+            const uint32_t lp = L == 0 ? lvp[0] : (L == 1 ? lvp[1] : (L == 2 ? lvp[2] : lvp[3]));
+            // two scratch accumulators per N tile (operand group 0 / 1, or alternating taps): two independent MFMA chains
+            f32x16 ae[2][NT];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ae[u][nt][r] = 0.f;
+            // cancel the wrong crossing taps: - dzpad[window + tap] . W_own[tap], one window ROW at a time (uniform: rows in which no
+            // lane of the level has a wrong tap are skipped -- the cells of an edge row only have row 0 or row 2).  Per row every LDS
+            // read (three pixel fragments and three weight fragments per operand group) is issued before the first MFMA: left to
+            // itself the compiler waits for each read in front of the MFMA that needs it, ~190 cycles per MFMA, 4 k per level.
+            if (!(P.tune & (1 << 21)))
+#pragma unroll
+            for (int a = 0; a < KS; ++a) {
+                if (!((lv_rows >> (3 * L + a)) & 1u)) continue;
+                uint4 px[KS][KCG], wq[KS][KCG][NT];
+#pragma unroll
+                for (int b = 0; b < KS; ++b)
+#pragma unroll
+                    for (int cgl = 0; cgl < KCG; ++cgl) {
+                        px[b][cgl] = *reinterpret_cast<const uint4 *>(lds_in + lb + (a * P.W2 + b) * RB + cgl * 32);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            wq[b][cgl][nt] = *reinterpret_cast<const uint4 *>(
+                                lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + a * KS + b) * 2 + half) * 512 + l31 * 16);
+                    }
+#pragma unroll
+                for (int b = 0; b < KS; ++b) {
+                    const bool on = (lp >> (12 + a * KS + b)) & 1u;
+#pragma unroll
+                    for (int cgl = 0; cgl < KCG; ++cgl) {
+                        uint4 &q = px[b][cgl];
+                        q.x = on ? q.x ^ SIGN : 0u; q.y = on ? q.y ^ SIGN : 0u; q.z = on ? q.z ^ SIGN : 0u; q.w = on ? q.w ^ SIGN : 0u;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < KS; ++b)
+#pragma unroll
+                    for (int cgl = 0; cgl < KCG; ++cgl)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) frag_mma<T>(ae[(b * KCG + cgl) & 1][nt], wq[b][cgl][nt], px[b][cgl]);
+            }
+            // add the true terms: + dzpad[the term's halo cell] . W_neighbour[its tap] (fragments in registers)
+            if (!(P.tune & (1 << 22))) {
+                uint4 px[3][KCG];
+                bool on[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int ps1 = (int)((lp >> (4 * k)) & 15u);
+                    on[k] = ps1 != 0;
+                    const int ps = max(ps1 - 1, 0), pa = ps / 3;
+                    const int off = lb + (pa * P.W2 + (ps - 3 * pa)) * RB;
+#pragma unroll
+                    for (int cgl = 0; cgl < KCG; ++cgl) px[k][cgl] = *reinterpret_cast<const uint4 *>(lds_in + off + cgl * 32);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int cgl = 0; cgl < KCG; ++cgl) {
+                        uint4 &q = px[k][cgl];
+                        q.x = on[k] ? q.x : 0u; q.y = on[k] ? q.y : 0u; q.z = on[k] ? q.z : 0u; q.w = on[k] ? q.w : 0u;
+                    }
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int cgl = 0; cgl < KCG; ++cgl)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) frag_mma<T>(ae[(k * KCG + cgl) & 1][nt], wfk[k][cgl][nt], px[k][cgl]);
+            }
+            // a lane's column of the scratch accumulators belongs to the M tile its level-L pixel lives in
+            const int lm = (int)(lp >> 21) - 1;
+            if (!(P.tune & (1 << 23)))
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float on = lm == mt ? 1.f : 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = __builtin_fmaf(on, ae[0][nt][r] + ae[1][nt][r], acc[mt][nt][r]);
+            }
+        }
+      }
+    };
+
     const bool lines = P.patches && (P.Cout % (16 / ES)) == 0;
     // FLOW: this wave's arrival for the PREVIOUS tile is posted behind the matrix phase of the current one: its stores have long
     // left by then, the wait costs nothing (posting right behind the epilogue would put a store round trip into every tile)
@@ -1022,6 +1248,9 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 if (my_mt >= MT) mma_chunk(ch, std::integral_constant<int, MT>{});
                 else if (my_mt == 2) mma_chunk(ch, std::integral_constant<int, 2>{});
                 else if (my_mt == 1) mma_chunk(ch, std::integral_constant<int, 1>{});
+            } else if constexpr (EDGE) {
+                mma_chunk(ch, std::integral_constant<int, MT>{});
+                if (lv_any != 0) edge_chunk(gq, ch);      // uniform; most tiles of the equatorial faces need no correction at all
             } else {
                 mma_chunk(ch, std::integral_constant<int, MT>{});
             }
@@ -1044,11 +1273,12 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 }
 
 // the per-layer launch: one workgroup per CU, workers laid out XCD-aware over the tile list
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false, bool MOUT = false>
-__global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P) {
+template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false, bool MOUT = false,
+          bool EDGE = false>
+__global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P, const ConvEdgeArgs E) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv_ws_body<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8, MOUT, false>(P, smem, xcd_remap(blockIdx.x, gridDim.x), (int)gridDim.x,
-                                                                              (int)blockIdx.y);
+    conv_ws_body<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8, MOUT, false, EDGE>(P, smem, xcd_remap(blockIdx.x, gridDim.x),
+                                                                                    (int)gridDim.x, (int)blockIdx.y, 0, E);
 }
 
 }  // namespace dlwpcs

@@ -266,7 +266,8 @@ __global__ void __launch_bounds__(256) src_pair_kernel(const V *__restrict__ dxp
 // gradient of one source of a halo==0 convolution input (no padding): channel window copy, optional 2x2 sum
 template <typename V>
 __global__ void __launch_bounds__(256) window_src_kernel(const V *__restrict__ dxv, V *__restrict__ dsrc, size_t total,
-                                                         int CSV, int CTV, int choffV, int N, int up) {
+                                                         int CSV, int CTV, int choffV, int N, int up,
+                                                         const V *__restrict__ msrc = nullptr, float m_alpha = 0.f, float m_vmax = 0.f) {
     const int No = up ? N / 2 : N;
     const int out_cells = 6 * No * No;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -283,6 +284,7 @@ __global__ void __launch_bounds__(256) window_src_kernel(const V *__restrict__ d
                 const int yy = up ? 2 * yo + uy : yo, xx = up ? 2 * xo + ux : xo;
                 acc = vadd(acc, VT<V>::ld(base + (size_t)((f * N + yy) * N + xx) * CTV));
             }
+        if (msrc) acc = vmaskacc(acc, VT<V>::ld(msrc + e), m_alpha, m_vmax);     // pre-masked gradients: x act'(the source itself)
         VT<V>::st(dsrc + e, acc);
     }
 }
@@ -806,7 +808,7 @@ int launch_mask_inplace(void *dx, const void *m, size_t n, float alpha, float vm
 // msrc (halo only): the source itself, the gradient is multiplied by act'(msrc); returns through *masked whether it was
 int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int N, int CT, int choff, int CS, int up,
                     int halo, int dtype, hipStream_t s, const void *msrc, float m_alpha, float m_vmax, int *masked) {
-    if (masked) *masked = (halo && msrc) ? 1 : 0;
+    if (masked) *masked = msrc ? 1 : 0;
     const int No = up ? N / 2 : N;
     // common divisor of the three channel counts decides the vector width
     int g = 8;
@@ -819,7 +821,7 @@ int launch_src_grad(const void *dxv, void *dsrc, const int32_t *inv, int B, int 
                                total, CS / w, CT / w, choff / w, N, up, (const V *)msrc, m_alpha, m_vmax);
         else
             hipLaunchKernelGGL(window_src_kernel<V>, stream_grid(total), dim3(256), 0, s, (const V *)dxv, (V *)dsrc, total,
-                               CS / w, CT / w, choff / w, N, up);
+                               CS / w, CT / w, choff / w, N, up, (const V *)msrc, m_alpha, m_vmax);
     });
     return check_launch("src_grad");
 }

@@ -74,6 +74,16 @@ int dlwpcs_halo_table(int N, int p, int32_t *out);
  * it besides its own identity copy at (face, row+p, col+p); unused slots are -1.  (Fan-out <= 5) */
 int dlwpcs_halo_inverse_table(int N, int p, int32_t *inv);
 
+/* Gather form of the data gradient (p = 1, 3x3 layers; the adjoint of DLWP/custom.py:1198-1308 folded into the kernel that
+ * computes the gradient, SURVEY 2a "cs_conv_dgrad ... with halo scatter folded in").  out[dlwpcs_dgrad_gather_plan_ints(N)]:
+ * the inverse table of dlwpcs_halo_inverse_table(N, 1) FIRST (so the buffer serves every call that takes inv_table_dev), then
+ * the plan: a data-gradient halo table (the forward's table where the neighbour contributes exactly the term the correlation
+ * forms, -1 elsewhere), six source slots per border cell and two weight-id triples per face for the terms it does not (see
+ * csrc/halo_table.cpp).  A data-gradient call whose inv_table_dev is such a buffer sets DLWPCS_CONV_DGRAD_GATHER.
+ * dlwpcs_dgrad_gather_plan_ints returns 0 for face sizes the plan does not serve (N < 8). */
+size_t dlwpcs_dgrad_gather_plan_ints(int N);
+int dlwpcs_dgrad_gather_plan(int N, int32_t *out);
+
 /* ------------------------------------------------------------------------------------------------------------- *
  * Stand-alone padding layer, channels_last.  x: (B,6,N,N,C)  y: (B,6,N+2p,N+2p,C)
  * ------------------------------------------------------------------------------------------------------------- */
@@ -112,6 +122,11 @@ int dlwpcs_pad_bwd(const void *dy, void *dx, int B, int N, int C, int p, int dty
                                           * halo ring stays in the workspace (dlwpcs_conv_ring_info) and the caller's next pass
                                           * over dsrc0 adds it (dlwpcs_avgpool2_bwd_ring).  Only where dlwpcs_conv_ring_info
                                           * returns 1 for the descriptor; ignored otherwise */
+#define DLWPCS_CONV_DGRAD_GATHER    64   /* conv_bwd_data[_masked], halo, k = 3, bf16 with 16-B channel vectors, gradient arriving as dz:
+                                          * inv_table_dev is a dlwpcs_dgrad_gather_plan buffer and the data gradient is computed in
+                                          * GATHER form on the N x N grid -- every border cell sums the terms of the neighbouring
+                                          * faces itself (extra MFMAs on gathered dz rows): no halo ring is written, no fix-up launch
+                                          * follows, dlwpcs_conv_ring_info returns 0.  Ignored where the kernel does not apply. */
 #define DLWPCS_CONV_OUT_PADDED      32   /* conv_fwd of the pointwise bf16 output layer (k = 1, 32 -> even C_out in 8..32, no halo): y has
                                         * C_out rounded up to a multiple of 8 channels per pixel, the padding written as zeros -- the
                                         * layout a following dlwpcs_conv_fwd takes as its source with c0_valid = C_out (an

@@ -25,14 +25,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--only', default='', help='comma-separated layer names')
+    ap.add_argument('--gather', type=int, default=0, help='1: data gradient in gather form (CONV_DGRAD_GATHER)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     lib = nat.lib()
     B = args.batch
     for (name, N, C0, C1, up0, Cout) in LAYERS:
+        if args.only and name not in args.only.split(','):
+            continue
         n0 = N // 2 if up0 else N
         d = nat.ConvDesc(B=B, N=N, C0=C0, C1=C1, Cout=Cout, ksize=3, halo=1, up0=up0, flip_north_pole=1, act=0, alpha=0., vmax=0.,
-                         dtype=nat.BF16, flags=0, c0_valid=0)
+                         dtype=nat.BF16, flags=nat.CONV_DGRAD_GATHER if args.gather else 0, c0_valid=0)
         cin = C0 + C1
         dz = torch.randn(B, 6, N, N, Cout, device=dev).to(torch.bfloat16)
         w = [torch.randn(3, 3, cin, Cout, device=dev) / (9 * cin) ** 0.5 for _ in range(2)]
