@@ -1120,6 +1120,9 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
       if constexpr (EDGE) {
         const char *lds_in = smem + (g & 1) * in_step, *lds_w = smem + w_base + (P.wstat ? ch : (g & 1)) * w_step;
         if (nchunks != 1) edge_wload(gq.f, ch);
+        // (the producer waves of this SIMD run at s_setprio 2 and the corrections are VALU / LDS work like the epilogue: tune bit 25 lets
+        // the consumers outrank them for the duration -- A/B switch)
+        if (P.tune & (1 << 25)) __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
         for (int L = 0; L < LV; ++L) {
             if (!((lv_any >> L) & 1u)) break;           // (levels fill from 0: the first empty one ends the list)
@@ -1148,6 +1151,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 for (int b = 0; b < KS; ++b)
 #pragma unroll
                     for (int cgl = 0; cgl < KCG; ++cgl) {
+                        if (a == 1 && b == 1) continue;         // (the window's centre is the cell itself: never wrong)
                         px[b][cgl] = *reinterpret_cast<const uint4 *>(lds_in + lb + (a * P.W2 + b) * RB + cgl * 32);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
@@ -1156,6 +1160,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                     }
 #pragma unroll
                 for (int b = 0; b < KS; ++b) {
+                    if (a == 1 && b == 1) continue;
                     const bool on = (lp >> (12 + a * KS + b)) & 1u;
 #pragma unroll
                     for (int cgl = 0; cgl < KCG; ++cgl) {
@@ -1166,9 +1171,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 #pragma unroll
                 for (int b = 0; b < KS; ++b)
 #pragma unroll
-                    for (int cgl = 0; cgl < KCG; ++cgl)
+                    for (int cgl = 0; cgl < KCG; ++cgl) {
+                        if (a == 1 && b == 1) continue;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) frag_mma<T>(ae[(b * KCG + cgl) & 1][nt], wq[b][cgl][nt], px[b][cgl]);
+                    }
             }
             // add the true terms: + dzpad[the term's halo cell] . W_neighbour[its tap] (fragments in registers)
             if (!(P.tune & (1 << 22))) {
@@ -1209,6 +1216,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = __builtin_fmaf(on, ae[0][nt][r] + ae[1][nt][r], acc[mt][nt][r]);
             }
         }
+        if (P.tune & (1 << 25)) __builtin_amdgcn_s_setprio(0);
       }
     };
 
