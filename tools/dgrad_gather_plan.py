@@ -14,8 +14,11 @@ The engine's data-gradient kernel computes this on the padded grid today and a s
   * EDGE terms: what is left, on border cells only: (source cell q, kernel variant v, tap) triples, grouped by `wid` = (v, tap) so
     that one MFMA pass serves 32 border cells with one weight fragment and a per-lane gathered dz row.
 This file builds both from T, checks the decomposition against autograd of the oracle (fp64) and prints the pass statistics the
-kernel design in DESIGN.md section 9 rests on.  Test infrastructure / design tool: imports the oracle, is not imported by the
-product.
+kernel design in DESIGN.md 4.8 rests on.  Test infrastructure / design tool: imports the oracle, is not imported by the product.
+(The SHIPPED plan -- dlwpcs_dgrad_gather_plan, csrc/halo_table.cpp, pinned by tests/test_dgrad_gather_plan.py -- states the same
+decomposition differently: the kernel keeps the forward's full halo in its LDS tile, so a border cell carries a mask of the crossing
+taps to CANCEL and, per edge term, the position of its source inside the cell's own 3 x 3 window instead of a flat source index;
+`-1` cells of Tdg here == the halo positions whose taps are cancelled there.)
 """
 import os
 import sys
