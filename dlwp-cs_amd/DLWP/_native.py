@@ -33,6 +33,7 @@ CONV_DEFER_REDUCE = 8
 CONV_DEFER_RING0 = 16
 CONV_OUT_PADDED = 32
 CONV_DGRAD_GATHER = 64
+CONSTRAINT_MAX_NORM, CONSTRAINT_NON_NEG, CONSTRAINT_UNIT_NORM, CONSTRAINT_MIN_MAX_NORM = 1, 2, 3, 4
 PACK_FWD, PACK_BWD, PACK_BIAS = 0, 1, 2
 WGRAD_BATCH_MAX = 24
 
@@ -152,6 +153,8 @@ PROTOTYPES = {
     'dlwpcs_cf_to_cl': (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_int, c_void_p]),
     'dlwpcs_cl_to_cf': (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_int, c_void_p]),
     'dlwpcs_add': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'dlwpcs_l1l2_regularize': (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_void_p, c_void_p]),
+    'dlwpcs_weight_constraint': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p]),
     'dlwpcs_mse_scratch_bytes': (c_size_t, []),
     'dlwpcs_mse_fwd_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_void_p,
                                    c_void_p]),

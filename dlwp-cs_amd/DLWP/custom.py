@@ -17,7 +17,7 @@ import numpy as np
 
 from . import ops
 from ._native import ACT_LEAKY_CLIP, ACT_NONE
-from .keras import engine
+from .keras import constraints, engine, regularizers
 from .keras.callbacks import Callback, EarlyStopping
 from .keras.engine import Layer
 
@@ -195,11 +195,11 @@ class CubeSphereConv2D(Layer):
         self.independent_north_pole = independent_north_pole
         self.kernel_initializer = engine.get_initializer(kernel_initializer)
         self.bias_initializer = engine.get_initializer(bias_initializer)
-        self.kernel_regularizer = engine._passthrough_get(kernel_regularizer)
-        self.bias_regularizer = engine._passthrough_get(bias_regularizer)
+        self.kernel_regularizer = regularizers.get(kernel_regularizer)
+        self.bias_regularizer = regularizers.get(bias_regularizer)
         self.activity_regularizer = engine._passthrough_get(activity_regularizer)
-        self.kernel_constraint = engine._passthrough_get(kernel_constraint)
-        self.bias_constraint = engine._passthrough_get(bias_constraint)
+        self.kernel_constraint = constraints.get(kernel_constraint)
+        self.bias_constraint = constraints.get(bias_constraint)
         self.rank = 3
 
         self.equatorial_kernel = None
@@ -224,20 +224,26 @@ class CubeSphereConv2D(Layer):
         kernel_shape = self.kernel_size + (input_dim, self.filters)
 
         self.equatorial_kernel = self.add_weight(shape=kernel_shape, initializer=self.kernel_initializer,
-                                                 name='equatorial_kernel')
+                                                 name='equatorial_kernel', regularizer=self.kernel_regularizer,
+                                                 constraint=self.kernel_constraint)
         self.polar_kernel = self.add_weight(shape=kernel_shape, initializer=self.kernel_initializer,
-                                            name='polar_kernel')
+                                            name='polar_kernel', regularizer=self.kernel_regularizer,
+                                            constraint=self.kernel_constraint)
         if self.independent_north_pole:
             self.north_pole_kernel = self.add_weight(shape=kernel_shape, initializer=self.kernel_initializer,
-                                                     name='north_pole_kernel')
+                                                     name='north_pole_kernel', regularizer=self.kernel_regularizer,
+                                                     constraint=self.kernel_constraint)
         if self.use_bias:
             self.equatorial_bias = self.add_weight(shape=(self.filters,), initializer=self.bias_initializer,
-                                                   name='equatorial_bias')
+                                                   name='equatorial_bias', regularizer=self.bias_regularizer,
+                                                   constraint=self.bias_constraint)
             self.polar_bias = self.add_weight(shape=(self.filters,), initializer=self.bias_initializer,
-                                              name='polar_bias')
+                                              name='polar_bias', regularizer=self.bias_regularizer,
+                                              constraint=self.bias_constraint)
             if self.independent_north_pole:
                 self.north_pole_bias = self.add_weight(shape=(self.filters,), initializer=self.bias_initializer,
-                                                       name='north_pole_bias')
+                                                       name='north_pole_bias', regularizer=self.bias_regularizer,
+                                                       constraint=self.bias_constraint)
         self.input_dim = input_dim
         self.built = True
 
@@ -310,11 +316,11 @@ class CubeSphereConv2D(Layer):
             'independent_north_pole': self.independent_north_pole,
             'kernel_initializer': engine.serialize_initializer(self.kernel_initializer),
             'bias_initializer': engine.serialize_initializer(self.bias_initializer),
-            'kernel_regularizer': self.kernel_regularizer,
-            'bias_regularizer': self.bias_regularizer,
+            'kernel_regularizer': regularizers.serialize(self.kernel_regularizer),
+            'bias_regularizer': regularizers.serialize(self.bias_regularizer),
             'activity_regularizer': self.activity_regularizer,
-            'kernel_constraint': self.kernel_constraint,
-            'bias_constraint': self.bias_constraint
+            'kernel_constraint': constraints.serialize(self.kernel_constraint),
+            'bias_constraint': constraints.serialize(self.bias_constraint)
         }
         base_config = super(CubeSphereConv2D, self).get_config()
         return dict(list(base_config.items()) + list(config.items()))

@@ -156,11 +156,12 @@ def serialize_activation(fn):
 
 
 def _passthrough_get(spec):
-    """regularizers / constraints: accepted and stored for config round-trips; None is the only value acted upon."""
+    """activity regularizers: accepted and stored for config round-trips; None is the only value acted upon (weight regularizers
+    and constraints are served: DLWP.keras.regularizers / constraints)."""
     if spec is None:
         return None
-    raise NotImplementedError('kernel/bias regularizers and constraints are not part of the DLWP-CS hot path '
-                              '(the reference scripts always pass None); got %r' % (spec,))
+    raise NotImplementedError('activity regularizers are not part of the DLWP-CS hot path (the reference scripts always pass '
+                              'None); got %r' % (spec,))
 
 
 # ------------------------------------------------------------------------------------------------------------------ #
@@ -181,6 +182,7 @@ class Layer(object):
         self.built = False
         self._weights = []          # list of torch tensors (views into the model's flat buffer once compiled)
         self._weight_names = []
+        self._weight_rules = []     # per weight: (regularizer | None, constraint | None), see DLWP.keras.Model._weight_rules
         self.input_spec = None
 
     # -- weights ----------------------------------------------------------------------------------------------------
@@ -192,6 +194,7 @@ class Layer(object):
         t.requires_grad_(bool(trainable and self.trainable))
         self._weights.append(t)
         self._weight_names.append('%s/%s:0' % (self.name, name))
+        self._weight_rules.append((regularizer, constraint))
         return t
 
     @property

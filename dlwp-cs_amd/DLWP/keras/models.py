@@ -551,6 +551,7 @@ class Model(object):
                 k += 1
             l._rebind(new)
         self._flat_params, self._flat_grads = flat, grads
+        self._wrules = None                                     # (the weight tensors were re-bound into the flat buffer)
         self._flat_len = off
         self._n_params = total
         self._exchange_cut = None
@@ -623,7 +624,8 @@ class Model(object):
         s = (sums / max(count, 1)).cpu().numpy()
         ops.chain_check()
         w = np.asarray(self.loss_weights, dtype=np.float64)
-        vals = [float(s[:, 0].sum())]
+        vals = [float(s[:, 0].sum())]                           # (a model with weight regularizers: its last row is the penalty)
+        s = s[:len(self.outputs)]
         if len(self.outputs) > 1:
             vals += [float(s[i, 0] / w[i]) if w[i] != 0 else 0.0 for i in range(len(self.outputs))]
             if self.metrics:
@@ -781,10 +783,53 @@ class Model(object):
         lo = self._plan_exchange()[1]
         return self._flat_grads[lo:], self._flat_grads[:lo]
 
+    # -- weight regularizers / constraints (CubeSphereConv2D(kernel_regularizer=..., kernel_constraint=...), DLWP/custom.py:837-842,
+    #    898-914).  Off the hot path: a model that has any trains through the eager step (no captured graph, optimizer not fused into
+    #    the reduction); the penalty's gradient joins the flat gradient buffer before the update, constraints follow it, and the
+    #    penalty itself travels as one extra row of the step's statistics ('loss' includes it, like keras).
+    def _weight_rules(self):
+        rules = getattr(self, '_wrules', None)
+        if rules is None:
+            rules = []
+            for lay in self._weight_layers():
+                for w, (reg, con) in zip(lay._weights, getattr(lay, '_weight_rules', [])):
+                    if w.requires_grad and (reg is not None or con is not None):
+                        rules.append((w, reg, con))
+            self._wrules = rules
+        return rules
+
+    def _grad_view(self, w):
+        off = (w.data_ptr() - self._flat_params.data_ptr()) // 4
+        return self._flat_grads[off:off + w.numel()]
+
+    def _penalty_row(self, add_grads, grad_scale=1.0):
+        """(1, 2) device tensor [sum of the regularization penalties, 0]; add_grads: their gradients join the flat buffer"""
+        from .._native import check, lib, ptr, stream_ptr
+        pen = torch.zeros((1, 2), dtype=torch.float32, device=self._flat_params.device)
+        for w, reg, _ in self._weight_rules():
+            if reg is None or (reg.l1 == 0.0 and reg.l2 == 0.0):
+                continue
+            g = self._grad_view(w) if add_grads else None
+            check(lib().dlwpcs_l1l2_regularize(ptr(w), ptr(g), w.numel(), reg.l1, reg.l2, 1.0 / float(grad_scale), ptr(pen), stream_ptr()),
+                  'dlwpcs_l1l2_regularize')
+        return pen
+
+    def _apply_constraints(self):
+        for w, _, con in self._weight_rules():
+            if con is not None:
+                con.apply(w)
+
+    def _update_with_rules(self, scale):
+        pen = self._penalty_row(True, scale) if self._weight_rules() else None
+        self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=scale)
+        if pen is not None:
+            self._apply_constraints()
+        self._packed_ok = False
+        return pen
+
     def _apply_gradients(self):
         scale = parallel.allreduce_gradients(self._flat_grads)  # RCCL over xGMI: one flat 2.7 MB buffer per step
-        self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=scale)
-        self._packed_ok = False
+        return self._update_with_rules(scale)
 
     def _train_step_eager(self, inputs, targets):
         self._flat_grads.zero_()
@@ -806,14 +851,13 @@ class Model(object):
                 hb = parallel.allreduce_start(self._exchange_slices()[1])
                 parallel.allreduce_wait(ha)
                 parallel.allreduce_wait(hb)
-                self.optimizer.apply(self._flat_params, self._flat_grads, grad_scale=1.0 / self._world)
-                self._packed_ok = False
-                return stats
-            self._apply_gradients()
-            return stats
+                pen = self._update_with_rules(1.0 / self._world)
+                return stats if pen is None else torch.cat([stats, pen], dim=0)
+            pen = self._apply_gradients()
+            return stats if pen is None else torch.cat([stats, pen], dim=0)
         stats = self._loss_and_backward(inputs, targets, True)
-        self._apply_gradients()
-        return stats
+        pen = self._apply_gradients()
+        return stats if pen is None else torch.cat([stats, pen], dim=0)
 
     def train_on_device_batch(self, inputs, targets):
         """
@@ -823,7 +867,7 @@ class Model(object):
         if not self._compiled:
             raise RuntimeError('You must compile your model before training/testing. Use `model.compile(...)`.')
         key = tuple(tuple(t.shape) for t in inputs + targets)
-        if not self.use_graphs:
+        if not self.use_graphs or self._weight_rules():
             return self._train_step_eager(inputs, targets)
         g = self._graphs.get(key)
         if g is None:
@@ -1093,7 +1137,7 @@ class Model(object):
                 break
             t0 = time.time()
             cbl.call('on_epoch_begin', epoch, None)
-            sums = torch.zeros((len(self.outputs), 2), dtype=torch.float32, device=dev)
+            sums = torch.zeros((len(self.outputs) + (1 if self._weight_rules() else 0), 2), dtype=torch.float32, device=dev)
             count = 0
             feed = self._feed(x, y, batch_size, shuffle)
             try:
@@ -1140,7 +1184,8 @@ class Model(object):
         if isinstance(x, tuple) and y is None and len(x) in (2, 3) and not hasattr(x, 'shape'):
             x, y = x[0], x[1]
         dev = backend.device()
-        sums = torch.zeros((len(self.outputs), 2), dtype=torch.float64, device=dev)
+        rules = bool(self._weight_rules())
+        sums = torch.zeros((len(self.outputs) + (1 if rules else 0), 2), dtype=torch.float64, device=dev)
         total = 0
         feed = self._feed(x, y, batch_size, False)
         try:
@@ -1150,6 +1195,8 @@ class Model(object):
                         break
                     n = dx[0].shape[0]
                     stats = self._loss_and_backward(dx, dt, train=False)
+                    if rules:
+                        stats = torch.cat([stats, self._penalty_row(False)], dim=0)
                     sums += stats.double() * n            # keras weights batches by their size
                     total += n
         finally:

@@ -1120,6 +1120,74 @@ extern "C" int dlwpcs_add(const void *a, const void *b, void *y, size_t n, int d
     return check_launch("add");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight regularizers and constraints of CubeSphereConv2D (DLWP/custom.py:837-842, 898-914: passed to add_weight): keras
+// regularizers.L1L2 -- penalty l1 * sum|w| + l2 * sum w^2 added to the loss, its gradient l1 * sign(w) + 2 * l2 * w to the weight's
+// gradient -- and keras constraints MaxNorm / NonNeg / UnitNorm / MinMaxNorm applied to the weight after every update (norms over
+// the LEADING axes: the weight as a (rows, cols) matrix, one norm per column; keras epsilon 1e-7).  fp32 master weights only;
+// ONE workgroup per call / per column: fixed summation order, reproducible.  Off the hot path (no reference script uses them).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) l1l2_kernel(const float *__restrict__ w, float *__restrict__ g, size_t n, float l1, float l2,
+                                                    float inv_grad_scale, float *__restrict__ penalty) {
+    __shared__ float red[1024];
+    float s1 = 0.f, s2 = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        const float x = w[i];
+        s1 += fabsf(x);
+        s2 += x * x;
+        if (g) g[i] += (l1 * (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f)) + 2.f * l2 * x) * inv_grad_scale;
+    }
+    red[threadIdx.x] = l1 * s1 + l2 * s2;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && penalty) *penalty += red[0];
+}
+
+// kind: 1 MaxNorm(a) | 2 NonNeg | 3 UnitNorm | 4 MinMaxNorm(a = min, b = max, rate)
+__global__ void __launch_bounds__(256) weight_constraint_kernel(float *__restrict__ w, int rows, int cols, int kind, float a, float b,
+                                                                float rate) {
+    const int c = blockIdx.x;
+    if (kind == 2) {
+        for (int r = threadIdx.x; r < rows; r += 256) { const float x = w[(size_t)r * cols + c]; w[(size_t)r * cols + c] = x >= 0.f ? x : 0.f; }
+        return;
+    }
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) { const float x = w[(size_t)r * cols + c]; s += x * x; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    const float norm = sqrtf(red[0]), eps = 1e-7f;
+    float scale;
+    if (kind == 1) scale = fminf(fmaxf(norm, 0.f), a) / (eps + norm);
+    else if (kind == 3) scale = 1.f / (eps + norm);
+    else scale = (rate * fminf(fmaxf(norm, a), b) + (1.f - rate) * norm) / (eps + norm);
+    for (int r = threadIdx.x; r < rows; r += 256) w[(size_t)r * cols + c] *= scale;
+}
+
+extern "C" int dlwpcs_l1l2_regularize(const float *w, float *g, size_t n, float l1, float l2, float inv_grad_scale, float *penalty,
+                                      dlwpcs_stream_t stream) {
+    REQUIRE(w && (g || penalty), "l1l2_regularize: null pointer");
+    REQUIRE(l1 >= 0.f && l2 >= 0.f, "l1l2_regularize: negative factor (l1=%g, l2=%g)", l1, l2);
+    if (n == 0) return DLWPCS_OK;
+    hipLaunchKernelGGL(l1l2_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, g, n, l1, l2, inv_grad_scale, penalty);
+    return check_launch("l1l2_regularize");
+}
+
+extern "C" int dlwpcs_weight_constraint(float *w, int rows, int cols, int kind, float a, float b, float rate, dlwpcs_stream_t stream) {
+    REQUIRE(w, "weight_constraint: null pointer");
+    REQUIRE(rows >= 1 && cols >= 1, "weight_constraint: bad shape %d x %d", rows, cols);
+    REQUIRE(kind >= DLWPCS_CONSTRAINT_MAX_NORM && kind <= DLWPCS_CONSTRAINT_MIN_MAX_NORM, "weight_constraint: unknown kind %d", kind);
+    hipLaunchKernelGGL(weight_constraint_kernel, dim3(cols), dim3(256), 0, (hipStream_t)stream, w, rows, cols, kind, a, b, rate);
+    return check_launch("weight_constraint");
+}
+
 extern "C" size_t dlwpcs_mse_scratch_bytes(void) { return (size_t)MSE_BLOCKS * 2 * sizeof(float); }
 
 extern "C" int dlwpcs_mse_fwd_bwd(const void *y, const void *t, void *dy, float *loss_out, size_t n, float weight,

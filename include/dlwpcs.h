@@ -491,6 +491,20 @@ int dlwpcs_adam_step_fused(float *p, float *g, float *m, float *v, size_t n, int
 int dlwpcs_adam_step_dev(float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev,
                          const float *hyper_dev, int flags, dlwpcs_stream_t stream);
 
+/* Weight regularizers / constraints of CubeSphereConv2D (DLWP/custom.py:837-842 -> add_weight(regularizer=, constraint=), :898-914).
+ * dlwpcs_l1l2_regularize: keras regularizers.L1L2 on one fp32 weight: *penalty += l1 * sum|w| + l2 * sum w^2 (penalty may be NULL)
+ * and g[i] += (l1 * sign(w[i]) + 2 * l2 * w[i]) * inv_grad_scale (g may be NULL; inv_grad_scale = 1 / the optimizer's grad_scale, so
+ * that the penalty's gradient is not averaged over the ranks).  One workgroup, fixed summation order.
+ * dlwpcs_weight_constraint: keras constraints on one fp32 weight viewed as a (rows, cols) matrix -- one norm per column, i.e. over
+ * the weight's leading axes (axis=[0,1,2] of a (k,k,Cin,Cout) kernel: rows = k*k*Cin, cols = Cout) -- applied in place. */
+#define DLWPCS_CONSTRAINT_MAX_NORM     1   /* a = max_value */
+#define DLWPCS_CONSTRAINT_NON_NEG      2
+#define DLWPCS_CONSTRAINT_UNIT_NORM    3
+#define DLWPCS_CONSTRAINT_MIN_MAX_NORM 4   /* a = min_value, b = max_value, rate */
+int dlwpcs_l1l2_regularize(const float *w, float *g, size_t n, float l1, float l2, float inv_grad_scale, float *penalty,
+                           dlwpcs_stream_t stream);
+int dlwpcs_weight_constraint(float *w, int rows, int cols, int kind, float a, float b, float rate, dlwpcs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------- *
  * Batch feed (reference ArrayDataGenerator.generate, DLWP/model/generators.py:872-984): with the whole data array
  * (T, V, S) fp32 resident in HBM (S = flattened space, e.g. 6*N*N), one launch assembles a batch window
