@@ -12,7 +12,8 @@ steps (the reference pays a numpy round trip, three concatenates and two transpo
 series is downloaded once.  Coordinates are plain numpy arrays (xarray is not part of this stack): the result is a small
 `Forecast` record with `.values`, `.dims` and `.coords` laid out exactly like the reference's DataArray.
 Not built (raises NotImplementedError): imputation, generators whose inputs are not all predicted, rank-2 lat/lon data,
-`keep_time_axis` generators, output time steps != input time steps.
+`keep_time_axis` generators, output time steps != input time steps.  `interval` != 1 is served as the reference serves it
+(see `predict`).
 """
 import numpy as np
 
@@ -148,8 +149,9 @@ class TimeSeriesEstimator(object):
         steps = int(steps)
         g = self.generator
         its, ots, iv = self._input_time_steps, self._output_time_steps, self._interval
-        if iv != 1:
-            raise NotImplementedError('TimeSeriesEstimator: interval != 1')
+        # interval != 1: the reference's feedback loop never reads it (the insolation times of extensions.py:279-287 and the
+        # re-assembly :289-306 advance by dt, not interval * dt) -- it reaches the initial batches (the generator's) and the
+        # f_hour coordinates only.  Same here, pinned by g10_estimator_interval2.npz.
         es = ots                                                   # keep_inputs branch (ots <= its), extensions.py:196-199
         effective_steps = int(np.ceil(steps / es))
         samples = np.arange(g._n_sample, dtype=np.int64) if len(samples) == 0 else np.asarray(samples, dtype=np.int64)
@@ -157,6 +159,9 @@ class TimeSeriesEstimator(object):
         t0 = t[0] if isinstance(t, (list, tuple)) else t
         t_shape = tuple(t0.shape)
         n_steps, time_dim = self.model._n_steps, self.model.time_dim
+        if iv != 1 and n_steps == 1:
+            # extensions.py:333,362: the single-step branch advances its sample coordinate by (es + interval - 1) * dt
+            raise NotImplementedError('TimeSeriesEstimator: interval != 1 with a single-step model')
         verbose = kwargs.get('verbose', 0)
         sol = None
         if n_steps > 1 and not self._add_insolation:

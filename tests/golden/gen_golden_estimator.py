@@ -125,61 +125,65 @@ def main():
     n_out = 2
     eng_dlwp = EngineFunctional(is_convolutional=True, time_dim=ITS)
     eng_dlwp._n_steps = n_out
-    from DLWP.model.generators import ArrayDataGenerator as EngGen
-    gen = EngGen(eng_dlwp, arr, rank=3, batch_size=4, input_time_steps=ITS, output_time_steps=ITS, sequence=n_out,
-                 insolation_array=sol_all[:T], constants=const, channels_last=True)
+    # interval = 1: g10_estimator.npz (the scripts' configuration); interval = 2: the same with strided samples -- in this branch
+    # of the reference the interval only reaches the f_hour coordinate (extensions.py:263-310 never reads it)
+    for interval, out_name in ((1, 'g10_estimator.npz'), (2, 'g10_estimator_interval2.npz')):
+        _iv = interval
+        from DLWP.model.generators import ArrayDataGenerator as EngGen
+        gen = EngGen(eng_dlwp, arr, rank=3, batch_size=4, input_time_steps=ITS, output_time_steps=ITS, sequence=n_out,
+                     insolation_array=sol_all[:T], constants=const, channels_last=True, interval=interval)
 
-    class DS(object):
-        dims = ('sample', 'varlev', 'x0', 'x1', 'x2')
-        variables = {'predictors': None}
-        sample = Coord(times[:T])
-        lat_ = Coord(lat)
-        lon_ = Coord(lon)
-        coords = {'varlev': Coord(np.arange(V))}
+        class DS(object):
+            dims = ('sample', 'varlev', 'x0', 'x1', 'x2')
+            variables = {'predictors': None}
+            sample = Coord(times[:T])
+            lat_ = Coord(lat)
+            lon_ = Coord(lon)
+            coords = {'varlev': Coord(np.arange(V))}
 
-        def __getitem__(self, k):
-            return {'sample': self.sample}[k]
-    DS.lat = DS.lat_
-    DS.lon = DS.lon_
+            def __getitem__(self, k):
+                return {'sample': self.sample}[k]
+        DS.lat = DS.lat_
+        DS.lon = DS.lon_
 
-    class FakeGen(SeriesDataGenerator):
-        ds = DS()
-        _add_insolation = True
-        _input_sel, _output_sel = {}, {}
-        _input_time_steps = _output_time_steps = ITS
-        _interval = 1
-        rank = 3
-        channels_last = True
-        _keep_time_axis = False
-        constants = const
-        convolution_shape = tuple(gen.convolution_shape)
-        output_convolution_shape = tuple(gen.output_convolution_shape)
-        shape = tuple(gen.shape)
-        _n_sample = gen._n_sample
+        class FakeGen(SeriesDataGenerator):
+            ds = DS()
+            _add_insolation = True
+            _input_sel, _output_sel = {}, {}
+            _input_time_steps = _output_time_steps = ITS
+            _interval = _iv
+            rank = 3
+            channels_last = True
+            _keep_time_axis = False
+            constants = const
+            convolution_shape = tuple(gen.convolution_shape)
+            output_convolution_shape = tuple(gen.output_convolution_shape)
+            shape = tuple(gen.shape)
+            _n_sample = gen._n_sample
 
-        def generate(self, samples, scale_and_impute=True):
-            return gen.generate(samples)
+            def generate(self, samples, scale_and_impute=True):
+                return gen.generate(samples)
 
-    net = te._StubNet(n_out)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        est = RefEstimator(DLWPFunctional(net, n_out, ITS), FakeGen())
-    store = {'array': arr, 'constants': const, 'lat': lat, 'lon': lon, 'times': times.astype('datetime64[ns]').astype(np.int64),
-             'insolation': sol_all, 'samples': np.array([0, 3, 5, 12])}
-    names = []
-    for steps in (3, 8, 11):
-        for keep in (False, True):
-            da = est.predict(steps, samples=list(store['samples']), keep_time_dim=keep)
-            name = 's%d_k%d' % (steps, int(keep))
-            names.append(name)
-            store[name + '_values'] = np.asarray(da.values, dtype=np.float32)
-            store[name + '_dims'] = np.array(da.dims)
-            store[name + '_f_hour'] = np.asarray(da.coords['f_hour'].values, dtype=np.float64)
-            store[name + '_time'] = np.asarray(da.coords['time'].values).astype('datetime64[ns]').astype(np.int64)
-            store[name + '_varlev'] = np.asarray(da.coords['varlev'].values)
-            print(name, da.dims, da.values.shape, da.coords['f_hour'].values[:4])
-    store['names'] = np.array(names)
-    np.savez_compressed(os.path.join(HERE, 'g10_estimator.npz'), **store)
+        net = te._StubNet(n_out)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            est = RefEstimator(DLWPFunctional(net, n_out, ITS), FakeGen())
+        store = {'array': arr, 'constants': const, 'lat': lat, 'lon': lon, 'times': times.astype('datetime64[ns]').astype(np.int64),
+                 'insolation': sol_all, 'samples': np.array([0, 3, 5, 12])}
+        names = []
+        for steps in (3, 8, 11):
+            for keep in (False, True):
+                da = est.predict(steps, samples=list(store['samples']), keep_time_dim=keep)
+                name = 's%d_k%d' % (steps, int(keep))
+                names.append(name)
+                store[name + '_values'] = np.asarray(da.values, dtype=np.float32)
+                store[name + '_dims'] = np.array(da.dims)
+                store[name + '_f_hour'] = np.asarray(da.coords['f_hour'].values, dtype=np.float64)
+                store[name + '_time'] = np.asarray(da.coords['time'].values).astype('datetime64[ns]').astype(np.int64)
+                store[name + '_varlev'] = np.asarray(da.coords['varlev'].values)
+                print(name, da.dims, da.values.shape, da.coords['f_hour'].values[:4])
+        store['names'] = np.array(names)
+        np.savez_compressed(os.path.join(HERE, out_name), **store)
 
 
 if __name__ == '__main__':

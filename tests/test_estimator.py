@@ -187,19 +187,20 @@ def test_estimator_device_rollout_matches_oracle_and_host_loop(dtype):
 # (tests/golden/gen_golden_estimator.py) for the sequence-model + insolation + constants configuration
 # --------------------------------------------------------------------------------------------------------------------- #
 
-def test_estimator_matches_reference_estimator(golden_dir):
+@pytest.mark.parametrize('interval', [1, 2])
+def test_estimator_matches_reference_estimator(golden_dir, interval):
     import os
     from DLWP.keras import backend
     backend.set_device('cpu')
     from DLWP.model import DLWPFunctional, TimeSeriesEstimator
     from DLWP.model.generators import ArrayDataGenerator
-    g = np.load(os.path.join(golden_dir, 'g10_estimator.npz'))
+    g = np.load(os.path.join(golden_dir, 'g10_estimator.npz' if interval == 1 else 'g10_estimator_interval2.npz'))
     n_out = 2
     dlwp = DLWPFunctional(is_convolutional=True, time_dim=ITS)
     dlwp.build_model(_StubNet(n_out), loss='mse')
     gen = ArrayDataGenerator(dlwp, g['array'], rank=3, batch_size=4, input_time_steps=ITS, output_time_steps=ITS,
                              sequence=n_out, insolation_array=g['insolation'][:T], constants=g['constants'],
-                             channels_last=True)
+                             channels_last=True, interval=interval)
     times = g['times'].astype('datetime64[ns]')
     est = TimeSeriesEstimator(dlwp, gen, sample_times=times[:T], lat=g['lat'], lon=g['lon'])
     samples = g['samples']
