@@ -345,6 +345,60 @@ def roofline_pass(st, steps=3):
     return agg
 
 
+def roofline_pass_graph(st, replays=8):
+    """Per-kernel durations INSIDE the replayed step graph: the step is captured once more with the library's profiler on, which
+    turns its two events per launch into external event-record nodes of the graph (csrc/prof.cpp); every replay records them
+    again.  Returns {kernel: [launches, ms, flops, bytes]} summed over `replays` replays, or None when the form does not apply
+    (inference, graphs off) or the runtime does not time such nodes -- the eager pass stands alone then."""
+    import gc
+    from DLWP import _native as nat
+    lib = nat.lib()
+    model = st['model']
+    if not (st['train'] and model.use_graphs):
+        return None
+    agg = {}
+    tag = ctypes.create_string_buffer(160)
+    ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    lib.dlwpcs_prof_reset()
+    model._graphs.clear()
+    model._seen_batch.clear()
+    try:
+        lib.dlwpcs_prof_enable(1)
+        run_step(st)                                    # eager warm-up of the shape
+        run_step(st)                                    # capture + first replay
+        torch.cuda.synchronize()
+        lib.dlwpcs_prof_enable(0)
+        if not model._graphs:
+            return None
+        n = lib.dlwpcs_prof_count()
+        for _ in range(replays):
+            run_step(st)
+            torch.cuda.synchronize()
+            for i in range(n):
+                # (records of a discarded trial capture were never recorded by a replay: their query fails -- skipped)
+                if lib.dlwpcs_prof_get(i, tag, 160, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)) != 0:
+                    continue
+                name = tag.value.decode()
+                if not name.endswith('@graph') or not (ms.value > 0.0):
+                    continue
+                a = agg.setdefault(name[:-len('@graph')], [0, 0.0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += ms.value
+                a[2] += fl.value
+                a[3] += by.value
+    except Exception as exc:                            # a runtime without timed external event nodes: keep the eager figures
+        sys.stderr.write('roofline_pass_graph: %s: %s\n' % (type(exc).__name__, exc))
+        agg = {}
+    finally:
+        lib.dlwpcs_prof_enable(0)
+        torch.cuda.synchronize()
+        model._graphs.clear()                           # the graph goes before the events its nodes record
+        model._seen_batch.clear()
+        gc.collect()
+        lib.dlwpcs_prof_reset()
+    return agg or None
+
+
 def allreduce_probe(model, world, reps=20):
     """Duration of the step's one exchange -- all_reduce(SUM) of the flat fp32 gradient buffer -- on its own (MAX over ranks)."""
     if world <= 1 or model._flat_grads is None:
@@ -551,6 +605,7 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
         noex_s = time_without_exchange(st, timed, per_block)
     # the roofline pass runs eager optimisation steps (gradient all-reduce included): EVERY rank takes part
     agg = roofline_pass(st) if with_roofline else None
+    agg_graph = roofline_pass_graph(st) if with_roofline else None
     if rank != 0:
         return None
     fps = flops_per_sample(args.workload, N, C, C, base)
@@ -614,8 +669,19 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
                         'frac': round(t_f / t, 4)}
             return {'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': round(t_b / t, 4)}
+        # durations: inside the replayed graph where the runtime times external event-record nodes (the form the timed region
+        # runs; this is what rocprofv3 sees under profiles/), else from the eager steps; the eager figure rides along
+        agg_eager = agg
+        if agg_graph:
+            agg = dict(agg_eager)
+            agg.update(agg_graph)
         name, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
         rf = bound_of(name, cnt, ms, fl, by)
+        rf['launch_time_from'] = ('HIP events as external event-record nodes inside the replayed step graph (csrc/prof.cpp), '
+                                  '%d replays' % cnt if (agg_graph and name in agg_graph) else
+                                  'HIP events around the launches of eager steps (graph form unavailable)')
+        if agg_graph and name in agg_graph and name in agg_eager:
+            rf['avg_launch_us_eager'] = round(1e3 * agg_eager[name][1] / agg_eager[name][0], 2)
         mp = (MEASURED_PEAKS['bf16_mfma_tflops'] if name.startswith(BF16_MFMA_KERNELS) else MEASURED_PEAKS['fp32_mfma_tflops']) \
             if rf['bound'] == 'mfma' else MEASURED_PEAKS['hbm_read_gbs']
         rf['measured_peaks'] = MEASURED_PEAKS
@@ -678,6 +744,8 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
                     pk['traffic'] = r2['traffic']
                 if r2.get('mfma_busy') is not None:
                     pk['mfma_busy'] = r2['mfma_busy']
+            if agg_graph and k in agg_graph and k in agg_eager:
+                pk['avg_us_eager'] = round(1e3 * agg_eager[k][1] / agg_eager[k][0], 2)
             rf['per_kernel'][k] = pk
         result['roofline'] = rf
     del model, st

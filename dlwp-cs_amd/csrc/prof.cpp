@@ -1,9 +1,12 @@
 // Opt-in per-launch timing of the MFMA kernels with HIP events recorded on the launch stream (used by bench.py for the
-// `roofline` object; off by default, never active inside graph capture).  This is the only mutable global state in the
-// library and it is inert unless dlwpcs_prof_enable(1) was called.
+// `roofline` object; off by default).  On a stream that is being CAPTURED the two events become external event-record nodes of
+// the graph (hipEventRecordExternal): every replay records them again, so dlwpcs_prof_get then returns the launch's duration
+// INSIDE the replayed graph -- the form the timed region runs; such records carry the suffix "@graph" in their tag.  This is the
+// only mutable global state in the library and it is inert unless dlwpcs_prof_enable(1) was called.
 #include <mutex>
 #include <string>
 #include <vector>
+#include <stdio.h>
 #include <string.h>
 #include "common.h"
 
@@ -21,19 +24,58 @@ static std::vector<ProfRecord> g_records;
 
 bool prof_enabled() { return g_enabled; }
 
+static bool capturing(hipStream_t s) {
+    if (s == nullptr) return false;                 // (the null stream cannot be captured; the query rejects it)
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();                    // the failed query must not be taken for a failed launch (check_launch)
+        return false;
+    }
+    return st == hipStreamCaptureStatusActive;
+}
+
+// An event record as a node of the graph being captured on s.  hipEventRecordExternal is what the API offers for it; the HIP
+// runtime bundled with PyTorch 2.10 (ROCm 7.0) rejects the flag during capture, so the node is added by hand there: an event-record
+// node behind the capture's current frontier, which becomes the new frontier.
+static hipError_t record_in_capture(hipEvent_t e, hipStream_t s) {
+    hipError_t r = hipEventRecordWithFlags(e, s, hipEventRecordExternal);
+    if (r == hipSuccess) return r;
+    (void)hipGetLastError();
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t g = nullptr;
+    const hipGraphNode_t *deps = nullptr;
+    size_t nd = 0;
+    if ((r = hipStreamGetCaptureInfo_v2(s, &st, &id, &g, &deps, &nd)) != hipSuccess) return r;
+    hipGraphNode_t node = nullptr;
+    if ((r = hipGraphAddEventRecordNode(&node, g, deps, nd, e)) != hipSuccess) return r;
+    return hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies);
+}
+
+static void record(hipEvent_t e, hipStream_t s) {
+    const bool cap = capturing(s);
+    const hipError_t r = cap ? record_in_capture(e, s) : hipEventRecord(e, s);
+    if (r != hipSuccess) {
+        fprintf(stderr, "dlwpcs prof: %s on stream %p failed: %s\n", cap ? "external event record (capture)" : "event record", (void *)s,
+                hipGetErrorString(r));
+        (void)hipGetLastError();                    // a profiler failure is not a launch failure
+    }
+}
+
 int prof_begin(const char *tag, double flops, double bytes, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     ProfRecord r;
     r.tag = tag; r.flops = flops; r.bytes = bytes;
+    if (capturing(s)) r.tag += "@graph";
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
-    (void)hipEventRecord(r.e0, s);
+    record(r.e0, s);
     g_records.push_back(r);
     return (int)g_records.size() - 1;
 }
 
 void prof_end(int idx, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (idx >= 0 && idx < (int)g_records.size()) (void)hipEventRecord(g_records[idx].e1, s);
+    if (idx >= 0 && idx < (int)g_records.size()) record(g_records[idx].e1, s);
 }
 
 }  // namespace dlwpcs

@@ -520,7 +520,10 @@ int dlwpcs_batch_gather(const void *array, int64_t T, int V, int64_t S, const in
 
 /* ------------------------------------------------------------------------------------------------------------- *
  * Opt-in launch profiler (bench.py `roofline`): when enabled, every MFMA convolution kernel launch is bracketed by two
- * HIP events recorded on the launch stream.  Off by default; do not enable while a stream is being graph-captured.
+ * HIP events recorded on the launch stream.  Off by default.  Enabled while a stream is being graph-captured, the events
+ * become external event-record nodes of that graph (tag suffix "@graph"): every replay records them again and
+ * dlwpcs_prof_get returns the duration of the launch inside the last completed replay; destroy the graph before
+ * dlwpcs_prof_reset.
  * dlwpcs_prof_get: tag = kernel name as rocprofv3 prints it (template arguments included), ms = event-elapsed time,
  * flops / bytes = ALGORITHMIC work of that launch (2*B*6*N^2*k^2*Cin*Cout; unpadded tensors touched once + weights).
  * ------------------------------------------------------------------------------------------------------------- */

@@ -192,3 +192,24 @@ print('DP_ONE_GRAPH_OK')
 ''' % ROOT
     out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'DP_ONE_GRAPH_OK' in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+def test_roofline_times_the_launches_inside_the_replayed_graph():
+    """bench.py's `roofline.avg_launch_us` comes from HIP events captured as external event-record nodes of the step graph
+    (csrc/prof.cpp: the form the timed region runs, the one rocprofv3 sees), with the eager figure beside it."""
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '3', '--batch', '4', '--face', '16',
+           '--base', '8', '--channels', '6', '--min-block-s', '0.05', '--blocks', '3', '--no-pmc', '--no-companion',
+           '--no-configs', '--no-cpu-baseline', '--no-dp-form']
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    rf = r['roofline']
+    assert rf['launch_time_from'].startswith('HIP events as external event-record nodes'), rf['launch_time_from']
+    assert rf['avg_launch_us'] > 0 and rf['avg_launch_us_eager'] > 0
+    # same kernels, same work: the two forms of timing agree within a factor (tiny launches: the eager ones carry host gaps)
+    assert 0.2 < rf['avg_launch_us'] / rf['avg_launch_us_eager'] < 5.0
+    timed = [k for k, v in rf['per_kernel'].items() if 'avg_us_eager' in v]
+    assert len(timed) >= 3, rf['per_kernel'].keys()
