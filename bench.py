@@ -20,8 +20,10 @@ bracketed the same way, MAX over ranks) and `value` / `ms_per_step` are the MEDI
 reported beside it (`k_step_window_ms_per_step`).
 
 Prints ONE JSON line on rank 0: value = whole-job samples/s, plus
-  roofline     -- dominant convolution kernel: algorithmic FLOPs and bytes per launch / HIP-event time per launch (events on
-                  the launch stream, library profiler) against the roofline that bounds it; `traffic`, `hbm_gbs` and
+  roofline     -- dominant convolution kernel: algorithmic FLOPs and bytes per launch / HIP-event time per launch (library
+                  profiler, events on the launch stream: as event-record nodes INSIDE the replayed step graph for training
+                  workloads -- `launch_time_from` -- with the eager figure beside it) against the roofline that bounds it;
+                  `traffic`, `hbm_gbs` and
                   `mfma_busy` from rocprofv3 PMC passes of THIS command's workload collected live (child processes, one
                   counter group per pass, --kernel-trace only) -- or, when rocprofv3 is not usable, from the newest committed
                   profiles/rNN_*_pmc.json (source and its git blob hash are stated);
