@@ -607,7 +607,9 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
         noex_s = time_without_exchange(st, timed, per_block)
     # the roofline pass runs eager optimisation steps (gradient all-reduce included): EVERY rank takes part
     agg = roofline_pass(st) if with_roofline else None
-    agg_graph = roofline_pass_graph(st) if with_roofline else None
+    # (N = 1 only: at N > 1 the captured step holds a collective, and a capture that failed on one rank alone would leave the
+    # others replaying it -- the eager pass above is the multi-rank form)
+    agg_graph = roofline_pass_graph(st) if (with_roofline and world == 1) else None
     if rank != 0:
         return None
     fps = flops_per_sample(args.workload, N, C, C, base)
