@@ -55,7 +55,6 @@ import torch         # noqa: E402
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense (measured 2495)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-BF16_MFMA_KERNELS = ('conv_mfma_ws_kernel<unsigned short', 'wgrad_bf16_kernel', 'wgrad_batch_kernel', 'pw_')
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
 N_SIMD = 1024                      # 256 CUs x 4 SIMDs
 N_XCC = 8
@@ -664,8 +663,13 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
     if with_roofline and agg:
         # per kernel: the roofline that bounds it = the larger of (algorithmic flops / matrix peak of the instruction it
         # issues) and (algorithmic bytes / HBM peak); frac = that bound time / measured time
+        # (the matrix peak is that of the instruction the STEP's dtype makes the kernel issue -- wgrad_batch_kernel carries bf16 and
+        # fp32 segment bodies under one name -- except for instantiations that name their element type)
+        def is_bf16_mfma(name):
+            return '<float' not in name and (dtype == 'bf16' or '<unsigned short' in name)
+
         def bound_of(name, cnt, ms, fl, by):
-            peak_f = PEAK_BF16_MFMA_TFLOPS if name.startswith(BF16_MFMA_KERNELS) else PEAK_FP32_MFMA_TFLOPS
+            peak_f = PEAK_BF16_MFMA_TFLOPS if is_bf16_mfma(name) else PEAK_FP32_MFMA_TFLOPS
             t_f, t_b = fl / (peak_f * 1e12), by / (PEAK_HBM_GBS * 1e9)
             t = ms * 1e-3
             if t_f >= t_b:
@@ -686,7 +690,7 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
                                   'HIP events around the launches of eager steps (graph form unavailable)')
         if agg_graph and name in agg_graph and name in agg_eager:
             rf['avg_launch_us_eager'] = round(1e3 * agg_eager[name][1] / agg_eager[name][0], 2)
-        mp = (MEASURED_PEAKS['bf16_mfma_tflops'] if name.startswith(BF16_MFMA_KERNELS) else MEASURED_PEAKS['fp32_mfma_tflops']) \
+        mp = (MEASURED_PEAKS['bf16_mfma_tflops'] if is_bf16_mfma(name) else MEASURED_PEAKS['fp32_mfma_tflops']) \
             if rf['bound'] == 'mfma' else MEASURED_PEAKS['hbm_read_gbs']
         rf['measured_peaks'] = MEASURED_PEAKS
         rf['frac_vs_measured_peak'] = round(rf['achieved'] / mp, 4)
@@ -712,9 +716,19 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
             doc['_source'] = src
             with open(args.pmc_out, 'w') as f:
                 json.dump(doc, f, indent=1, sort_keys=True)
-        rec = (recs or {}).get(name)
-        if rec is None and recs:
-            rec = next((v for k, v in recs.items() if k.startswith(name[:84])), None)
+        # profiler tag -> PMC record: the tag IS the kernel's name as rocprofv3 prints it (tests/test_abi.py pins every tag to the
+        # library's symbol table); "(mode)" suffixes of a tag name a mode of the same kernel
+        def pmc_of(k):
+            import re
+            if not recs:
+                return None
+            base = re.sub(r'\(.*\)$', '', k)
+            return recs.get(k) or recs.get(base) or next((v for kk, v in recs.items() if kk.replace(' ', '') == base.replace(' ', '')), None)
+        rec = pmc_of(name)
+        # (a kernel of the step without a counter record must not pass silently)
+        rf['pmc_missing'] = sorted(k for k in agg if pmc_of(k) is None) if (with_pmc and recs) else None
+        if rf['pmc_missing']:
+            sys.stderr.write('bench.py: ERROR: no PMC record for %s in: %s\n' % (rf['pmc_missing'], src))
         if rec is None:
             rf.update({'traffic': None, 'hbm_gbs': None, 'mfma_busy': None})
             rf['pmc_error'] = 'NO PMC RECORD for the dominant kernel %r in: %s' % (name, src)
@@ -742,7 +756,7 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
             bk = bound_of(k, *v)
             pk = {'launches': v[0], 'avg_us': round(1e3 * v[1] / v[0], 2),
                   'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2), 'bound': bk['bound'], 'frac': bk['frac']}
-            r2 = (recs or {}).get(k)
+            r2 = pmc_of(k)
             if r2:
                 if r2.get('traffic'):
                     pk['traffic'] = r2['traffic']
@@ -876,7 +890,7 @@ def main():
                 ent['roofline'] = {k: rf2.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_vs_measured_peak',
                                                            'avg_launch_us', 'launches', 'algorithmic_gflop_per_launch',
                                                            'algorithmic_mbytes_per_launch', 'traffic', 'traffic_raw_counters',
-                                                           'traffic_vs_algorithmic', 'hbm_gbs', 'pmc_source', 'pmc_error')
+                                                           'traffic_vs_algorithmic', 'hbm_gbs', 'mfma_busy', 'pmc_source', 'pmc_error', 'pmc_missing')
                                    if k in rf2}
             result['configs'][key] = ent
     if rank == 0 and single and not args.no_cpu_baseline:

@@ -176,11 +176,14 @@ PROTOTYPES = {
                                      c_void_p]),
     'dlwpcs_batch_gather': (c_int, [c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int, c_void_p, c_int,
                                     c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_lds_oob_probe': (c_int, [c_void_p, c_void_p]),
     'dlwpcs_prof_enable': (c_int, [c_int]),
     'dlwpcs_prof_reset': (c_int, []),
     'dlwpcs_prof_count': (c_int, []),
     'dlwpcs_prof_get': (c_int, [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(ctypes.c_double),
                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    'dlwpcs_prof_known_tags': (c_int, []),
+    'dlwpcs_prof_known_tag': (c_int, [c_int, ctypes.c_char_p, c_int]),
 }
 
 _lib = None

@@ -17,7 +17,8 @@ TAG = os.environ.get('DLWPCS_LIB_TAG', '')          # development only: instrume
 OBJ = os.path.join(HERE, 'build' + ('_' + TAG if TAG else ''))
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdlwpcs%s.so' % ('_' + TAG if TAG else ''))
-SOURCES = ['halo_table.cpp', 'prof.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_chain.hip', 'conv_generic.hip', 'wgrad_batch.hip']
+SOURCES = ['halo_table.cpp', 'prof.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_inst_f32.hip', 'conv_inst_bf16.hip', 'conv_inst_edge.hip',
+           'conv_chain.hip', 'conv_generic.hip', 'wgrad_batch.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 CFLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-x', 'hip', '-Wall', '-Wno-unused-function'] + \
@@ -39,7 +40,20 @@ def _newer(src, dst, extra=()):
     if not os.path.exists(dst):
         return True
     t = os.path.getmtime(dst)
-    return any(os.path.getmtime(s) > t for s in (src,) + tuple(extra))
+    return any((not os.path.exists(s)) or os.path.getmtime(s) > t for s in (src,) + tuple(extra))
+
+
+def _deps(obj, fallback):
+    """Headers the object was compiled from (the compiler's own -MD list beside it); every header when there is no list yet."""
+    d = os.path.splitext(obj)[0] + '.d'
+    if not os.path.exists(d):
+        return fallback
+    try:
+        words = open(d).read().replace('\\\n', ' ').split()
+    except OSError:
+        return fallback
+    own = os.path.dirname(HERE)
+    return tuple(w for w in words[1:] if w.endswith('.h') and os.path.abspath(w).startswith(own))
 
 
 def build(force=False, verbose=True):
@@ -53,8 +67,8 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, os.path.splitext(src)[0] + '.o')
         objs.append(o)
-        if force or _newer(s, o, headers):
-            jobs.append([HIPCC] + CFLAGS + ['-c', s, '-o', o])
+        if force or _newer(s, o, _deps(o, headers)):
+            jobs.append([HIPCC] + CFLAGS + ['-MD', '-MF', os.path.splitext(o)[0] + '.d', '-c', s, '-o', o])
 
     def run(cmd):
         if verbose:
@@ -65,7 +79,7 @@ def build(force=False, verbose=True):
         if verbose and r.stderr.strip():
             print(r.stderr[-4000:])
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(LIB):
         # Link with g++ (like torch.utils.cpp_extension) so that WE choose which libamdhip64 is recorded as NEEDED:

@@ -23,6 +23,36 @@ inline int check_launch(const char *what) {
 bool prof_enabled();
 int prof_begin(const char *tag, double flops, double bytes, hipStream_t s);
 void prof_end(int idx, hipStream_t s);
+// Every tag the library can hand to prof_begin is registered when the library is LOADED (dlwpcs_prof_known_tag enumerates them
+// without a device): bench.py joins rocprofv3's per-kernel counter records on these names, so a tag that is not the kernel's name
+// as the code object spells it silently loses the counters (round 4: a tag built with 12 of a kernel's 13 template arguments).
+// tests/test_abi.py compares the registry with the kernel symbols of libdlwpcs.so.
+int prof_register_tag(const char *tag);
+// KTag<Name, T, Vs...>::tag(): "name<T, v1, v2, ...>" with bools as true / false -- the instantiation's name as the demangler
+// prints it -- built once and registered by a static initialiser of the instantiation (i.e. at load time, whether or not the kernel
+// is ever launched).  Name: a type with `static const char *str()`; T: float / unsigned short (bf16 storage) / void (no type argument).
+template <typename T> struct KTagType { static const char *str() { return nullptr; } };
+template <> struct KTagType<float> { static const char *str() { return "float"; } };
+template <> struct KTagType<unsigned short> { static const char *str() { return "unsigned short"; } };
+template <typename Name, typename T, auto... Vs> struct KTag {
+    static void fmt(char *&p, char *end, bool v) { p += snprintf(p, end - p, "%s", v ? "true" : "false"); }
+    static void fmt(char *&p, char *end, int v) { p += snprintf(p, end - p, "%d", v); }
+    static const char *str() {
+        static char buf[200];
+        if (!buf[0]) {
+            char *p = buf, *end = buf + sizeof(buf);
+            p += snprintf(p, end - p, "%s<", Name::str());
+            bool first = true;
+            if (KTagType<T>::str()) { p += snprintf(p, end - p, "%s", KTagType<T>::str()); first = false; }
+            ((p += snprintf(p, end - p, "%s", first ? "" : ", "), fmt(p, end, Vs), first = false), ...);
+            snprintf(p, end - p, ">");
+        }
+        return buf;
+    }
+    static const int reg;
+    static const char *tag() { return reg >= 0 ? str() : str(); }      // (odr-use of reg: the registration is instantiated)
+};
+template <typename Name, typename T, auto... Vs> const int KTag<Name, T, Vs...>::reg = prof_register_tag(KTag<Name, T, Vs...>::str());
 
 // dlwpcs_dgrad_gather_plan buffer (halo_table.cpp): [inverse table 6*N*N*4][header][T 6*M*M][border cells 6*(4N-4)*8][triples 6*2*3]
 constexpr int DGG_HEADER = 8;

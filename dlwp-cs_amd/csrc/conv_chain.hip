@@ -23,6 +23,8 @@
 #include "conv_ws.h"
 
 namespace dlwpcs {
+static const int g_chain_tag = prof_register_tag("conv_chain_kernel");
+
 
 constexpr int CHAIN_MAX_PHASES = DLWPCS_CHAIN_MAX;
 

@@ -66,6 +66,7 @@ struct ConvKParams {
     uint32_t *flow_done, *flow_abort;
     int flow_phase, flow_bmax, flow_need, flow_rot;
     uint32_t flow_spin;
+    int edge_cost;              // EDGE: cost of a polar face's tile in sixteenths of an equatorial one (the tile list is cut by cost); <= 16: by count
     int split_gb, split_fb;     // ILV cost split (launch_conv_cfg): the LAST split_gb workers take all the short tiles (the last band
                                 // of every face) and split_fb of the full ones, the others the remaining full tiles; 0: plain split
     long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
@@ -239,8 +240,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     constexpr int Q = KC / VW;
     constexpr int NTB = NT * WN;
     constexpr int NCT = 64 * WM * WN;               // consumer threads == producer threads
-    constexpr int WF4 = NTB * KCG * TAPS * 64;      // 16-B entries per weight chunk
-    constexpr int GF4 = TAPS * 64;
+    constexpr int GF4 = TAPS * 64;                  // 16-B entries per (variant, n tile, operand group) of the packed operands
+    // EDGE: three more tap slots per operand group in the LDS weight area -- the substitute fragments of the tile's weight-id triple
+    constexpr int TAPSW = EDGE ? TAPS + 3 : TAPS;
+    constexpr int GF4L = TAPSW * 64;
+    constexpr int WF4 = NTB * KCG * TAPSW * 64;     // 16-B entries per weight chunk
     constexpr int ITS = 3 * KC / VW;                // input vectors per producer thread per chunk (3*NCT pixels)
     constexpr int ITW = (WF4 + NCT - 1) / NCT;
     static_assert(NCT % Q == 0, "thread -> channel-vector mapping must not depend on the item");
@@ -285,9 +289,20 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // 64 workers x (3 full + 3 short) (cost 36) where the plain split has workgroups with 6 full tiles (42).
     const int nbl = P.nblk_face;
     const bool csplit = ilv && P.split_gb > 0;
+    // EDGE (data gradient in gather form): every tile of a polar face runs the substitute steps in all of its waves, a tile of an
+    // equatorial face in at most one -- and with contiguous ranges a worker's 4.5 tiles are all of one kind: the polar workers set
+    // the launch time.  The ranges stay contiguous (a second (face, band) run per worker costs a halo-table round trip and a weight
+    // reload in the producers' path: measured +4 us per launch, more than the imbalance) but are cut by COST: a polar tile counts
+    // P.edge_cost sixteenths of an equatorial one.
     int t_first = 0, t_last = 0;            // plain split
     int f0 = 0, f1 = 0, s0 = 0, s1 = 0;     // cost split: ranges in the full list / in the short list
-    if (csplit) {
+    if (EDGE && P.edge_cost > 16) {
+        const long nE = 4l * nbl * P.B, nP = 2l * nbl * P.B, cp = P.edge_cost;
+        const long total = 16 * nE + cp * nP;
+        auto pos = [&](long c) { return c <= 16 * nE ? (c + 8) / 16 : nE + (c - 16 * nE + cp / 2) / cp; };
+        t_first = (int)pos(total * lw / G);
+        t_last = (int)pos(total * (lw + 1) / G);
+    } else if (csplit) {
         const int GB = P.split_gb, GA = G - GB;
         const int Ftot = 6 * (nbl - 1) * P.B, Stot = 6 * P.B, FA = Ftot - P.split_fb;
         if ((int)lw < GA) {
@@ -330,11 +345,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // costs twice a later one).  Measured on the bf16 training step, 0 / 1 / 2 / 3 / 4 / 6 / 8 sleeps: 0.6842 / 0.6795 / 0.6781 /
     // 0.6768 / 0.6775 / 0.6786 / 0.6797 ms; 16 sleeps +24 us.
     // (not with the cost split: there every workgroup's list is as expensive as the next one's, whatever its length)
-    if ((P.tune & TUNE_CONV_STAGGER) && !csplit && !flow && (t_last - t_first) * G < P.ntiles) {
+    if ((P.tune & TUNE_CONV_STAGGER) && !csplit && !flow && n_my * G < P.ntiles) {
 #pragma unroll 1
         for (int i = 0; i < ((P.tune >> 12) & 63); ++i) __builtin_amdgcn_s_sleep(16);
     }
-    struct Geo { int b, f, v, combo, m0, npix, y0, nitems; };
+    struct Geo { int b, f, v, combo, m0, npix, y0, nitems, fcls; };
     auto geo_of = [&](int t) __attribute__((always_inline)) {
         Geo gq;
         gq.combo = P.magicB ? __umulhi((uint32_t)t, P.magicB) : t;                      // t / B   (magic 0 <=> divisor 1)
@@ -347,6 +362,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         gq.y0 = __umulhi((uint32_t)gq.m0, P.magicNo);
         const int ylast = __umulhi((uint32_t)(gq.m0 + gq.npix - 1), P.magicNo);
         gq.nitems = (ylast - gq.y0 + KS) * P.W2 * Q;
+        gq.fcls = 2 * gq.f + (ylast == P.No - 1 ? 1 : 0);     // EDGE: which weight-id triple (face; the tile holds the face's last row)
         return gq;
     };
 
@@ -442,15 +458,32 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             }
         };
         // weight fragments of (face variant v, chunk ch) -> registers -> the weight area of LDS buffer b
-        auto load_w = [&](int v, int ch, uint4 (&wv)[ITW]) __attribute__((always_inline)) {
+        auto load_w = [&](int v, int fcls, int ch, uint4 (&wv)[ITW]) __attribute__((always_inline)) {
+            // EDGE: slot TAPS + k of an operand group = fragment (variant, tap) = weight id k of the tile's triple (E.wids, -1: none)
+            int wid[ITW];
+            if constexpr (EDGE) {
+#pragma unroll
+                for (int u = 0; u < ITW; ++u) {
+                    const int w = min(ptid + u * NCT, WF4 - 1) % GF4L;
+                    wid[u] = (int)E.wids[fcls * 3 + max(w / 64 - TAPS, 0)];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < ITW; ++u) {
                 const int idx = min(ptid + u * NCT, WF4 - 1);
-                const int gg = idx / GF4, w = idx % GF4;
+                const int gg = idx / GF4L, w = idx % GF4L;
                 const int ntl = gg / KCG, cgl = gg % KCG;
                 const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
-                const bool ok = ntile < P.NTtot && cg < P.CG;
-                wv[u] = vsel(ok, wsrc[ok ? (((size_t)v * P.NTtot + ntile) * P.CG + cg) * GF4 + w : 0]);
+                bool ok = ntile < P.NTtot && cg < P.CG;
+                int vv = v, ww = w;
+                if constexpr (EDGE) {
+                    const bool sub = w >= GF4;
+                    const int id = max(wid[u], 0);
+                    ok = ok && (!sub || wid[u] >= 0);
+                    vv = sub ? id / 9 : v;
+                    ww = sub ? (id % 9) * 64 + (w & 63) : w;
+                }
+                wv[u] = vsel(ok, wsrc[ok ? (((size_t)vv * P.NTtot + ntile) * P.CG + cg) * GF4 + ww : 0]);
             }
         };
         auto store_w = [&](int area, const uint4 (&wv)[ITW]) __attribute__((always_inline)) {
@@ -463,7 +496,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         };
         // issue(): (rarely) the weight fragments -> LDS buffer g & 1, then every load of the chunk's input tile, back to back
         auto issue = [&](const Geo &gc, int ch, V (&val)[ITS], V (&ymv)[MASK ? ITS : 1], uint32_t &okm) __attribute__((always_inline)) {
-            const int wkey = gc.v * 1024 + ch;
+            // (EDGE: the area also holds the substitute fragments of the tile's triple -- keyed by face and edge-row class)
+            const int wkey = (EDGE ? gc.fcls : gc.v) * 1024 + ch;
             const int area = P.wstat ? ch : (g & 1);
             const bool need_w = !(P.tune & TUNE_CONV_WEIGHTS_STAY) || wres[area] != wkey;
             wres[area] = wkey;
@@ -472,7 +506,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 // flight at once (fetching them four at a time cost 2-3 serial L2 round trips on each workgroup's first tiles:
                 // +5 % on the whole training step)
                 uint4 wv[ITW];
-                load_w(gc.v, ch, wv);
+                load_w(gc.v, gc.fcls, ch, wv);
                 store_w(area, wv);
             }
             const T *sb; int cstride, cs_ld, sh; bool c_ok, up;
@@ -606,39 +640,25 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     TL_MARK();
     int abase[MT];
     int cur_combo = -1, cur_v = -1;
-    // EDGE: per (face, band).  A lane owns pixel l31 of each of the wave's MT M tiles; the few of them that are border cells with
-    // corrections are compacted into LEVELS: level L of a lane = its L-th such pixel (a cube corner, with two terms per weight id,
-    // takes two): lvm = the M tile it belongs to (-1: none), lvb = the LDS offset of its window's first cell (abase), lvw = its
-    // wrong-tap mask, lvo = the LDS offsets of the halo cells its three true terms read (-1: none).  One level of the whole wave is
-    // ONE edge M tile whose scratch accumulator is added to the accumulator of the M tile each lane's pixel lives in.  Uniform:
-    // lv_any (bit L: some lane has a level L), wcls (the wave holds
-    // cells of the face's last row: second weight-id triple; launch_conv_cfg guarantees a wave never holds both edge rows).
-    // (register budget: two VGPRs per level -- lvb, and lvp = positions + 1 of the three slots (4 bits each, 0 = none) | wrong-tap mask
-    // << 12 | (M tile + 1) << 21; the uniform "does any lane ..." questions are asked with a ballot where they are needed)
-    constexpr int LV = 4;
-    int lvb[EDGE ? LV : 1];
-    uint32_t lvp[EDGE ? LV : 1];
-    uint32_t lv_any = 0, wcls = 0, lv_rows = 0;     // lv_rows: bit 3 * L + a = some lane of level L has a wrong tap in window row a
-    // the true terms' weight fragments (variant, tap) x operand groups of a chunk out of the packed operands: per (face, band) when the
-    // layer is one chunk (they stay in registers across the tiles of a combo), else fetched by every edge_chunk (an exposed L2 round trip)
-    uint4 wfk[EDGE ? 3 : 1][EDGE ? KCG : 1][EDGE ? NT : 1];
-    auto edge_wload = [&](int f, int ch) {
-        if constexpr (EDGE) {
-            const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.wpk);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int wid = max((int)E.wids[(f * 2 + (int)wcls) * 3 + k], 0);
-                const int wv = wid / 9, wtap = wid - wv * 9;
-#pragma unroll
-                for (int cgl = 0; cgl < KCG; ++cgl)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int ntile = min(nt0 + wn * NT + nt, P.NTtot - 1), cg = min(ch * KCG + cgl, P.CG - 1);
-                        wfk[k][cgl][nt] = wsrc[(((size_t)wv * P.NTtot + ntile) * P.CG + cg) * GF4 + wtap * 64 + lane];
-                    }
-            }
-        }
-    };
+    // EDGE: per (face, band).  A lane owns pixel l31 of each of the wave's MT M tiles.  For a border cell the plan record
+    // (dlwpcs_dgrad_gather_plan) says which taps of its 3 x 3 window are WRONG (they cross an edge behind which the neighbour's
+    // kernel, rotated into this face's frame, applies) and where the cell's true terms read instead: term k of the first / second
+    // slot set = the dz row of the halo cell at window position slot[k] / slot[3 + k] times weight id k of the tile's triple.
+    // Both are pure ADDRESSING for the matrix phase: a lane whose tap is wrong reads its pixel operand from an LDS address beyond
+    // the workgroup's allocation -- the hardware returns zeros there (dlwpcs_lds_oob_probe,
+    // tests/test_gpu_dgrad_gather.py::test_lds_reads_beyond_the_allocation_return_zero) -- so the own-kernel MFMA of that tap adds
+    // nothing to the lane's pixel column, and three (six in waves that hold a cube corner) more steps per operand group run the
+    // substitute fragments (tap slots TAPS + k of the LDS weight area: the producers stage the tile's triple beside the nine taps)
+    // against per-lane operand addresses (out of range = no such term).  No cancellation, no scratch accumulator, no per-level
+    // loop, no global load in the consumers' path: the corrections are steps of the same software pipeline as the nine taps.
+    //   Per lane and M tile, packed (the matrix phase has few registers to spare): es[mt][j >> 1], 16 bits each = the LDS
+    //   offset / 16 of term j = set * 3 + k inside the chunk buffer, bit 15 = no such term (<< 4 it lands beyond the allocation);
+    //   ewp = the wrong-tap masks, 8 bits per M tile (the centre tap is never wrong: bits 0-3 = taps 0-3, 4-7 = taps 5-8).  Uniform:
+    //   e_any (some lane of the wave has a correction in this (face, band): the wave runs mma_chunk_edge), e_two (some lane has a
+    //   second-slot term: cube corners).
+    uint32_t es[EDGE ? MT : 1][3];
+    uint32_t ewp[EDGE ? (MT + 3) / 4 : 1];
+    uint32_t e_any = 0, e_two = 0;
     float4 bq[NT][4];
     // store pass (nt, mt, ps) of this lane: byte offset of its 16 B inside ONE sample of the destination (ST_SKIP: nothing to
     // store) and, data gradient in direct mode, which destination (2 bits each: 0 = out, 1 = d0, 2 = d1).  Like the LDS
@@ -672,7 +692,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 
     constexpr int PROW = 32 * ES + 16;          // patch row: one pixel's 32 channels + pad
     // pooling as a second output: one patch per M tile of the wave (all of them are read back once the wave's rows are complete)
-    const bool pooling = MODE != MODE_ZERO && P.pool_out != nullptr;
+    const bool pooling = MODE != MODE_ZERO && !EDGE && P.pool_out != nullptr;      // (EDGE is a data gradient: nothing to pool)
     char *const patch0 = smem + patch_base + wave * (32 * PROW) * (pooling ? MT : 1);
     const int patch_step = pooling ? 32 * PROW : 0;
     // ---- pooled second output.  The wave's MT * 32 pixels are whole pairs of tile rows: pooled pixel pp of the wave is the
@@ -721,25 +741,14 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 abase[mt] = base + half * 16;
             }
             if constexpr (EDGE) {
-                // ONE memory round trip per (face, band): the weight fragments of the face's triple and the border-cell records are
-                // requested together (nothing here depends on a loaded value until both are waited for below).  Consumer waves do
-                // this while the producers' first loads are in flight -- a chain of dependent round trips here (records -> triple ->
-                // fragments) cost 12 us per launch, more than all corrections together.
-                bool last_row = false;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int m = tile_pix(mt * 32 + l31);
-                    const int oy = __umulhi((uint32_t)(gq.m0 + min(m, gq.npix - 1)), P.magicNo);
-                    last_row |= m < gq.npix && oy == P.No - 1;
-                }
-                wcls = __builtin_amdgcn_ballot_w64(last_row) != 0 ? 1u : 0u;
+                // ONE memory round trip per (face, band): the border-cell records.  Consumer waves do this while the producers' first
+                // loads are in flight.
                 // (equatorial faces: only the bands that hold the first or the last row have corrections)
                 const int ylast = __umulhi((uint32_t)(gq.m0 + gq.npix - 1), P.magicNo);
                 const bool maybe = gq.f >= 4 || gq.y0 == 0 || ylast == P.No - 1;
-                if (maybe && nchunks == 1) edge_wload(gq.f, 0);
-                int cnt = 0;
+                bool any = false, two = false;
 #pragma unroll
-                for (int L = 0; L < LV; ++L) { lvb[L] = 0; lvp[L] = 0; }
+                for (int w = 0; w < (MT + 3) / 4; ++w) ewp[w] = 0;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int m = tile_pix(mt * 32 + l31);
@@ -749,49 +758,30 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                     const int ord = oy == 0 ? ox : (oy == P.No - 1 ? P.No + ox : 2 * P.No + 2 * (oy - 1) + (ox ? 1 : 0));
                     int4 e0 = make_int4(-1, -1, -1, -1), e1 = make_int4(-1, -1, 0, 0);
                     if (maybe) {
-                        const int4 *es = reinterpret_cast<const int4 *>(E.src + ((size_t)gq.f * (4 * P.No - 4) + (border ? ord : 0)) * 8);
-                        e0 = es[0]; e1 = es[1];
+                        const int4 *esrc = reinterpret_cast<const int4 *>(E.src + ((size_t)gq.f * (4 * P.No - 4) + (border ? ord : 0)) * 8);
+                        e0 = esrc[0]; e1 = esrc[1];
                     }
+                    // window position a * 3 + b -> the halo cell's operand in the chunk buffer (abase = the window's first cell)
+                    auto fld = [&](int pos) {
+                        const int pa = (max(pos, 0) * 11) >> 5, pb = max(pos, 0) - 3 * pa;
+                        return (border && pos >= 0) ? (uint32_t)(abase[mt] + (pa * P.W2 + pb) * RB) >> 4 : 0x8000u;
+                    };
+                    es[mt][0] = fld(e0.x) | fld(e0.y) << 16;
+                    es[mt][1] = fld(e0.z) | fld(e0.w) << 16;
+                    es[mt][2] = fld(e1.x) | fld(e1.y) << 16;
                     const uint32_t wrong = border ? (uint32_t)e1.z : 0u;
-                    // (slot values are -1 or 0..8: + 1 packs them as 0 = none)
-                    const uint32_t p0 = border ? (uint32_t)(e0.x + 1) | (uint32_t)(e0.y + 1) << 4 | (uint32_t)(e0.z + 1) << 8 : 0u;
-                    const uint32_t p1 = border ? (uint32_t)(e0.w + 1) | (uint32_t)(e1.x + 1) << 4 | (uint32_t)(e1.y + 1) << 8 : 0u;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {       // the first three slots (+ the cancellations), then the second terms of a cube corner
-                        const uint32_t rec = (h == 0 ? (p0 | wrong << 12) : p1);
-                        const bool have = rec != 0;
-#pragma unroll
-                        for (int L = 0; L < LV; ++L) {
-                            const bool here = have && cnt == L;
-                            lvb[L] = here ? abase[mt] : lvb[L];
-                            lvp[L] = here ? (rec | (uint32_t)(mt + 1) << 21) : lvp[L];
-                        }
-                        cnt += have ? 1 : 0;
-                    }
+                    ewp[mt / 4] |= ((wrong & 15u) | ((wrong >> 5) << 4)) << (8 * (mt % 4));
+                    any |= border && (wrong != 0 || e0.x >= 0 || e0.y >= 0 || e0.z >= 0 || e0.w >= 0 || e1.x >= 0 || e1.y >= 0);
+                    two |= border && (e0.w >= 0 || e1.x >= 0 || e1.y >= 0);
                 }
-                lv_any = 0; lv_rows = 0;
+                e_any = __builtin_amdgcn_ballot_w64(any) != 0 ? 1u : 0u;
+                e_two = __builtin_amdgcn_ballot_w64(two) != 0 ? 1u : 0u;
+                if (P.tune & (1 << 20)) e_any = 0;          // DEV ablation (wrong borders): plain loop everywhere
+                if (P.tune & (1 << 21)) e_two = 0;          // DEV ablation: no second-slot steps
 #pragma unroll
-                for (int L = 0; L < LV; ++L) {
-                    if (__builtin_amdgcn_ballot_w64(lvp[L] != 0) != 0) lv_any |= 1u << L;
+                for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(es[mt][0]), "+v"(es[mt][1]), "+v"(es[mt][2]));
 #pragma unroll
-                    for (int a = 0; a < 3; ++a)
-                        if (__builtin_amdgcn_ballot_w64(((lvp[L] >> (12 + 3 * a)) & 7u) != 0) != 0) lv_rows |= 1u << (3 * L + a);
-                }
-                if (P.tune & (1 << 20)) lv_any = 0;         // (ablation, timing only: no corrections -- wrong border cells)
-                if (maybe && nchunks == 1) {
-                    // the fragments are waited for HERE, inside the (rare) branch (the empty asm redefines the registers: nothing is
-                    // pending on them at the join) -- else every tile's first use sits behind s_waitcnt vmcnt(0), i.e. behind the
-                    // acknowledgement of the previous tile's stores
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-#pragma unroll
-                        for (int cgl = 0; cgl < KCG; ++cgl)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                asm volatile("" : "+v"(wfk[k][cgl][nt].x), "+v"(wfk[k][cgl][nt].y), "+v"(wfk[k][cgl][nt].z), "+v"(wfk[k][cgl][nt].w));
-                }
-#pragma unroll
-                for (int L = 0; L < LV; ++L) asm volatile("" : "+v"(lvb[L]), "+v"(lvp[L]));
+                for (int w = 0; w < (MT + 3) / 4; ++w) asm volatile("" : "+v"(ewp[w]));
             }
             if constexpr (MODE != MODE_ZERO) {
                 if (pooling) pool_setup(gq);
@@ -812,7 +802,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         }
         // the bias quads of the face variant (the packed bias vector is zero-padded to NTtot*32 floats, so every quad is
         // readable; an N tile beyond C_out -- NTtot not a multiple of the workgroup's N tiles -- re-reads the last tile's)
-        if (gq.v != cur_v) {
+        if (!EDGE && gq.v != cur_v) {
             cur_v = gq.v;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -839,6 +829,10 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int jq = 0; jq < 4; ++jq) {
+                    if constexpr (EDGE) {       // (a data gradient has no bias: no quads to keep)
+                        acc[mt][nt][4 * jq] = 0.f; acc[mt][nt][4 * jq + 1] = 0.f; acc[mt][nt][4 * jq + 2] = 0.f; acc[mt][nt][4 * jq + 3] = 0.f;
+                        continue;
+                    }
                     acc[mt][nt][4 * jq] = bq[nt][jq].x; acc[mt][nt][4 * jq + 1] = bq[nt][jq].y;
                     acc[mt][nt][4 * jq + 2] = bq[nt][jq].z; acc[mt][nt][4 * jq + 3] = bq[nt][jq].w;
                 }
@@ -955,7 +949,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         }
         __builtin_amdgcn_wave_barrier();
     };
-    auto epi_slice = [&](auto fast_tag, int i, const Geo &gq, rsrc_t d_out, rsrc_t d_0, rsrc_t d_1, const auto &A) {
+    auto epi_slice = [&](auto fast_tag, auto ud_tag, int i, const Geo &gq, rsrc_t d_out, rsrc_t d_0, rsrc_t d_1, const rsrc_t (&dsel)[NT],
+                         const auto &A) {
         const int pr = i / SPP, k = i % SPP;
         const int nt = pr / MT, mt = pr % MT;
         char *const patch = patch0 + mt * patch_step;
@@ -987,7 +982,10 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 #ifdef DLWPCS_TIMELINE
             if (P.abl & 1) boff = ST_SKIP;          // ablation: no global stores
 #endif
-            if constexpr (DIRECT) {
+            if constexpr (decltype(ud_tag)::value) {
+                // gather form, whole 32-channel n tiles per source: the destination is the same for every lane of the pass
+                bst128(v, dsel[nt], boff);
+            } else if constexpr (DIRECT) {
                 // three possible destinations: one store each, the lanes of the other two skip
                 bst128(v, d_out, sel == 0 ? boff : ST_SKIP);
                 bst128(v, d_0, sel == 1 ? boff : ST_SKIP);
@@ -1023,18 +1021,35 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         const rsrc_t d_0 = DIRECT ? d0_of(gq) : d_out, d_1 = DIRECT ? d1_of(gq) : d_out;
         const rsrc_t d_pool = pool_of(gq);
         // (the pooled output is written when the slices of an n tile are through: its patches are complete then)
-        auto run = [&](auto tag) {
+        // EDGE: every cell goes straight to a source's gradient (or, an upsampled source, to the workspace); when the sources' channel
+        // counts are multiples of 32 an n tile belongs to ONE of them and a store pass is one store instruction instead of three
+        rsrc_t dsel[NT];
+        bool ud = false;
+        if constexpr (EDGE) {
+            ud = (P.dsplit & 31) == 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool in0 = (nt0 + wn * NT + nt) * 32 < P.dsplit;
+                dsel[nt] = (in0 ? P.d0 : P.d1) != nullptr ? (in0 ? d_0 : d_1) : d_out;
+            }
+        }
+        auto run = [&](auto tag, auto ud_tag) {
 #pragma unroll
             for (int i = 0; i < NSLICE; ++i) {
-                if ((i / SPP) % MT < MTA) epi_slice(tag, i, gq, d_out, d_0, d_1, A);        // (compile-time: the loop is unrolled)
+                if ((i / SPP) % MT < MTA) epi_slice(tag, ud_tag, i, gq, d_out, d_0, d_1, dsel, A);   // (compile-time: the loop is unrolled)
                 if constexpr (MODE != MODE_ZERO) {
                     if ((i + 1) % (MT * SPP) == 0 && pooling) pool_pass(i / (MT * SPP), d_pool);
                 }
             }
         };
-        if (P.act != DLWPCS_ACT_LEAKY_CLIP) run(std::integral_constant<int, 2>{});
-        else if (fast_act) run(std::integral_constant<int, 1>{});
-        else run(std::integral_constant<int, 0>{});
+        if constexpr (EDGE) {                                                // (a data gradient never has an activation)
+            if (ud) run(std::integral_constant<int, 2>{}, std::true_type{});
+            else run(std::integral_constant<int, 2>{}, std::false_type{});
+        }
+        else if constexpr (DIRECT) run(std::integral_constant<int, 2>{}, std::false_type{});
+        else if (P.act != DLWPCS_ACT_LEAKY_CLIP) run(std::integral_constant<int, 2>{}, std::false_type{});
+        else if (fast_act) run(std::integral_constant<int, 1>{}, std::false_type{});
+        else run(std::integral_constant<int, 0>{}, std::false_type{});
         TL_MARK();
     };
     // fallback (odd channel counts, or no LDS room for the patches): quads / scalars straight from the accumulators
@@ -1092,9 +1107,13 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 bw[nt] = *reinterpret_cast<const uint4 *>(
-                    lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 512 + l31 * 16);
+                    lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPSW + tap) * 2 + half) * 512 + l31 * 16);
         };
         load_frag(0, fa[0], fb[0]);
+        // (the groups of all sched_group_barriers of the unrolled block form ONE pipeline, filled in program order: without a group
+        // of its own for step 0's reads the first DS group takes THEM, the first MFMA group step 0's MFMAs, and so on -- reads and
+        // MFMAs of the same step back to back, one fragment set, every step waiting for its own reads (what rounds 1-4 shipped))
+        __builtin_amdgcn_sched_group_barrier(0x100, MTA + NT, 0);
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
             const int cur = step & 1;
@@ -1112,111 +1131,67 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         }
     };
 
-    // ---- EDGE: the corrections of one channel chunk (see the head of the function).  edge_wload: the true terms' weight fragments
-    // (variant, tap) of the chunk's operand groups out of the packed operands, issued BEFORE the chunk's main MFMAs; edge_chunk: behind
-    // them, between the same two barriers (the chunk's LDS buffer is still this workgroup's).
-    constexpr uint32_t SIGN = ES == 2 ? 0x80008000u : 0x80000000u;
-    auto edge_chunk = [&](const Geo &gq, int ch) {
+    // ---- EDGE: the chunk of a wave that holds border cells with corrections (e_any).  The nine tap steps with the wrong taps'
+    // lanes reading zeros, then -- same register pipeline -- the substitute steps: (slot set, weight id k, operand group) with the
+    // fragment of tap slot TAPS + k as the A operand and per-lane operand addresses.
+    auto mma_chunk_edge = [&](const Geo &gq, int ch, auto two_tag) {
       if constexpr (EDGE) {
+        constexpr int NSETS = decltype(two_tag)::value ? 2 : 1;
+        constexpr int NX = NSETS * 3 * KCG;
         const char *lds_in = smem + (g & 1) * in_step, *lds_w = smem + w_base + (P.wstat ? ch : (g & 1)) * w_step;
-        if (nchunks != 1) edge_wload(gq.f, ch);
-        // (the producer waves of this SIMD run at s_setprio 2 and the corrections are VALU / LDS work like the epilogue: tune bit 25 lets
-        // the consumers outrank them for the duration -- A/B switch)
-        if (P.tune & (1 << 25)) __builtin_amdgcn_s_setprio(3);
-#pragma unroll 1
-        for (int L = 0; L < LV; ++L) {
-            if (!((lv_any >> L) & 1u)) break;           // (levels fill from 0: the first empty one ends the list)
-            if ((P.tune & (1 << 24)) && L > 0) break;   // (ablations, timing only: bits 21 / 22 / 23 / 24 = no cancel / no true terms / no merge / level 0 only)
-            // (runtime loop, static register indices: the level's two registers are selected, not indexed)
-            const int lb = L == 0 ? lvb[0] : (L == 1 ? lvb[1] : (L == 2 ? lvb[2] : lvb[3]));
-            const uint32_t lp = L == 0 ? lvp[0] : (L == 1 ? lvp[1] : (L == 2 ? lvp[2] : lvp[3]));
-            // two scratch accumulators per N tile (operand group 0 / 1, or alternating taps): two independent MFMA chains
-            f32x16 ae[2][NT];
+        // (the packed records are redefined per chunk -- empty asm, in place -- so that their decoding stays INSIDE the chunk: hoisted
+        // out of the tile loop, the 24 masked bases and 18 operand addresses are 40 more live registers, i.e. spills -- and a spill
+        // reloaded in the epilogue is a scratch load behind s_waitcnt vmcnt(0), i.e. behind the acknowledgement of every store
+        // issued so far: measured 39 -> 65 us on the 32 -> 32 layer at N = 48)
+        uint32_t (&rs)[MT][3] = es;
+        uint32_t (&rw)[(MT + 3) / 4] = ewp;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(rs[mt][0]), "+v"(rs[mt][1]), "+v"(rs[mt][2]));
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+        for (int w = 0; w < (MT + 3) / 4; ++w) asm volatile("" : "+v"(rw[w]));
+        uint4 fa[2][MT], fb[2][NT];
+        auto load_frag = [&](int step, uint4 (&a)[MT], uint4 (&bw)[NT]) {
+            if (step < NSTEP) {
+                const int cgl = step / TAPS, tap = step % TAPS;
+                const int dy = tap / KS, dx = tap % KS;
+                const int tapoff = (dy * P.W2 + dx) * RB + cgl * 32;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) ae[u][nt][r] = 0.f;
-            // cancel the wrong crossing taps: - dzpad[window + tap] . W_own[tap], one window ROW at a time (uniform: rows in which no
-            // lane of the level has a wrong tap are skipped -- the cells of an edge row only have row 0 or row 2).  Per row every LDS
-            // read (three pixel fragments and three weight fragments per operand group) is issued before the first MFMA: left to
-            // itself the compiler waits for each read in front of the MFMA that needs it, ~190 cycles per MFMA, 4 k per level.
-            if (!(P.tune & (1 << 21)))
-#pragma unroll
-            for (int a = 0; a < KS; ++a) {
-                if (!((lv_rows >> (3 * L + a)) & 1u)) continue;
-                uint4 px[KS][KCG], wq[KS][KCG][NT];
-#pragma unroll
-                for (int b = 0; b < KS; ++b)
-#pragma unroll
-                    for (int cgl = 0; cgl < KCG; ++cgl) {
-                        if (a == 1 && b == 1) continue;         // (the window's centre is the cell itself: never wrong)
-                        px[b][cgl] = *reinterpret_cast<const uint4 *>(lds_in + lb + (a * P.W2 + b) * RB + cgl * 32);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            wq[b][cgl][nt] = *reinterpret_cast<const uint4 *>(
-                                lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + a * KS + b) * 2 + half) * 512 + l31 * 16);
-                    }
-#pragma unroll
-                for (int b = 0; b < KS; ++b) {
-                    if (a == 1 && b == 1) continue;
-                    const bool on = (lp >> (12 + a * KS + b)) & 1u;
-#pragma unroll
-                    for (int cgl = 0; cgl < KCG; ++cgl) {
-                        uint4 &q = px[b][cgl];
-                        q.x = on ? q.x ^ SIGN : 0u; q.y = on ? q.y ^ SIGN : 0u; q.z = on ? q.z ^ SIGN : 0u; q.w = on ? q.w ^ SIGN : 0u;
-                    }
+                for (int mt = 0; mt < MT; ++mt) {
+                    // a wrong tap's lanes read 8 MB up: zeros (the window's centre is the cell itself: never wrong)
+                    int base = abase[mt];
+                    if (tap != TAPS / 2) base += (int)((rw[mt / 4] >> (8 * (mt % 4) + (tap < TAPS / 2 ? tap : tap - 1))) & 1u) << 23;
+                    a[mt] = *reinterpret_cast<const uint4 *>(lds_in + base + tapoff);
                 }
 #pragma unroll
-                for (int b = 0; b < KS; ++b)
+                for (int nt = 0; nt < NT; ++nt)
+                    bw[nt] = *reinterpret_cast<const uint4 *>(
+                        lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPSW + tap) * 2 + half) * 512 + l31 * 16);
+            } else {
+                const int x = step - NSTEP, j = x / KCG, cgl = x % KCG;       // j = set * 3 + k
 #pragma unroll
-                    for (int cgl = 0; cgl < KCG; ++cgl) {
-                        if (a == 1 && b == 1) continue;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) frag_mma<T>(ae[(b * KCG + cgl) & 1][nt], wq[b][cgl][nt], px[b][cgl]);
-                    }
-            }
-            // add the true terms: + dzpad[the term's halo cell] . W_neighbour[its tap] (fragments in registers)
-            if (!(P.tune & (1 << 22))) {
-                uint4 px[3][KCG];
-                bool on[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int ps1 = (int)((lp >> (4 * k)) & 15u);
-                    on[k] = ps1 != 0;
-                    const int ps = max(ps1 - 1, 0), pa = ps / 3;
-                    const int off = lb + (pa * P.W2 + (ps - 3 * pa)) * RB;
-#pragma unroll
-                    for (int cgl = 0; cgl < KCG; ++cgl) px[k][cgl] = *reinterpret_cast<const uint4 *>(lds_in + off + cgl * 32);
+                for (int mt = 0; mt < MT; ++mt) {
+                    const uint32_t f16 = (j & 1) ? rs[mt][j >> 1] >> 16 : rs[mt][j >> 1] & 0xffffu;
+                    a[mt] = *reinterpret_cast<const uint4 *>(lds_in + (int)(f16 << 4) + cgl * 32);
                 }
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int cgl = 0; cgl < KCG; ++cgl) {
-                        uint4 &q = px[k][cgl];
-                        q.x = on[k] ? q.x : 0u; q.y = on[k] ? q.y : 0u; q.z = on[k] ? q.z : 0u; q.w = on[k] ? q.w : 0u;
-                    }
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int cgl = 0; cgl < KCG; ++cgl)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) frag_mma<T>(ae[(k * KCG + cgl) & 1][nt], wfk[k][cgl][nt], px[k][cgl]);
+                for (int nt = 0; nt < NT; ++nt)         // the substitute fragment: tap slot TAPS + k of the weight area
+                    bw[nt] = *reinterpret_cast<const uint4 *>(
+                        lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPSW + TAPS + j % 3) * 2 + half) * 512 + l31 * 16);
             }
-            // a lane's column of the scratch accumulators belongs to the M tile its level-L pixel lives in
-            const int lm = (int)(lp >> 21) - 1;
-            if (!(P.tune & (1 << 23)))
+        };
+        load_frag(0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);       // (step 0's reads: a group of their own, see mma_chunk)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float on = lm == mt ? 1.f : 0.f;
+        for (int step = 0; step < NSTEP + NX; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < NSTEP + NX) load_frag(step + 1, fa[cur ^ 1], fb[cur ^ 1]);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = __builtin_fmaf(on, ae[0][nt][r] + ae[1][nt][r], acc[mt][nt][r]);
-            }
+                for (int nt = 0; nt < NT; ++nt) frag_mma<T>(acc[mt][nt], fb[cur][nt], fa[cur][mt]);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MmaPerFrag<T>::N * MT * NT, 0);
         }
-        if (P.tune & (1 << 25)) __builtin_amdgcn_s_setprio(0);
       }
     };
 
@@ -1257,8 +1232,10 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 else if (my_mt == 2) mma_chunk(ch, std::integral_constant<int, 2>{});
                 else if (my_mt == 1) mma_chunk(ch, std::integral_constant<int, 1>{});
             } else if constexpr (EDGE) {
-                mma_chunk(ch, std::integral_constant<int, MT>{});
-                if (lv_any != 0) edge_chunk(gq, ch);      // uniform; most tiles of the equatorial faces need no correction at all
+                // (uniform per (face, band) and wave; most waves of the equatorial faces have no correction at all)
+                if (!e_any) mma_chunk(ch, std::integral_constant<int, MT>{});
+                else if (!e_two) mma_chunk_edge(gq, ch, std::false_type{});
+                else mma_chunk_edge(gq, ch, std::true_type{});
             } else {
                 mma_chunk(ch, std::integral_constant<int, MT>{});
             }

@@ -1311,3 +1311,42 @@ extern "C" int dlwpcs_batch_gather(const void *array, int64_t T, int V, int64_t 
     }
     return check_launch("batch_gather");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// dlwpcs_lds_oob_probe: the gather-form data gradient (conv_ws.h, EDGE) masks operands by ADDRESS -- a lane that must contribute
+// nothing to an MFMA reads its operand from beyond the workgroup's LDS allocation, where the hardware returns zeros (GCN / CDNA:
+// out-of-range LDS reads return 0).  This probe reads 16 B per lane at the three offsets the kernel uses and counts non-zero dwords.
+// ------------------------------------------------------------------------------------------------------------------
+namespace dlwpcs {
+__global__ void lds_oob_probe_kernel(int32_t *nonzero) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t probe_smem[];
+    for (int i = threadIdx.x; i < 40 * 1024; i += blockDim.x) probe_smem[i] = 0xdead0000u + i;      // 160 KB, all non-zero
+    __syncthreads();
+    const uint32_t offs[3] = {0x00f00000u, 1u << 23, 0x8000u << 4};
+    int nz = 0;
+    for (int u = 0; u < 3; ++u) {
+        uint4 v;
+        const uint32_t addr = offs[u] + threadIdx.x * 16 + (u == 0 ? 8160u + 32u : 0u);
+        asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        nz += (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
+    }
+    // (and an in-range read must still see the data)
+    uint4 w;
+    const uint32_t inr = threadIdx.x * 16;
+    asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(inr) : "memory");
+    if (w.x != 0xdead0000u + threadIdx.x * 4) nz += 1000;
+    if (nz) atomicAdd(nonzero, nz);
+}
+}  // namespace dlwpcs
+
+extern "C" int dlwpcs_lds_oob_probe(int32_t *nonzero_dev, dlwpcs_stream_t stream) {
+    REQUIRE(nonzero_dev, "lds_oob_probe: null output");
+    hipStream_t s = (hipStream_t)stream;
+    const int lds = 160 * 1024;
+    hipError_t e = hipFuncSetAttribute((const void *)lds_oob_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "lds_oob_probe: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    e = hipMemsetAsync(nonzero_dev, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "lds_oob_probe: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(4), dim3(256), lds, s, nonzero_dev);
+    return check_launch("lds_oob_probe");
+}

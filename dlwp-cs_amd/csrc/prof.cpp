@@ -24,6 +24,15 @@ static std::vector<ProfRecord> g_records;
 
 bool prof_enabled() { return g_enabled; }
 
+// (function-local: the registrations run from other translation units' static initialisers)
+static std::vector<std::string> &known_tags() { static std::vector<std::string> v; return v; }
+int prof_register_tag(const char *tag) {
+    auto &v = known_tags();
+    for (size_t i = 0; i < v.size(); ++i) if (v[i] == tag) return (int)i;
+    v.push_back(tag);
+    return (int)v.size() - 1;
+}
+
 static bool capturing(hipStream_t s) {
     if (s == nullptr) return false;                 // (the null stream cannot be captured; the query rejects it)
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -111,5 +120,15 @@ extern "C" int dlwpcs_prof_get(int i, char *tag, int tag_len, double *ms, double
     strncpy(tag, r.tag.c_str(), tag_len - 1);
     tag[tag_len - 1] = 0;
     *ms = t; *flops = r.flops; *bytes = r.bytes;
+    return DLWPCS_OK;
+}
+
+extern "C" int dlwpcs_prof_known_tags(void) { return (int)known_tags().size(); }
+
+extern "C" int dlwpcs_prof_known_tag(int i, char *tag, int tag_len) {
+    const auto &v = known_tags();
+    if (i < 0 || i >= (int)v.size() || !tag || tag_len < 1) return fail(DLWPCS_E_INVALID, "prof_known_tag: bad arguments");
+    strncpy(tag, v[i].c_str(), tag_len - 1);
+    tag[tag_len - 1] = 0;
     return DLWPCS_OK;
 }

@@ -27,6 +27,9 @@
 #include "mfma_common.h"
 
 namespace dlwpcs {
+static const int g_wb_tags[] = {prof_register_tag("wgrad_batch_kernel"), prof_register_tag("wb_reduce_kernel"),
+                                prof_register_tag("wb_reduce_kernel(apply)")};
+
 
 constexpr int WB_MAX_LAYERS = DLWPCS_WGRAD_BATCH_MAX;
 constexpr uint32_t WB_MAGIC = 0x57424c31u;       // 'WBL1'

@@ -519,6 +519,14 @@ int dlwpcs_batch_gather(const void *array, int64_t T, int V, int64_t S, const in
                         int Ctot, int c_off, int c_stride, int channels_last, int dtype, dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
+ * Hardware self-check of the gather-form data gradient (DLWPCS_CONV_DGRAD_GATHER): its kernel masks MFMA operands by
+ * address -- lanes that must add nothing read LDS beyond the workgroup's allocation, which returns zeros on gfx950.
+ * Writes to *nonzero_dev (device int32, caller-owned) the number of non-zero dwords such reads returned at the offsets
+ * the kernel uses: 0 = the assumption holds on this device.
+ * ------------------------------------------------------------------------------------------------------------- */
+int dlwpcs_lds_oob_probe(int32_t *nonzero_dev, dlwpcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------- *
  * Opt-in launch profiler (bench.py `roofline`): when enabled, every MFMA convolution kernel launch is bracketed by two
  * HIP events recorded on the launch stream.  Off by default.  Enabled while a stream is being graph-captured, the events
  * become external event-record nodes of that graph (tag suffix "@graph"): every replay records them again and
@@ -531,6 +539,11 @@ int dlwpcs_prof_enable(int on);
 int dlwpcs_prof_reset(void);
 int dlwpcs_prof_count(void);
 int dlwpcs_prof_get(int i, char *tag, int tag_len, double *ms, double *flops, double *bytes);
+/* Host only, no device needed: the tags the profiler can report -- one per kernel instantiation the library carries, registered
+ * when the library is loaded.  A tag is the kernel's name exactly as the code object / rocprofv3 / `nm -C` spell it (a suffix in
+ * parentheses names a mode of the same kernel).  dlwpcs_prof_known_tags: how many; dlwpcs_prof_known_tag: the i-th. */
+int dlwpcs_prof_known_tags(void);
+int dlwpcs_prof_known_tag(int i, char *tag, int tag_len);
 
 #ifdef __cplusplus
 }

@@ -103,3 +103,40 @@ def test_product_path_has_no_cpu_fallback(native):
     from DLWP import ops
     with pytest.raises(native.NativeError):
         ops.cs_pad(torch.zeros(1, 6, 4, 4, 1), 1)
+
+
+def test_profiler_tags_are_the_kernels_names(native):
+    """Every tag the launch profiler can report (dlwpcs_prof_known_tag: registered at load time, one per kernel instantiation) is
+    the name of a kernel of libdlwpcs.so exactly as its symbol table spells it: bench.py joins rocprofv3's per-kernel counter
+    records on these names (round 4 shipped a convolution tag with 12 of the kernel's 13 template arguments: no PMC record)."""
+    import shutil
+    import subprocess
+    if shutil.which('nm') is None:
+        pytest.skip('binutils nm not available')
+    lib = native.lib()
+    n = lib.dlwpcs_prof_known_tags()
+    assert n > 60                                   # the convolution template alone has > 60 instantiations
+    buf = ctypes.create_string_buffer(256)
+    tags = []
+    for i in range(n):
+        assert lib.dlwpcs_prof_known_tag(i, buf, 256) == 0
+        tags.append(buf.value.decode())
+    assert lib.dlwpcs_prof_known_tag(n, buf, 256) == -1
+    out = subprocess.run(['nm', '-C', '--defined-only', native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    kernels = set()
+    for line in out.splitlines():
+        m = re.match(r'^[0-9a-f]+ \w (?:void )?dlwpcs::(?!__device_stub__)(.+)$', line)
+        if m:
+            name = m.group(1)
+            depth, cut = 0, len(name)
+            for j, ch in enumerate(name):           # strip the parameter list: the first '(' outside the template arguments
+                depth += ch == '<'
+                depth -= ch == '>'
+                if ch == '(' and depth == 0:
+                    cut = j
+                    break
+            kernels.add(name[:cut])
+    conv = [t for t in tags if t.startswith('conv_mfma_ws_kernel<')]
+    assert len(conv) > 60 and all(t.count(',') == 12 for t in conv)
+    for t in tags:
+        assert re.sub(r'\(.*\)$', '', t) in kernels, 'profiler tag %r is not a kernel of the library' % t

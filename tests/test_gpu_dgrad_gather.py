@@ -105,8 +105,8 @@ def test_gather_form_matches_the_oracle(case):
     seed = abs(hash(case)) % (2 ** 31)
     (g0, g1), (src0, src1, w, dz) = _run(case, True, seed)
     r0, r1 = _oracle(src0.float(), src1.float() if src1 is not None else None, up0, w[0], w[1], dz.float(), mask0, mask1)
-    # (N <= 12: a consumer wave holds both edge rows of a face -> the library keeps the padded-grid path, whose border cells round twice)
-    one = 1.0 if N >= 16 else 3.0
+    # (N <= 16: a tile holds both edge rows of a face -> the library keeps the padded-grid path, whose border cells round twice)
+    one = 1.0 if N >= 24 else 3.0
     for g, r, ulps in ((g0, r0, 3.0 if up0 else one), (g1, r1, one)):
         if g is None:
             continue
@@ -182,3 +182,13 @@ def test_unet2_training_in_gather_form(N):
     cos = float(np.dot(d_off, d_on) / (np.linalg.norm(d_off) * np.linalg.norm(d_on)))
     assert np.isfinite(p_on).all() and cos > 0.99, cos
     assert abs(s_on[0, 0] - s_off[0, 0]) <= 5e-3 * abs(s_off[0, 0])
+
+
+def test_lds_reads_beyond_the_allocation_return_zero():
+    """The gather form masks MFMA operands by address: lanes that must add nothing read LDS beyond the workgroup's allocation
+    (csrc/conv_ws.h, EDGE).  The hardware returns zeros there; dlwpcs_lds_oob_probe checks it on THIS device."""
+    from DLWP import _native as nat
+    nz = torch.full((1,), -1, dtype=torch.int32, device=_dev())
+    nat.check(nat.lib().dlwpcs_lds_oob_probe(nat.ptr(nz), nat.stream_ptr()), 'lds_oob_probe')
+    torch.cuda.synchronize()
+    assert int(nz.item()) == 0
