@@ -801,12 +801,13 @@ class _CSConv(torch.autograd.Function):
 
 _ring_info_cache = {}
 
-# Data gradient in gather form (dlwpcs.h: DLWPCS_CONV_DGRAD_GATHER): bf16 3x3 halo layers whose gradient arrives as dz compute every
-# border cell completely inside the data-gradient kernel (no halo ring, no fix-up launch; window_src 2 x 2 sums for upsampled
-# sources).  Built and bit-checked in round 4 (tests/test_gpu_dgrad_gather.py: <= 1 bf16 ulp against the fp64 oracle), but NOT yet
-# faster than the padded-grid kernel + fix-up launches it replaces (0.766 against 0.684 ms per unet2 step): opt-in,
-# DLWPCS_DGRAD_GATHER=1.
-DGRAD_GATHER = os.environ.get('DLWPCS_DGRAD_GATHER', '0') == '1'
+# Data gradient in gather form (dlwpcs.h: DLWPCS_CONV_DGRAD_GATHER; the adjoint of CubeSpherePadding2D, DLWP/custom.py:1198-1308, folded
+# into the data-gradient kernel): bf16 3x3 halo layers whose gradient arrives as dz compute every border cell completely inside the
+# kernel -- no halo ring is materialised, no fix-up launch, one rounding per cell (tests/test_gpu_dgrad_gather.py: <= 1 bf16 ulp against
+# the fp64 oracle); window_src 2 x 2 sums for upsampled sources.  Default since round 5 (weight substitution inside the matrix phase:
+# as fast as the padded-grid kernel + the fix-up launches it replaces, 24 instead of 31 launches per unet2 step); faces whose tile
+# holds both edge rows (N <= 16) and the exact-fp32 mode keep the padded-grid path.  DLWPCS_DGRAD_GATHER=0 restores it everywhere.
+DGRAD_GATHER = os.environ.get('DLWPCS_DGRAD_GATHER', '1') == '1'
 
 
 def _gather_flag(d, dev):

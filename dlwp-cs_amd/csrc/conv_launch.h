@@ -45,10 +45,6 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     P.tile_rows_max = tile_rows_for(pix, P.No) + (KS - 1);
     P.ntiles = P.B * 6 * P.nblk_face;
     P.split_gb = P.split_fb = 0;
-    {   // (development: DLWPCS_EDGE_COST=<sixteenths> overrides the measured default)
-        static const int ec = [] { const char *e = getenv("DLWPCS_EDGE_COST"); return e ? atoi(e) : 22; }();
-        P.edge_cost = EDGE ? ec : 0;
-    }
     P.tune = tune_bits();
     P.dbg = nullptr;
 #ifdef DLWPCS_TIMELINE

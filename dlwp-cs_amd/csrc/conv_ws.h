@@ -66,7 +66,6 @@ struct ConvKParams {
     uint32_t *flow_done, *flow_abort;
     int flow_phase, flow_bmax, flow_need, flow_rot;
     uint32_t flow_spin;
-    int edge_cost;              // EDGE: cost of a polar face's tile in sixteenths of an equatorial one (the tile list is cut by cost); <= 16: by count
     int split_gb, split_fb;     // ILV cost split (launch_conv_cfg): the LAST split_gb workers take all the short tiles (the last band
                                 // of every face) and split_fb of the full ones, the others the remaining full tiles; 0: plain split
     long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
@@ -289,20 +288,13 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // 64 workers x (3 full + 3 short) (cost 36) where the plain split has workgroups with 6 full tiles (42).
     const int nbl = P.nblk_face;
     const bool csplit = ilv && P.split_gb > 0;
-    // EDGE (data gradient in gather form): every tile of a polar face runs the substitute steps in all of its waves, a tile of an
-    // equatorial face in at most one -- and with contiguous ranges a worker's 4.5 tiles are all of one kind: the polar workers set
-    // the launch time.  The ranges stay contiguous (a second (face, band) run per worker costs a halo-table round trip and a weight
-    // reload in the producers' path: measured +4 us per launch, more than the imbalance) but are cut by COST: a polar tile counts
-    // P.edge_cost sixteenths of an equatorial one.
+    // (EDGE, measured: every tile of a polar face runs the substitute steps in all of its waves, a tile of an equatorial face in at
+    // most one, and a worker's 4.5 contiguous tiles are all of one kind -- but neither an equatorial + a polar run per worker (a second
+    // (face, band) costs a halo-table round trip and a weight reload in the producers' path: +4 us per launch) nor ranges cut by cost
+    // (a polar tile = 20 .. 28 sixteenths: +-0 .. +3 us, the longer equatorial lists lose what the polar ones gain) beat the plain split)
     int t_first = 0, t_last = 0;            // plain split
     int f0 = 0, f1 = 0, s0 = 0, s1 = 0;     // cost split: ranges in the full list / in the short list
-    if (EDGE && P.edge_cost > 16) {
-        const long nE = 4l * nbl * P.B, nP = 2l * nbl * P.B, cp = P.edge_cost;
-        const long total = 16 * nE + cp * nP;
-        auto pos = [&](long c) { return c <= 16 * nE ? (c + 8) / 16 : nE + (c - 16 * nE + cp / 2) / cp; };
-        t_first = (int)pos(total * lw / G);
-        t_last = (int)pos(total * (lw + 1) / G);
-    } else if (csplit) {
+    if (csplit) {
         const int GB = P.split_gb, GA = G - GB;
         const int Ftot = 6 * (nbl - 1) * P.B, Stot = 6 * P.B, FA = Ftot - P.split_fb;
         if ((int)lw < GA) {
@@ -776,8 +768,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 }
                 e_any = __builtin_amdgcn_ballot_w64(any) != 0 ? 1u : 0u;
                 e_two = __builtin_amdgcn_ballot_w64(two) != 0 ? 1u : 0u;
-                if (P.tune & (1 << 20)) e_any = 0;          // DEV ablation (wrong borders): plain loop everywhere
-                if (P.tune & (1 << 21)) e_two = 0;          // DEV ablation: no second-slot steps
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(es[mt][0]), "+v"(es[mt][1]), "+v"(es[mt][2]));
 #pragma unroll
@@ -950,7 +940,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         __builtin_amdgcn_wave_barrier();
     };
     auto epi_slice = [&](auto fast_tag, auto ud_tag, int i, const Geo &gq, rsrc_t d_out, rsrc_t d_0, rsrc_t d_1, const rsrc_t (&dsel)[NT],
-                         const auto &A) {
+                         uint32_t on_u, const auto &A) {
         const int pr = i / SPP, k = i % SPP;
         const int nt = pr / MT, mt = pr % MT;
         char *const patch = patch0 + mt * patch_step;
@@ -973,7 +963,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 // around this block made the step 25 us SLOWER.)
                 uint4 vm = v;
                 vmask_pk(vm, ymq[nt][mt][ps], P.m_alpha, P.m_thr1);
-                const bool on = (sel == 1 && P.m0 != nullptr) || (sel == 2 && P.m1 != nullptr);
+                // (uniform destinations: which n tiles are masked was decided per tile, as a scalar)
+                const bool on = decltype(ud_tag)::value ? ((on_u >> nt) & 1u) != 0 : ((sel == 1 && P.m0 != nullptr) || (sel == 2 && P.m1 != nullptr));
                 // component by component: `v = on ? vm : v` on the uint4 becomes a select of two STACK ADDRESSES in LLVM -- both
                 // values went to scratch memory and came back through a scratch load behind s_waitcnt vmcnt(0), which also
                 // waited for the stores of the previous slice (measured: 43.8 us against 26.1 us unmasked, 32 -> 32 at N = 48)
@@ -1024,19 +1015,27 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         // EDGE: every cell goes straight to a source's gradient (or, an upsampled source, to the workspace); when the sources' channel
         // counts are multiples of 32 an n tile belongs to ONE of them and a store pass is one store instruction instead of three
         rsrc_t dsel[NT];
+        uint32_t on_u = 0;
         bool ud = false;
         if constexpr (EDGE) {
             ud = (P.dsplit & 31) == 0;
+            // (base pointer and size are chosen as scalars and the descriptor built from them: a select of two descriptors becomes
+            // control flow around every store)
+            const int spix = 6 * P.No * P.No, c1 = P.Cout - P.dsplit;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const bool in0 = (nt0 + wn * NT + nt) * 32 < P.dsplit;
-                dsel[nt] = (in0 ? P.d0 : P.d1) != nullptr ? (in0 ? d_0 : d_1) : d_out;
+                const bool have = (in0 ? P.d0 : P.d1) != nullptr;
+                const int cs = have ? (in0 ? P.dsplit : c1) : P.Cout;
+                T *const base = have ? (in0 ? reinterpret_cast<T *>(P.d0) : reinterpret_cast<T *>(P.d1)) : reinterpret_cast<T *>(P.out);
+                dsel[nt] = make_rsrc(base + (size_t)gq.b * spix * cs, (uint32_t)(spix * cs * ES));
+                if (have && (in0 ? P.m0 : P.m1) != nullptr) on_u |= 1u << nt;
             }
         }
         auto run = [&](auto tag, auto ud_tag) {
 #pragma unroll
             for (int i = 0; i < NSLICE; ++i) {
-                if ((i / SPP) % MT < MTA) epi_slice(tag, ud_tag, i, gq, d_out, d_0, d_1, dsel, A);   // (compile-time: the loop is unrolled)
+                if ((i / SPP) % MT < MTA) epi_slice(tag, ud_tag, i, gq, d_out, d_0, d_1, dsel, on_u, A);   // (compile-time: the loop is unrolled)
                 if constexpr (MODE != MODE_ZERO) {
                     if ((i + 1) % (MT * SPP) == 0 && pooling) pool_pass(i / (MT * SPP), d_pool);
                 }
