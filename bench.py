@@ -310,12 +310,10 @@ def run_step(st):
     if st['train']:
         st['model'].train_on_device_batch(st['dx'], st['dt'])
         return
-    state = st['dx'][0]                    # one "step" = one 40-step rollout of the batch, state resident in HBM
-    model = st['model']
-    for i in range(st['n_fwd']):
-        # (padded_io: from the second pass on the state travels with its 26 channels padded to 32 -- zero channels -- per pixel)
-        state = model.predict_on_device(state, repack=(i == 0), padded_io=os.environ.get('DLWPCS_PADDED_IO', '1') == '1')
-    st['last'] = state
+    # one "step" = one 40-step rollout of the batch, state resident in HBM: the chain of forward passes the product's
+    # predict_timeseries runs (Model.rollout_passes_on_device: one hipGraph replay per rollout when graphs are on; from the second
+    # pass on the state travels with its 26 channels padded to 32 -- zero channels -- per pixel)
+    st['last'] = st['model'].rollout_passes_on_device(st['dx'][0], st['n_fwd'])
 
 
 def roofline_pass(st, steps=3):

@@ -104,6 +104,8 @@ class Model(object):
         self._flat_params = self._flat_grads = None
         self._grads_clean = False
         self._graphs = {}
+        self._infer_graphs = {}         # rollout_passes_on_device: captured chains of forward passes
+        self._rollout_series = {}       # rollout_on_device: the device buffer a batch's series is written to
         self._seen_batch = {}
         self._toposort()
         self._build_plan()
@@ -594,9 +596,12 @@ class Model(object):
         self.metrics = metrics
         self._flatten_parameters()
         self._graphs.clear()
+        self._infer_graphs.clear()          # (captured with the parameters' old addresses)
         self._seen_batch.clear()
         self._world = parallel.world()[1]
-        if self.use_chain and parallel.device_is_shared():
+        # (device_is_shared is a collective: every rank asks, whatever its own DLWPCS_CHAIN says)
+        shared = parallel.device_is_shared()
+        if self.use_chain and shared:
             self.use_chain = False          # two ranks on one GPU: their persistent launches could keep each other from being resident
         parallel.broadcast_parameters(self._flat_params)     # identical replicas: rank 0's initial weights everywhere
         self._compiled = True
@@ -1272,10 +1277,12 @@ class Model(object):
         own (eager steps, other graphs; they clear _packed_ok) or in-place torch operations on the parameter tensors (set_weights,
         load_weights: they move the flat buffer's version counter)."""
         st = self._pack_state(device)
-        if st['n'] and not (self._packed_ok and st.get('packed') and st.get('packed_version') == self._flat_params._version):
+        # (a model that was never compiled has no flat parameter buffer whose version counter could be watched: it packs every time)
+        ver = self._flat_params._version if self._flat_params is not None else None
+        if st['n'] and not (ver is not None and self._packed_ok and st.get('packed') and st.get('packed_version') == ver):
             ops.pack_batch(st['items'], st['n'])
             st['packed'] = True
-            st['packed_version'] = self._flat_params._version
+            st['packed_version'] = ver
             self._packed_ok = True
 
     def predict_on_device(self, inputs, repack=True, padded_io=False):
@@ -1295,6 +1302,72 @@ class Model(object):
             self._padded_io = False
         return outs[0] if self._single_output else outs
 
+    def rollout_passes_on_device(self, state, passes, series=None, n_steps=1):
+        """
+        `passes` forward passes state -> model(state) -> ... with the state resident in HBM (the inner loop of the reference's
+        predict_timeseries, DLWP/model/models.py:446-454, without its per-step numpy round trip); returns the last state.
+        `series` (device, fp32, (passes * n_steps,) + state.shape): output k of pass t is written to series[t * n_steps + k].
+        With use_graphs the whole chain -- passes x (the plan's launches + the series copies) -- is captured into ONE hipGraph on
+        the second call with the same shapes and replayed afterwards: no launch gaps between the ~11 kernels of a pass, one
+        graph launch per rollout (BASELINE config 5: 20 passes = 221 launches).  The weights must not change between the
+        capture and a replay without going through this model (set_weights / an optimizer step re-pack before the replay).
+        The returned state lives in the graph's memory pool: it is overwritten by the next call with the same key.
+        """
+        passes = int(passes)
+        C = state.shape[-1]
+        padded = (state.dtype == torch.bfloat16 and C % 8 != 0 and self._padded_io_ok
+                  and os.environ.get('DLWPCS_PADDED_IO', '1') == '1')
+        shape0 = tuple(state.shape)
+
+        def chain(x, repack_first):
+            self._padded_io = padded
+            try:
+                for t in range(passes):
+                    res = self._forward([x], repack=(repack_first and t == 0))
+                    if tuple(res[-1].shape[:-1]) != shape0[:-1] or res[-1].shape[-1] not in (C, (C + 7) // 8 * 8):
+                        raise ValueError('could not broadcast model output of shape %s into the input of shape %s'
+                                         % (tuple(res[-1].shape), shape0))
+                    x = res[-1]
+                    if series is not None:
+                        for k in range(n_steps):
+                            series[t * n_steps + k].copy_(res[k][..., :C])
+            finally:
+                self._padded_io = False
+            return x
+
+        graphs_ok = (self.use_graphs and state.is_cuda and not self.use_chain and passes > 0)
+        key = ('rollout', shape0, str(state.dtype), passes, n_steps, None if series is None else (series.data_ptr(), tuple(series.shape)))
+        with torch.no_grad():
+            if not graphs_ok:
+                return chain(state, True)
+            g = self._infer_graphs.get(key)
+            if g is None:
+                n = self._seen_batch.get(key, 0)
+                self._seen_batch[key] = n + 1
+                if n == 0:
+                    return chain(state, True)                       # warm-up: allocations, workspace growth, packing
+                self._ensure_packed(state.device)
+                sin = state if self.static_batch_buffers else torch.empty_like(state).copy_(state)
+                torch.cuda.synchronize()
+                graph = _new_graph()
+                gc_was_enabled = gc.isenabled()
+                gc.collect()
+                gc.disable()
+                try:
+                    mode = 'thread_local' if parallel.group_alive() else 'global'
+                    with torch.cuda.graph(graph, capture_error_mode=mode):
+                        out = chain(sin, False)
+                finally:
+                    if gc_was_enabled:
+                        gc.enable()
+                g = {'graph': graph, 'in': sin, 'out': out}
+                self._infer_graphs[key] = g
+            if g['in'].data_ptr() != state.data_ptr():
+                g['in'].copy_(state, non_blocking=True)
+            self._ensure_packed(state.device)                       # (a launch only if something changed the parameters)
+            g['graph'].replay()
+            return g['out']
+
     def rollout_on_device(self, predictors, steps, n_steps, out_series, verbose=0, batch_size=None):
         """
         Autoregressive rollout with the state resident in HBM (replaces the per-step numpy round trip of the reference's
@@ -1311,23 +1384,17 @@ class Model(object):
                 self._check_shapes([state], self.inputs, 'input')
                 # the whole series of this batch is written into ONE device buffer and downloaded once: no host
                 # synchronisation inside the step loop
-                series = torch.empty((steps * n_steps,) + tuple(state.shape), dtype=torch.float32, device=state.device)
-                shape0, C = tuple(state.shape), state.shape[-1]
-                self._padded_io = (state.dtype == torch.bfloat16 and C % 8 != 0          # (see predict_on_device)
-                                   and self._padded_io_ok and os.environ.get('DLWPCS_PADDED_IO', '1') == '1')
-                try:
+                # (batches of one shape share the series buffer -- the download below synchronises -- so that the second one on
+                # replays the chain captured for it)
+                skey = ((steps * n_steps,) + tuple(state.shape), str(state.device))
+                series = self._rollout_series.get(skey)
+                if series is None:
+                    self._rollout_series.clear()                    # (one shape at a time: a C96 series of 40 steps is 18 GB)
+                    series = self._rollout_series[skey] = torch.empty(skey[0], dtype=torch.float32, device=state.device)
+                if verbose > 0 and s == 0:
                     for t in range(steps):
-                        if verbose > 0 and s == 0:
-                            print('Prediction step %d/%d' % (t + 1, steps))
-                        res = self._forward([state], repack=(t == 0 and s == 0))   # weights are fixed during a rollout
-                        if tuple(res[-1].shape[:-1]) != shape0[:-1] or res[-1].shape[-1] not in (C, (C + 7) // 8 * 8):
-                            raise ValueError('could not broadcast model output of shape %s into the input of shape %s'
-                                             % (tuple(res[-1].shape), shape0))
-                        state = res[-1]
-                        for k in range(n_steps):
-                            series[t * n_steps + k].copy_(res[k][..., :C])
-                finally:
-                    self._padded_io = False
+                        print('Prediction step %d/%d' % (t + 1, steps))
+                self.rollout_passes_on_device(state, steps, series=series, n_steps=n_steps)
                 out_series[:, s:s + bs] = series.cpu().numpy()
                 ops.chain_check()
 
