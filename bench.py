@@ -502,6 +502,8 @@ def dp_form_probe(args, dtype, plain_ms):
                 'launches': None if nodes is None else nodes['kernel'], 'graph_nodes': nodes,
                 'exposed_us': round(1e3 * (ms - noex), 1), 'ms_per_step_without_exchange': round(noex, 4),
                 'backend': torch.distributed.get_backend(), 'ranks': torch.distributed.get_world_size(),
+                'collective': 'dlwpcs_allreduce_f32 (library-owned RCCL communicator, compute stream)' if _par.native_comm() is not None
+                else 'torch.distributed.all_reduce (ProcessGroupNCCL stream)',
                 'note': 'the step as it runs at N > 1 (reduction | all-reduce captured in the step graph | one launch: scale + Adam '
                         '+ gradient clear + packed operands + loss tail), here with a one-rank RCCL group: the collective itself '
                         'moves nothing, what is measured is the form of the step'}
@@ -514,6 +516,7 @@ def dp_form_probe(args, dtype, plain_ms):
         else:
             os.environ['DLWPCS_EXCHANGE_FORCE'] = prev
         if own_group and torch.distributed.is_initialized():
+            _par.native_comm_release()
             torch.distributed.destroy_process_group()
 
 
@@ -901,7 +904,9 @@ def main():
             sys.stdout.write(line)
             sys.stdout.flush()
     if world > 1:
+        from DLWP import parallel as _par
         torch.distributed.barrier()
+        _par.native_comm_release()
         torch.distributed.destroy_process_group()
 
 

@@ -176,6 +176,11 @@ PROTOTYPES = {
                                      c_void_p]),
     'dlwpcs_batch_gather': (c_int, [c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int, c_void_p, c_int,
                                     c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dlwpcs_comm_load': (c_int, [ctypes.c_char_p]),
+    'dlwpcs_comm_unique_id': (c_int, [c_void_p]),
+    'dlwpcs_comm_init': (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int]),
+    'dlwpcs_comm_destroy': (c_int, [c_void_p]),
+    'dlwpcs_allreduce_f32': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'dlwpcs_lds_oob_probe': (c_int, [c_void_p, c_void_p]),
     'dlwpcs_prof_enable': (c_int, [c_int]),
     'dlwpcs_prof_reset': (c_int, []),

@@ -1002,6 +1002,15 @@ class Model(object):
                         g1 = _new_graph()
                         no_pack_entry = False
                         self._flat_grads.zero_()
+                if one and dp and self._world > 1 and not parallel.all_ranks_agree(done):
+                    # some rank could not capture the exchange inside its step graph: EVERY rank takes the two-graph form (a rank
+                    # replaying a graph with a collective inside would wait for peers that issue theirs from the host)
+                    if done:
+                        torch.cuda.synchronize()
+                        g1, g2 = _new_graph(), _new_graph()
+                        no_pack_entry = False
+                        self._flat_grads.zero_()
+                    done = False
                 if not done:
                     with torch.cuda.graph(g1, capture_error_mode=mode):
                         stats = self._loss_and_backward(static_in, static_tg, True, fuse_update=None)

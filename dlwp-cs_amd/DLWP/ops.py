@@ -190,10 +190,26 @@ def _wb_covers(entries, n_elems):
     return covered == n_elems
 
 
+_wb_anchor = {}
+
+
 def flushed_wgrad_entries():
-    """the entries run by flush_wgrad_batch() since the last drop (a caller that applies the update after the backward pass's
-    clean-up keeps this list for apply_wgrad_batch)"""
-    return list(_wb_flushed)
+    """the entries run by flush_wgrad_batch() since the last drop, for a caller that applies the update after the backward pass's
+    clean-up (apply_wgrad_batch / prepare_wgrad_plan) -- WITHOUT the layers' saved inputs, outputs and output gradients: the
+    apply launch names the layers' descriptors and gradient views only, and a model that kept the full entries would hold one
+    step's activations until the end of the next one (twice the peak memory of eager steps).  dz / y are replaced by a one-element
+    tensor of the same device (the plan key asks which device, and whether a layer masks on load)."""
+    out = []
+    for ent in _wb_flushed:
+        dev = ent[3].device
+        a = _wb_anchor.get(dev)
+        if a is None:
+            a = _wb_anchor[dev] = torch.zeros(1, dtype=torch.uint8, device=dev)
+        slim = (ent[0], None, None, a, ent[4], ent[5])
+        if len(ent) > 6:
+            slim += ((a if ent[6] is not None else None),)
+        out.append(slim)
+    return out
 
 
 def apply_wgrad_batch(adam, pack_lookup=None, entries=None):

@@ -17,7 +17,7 @@ TAG = os.environ.get('DLWPCS_LIB_TAG', '')          # development only: instrume
 OBJ = os.path.join(HERE, 'build' + ('_' + TAG if TAG else ''))
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdlwpcs%s.so' % ('_' + TAG if TAG else ''))
-SOURCES = ['halo_table.cpp', 'prof.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_inst_f32.hip', 'conv_inst_bf16.hip', 'conv_inst_edge.hip',
+SOURCES = ['halo_table.cpp', 'prof.cpp', 'comm.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_inst_f32.hip', 'conv_inst_bf16.hip', 'conv_inst_edge.hip',
            'conv_chain.hip', 'conv_generic.hip', 'wgrad_batch.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
@@ -89,7 +89,7 @@ def build(force=False, verbose=True):
         tl = _torch_lib_dir()
         if tl:
             link += ['-L' + tl]
-        link += ['-L/opt/rocm/lib', '-lamdhip64', '-Wl,-rpath,/opt/rocm/lib', '-Wl,--no-undefined']
+        link += ['-L/opt/rocm/lib', '-lamdhip64', '-ldl', '-Wl,-rpath,/opt/rocm/lib', '-Wl,--no-undefined']
         run(link)
     return LIB
 

@@ -519,6 +519,23 @@ int dlwpcs_batch_gather(const void *array, int64_t T, int V, int64_t S, const in
                         int Ctot, int c_off, int c_stride, int channels_last, int dtype, dlwpcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------- *
+ * Data-parallel exchange: ONE in-place sum of the flat fp32 gradient buffer over the ranks, through an RCCL
+ * communicator the caller owns, enqueued on the CALLER's stream -- inside a captured training step the collective is a plain
+ * node of the step's graph between dlwpcs_wgrad_batch (reduction into the buffer) and dlwpcs_wgrad_batch_apply.
+ * Reference counterpart: keras.utils.multi_gpu_model, DLWP/model/models.py:369-374 (host-side averaging over replicas).
+ *   dlwpcs_comm_load(path):    dlopen RCCL (the librccl.so PyTorch ships: one RCCL per process); once per process
+ *   dlwpcs_comm_unique_id(id): 128 bytes from ncclGetUniqueId -- rank 0 calls it and hands the bytes to the other ranks
+ *   dlwpcs_comm_init(&comm, id, rank, world): ncclCommInitRank on the calling thread's current device (collective: every rank)
+ *   dlwpcs_allreduce_f32(comm, buf, n, stream): ncclAllReduce(sum, in place); capturable; no host synchronisation
+ *   dlwpcs_comm_destroy(comm)
+ * ------------------------------------------------------------------------------------------------------------- */
+int dlwpcs_comm_load(const char *librccl_path);
+int dlwpcs_comm_unique_id(void *id128);
+int dlwpcs_comm_init(void **comm, const void *id128, int rank, int world);
+int dlwpcs_comm_destroy(void *comm);
+int dlwpcs_allreduce_f32(void *comm, float *buf, size_t n, dlwpcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------- *
  * Hardware self-check of the gather-form data gradient (DLWPCS_CONV_DGRAD_GATHER): its kernel masks MFMA operands by
  * address -- lanes that must add nothing read LDS beyond the workgroup's allocation, which returns zeros on gfx950.
  * Writes to *nonzero_dev (device int32, caller-owned) the number of non-zero dwords such reads returned at the offsets

@@ -65,10 +65,42 @@ dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, wor
 assert dist.get_backend() == 'nccl'
 g = torch.arange(673628, dtype=torch.float32, device='cuda')
 ref = g.clone()
+os.environ['DLWPCS_EXCHANGE_FORCE'] = '1'
+# the library-owned communicator (dlwpcs_comm_*): created over the torch group, its all-reduce runs on the CURRENT stream ...
+assert parallel.native_comm() is not None
 scale = parallel.allreduce_gradients(g)
 parallel.broadcast_parameters(g)
 torch.cuda.synchronize()
 assert scale == 1.0 and torch.equal(g, ref)
+# ... so that a capture holds it as ONE kernel node on the capturing stream: no event / wait nodes of a side stream around it
+gr = torch.cuda.CUDAGraph(keep_graph=True)
+with torch.cuda.graph(gr, capture_error_mode='thread_local'):
+    parallel.allreduce_gradients(g)
+import ctypes
+hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+n = ctypes.c_size_t(0)
+assert hip.hipGraphGetNodes(ctypes.c_void_p(gr.raw_cuda_graph()), None, ctypes.byref(n)) == 0
+nodes = (ctypes.c_void_p * n.value)()
+hip.hipGraphGetNodes(ctypes.c_void_p(gr.raw_cuda_graph()), nodes, ctypes.byref(n))
+kinds = []
+for nd in nodes:
+    t = ctypes.c_int(-1)
+    hip.hipGraphNodeGetType(ctypes.c_void_p(nd), ctypes.byref(t))
+    kinds.append(t.value)
+assert all(k == 0 for k in kinds), kinds        # kernel nodes only (none at all here: RCCL makes an in-place sum over ONE rank a no-op)
+for _ in range(3):
+    gr.replay()
+torch.cuda.synchronize()
+assert torch.equal(g, ref)
+del gr
+# torch's own all_reduce serves when the library's communicator is switched off
+parallel.native_comm_release()
+os.environ['DLWPCS_NATIVE_RCCL'] = '0'
+assert parallel.native_comm() is None
+parallel.allreduce_gradients(g)
+torch.cuda.synchronize()
+assert torch.equal(g, ref)
+os.environ.pop('DLWPCS_EXCHANGE_FORCE')
 # the captured form of the step: all-reduce between two graph replays
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
@@ -76,6 +108,8 @@ with torch.cuda.stream(s):
         dist.all_reduce(g)
 torch.cuda.synchronize()
 assert torch.equal(g, ref)
+from DLWP import parallel as _par
+_par.native_comm_release()
 dist.destroy_process_group()
 print('RCCL_OK')
 ''' % ROOT
@@ -122,6 +156,8 @@ g = next(iter(m2._graphs.values()))
 assert g['bwd_b'] is not None and g['update'] is not None and m2._did_split
 assert np.array_equal(plain, one), np.abs(plain - one).max()
 assert np.abs(plain - two).max() <= 1e-6 * np.abs(plain).max()
+from DLWP import parallel as _par
+_par.native_comm_release()
 dist.destroy_process_group()
 print('RCCL_BUCKETS_OK')
 ''' % ROOT
@@ -187,6 +223,8 @@ for pol, N, C, base in cases:
         assert np.array_equal(lref, lgot), (pol, one_graph)
         if pol != 'float32':
             assert m._wb_done and len(m._wb_done) == 11           # the apply launch covered every layer
+from DLWP import parallel as _par
+_par.native_comm_release()
 dist.destroy_process_group()
 print('DP_ONE_GRAPH_OK')
 ''' % ROOT
