@@ -72,14 +72,6 @@ class WgradItem(ctypes.Structure):
                                                                     'dw_np', 'db_eq', 'db_pol', 'db_np')]
 
 
-class ChainItem(ctypes.Structure):
-    """struct dlwpcs_chain_item (include/dlwpcs.h)"""
-    _fields_ = [('d', ConvDesc)] + [(n, ctypes.c_void_p) for n in ('src0', 'src1', 'wpk_fwd', 'bias_pk', 'y', 'y_pooled', 'table_dev')]
-
-
-CHAIN_MAX = 11              # DLWPCS_CHAIN_MAX
-
-
 class LossTail(ctypes.Structure):
     """struct dlwpcs_loss_tail (include/dlwpcs.h)"""
     _fields_ = [('partial', ctypes.c_void_p), ('loss_out', ctypes.c_void_p), ('nblocks', ctypes.c_int32), ('inv_n', ctypes.c_float),
@@ -129,10 +121,6 @@ PROTOTYPES = {
                                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dlwpcs_wgrad_batch_apply': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'dlwpcs_conv_chain_sync_bytes': (c_size_t, []),
-    'dlwpcs_conv_chain_supported': (c_int, [c_void_p, c_int]),
-    'dlwpcs_conv_chain_fwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
-    'dlwpcs_conv_chain_status': (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     'dlwpcs_gconv_fwd': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),
     'dlwpcs_gconv_bwd_data': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 6),
     'dlwpcs_gconv_bwd_weights': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),

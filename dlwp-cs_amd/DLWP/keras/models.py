@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from .. import ops, parallel
+from ..options import option
 from .._native import ACT_LEAKY_CLIP, ACT_NONE
 from . import backend, callbacks as cbks, optimizers, staging
 from .engine import KTensor, Layer
@@ -60,32 +61,27 @@ class Model(object):
         self.loss_weights = None
         self.metrics = []
         self.history = None
-        self.use_graphs = os.environ.get('DLWPCS_GRAPHS', '1') != '0'
+        self.use_graphs = option('graphs')
         # activation dtype on the device ('float32' | 'bfloat16'); parameters / gradients / Adam state are always fp32
         self.compute_dtype = backend.compute_dtype()
-        self.prepack_weights = os.environ.get('DLWPCS_PREPACK', '1') != '0'
-        self.wgrad_side_stream = os.environ.get('DLWPCS_SIDE_STREAM', '0') == '1'   # measured slower on MI355X: off
+        self.prepack_weights = True
+        self.wgrad_side_stream = False     # (weight gradients on a second stream: measured slower on MI355X)
         # one reduction launch for all layers' weight-gradient partials (DLWPCS_CONV_DEFER_REDUCE)
-        self.defer_wgrad_reduce = os.environ.get('DLWPCS_DEFER_REDUCE', '1') == '1'
+        self.defer_wgrad_reduce = True
         # one persistent launch for the weight gradients of all layers of a step (ops.wgrad_batch)
-        self.batch_wgrad = os.environ.get('DLWPCS_WGRAD_BATCH', '1') == '1'
-        self.check_finite = os.environ.get('DLWPCS_CHECK_FINITE', '0') == '1'
+        self.batch_wgrad = option('wgrad_batch')
+        self.check_finite = option('check_finite')
         # the optimizer inside the reduction of the batched weight gradients (dlwpcs_wgrad_batch_adam; world size 1)
-        self.fuse_adam = os.environ.get('DLWPCS_FUSE_ADAM', '1') == '1'
+        self.fuse_adam = option('fuse_adam')
         # ring fix-up of a pooled tensor's gradient inside the pooling adjoint (dlwpcs_avgpool2_bwd_ring)
-        self.fold_ring = os.environ.get('DLWPCS_FOLD_RING', '1') == '1'
+        self.fold_ring = option('fold_ring')
         # 2x2 average pooling written by the epilogue of the convolution in front of it (dlwpcs_conv_fwd_pool)
-        self.fuse_pool = os.environ.get('DLWPCS_FUSE_POOL', '1') == '1'
+        self.fuse_pool = option('fuse_pool')
         # second stage of the fused head's loss reduction inside the step's last launch (dlwpcs_wgrad_batch_adam_tail)
-        self.fold_loss_tail = os.environ.get('DLWPCS_FOLD_LOSS_TAIL', '1') == '1'
+        self.fold_loss_tail = option('fold_loss_tail')
         # hipGraph-replayed steps: the reduction + optimizer launch also refreshes the packed bf16 operands, the step starts
         # without the packing launch (dlwpcs_wgrad_batch_adam_tail with pack items)
-        self.fuse_pack = os.environ.get('DLWPCS_FUSE_PACK', '1') == '1'
-        # runs of same-tiling fused convolutions of a forward pass as ONE persistent launch (ops.CHAIN, dlwpcs_conv_chain_fwd): bf16
-        # models.  Built, bit-identical, bounded -- and measured SLOWER than the per-layer launches on MI355X (round 4, DESIGN.md 9:
-        # unet2 step 0.707 against 0.675 ms, C96 rollout 13.5 against 11.1 ms), so it is opt-in (DLWPCS_CHAIN=1 / use_chain = True).
-        # Always off when two ranks share a device (compile() checks): the launch needs its workgroups co-resident
-        self.use_chain = os.environ.get('DLWPCS_CHAIN', '0') == '1'
+        self.fuse_pack = option('fuse_pack')
         self._packed_ok = False             # the packed operands hold the current parameters (see _ensure_packed)
         # data-parallel exchange in two buckets (exchange_buckets = 2 / DLWPCS_EXCHANGE_BUCKETS=2): the gradients of the
         # decoder-side layers are summed over the ranks WHILE the encoder-side half of the backward pass runs.  Default 1: one
@@ -95,7 +91,7 @@ class Model(object):
         self.exchange_buckets = int(os.environ.get('DLWPCS_EXCHANGE_BUCKETS', '1'))
         self._stager = None                 # pinned-memory / copy-stream feed of fit() on host arrays (keras/staging.py)
         # training step: output layer + loss + loss gradient + the layer's data gradient as one launch (ops.head_mse)
-        self.fuse_head_loss = os.environ.get('DLWPCS_FUSE_HEAD', '1') == '1'
+        self.fuse_head_loss = option('fuse_head')
         # True: the caller feeds every step through the SAME device tensors (e.g. a generator that assembles each batch in
         # place): the captured graphs read them directly instead of copying each batch into private static buffers
         self.static_batch_buffers = False
@@ -162,7 +158,7 @@ class Model(object):
             if isinstance(lay, Concatenate):
                 return lay._axis(len(t.shape)) == 1
             return isinstance(lay, ReLU)
-        self._cf_model = (os.environ.get('DLWPCS_CF_MODEL', '1') == '1' and all(cf_layer(t) for t in self._nodes)
+        self._cf_model = (option('cf_model') and all(cf_layer(t) for t in self._nodes)
                           and any(isinstance(t.layer, (CubeSphereConv2D, CubeSpherePadding2D)) for t in self._nodes))
         fmt = 'channels_first' if self._cf_model else 'channels_last'
         virtual = set()          # tensors never materialised
@@ -342,7 +338,7 @@ class Model(object):
 
     def _premask_on(self):
         return (self.compute_dtype == 'bfloat16' and torch.is_grad_enabled()
-                and os.environ.get('DLWPCS_PREMASK', '1') == '1')
+                and option('premask'))
 
     def _pack_state(self, device):
         """Packed-weight buffers + the device item table of every matrix-core convolution layer (built once per
@@ -386,15 +382,10 @@ class Model(object):
                 st['packed_version'] = self._flat_params._version if self._flat_params is not None else None
                 self._packed_ok = True
             ops.PREPACKED = st['table']
-            chain = self.use_chain and self.compute_dtype == 'bfloat16'
-            if chain:
-                ops.chain_begin()
             try:
                 return self._run_plan(inputs, fuse_targets)
             finally:
                 ops.PREPACKED = {}
-                if chain:
-                    ops.chain_end()
         return self._run_plan(inputs, fuse_targets)
 
     def _run_plan(self, inputs, fuse_targets=None):
@@ -424,8 +415,6 @@ class Model(object):
                     if u in need and isinstance(v, torch.Tensor) and v.requires_grad and id(v) not in seen:
                         seen.add(id(v))
                         self._cut_tensors.append(v)
-            if st[0] not in ('fused_conv', 'pool_skip'):
-                ops.chain_flush()               # (recorded convolutions run before anything else touches their outputs)
             if st[0] == 'fused_conv':
                 _, out_uid, lay, s0, s1, up0, act, alpha, vmax = st
                 m0, m1 = self._src_mask[i]
@@ -484,7 +473,6 @@ class Model(object):
                     continue
                 values[out_uid] = lay.call(args if (takes_list or len(args) > 1) else args[0])
         if cf and not getattr(self, '_loss_in_cl', False):
-            ops.chain_flush()
             return [values[o.uid] if o.uid in self._fused_outputs else ops.channels_last_to_first(values[o.uid])
                     for o in self.outputs]
         return [values[o.uid] for o in self.outputs]
@@ -599,10 +587,6 @@ class Model(object):
         self._infer_graphs.clear()          # (captured with the parameters' old addresses)
         self._seen_batch.clear()
         self._world = parallel.world()[1]
-        # (device_is_shared is a collective: every rank asks, whatever its own DLWPCS_CHAIN says)
-        shared = parallel.device_is_shared()
-        if self.use_chain and shared:
-            self.use_chain = False          # two ranks on one GPU: their persistent launches could keep each other from being resident
         parallel.broadcast_parameters(self._flat_params)     # identical replicas: rank 0's initial weights everywhere
         self._compiled = True
 
@@ -627,7 +611,6 @@ class Model(object):
     def _assemble_logs(self, sums, count):
         """sums: (n_out, 2) tensor of [weighted mse, mae] sums over `count` batches -> ordered keras values."""
         s = (sums / max(count, 1)).cpu().numpy()
-        ops.chain_check()
         w = np.asarray(self.loss_weights, dtype=np.float64)
         vals = [float(s[:, 0].sum())]                           # (a model with weight regularizers: its last row is the penalty)
         s = s[:len(self.outputs)]
@@ -1046,7 +1029,7 @@ class Model(object):
     def _feed(self, x, y, batch_size, shuffle):
         """(device inputs, device targets) per batch.  On a HIP device host arrays go through pinned staging buffers and a copy
         stream (keras/staging.py): the upload of a batch overlaps the training of the one before."""
-        if backend.device().type != 'cuda' or os.environ.get('DLWPCS_HOST_STAGING', '1') != '1':
+        if backend.device().type != 'cuda' or not option('host_staging'):
             for bx, by in self._batches_from(x, y, batch_size, shuffle):
                 yield [self._to_device(a) for a in bx], [self._to_device(a, target=True) for a in by]
             return
@@ -1229,7 +1212,7 @@ class Model(object):
         bs = 32 if batch_size is None else int(batch_size)
         outs = None
         dev = backend.device()
-        staged = dev.type == 'cuda' and os.environ.get('DLWPCS_HOST_STAGING', '1') == '1'
+        staged = dev.type == 'cuda' and option('host_staging')
         if staged:
             # inputs through pinned memory + the copy stream, results back through a second copy stream: upload, forward pass and
             # download of neighbouring batches overlap (keras/staging.py)
@@ -1264,7 +1247,6 @@ class Model(object):
                         o[s:s + bs] = r.float().cpu().numpy()
             if staged:
                 down.flush()
-            ops.chain_check()
         if outs is None:
             outs = [np.empty((0,) + tuple(o.shape[1:]), dtype=np.float32) for o in self.outputs]
         return outs[0] if self._single_output else outs
@@ -1325,7 +1307,7 @@ class Model(object):
         passes = int(passes)
         C = state.shape[-1]
         padded = (state.dtype == torch.bfloat16 and C % 8 != 0 and self._padded_io_ok
-                  and os.environ.get('DLWPCS_PADDED_IO', '1') == '1')
+                  and option('padded_io'))
         shape0 = tuple(state.shape)
 
         def chain(x, repack_first):
@@ -1344,7 +1326,7 @@ class Model(object):
                 self._padded_io = False
             return x
 
-        graphs_ok = (self.use_graphs and state.is_cuda and not self.use_chain and passes > 0)
+        graphs_ok = (self.use_graphs and state.is_cuda and passes > 0)
         key = ('rollout', shape0, str(state.dtype), passes, n_steps, None if series is None else (series.data_ptr(), tuple(series.shape)))
         with torch.no_grad():
             if not graphs_ok:
@@ -1405,7 +1387,6 @@ class Model(object):
                         print('Prediction step %d/%d' % (t + 1, steps))
                 self.rollout_passes_on_device(state, steps, series=series, n_steps=n_steps)
                 out_series[:, s:s + bs] = series.cpu().numpy()
-                ops.chain_check()
 
     def _input_roles(self):
         """(main, [solar...], constants | None) indices into self.inputs: by the names the reference scripts use

@@ -10,6 +10,7 @@ import os
 import torch
 
 from . import _native as nat
+from .options import option
 from ._native import ConvDesc, GConvDesc, check, lib, ptr, require_device, stream_ptr
 
 # When True, convolution backward accumulates weight gradients directly into the parameters' preset `.grad` buffers
@@ -331,118 +332,6 @@ def wgrad_batch(entries, adam=None, packs=None):
               'dlwpcs_wgrad_batch')
 
 
-# ------------------------------------------------------------------------------------------------------------------ #
-# Convolution chains (dlwpcs_conv_chain_fwd): consecutive fused convolutions of a forward pass as ONE persistent launch
-# ------------------------------------------------------------------------------------------------------------------ #
-# While CHAIN is a list (DLWP.keras.Model turns recording on around its forward pass), a fused bf16 3x3 halo convolution with
-# pre-packed operands whose shape has a chain phase does NOT launch: it allocates its output(s), records a dlwpcs_chain_item and
-# returns; chain_flush() launches what has been recorded -- one dlwpcs_conv_chain_fwd for two or more layers, the ordinary
-# per-layer launch for a single one.  Everything else that launches on these tensors must flush first: the Model flushes before
-# every step of its plan that is not such a convolution (and this module before the few launches it issues itself in between).
-CHAIN = None
-_chain_sync = {}            # device -> the barrier words of dlwpcs_conv_chain_fwd (zeroed once)
-_chain_ok = {}              # geometry -> does the layer have a chain phase?
-_chain_used = set()         # devices whose sync buffer a chain launch has used since the last chain_check()
-
-
-def _chain_item(d, src0, src1, wpk, bpk, y, yp, table):
-    it = nat.ChainItem()
-    it.d = d
-    it.src0, it.src1, it.wpk_fwd, it.bias_pk = ptr(src0), ptr(src1), ptr(wpk), ptr(bpk)
-    it.y, it.y_pooled, it.table_dev = ptr(y), ptr(yp), ptr(table)
-    return it
-
-
-def _chain_key(d, pooled):
-    return (d.B, d.N, d.C0, d.C1, d.Cout, d.ksize, d.halo, d.up0, d.dtype, d.c0_valid, d.act, bool(pooled))
-
-
-def chain_supported(layers):
-    """layers = [(ConvDesc, pooled second output?)]: can these layers (pre-packed operands), in this order, be ONE chain launch?
-    (every layer needs a chain phase)"""
-    key = tuple(_chain_key(d, p) for d, p in layers)
-    ok = _chain_ok.get(key)
-    if ok is None:
-        arr = (nat.ChainItem * len(layers))()
-        one = 0x1000                                    # geometry only: placeholder addresses, nothing is dereferenced
-        for it, (d, pooled) in zip(arr, layers):
-            it.d = d
-            it.d.flags |= nat.CONV_PREPACKED
-            it.src0, it.src1, it.wpk_fwd, it.bias_pk, it.y, it.table_dev = one, (one if d.C1 else 0), one, 0, one, one
-            it.y_pooled = one if pooled else 0
-        ok = len(layers) <= nat.CHAIN_MAX and bool(lib().dlwpcs_conv_chain_supported(arr, len(layers)))
-        _chain_ok[key] = ok
-    return ok
-
-
-def _chain_sync_buffer(device):
-    key = str(device)
-    buf = _chain_sync.get(key)
-    if buf is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise nat.NativeError('the chain barrier words would have to be allocated during graph capture; run one eager step first')
-        buf = torch.zeros(int(lib().dlwpcs_conv_chain_sync_bytes()), dtype=torch.uint8, device=device)
-        _chain_sync[key] = buf
-    return buf
-
-
-def chain_flush():
-    """Launch the recorded convolutions (recording stays on)."""
-    if not CHAIN:
-        return
-    rec = list(CHAIN)
-    del CHAIN[:]
-    import os
-    maxlen = int(os.environ.get('DLWPCS_CHAIN_MAXLEN', nat.CHAIN_MAX))      # (experiments: shorter chains; 1 with ..._SINGLE=1)
-    single_too = os.environ.get('DLWPCS_CHAIN_SINGLE', '0') == '1'
-    while rec:
-        part, rec = rec[:maxlen], rec[maxlen:]
-        if len(part) == 1 and not single_too:
-            d, src0, src1, wpk, bpk, y, yp, table, ws = part[0]
-            wargs = (ptr(wpk), 0, 0, ptr(bpk), 0, 0)
-            if yp is not None:
-                check(lib().dlwpcs_conv_fwd_pool(ctypes.byref(d), ptr(src0), ptr(src1), *wargs, ptr(y), ptr(yp), ptr(table), ptr(ws),
-                                                 ws.numel(), stream_ptr()), 'dlwpcs_conv_fwd_pool')
-            else:
-                check(lib().dlwpcs_conv_fwd(ctypes.byref(d), ptr(src0), ptr(src1), *wargs, ptr(y), ptr(table), ptr(ws), ws.numel(),
-                                            stream_ptr()), 'dlwpcs_conv_fwd')
-            continue
-        arr = (nat.ChainItem * len(part))(*[_chain_item(*r[:8]) for r in part])
-        dev = part[0][5].device
-        check(lib().dlwpcs_conv_chain_fwd(arr, len(part), ptr(_chain_sync_buffer(dev)), stream_ptr()), 'dlwpcs_conv_chain_fwd')
-        _chain_used.add(str(dev))
-
-
-def chain_begin():
-    global CHAIN
-    CHAIN = []
-
-
-def chain_end():
-    """Flush and stop recording."""
-    global CHAIN
-    try:
-        chain_flush()
-    finally:
-        CHAIN = None
-
-
-def chain_check():
-    """Did a chain launch since the last check give up at a barrier (device shared with another process: its 256 workgroups
-    were not co-resident)?  Blocking; call where the host synchronises anyway.  Raises NativeError and re-arms the barrier words."""
-    for key in list(_chain_used):
-        _chain_used.discard(key)
-        buf = _chain_sync.get(key)
-        if buf is None:
-            continue
-        ab = ctypes.c_int(0)
-        check(lib().dlwpcs_conv_chain_status(ptr(buf), ctypes.byref(ab)), 'dlwpcs_conv_chain_status')
-        if ab.value:
-            buf.zero_()
-            raise nat.NativeError('a convolution chain launch timed out at a group barrier (is the GPU shared with another process? '
-                                  'its workgroups must be co-resident): the results of that pass are invalid; set DLWPCS_CHAIN=0')
-
-
 # Deferred ring fix-up (DLWPCS_CONV_DEFER_RING0): a data-gradient call whose source 0 is a pooled tensor with no other
 # consumer leaves the halo ring of that source in its workspace; the pooling adjoint that receives the gradient next adds it
 # while it spreads the gradient (dlwpcs_avgpool2_bwd_ring) -- one launch less per pooling level.  Keyed by the address of the
@@ -518,7 +407,6 @@ class _PadChannels(torch.autograd.Function):
         C = x.shape[-1]
         rows = x.numel() // C if C else 0
         y = torch.empty(tuple(x.shape[:-1]) + (cp,), dtype=x.dtype, device=x.device)
-        chain_flush()
         check(lib().dlwpcs_pad_channels(ptr(x), ptr(y), rows, C, cp, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_pad_channels')
         ctx.c = C
         return y
@@ -551,13 +439,10 @@ def channel_vector(dtype):
 def padded_channels(c, dtype, even_too=None):
     """Physical channel count the engine stores a c-channel NETWORK INPUT with: odd counts (7 variables) are always padded
     to the next 16-B vector (the scalar-load kernel paths spill registers and run at a fraction of the vector paths); even
-    counts that are not vector multiples (14 = 7 x 2) only when DLWPCS_PAD_EVEN=1 (they have 4-B-vector / shifted-tail paths)."""
-    import os
+    counts that are not vector multiples (14 = 7 x 2) only when asked to (they have 4-B-vector / shifted-tail paths)."""
     v = channel_vector(dtype)
     if c % v == 0:
         return c
-    if even_too is None:
-        even_too = os.environ.get('DLWPCS_PAD_EVEN', '0') == '1'
     if c % 2 == 1 or even_too:
         return (c + v - 1) // v * v
     return c
@@ -694,21 +579,11 @@ class _CSConv(torch.autograd.Function):
                  (ptr(w_eq), ptr(w_pol), ptr(w_np), ptr(b_eq), ptr(b_pol), ptr(b_np)))
         if packed is not None:
             d.flags |= nat.CONV_PREPACKED
-        chainable = (CHAIN is not None and packed is not None and d.dtype == nat.BF16 and ksize == 3 and halo and not out_padded
-                     and B > 0 and chain_supported([(d, yp is not None)]))
-        if chainable and CHAIN and not chain_supported([(r[0], r[6] is not None) for r in CHAIN] + [(d, yp is not None)]):
-            chain_flush()                       # (the recorded run cannot take this layer too: it is launched, a new one starts)
-        if chainable:
-            CHAIN.append((ConvDesc.from_buffer_copy(d), src0, src1, packed[1], packed[2] if b_eq is not None else None, y, yp, table, ws))
-            if yp is not None:
-                _POOLED[y.data_ptr()] = yp
-        elif yp is not None:
-            chain_flush()
+        if yp is not None:
             check(lib().dlwpcs_conv_fwd_pool(ctypes.byref(d), ptr(src0), ptr(src1), *wargs, ptr(y), ptr(yp), ptr(table), ptr(ws),
                                              ws.numel(), stream_ptr()), 'dlwpcs_conv_fwd_pool')
             _POOLED[y.data_ptr()] = yp
         else:
-            chain_flush()
             check(lib().dlwpcs_conv_fwd(ctypes.byref(d), ptr(src0), ptr(src1), *wargs, ptr(y), ptr(table), ptr(ws),
                                         ws.numel(), stream_ptr()), 'dlwpcs_conv_fwd')
         if premask0 is not None and premask1 is not None and tuple(premask0) != tuple(premask1):
@@ -822,12 +697,12 @@ _ring_info_cache = {}
 # kernel -- no halo ring is materialised, no fix-up launch, one rounding per cell (tests/test_gpu_dgrad_gather.py: <= 1 bf16 ulp against
 # the fp64 oracle); window_src 2 x 2 sums for upsampled sources.  Default since round 5 (weight substitution inside the matrix phase:
 # as fast as the padded-grid kernel + the fix-up launches it replaces, 24 instead of 31 launches per unet2 step); faces whose tile
-# holds both edge rows (N <= 16) and the exact-fp32 mode keep the padded-grid path.  DLWPCS_DGRAD_GATHER=0 restores it everywhere.
-DGRAD_GATHER = os.environ.get('DLWPCS_DGRAD_GATHER', '1') == '1'
+# holds both edge rows (N <= 16) and the exact-fp32 mode keep the padded-grid path.  Engine option dgrad_gather=0 (DLWP/options.py)
+# restores it everywhere.
 
 
 def _gather_flag(d, dev):
-    if DGRAD_GATHER and d.halo and d.ksize == 3 and d.dtype == nat.BF16 and nat.dgrad_gather_ready(d.N, 1, dev):
+    if option('dgrad_gather') and d.halo and d.ksize == 3 and d.dtype == nat.BF16 and nat.dgrad_gather_ready(d.N, 1, dev):
         return nat.CONV_DGRAD_GATHER
     return 0
 
@@ -1064,7 +939,6 @@ class _AvgPool2Skip(torch.autograd.Function):
         x = _c(x)
         y = _POOLED.pop(x.data_ptr(), None)         # the producing convolution pooled in its epilogue (want_pool)
         if y is None or tuple(y.shape) != (B, 6, N // 2, N // 2, C) or y.dtype != x.dtype:
-            chain_flush()
             y = torch.empty((B, 6, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
             check(lib().dlwpcs_avgpool2_fwd(ptr(x), ptr(y), B, N, C, nat.dtype_tag(x), stream_ptr()), 'dlwpcs_avgpool2_fwd')
         ctx.shape = (B, N, C)

@@ -18,7 +18,7 @@ OBJ = os.path.join(HERE, 'build' + ('_' + TAG if TAG else ''))
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdlwpcs%s.so' % ('_' + TAG if TAG else ''))
 SOURCES = ['halo_table.cpp', 'prof.cpp', 'comm.cpp', 'elementwise.hip', 'conv_mfma.hip', 'conv_inst_f32.hip', 'conv_inst_bf16.hip', 'conv_inst_edge.hip',
-           'conv_chain.hip', 'conv_generic.hip', 'wgrad_batch.hip']
+           'conv_generic.hip', 'wgrad_batch.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 CFLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-x', 'hip', '-Wall', '-Wno-unused-function'] + \

@@ -287,12 +287,7 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
         const size_t sample_elems = from0 ? (size_t)6 * g0 * g0 * P.C0 : (size_t)6 * P.Nin * P.Nin * P.C1;
         const T *src_base = reinterpret_cast<const T *>(from0 ? P.src0 : P.src1);
         Item cur = item_of(0);
-#ifdef DLWPCS_TIMELINE
-        int pli = 0;
-        long long *plp = (P.dbg && ptid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
-#endif
         for (int k = 0; k < n_my; ++k) {
-            PL_MARK();
             float *buf = smem + (k & 1) * buf_floats;
             const Item nxt = item_of(k + 1);
             if (cur.combo != cur_combo) rebuild(cur);              // uniform, a few times per worker
@@ -374,7 +369,6 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
                         dok[i] = true;
                     }
                 }
-                if (h == DG - 1) PL_MARK();
                 // dZ = dy * act'(y), applied only after EVERY load of the item (of the half) has been issued
 #pragma unroll
                 for (int u = 0; u < DN; ++u) {
@@ -410,7 +404,6 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
             // ---- registers -> LDS
             if constexpr (XG == 1) x_store(0);
             if constexpr (DG == 1) dz_store(0);
-            PL_MARK();
             __syncthreads();            // B_k: item k is in LDS
             cur = nxt;
         }
@@ -446,14 +439,8 @@ __global__ void __launch_bounds__(512) wgrad_mfma_kernel(const WgradKParams W) {
 
     const int nsteps = pix_cap / 2;             // pixel pairs per item
     const int S = (((nsteps + 3) / 4) + 1) & ~1; // steps per consumer wave, rounded up to even (extra steps add zero)
-#ifdef DLWPCS_TIMELINE
-    int tli = 0;
-    long long *tlp = (P.dbg && tid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
-#endif
     for (int k = 0; k < n_my; ++k) {
-        TL_MARK();
         __syncthreads();                        // B_k
-        TL_MARK();
         const float *lds_x = smem + (k & 1) * buf_floats, *lds_dy = lds_x + x_floats;
         const Item it = item_of(k);
         // operands of step si: pixel kk = 2*s + half, s = wave + 4*si.  Branch-free: out-of-range steps read a clamped
@@ -658,20 +645,8 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             DVec dv[IT_DY], yv[MASK ? IT_DY : 1];
             bool xok[IT_X], dok[IT_DY];
         };
-#ifdef DLWPCS_TIMELINE
-        int pli = 0;
-        long long *plp = (P.dbg && ptid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
-        PL_MARK();
-#endif
         auto issue = [&](const Item &it, Stage &st) {
-#ifdef DLWPCS_TIMELINE
-            const bool first = cur_combo < 0;
-            if (first) PL_MARK();
-#endif
             if (it.combo != cur_combo) rebuild(it);                 // uniform, <= 2-3 times per worker
-#ifdef DLWPCS_TIMELINE
-            if (first) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PL_MARK(); }
-#endif
             const bf16_t *sb = src_base + (size_t)it.b * sample_elems;
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
@@ -696,13 +671,11 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         };
         auto commit = [&](const Item &it, int k, Stage &st) {
             char *buf = smem + (k & 1) * buf_bytes;
-            PL_MARK();
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
                 if (MASK) vmask(st.dv[i], st.yv[i], P.alpha, P.vmax);
                 st.dv[i] = vsel(st.dok[i], st.dv[i]);
             }
-            PL_MARK();
             // DLWPCS_CONV_REUSE_DZ: the workers of ci tile 0 see every dZ element exactly once -> they hand dz to the
             // data-gradient kernel that follows (which then needs neither y nor the act' arithmetic)
             if (MASK && W.dz_out != nullptr && cit == 0) {
@@ -711,7 +684,6 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
 #pragma unroll
                 for (int i = 0; i < IT_DY; ++i) bstv(st.dv[i], dzr, st.dok[i] ? (uint32_t)doff[i] * 2 : ST_SKIP);
             }
-            PL_MARK();
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int e = ptid + i * NCT;
@@ -719,7 +691,6 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                     *reinterpret_cast<XVec *>(buf + ((ptid % QXT) / QX) * plane_bytes + (size_t)(e / QXT) * PB +
                                               ((ptid % QXT) % QX) * (XV * 2)) = vsel(st.xok[i], st.xv[i]);
             }
-            PL_MARK();
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
                 const int e = ptid + i * NCT;
@@ -734,13 +705,11 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
                     }
                 }
             }
-            PL_MARK();
             // B_k: item k is in LDS.  A RAW barrier behind an explicit LDS wait: __syncthreads() makes hipcc drain vmcnt(0)
             // first, i.e. wait for the loads of item k+1 that were issued a moment ago -- the whole HBM latency (~4 k cycles,
             // measured with the s_memtime marks) would be paid at every barrier, with the consumers idling behind it.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            PL_MARK();
         };
         if (n_my > 0) {
             Stage A, B;
@@ -795,14 +764,8 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
     const int nslab = pix_cap / 16;             // K slabs (16 pixels) per item
     const int S = (((nslab + NPH - 1) / NPH) + 1) & ~1;   // slabs per consumer wave, rounded up to even (extras add zero)
     const int ct = wave % CT, ph = wave / CT;   // this wave's ci tile and slab phase
-#ifdef DLWPCS_TIMELINE
-    int tli = 0;
-    long long *tlp = (P.dbg && tid == 0 && cit == 0 && cot == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
-#endif
     for (int k = 0; k < n_my; ++k) {
-        TL_MARK();
         __syncthreads();                        // B_k
-        TL_MARK();
         const char *lds_x0 = smem + (k & 1) * buf_bytes, *lds_dy = lds_x0 + x_bytes, *lds_x = lds_x0 + ct * plane_bytes;
         const Item it = item_of(k);
         // operands of slab si of this wave: K index kk = 8*half + 4*jj + prow (jj = 0, 1) <-> flat pixel 16*s + kk.
@@ -843,7 +806,6 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);
         }
     }
-    TL_MARK();
     __syncthreads();                            // all consumers finished reading the last buffer
     // Cross-wave reduction, ONE LDS round for all taps: the NPH waves of a ci tile hold K-split partial sums of the same
     // (taps, 32, 32) block.  Tap t belongs to the wave of phase t % NPH; the others park their 16 accumulator registers of
@@ -864,7 +826,6 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
         }
     }
     __syncthreads();                            // (the producers staged their bias sums meanwhile)
-    TL_MARK();
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
         if (ph == t % NPH) {
@@ -891,11 +852,6 @@ __global__ void __launch_bounds__(512) wgrad_bf16_kernel(const WgradKParams W) {
             }
         }
     }
-    TL_MARK();
-#ifdef DLWPCS_TIMELINE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TL_MARK();
-#endif
 }
 
 // Sum the per-slot partials in a fixed order and route them to the weight groups.  Workgroup = 16 output groups x 16 slot
@@ -1591,8 +1547,7 @@ extern "C" int dlwpcs_pack_batch(const dlwpcs_pack_item *items_dev, int n_items,
     // 96 x n_items workgroups (the largest U-Net layer packs ~0.9 M values = ~110 k 16-B entries per direction, 4-5 per thread;
     // small layers' surplus workgroups exit at once).  Measured on the unet2 step, 32 / 64 / 96 / 128 / 192 / 448 per item:
     // 11.5 / 8.9 / 8.5 / 9.7 / 8.9 / 9.7 us.
-    static int gx = 0;
-    if (!gx) { const char *e = getenv("DLWPCS_PACK_GRID"); gx = e ? atoi(e) : 96; if (gx < 1) gx = 1; }
+    const int gx = 96;
     hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)gx, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
     return check_launch("pack_batch");
 }
@@ -1678,22 +1633,7 @@ static int conv_fwd_impl(const dlwpcs_conv_desc *d, const void *src0, const void
                          const void *w_eq, const void *w_pol, const void *w_np,
                          const void *b_eq, const void *b_pol, const void *b_np,
                          void *y, const int32_t *table_dev,
-                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream, void *y_pooled, int *pool_done,
-                         ConvPlanOut *plan = nullptr);
-
-int dlwpcs::conv_fwd_plan(const dlwpcs_conv_desc *d, const void *src0, const void *src1, const void *wpk_fwd, const void *bias_pk,
-                          void *y, void *y_pooled, const int32_t *table_dev, ConvPlanOut *out) {
-    if (!d || !out) return fail(DLWPCS_E_INVALID, "conv_fwd_plan: null pointer");
-    if (!(d->flags & DLWPCS_CONV_PREPACKED)) return fail(DLWPCS_E_INVALID, "conv_fwd_plan: needs DLWPCS_CONV_PREPACKED operands");
-    out->cfg = -1; out->gy = 1; out->lds = 0;
-    int pool_done = 0;
-    char dummy = 0;                 // (no workspace is touched with pre-packed operands; the size check wants a non-null pointer)
-    const int rc = conv_fwd_impl(d, src0, src1, wpk_fwd, nullptr, nullptr, bias_pk, nullptr, nullptr, y, table_dev, &dummy,
-                                 (size_t)-1, nullptr, y_pooled, &pool_done, out);
-    if (rc) return rc;
-    if (y_pooled && !pool_done) out->cfg = -1;       // (this tiling cannot pool in its epilogue: the caller keeps the layer out)
-    return DLWPCS_OK;
-}
+                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream, void *y_pooled, int *pool_done);
 
 extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
                                const void *w_eq, const void *w_pol, const void *w_np,
@@ -1725,8 +1665,7 @@ static int conv_fwd_impl(const dlwpcs_conv_desc *d, const void *src0, const void
                          const void *w_eq, const void *w_pol, const void *w_np,
                          const void *b_eq, const void *b_pol, const void *b_np,
                          void *y, const int32_t *table_dev,
-                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream, void *y_pooled, int *pool_done,
-                         ConvPlanOut *plan) {
+                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream, void *y_pooled, int *pool_done) {
     int rc = validate(d, "conv_fwd");
     if (rc) return rc;
     if (!src0 || !w_eq || (!w_pol && !(d->flags & DLWPCS_CONV_PREPACKED)) || !y || !workspace)
@@ -1759,11 +1698,9 @@ static int conv_fwd_impl(const dlwpcs_conv_desc *d, const void *src0, const void
     P.mode = d->halo ? MODE_HALO : MODE_DIRECT;
     P.act = d->act; P.alpha = d->alpha; P.vmax = d->vmax;
     P.pool_out = y_pooled; P.pool_done = pool_done;
-    if (plan) { P.dry_run = 1; P.plan = plan; }
     if ((d->flags & DLWPCS_CONV_OUT_PADDED) && !pw_applies(d))
         return fail(DLWPCS_E_UNSUPPORTED, "conv_fwd: DLWPCS_CONV_OUT_PADDED serves the bf16 pointwise output layer only");
     if (pw_applies(d)) {
-        if (plan) return DLWPCS_OK;                 // (the pointwise head kernel is not a chain phase: cfg stays -1)
         PwParams Q{};
         Q.in = (const bf16_t *)src0; Q.wpk = (const bf16_t *)wpk; Q.bias = b_eq ? bpk : nullptr; Q.out = (bf16_t *)y;
         Q.ngroups = (long)d->B * 6 * d->N * d->N / 16; Q.groups_per_face = d->N * d->N / 16; Q.Cout = d->Cout;
@@ -2049,10 +1986,6 @@ extern "C" int dlwpcs_conv_bwd_weights(const dlwpcs_conv_desc *d, const void *sr
     P.magicN = div_magic(P.Nin);
     P.tune = tune_bits();
     W.magicB = P.B > 1 ? div_magic(P.B) : 0; W.magicNb = P.nblk_face > 1 ? div_magic(P.nblk_face) : 0;
-    P.dbg = nullptr;
-#ifdef DLWPCS_TIMELINE
-    { const char *e = getenv("DLWPCS_DBG_PTR"); P.dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
-#endif
     if (P.C1 == 0) P.src1 = P.src0;
     const bool mask = d->act != DLWPCS_ACT_NONE;
     dim3 grid((unsigned)(L.n_eq + L.n_4 + L.n_5), (unsigned)(CinP / 32), (unsigned)(CoutP / 32));

@@ -1,5 +1,5 @@
-// Forward / data-gradient convolution of libdlwpcs (gfx950): the persistent, wave-specialised kernel BODY as a device function,
-// shared by the per-layer launch (conv_mfma.hip: conv_mfma_ws_kernel) and the multi-layer chain launch (conv_chain.hip).
+// Forward / data-gradient convolution of libdlwpcs (gfx950): the persistent, wave-specialised kernel (body: conv_ws_body, launched
+// per layer by conv_launch.h through conv_mfma_ws_kernel).
 #pragma once
 #include <stdlib.h>
 #include <type_traits>
@@ -46,7 +46,6 @@ struct ConvKParams {
     int *direct_done;           // HOST pointer: set to 1 by launch_conv_cfg when the kernel it launched honours d0 / d1
     int *mask_done;             // HOST pointer: bit 0 / 1 set when the launched kernel masks what it stores to d0 / d1
     int dry_run;                // host only: choose the configuration, report direct_done / mask_done, launch nothing
-    struct ConvPlanOut *plan;   // host only (conv_chain.hip): with dry_run, the finished parameter block + configuration go here
     // Forward pass with the 2x2 average pooling of the output as a SECOND output (Azure/train_cs.py:282,287: AveragePooling3D
     // behind the block's last convolution): (B,6,No/2,No/2,Cout), written by the epilogue out of the LDS patches (launch_conv_cfg
     // checks the tiling: every consumer wave owns whole pairs of rows).  pool_done: HOST pointer, set to 1 when the launched
@@ -54,46 +53,18 @@ struct ConvKParams {
     void *pool_out;
     int *pool_done;
     int colsplit;               // pooled output, faces whose row is exactly one wave's 32 * MT pixels (N = 96): see launch_conv_cfg
-    int abl;                    // development only (-DDLWPCS_TIMELINE): epilogue ablation bits
     int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
     int tile_rows_max;          // rows reserved in LDS
     int ntiles;                 // B * 6 * nblk_face (persistent kernel)
-    // FLOW (chain launch without barriers, conv_chain.hip): per-(phase, sample) completion counters.  flow_done != nullptr: this
-    // call is phase flow_phase of a flow launch -- its tile list is dealt sample-MAJOR and round-robin (tile w + q * G of the list
-    // ordered (sample, face, band), rotated by flow_rot workers), a tile of sample s starts when flow_done[(flow_phase - 1) * flow_bmax
-    // + s] has reached flow_need (every consumer wave of every tile of the previous phase has arrived), and every consumer wave
-    // adds 1 to flow_done[flow_phase * flow_bmax + s] when its stores of a tile of sample s have left.
-    uint32_t *flow_done, *flow_abort;
-    int flow_phase, flow_bmax, flow_need, flow_rot;
-    uint32_t flow_spin;
     int split_gb, split_fb;     // ILV cost split (launch_conv_cfg): the LAST split_gb workers take all the short tiles (the last band
                                 // of every face) and split_fb of the full ones, the others the remaining full tiles; 0: plain split
-    long long *dbg;             // development only (-DDLWPCS_TIMELINE): s_memtime checkpoints [nblocks][64]
 };
 
 // EDGE instantiations: `P.table` is the forward halo table inside a dlwpcs_dgrad_gather_plan buffer, `src` its border-cell records
 // [6][4 No - 4][8] (six window positions, the wrong-tap mask, 0), `wids` the two weight-id triples per face [6][2][3] BY VALUE (scalar
 // loads out of the kernel arguments: no memory round trip in front of the fragment loads that need them).  A kernel argument of
-// its own: the chain launch packs eight ConvKParams into the 4 KB argument segment.
+// its own.
 struct ConvEdgeArgs { const int32_t *src; int8_t wids[36]; };
-
-// What a chain launch needs of one layer: the parameter block launch_conv_cfg finished, which instantiation it chose (chain_cfg
-// below; -1 = none the chain kernel carries), its grid's y extent and its LDS bytes.
-struct ConvPlanOut { ConvKParams P; int cfg, gy; size_t lds; };
-enum { CHAIN_CFG_3_32_3141 = 0, CHAIN_CFG_3_32_3122, CHAIN_CFG_3_16_5114, CHAIN_CFG_3_16_3141_T8, CHAIN_CFG_3_32_3141_T8, CHAIN_NCFG };
-template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8, bool MOUT>
-constexpr int chain_cfg() {
-    if (!(sizeof(T) == 2 && KS == 3 && VW == 8 && MODE == MODE_HALO && !MASK && !MOUT)) return -1;
-    if (!TAIL8 && KC == 32 && MT == 3 && NT == 1 && WM == 4 && WN == 1) return CHAIN_CFG_3_32_3141;
-    if (!TAIL8 && KC == 32 && MT == 3 && NT == 1 && WM == 2 && WN == 2) return CHAIN_CFG_3_32_3122;
-    if (!TAIL8 && KC == 16 && MT == 5 && NT == 1 && WM == 1 && WN == 4) return CHAIN_CFG_3_16_5114;
-    if (TAIL8 && KC == 16 && MT == 3 && NT == 1 && WM == 4 && WN == 1) return CHAIN_CFG_3_16_3141_T8;
-    if (TAIL8 && KC == 32 && MT == 3 && NT == 1 && WM == 4 && WN == 1) return CHAIN_CFG_3_32_3141_T8;
-    return -1;
-}
-// (conv_mfma.hip) the forward layer `d` as a plan: validation, tiling and instantiation choice of dlwpcs_conv_fwd, nothing launched
-int conv_fwd_plan(const dlwpcs_conv_desc *d, const void *src0, const void *src1, const void *wpk_fwd, const void *bias_pk, void *y,
-                  void *y_pooled, const int32_t *table_dev, ConvPlanOut *out);
 
 // Scheduling tunables, bit set.  Defaults are the measured-best values; DLWPCS_TUNE=<int> overrides them for A/B runs.
 //   1: weight-gradient kernels: producer waves run at s_setprio 2 (they are the second-dispatched, i.e. arbitration-losing,
@@ -117,62 +88,8 @@ static int tune_bits() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_WG_PRODUCER_PRIO | TUNE_CONV_PRODUCER_PRIO | TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT |
                                TUNE_CONV_STAGGER | TUNE_CONV_ILV | (3 << 12));
-                 const char *o = getenv("DLWPCS_TUNE_OR"); if (o) v |= atoi(o); }     // (A/B runs: extra bits on top of the defaults)
+                 }
     return v;
-}
-
-#ifdef DLWPCS_TIMELINE
-#define TL_MARK() do { if (tlp && tli < 32) tlp[tli++] = __builtin_amdgcn_s_memtime(); } while (0)
-#define PL_MARK() do { if (plp && pli < 32) plp[pli++] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define TL_MARK() do { } while (0)
-#define PL_MARK() do { } while (0)
-#endif
-
-// activation loads of the body: plain, or (CHAIN, see below) nontemporal = bypassing this CU's vector L1 (MI355X_MICROARCH.md, "Workgroup
-// dispatch, XCD placement & inter-workgroup visibility": `nt` loads are L2-served), for data another workgroup of the SAME launch
-// stored write-through before a barrier
-typedef unsigned int nt_q4 __attribute__((ext_vector_type(4)));
-typedef nt_q4 nt_q4_a4 __attribute__((aligned(4)));
-// (Measured, round 4: WITH the nontemporal loads the chained forward pass of the U-Net took 254 us against 190 us for ten launches,
-// the C96 rollout +18 % -- the halo rows two neighbouring tiles share and the inputs two N-tile groups share are re-read from HBM
-// instead of L1 / L2.  The chain launch therefore invalidates the CU's L1 ONCE per phase (agent-scope acquire behind the group
-// barrier, conv_chain.hip) and the body loads plainly; -DDLWPCS_CHAIN_NT restores the per-load bypass for A/B runs.)
-#ifdef DLWPCS_CHAIN_NT
-constexpr bool CHAIN_NT_LOADS = true;
-#else
-constexpr bool CHAIN_NT_LOADS = false;
-#endif
-template <bool CHAIN, typename V, typename T> __device__ __forceinline__ V ld_act(const T *p) {
-    if constexpr (!CHAIN || !CHAIN_NT_LOADS) {
-        return *reinterpret_cast<const V *>(p);
-    } else if constexpr (sizeof(V) == 16) {
-        V out;
-        if constexpr (alignof(V) >= 16) {
-            const nt_q4 r = __builtin_nontemporal_load((const __attribute__((address_space(1))) nt_q4 *)p);
-            __builtin_memcpy(&out, &r, 16);
-        } else {
-            const nt_q4 r = __builtin_nontemporal_load((const __attribute__((address_space(1))) nt_q4_a4 *)p);
-            __builtin_memcpy(&out, &r, 16);
-        }
-        return out;
-    } else if constexpr (sizeof(V) == 8) {
-        typedef unsigned int q2 __attribute__((ext_vector_type(2)));
-        const q2 r = __builtin_nontemporal_load((const __attribute__((address_space(1))) q2 *)p);
-        V out;
-        __builtin_memcpy(&out, &r, 8);
-        return out;
-    } else if constexpr (sizeof(V) == 4) {
-        const unsigned int r = __builtin_nontemporal_load((const __attribute__((address_space(1))) unsigned int *)p);
-        V out;
-        __builtin_memcpy(&out, &r, 4);
-        return out;
-    } else {
-        const unsigned short r = __builtin_nontemporal_load((const __attribute__((address_space(1))) unsigned short *)p);
-        V out;
-        __builtin_memcpy(&out, &r, 2);
-        return out;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -209,28 +126,22 @@ template <bool CHAIN, typename V, typename T> __device__ __forceinline__ V ld_ac
 // the activation is max + min instead of compare + select, store addresses are per-(face, band) constants -- 1.75 k + 0.44 k cycles now -- and then
 // the producers' address arithmetic per load was cut to one multiply-add (see `sup`): the two sides are now balanced within
 // ~10 % (4.4 k consumer vs ~4.9 k producer cycles per tile).
-// conv_ws_body: the work of worker `lw` of `G` (the workers of one launch -- or, in a chain launch, of one sample group -- share
-// the tile list -- P.B samples from sample `b0` on; `by` = which group of N tiles).  Every one of the workgroup's 2 * 64 * WM * WN threads calls it and RETURNS from it
-// (no early exits: a chain launch meets at a workgroup barrier behind it).  CHAIN: the activations this call reads may have been
-// written EARLIER IN THE SAME LAUNCH by other workgroups (write-through stores): their loads bypass this CU's L1
-// (nontemporal: L2-served), see conv_chain.hip.
-// EDGE (round 4): the DATA GRADIENT IN GATHER FORM.  MODE_HALO on the N x N grid with the flipped operand pack: the main loop is the
-// plain correlation of the HALO-PADDED dz (the forward's own gather).  Taps that stay inside the face, and taps that cross an
+// conv_ws_body: the work of worker `lw` of the launch's `G` workers (they share the tile list); `by` = which group of N tiles.  Every
+// one of the workgroup's 2 * 64 * WM * WN threads calls it and RETURNS from it.
+// EDGE (round 5 form): the DATA GRADIENT IN GATHER FORM.  MODE_HALO on the N x N grid with the flipped operand pack: the main loop is
+// the plain correlation of the HALO-PADDED dz (the forward's own gather).  Taps that stay inside the face, and taps that cross an
 // equatorial-equatorial edge (same kernel, same orientation), are terms of the adjoint of DLWP/custom.py:1198-1308 as they are.  A
 // tap that crosses any other edge is WRONG: the adjoint wants the same halo cell's dz row times a tap of the NEIGHBOUR's kernel
-// (rotated into this face's frame).  Both corrections run per channel chunk right behind the chunk's MFMAs, out of the SAME LDS
-// tile, for the few border pixels of a wave compacted into "levels" (one edge M tile each): the wrong taps are cancelled (pixel
-// operand negated, the face's own fragments out of the LDS weight area), the true terms added (fragments of (variant, tap) out of the
-// packed operands, fetched from L2 while the chunk's main MFMAs run).  No global gathers, no memory latency in the consumers' path;
-// every cell is complete when it is stored: no halo ring, no fix-up launch, one rounding.  Stores go to d0 / d1 like the direct
+// (rotated into this face's frame) -- a WEIGHT SUBSTITUTION, done inside the matrix phase by addressing alone (see the consumers).
+// Every cell is complete when it is stored: no halo ring, no fix-up launch, one rounding.  Stores go to d0 / d1 like the direct
 // mode's interior cells (all cells are interior here), masks (MOUT) included.
 template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, int MODE, bool MASK, bool TAIL8 = false, bool MOUT = false,
-          bool CHAIN = false, bool EDGE = false>
+          bool EDGE = false>
 __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, const uint32_t lw, const int G, const int by,
-                                             const int b0 = 0, const ConvEdgeArgs &E = ConvEdgeArgs{}) {
+                                             const ConvEdgeArgs &E = ConvEdgeArgs{}) {
     static_assert(!TAIL8 || (VW == 8 && sizeof(T) == 2 && !MASK), "TAIL8: bf16 16-B vectors, forward only");
     static_assert(!MOUT || ((MODE == MODE_ZERO || EDGE) && KS == 3 && sizeof(T) == 2 && !MASK), "MOUT: bf16 data gradient, direct mode");
-    static_assert(!EDGE || (MODE == MODE_HALO && KS == 3 && !MASK && !TAIL8 && !CHAIN && VW * sizeof(T) == 16), "EDGE: gather-form data gradient");
+    static_assert(!EDGE || (MODE == MODE_HALO && KS == 3 && !MASK && !TAIL8 && VW * sizeof(T) == 16), "EDGE: gather-form data gradient");
     constexpr int ES = sizeof(T);
     constexpr int CGW = 32 / ES;                    // channels per MFMA operand group (two 16-B half fragments)
     constexpr int TAPS = KS * KS;
@@ -308,23 +219,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         t_first = (int)(((long)P.ntiles * lw) / G);
         t_last = (int)(((long)P.ntiles * (lw + 1)) / G);
     }
-    // FLOW: tile w' + q * G of the SAMPLE-major list (w' = the worker rotated by flow_rot: who gets the longer list alternates
-    // from phase to phase)
-    const bool flow = CHAIN && P.flow_done != nullptr;
-    const int ncombo = 6 * nbl;
-    // FLOW dealing (flow_rot >= 0): a worker OWNS one (face, band) and a share of its samples -- M = G / (faces x bands) workers
-    // per (face, band), worker i of them takes samples i, i + M, i + 2 M, ... (i rotated by flow_rot from phase to phase: who gets
-    // the longer list changes).  Consecutive tiles of a worker stay the same (face, band) -- the halo-table gather and the store
-    // offsets are set up once per phase, as in the plain order -- and every round of the chip covers ALL (face, band)s of M
-    // samples, so a sample is complete M-samples-at-a-time, rounds before the next phase needs it: nobody waits.
-    // (flow_rot < 0, or more (face, band)s than workers: the plain contiguous ranges; dependencies then act like a barrier.)
-    const int fM = flow && P.flow_rot >= 0 ? G / ncombo : 0;
-    const bool fdeal = fM >= 1;
-    const int fc = fdeal ? (int)lw / fM : 0, fi = fdeal ? (int)(((int)lw % fM + P.flow_rot) % fM) : 0;
-    const int n_my = fdeal ? ((fc < ncombo && fi < P.B) ? (P.B - fi + fM - 1) / fM : 0)
-                           : (csplit ? (f1 - f0) + (s1 - s0) : t_last - t_first);
+    const int n_my = csplit ? (f1 - f0) + (s1 - s0) : t_last - t_first;
     auto tile_of = [&](int q) __attribute__((always_inline)) {
-        if (fdeal) return fc * P.B + fi + q * fM;
         if (!csplit) return t_first + q;
         const int nf = f1 - f0, perF = (nbl - 1) * P.B;
         if (q < nf) { const int i = f0 + q, f = i / perF; return f * nbl * P.B + (i - f * perF); }
@@ -337,7 +233,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // costs twice a later one).  Measured on the bf16 training step, 0 / 1 / 2 / 3 / 4 / 6 / 8 sleeps: 0.6842 / 0.6795 / 0.6781 /
     // 0.6768 / 0.6775 / 0.6786 / 0.6797 ms; 16 sleeps +24 us.
     // (not with the cost split: there every workgroup's list is as expensive as the next one's, whatever its length)
-    if ((P.tune & TUNE_CONV_STAGGER) && !csplit && !flow && n_my * G < P.ntiles) {
+    if ((P.tune & TUNE_CONV_STAGGER) && !csplit && n_my * G < P.ntiles) {
 #pragma unroll 1
         for (int i = 0; i < ((P.tune >> 12) & 63); ++i) __builtin_amdgcn_s_sleep(16);
     }
@@ -345,7 +241,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     auto geo_of = [&](int t) __attribute__((always_inline)) {
         Geo gq;
         gq.combo = P.magicB ? __umulhi((uint32_t)t, P.magicB) : t;                      // t / B   (magic 0 <=> divisor 1)
-        gq.b = t - gq.combo * P.B + b0;             // (b0: first sample of this worker group's sub-batch, chain launches; addressing only)
+        gq.b = t - gq.combo * P.B;
         gq.f = P.magicNblk ? __umulhi((uint32_t)gq.combo, P.magicNblk) : gq.combo;     // combo / nblk_face
         const int blk = gq.combo - gq.f * P.nblk_face;
         gq.v = gq.f < 4 ? 0 : (gq.f == 4 ? 1 : 2);
@@ -364,10 +260,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         const int qv = (ptid % Q) * VW;
         const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.wpk);
         if (P.tune & TUNE_CONV_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(2);
-#ifdef DLWPCS_TIMELINE
-        int pli = 0;
-        long long *plp = (P.dbg && ptid == 0 && by == 0) ? P.dbg + (size_t)blockIdx.x * 64 + 32 : nullptr;
-#endif
         // Tile-invariant slot constants: slot i of this thread is tile pixel (ty, tx) in EVERY tile (only the band's first
         // row y0, the face and the sample change), so the divisions happen once per kernel.  Packed per slot:
         //   bits 4:0 = ty, bit 5 = column valid (MODE_ZERO border), bits 31:6 = OFF + offset of (ty, tx) from the band's
@@ -504,7 +396,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             const T *sb; int cstride, cs_ld, sh; bool c_ok, up;
             chunk_src(gc, ch, sb, cstride, cs_ld, sh, c_ok, up);
             const T *ymb = MASK ? reinterpret_cast<const T *>(P.ymask) + (size_t)gc.b * 6 * g0 * g0 * P.C0 : nullptr;
-            PL_MARK();
             okm = 0;
 #pragma unroll
             for (int i = 0; i < ITS; ++i) {
@@ -514,17 +405,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 int pix = ok ? idx : 0;
                 if constexpr (!SUP) pix = up ? upmap(pix) : pix;
                 const size_t oo = ok ? (size_t)pix * cstride + cs_ld : 0;
-                if constexpr (CHAIN && CHAIN_NT_LOADS) {
-                    // sc1: served by the L2, never by this CU's L1 (measured: the forward pass +35 us; see ld_act)
-                    static_assert(!CHAIN || (VW * ES == 16 && !MASK), "chain phases: 16-B activation vectors");
-                    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(sb, 0x7ffffff0u), (uint32_t)oo * ES, 0, 16);
-                    val[i] = V{r.x, r.y, r.z, r.w};
-                } else if constexpr (TAIL8) val[i] = ld_act<false, uint4_a4>(sb + oo);
-                else val[i] = ld_act<false, V>(sb + oo);
-                if (MASK) ymv[i] = ld_act<false, V>(ymb + oo);
+                if constexpr (TAIL8) val[i] = *reinterpret_cast<const uint4_a4 *>(sb + oo);
+                else val[i] = *reinterpret_cast<const V *>(sb + oo);
+                if (MASK) ymv[i] = *reinterpret_cast<const V *>(ymb + oo);
                 okm |= (uint32_t)ok << i;
             }
-            PL_MARK();
         };
         // commit(): the loaded vectors -> LDS buffer g & 1, barrier B_g
         auto commit = [&](const Geo &gc, int ch, V (&val)[ITS], V (&ymv)[MASK ? ITS : 1], uint32_t okm) __attribute__((always_inline)) {
@@ -547,7 +432,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 const int e = ptid + i * NCT;
                 if (e < gc.nitems) *reinterpret_cast<V *>(buf + (e / Q) * RB + qv * ES) = vsel(((okm >> i) & 1u) != 0, val[i]);
             }
-            PL_MARK();
             __syncthreads();            // B_g: chunk g is in LDS
             ++g;
         };
@@ -563,36 +447,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         // its input vectors before the weight stores -- two dependent round trips instead of three at the start of the kernel
         // -- made the training step 3 % SLOWER; the first chunk's fragments alone before the lookup: 1 % slower.  The loads of a
         // wave return in order: whatever is requested ahead of the table entries delays them.)
-        // FLOW: the dependency flag of a tile's sample ((phase - 1, sample) complete?) is fetched one tile ahead, behind the
-        // current tile's loads; normally it says "long since".  Else poll, bounded: a wait that does not end sets the abort word,
-        // every later wait gives up at once.
-        uint32_t fv = 0xffffffffu;
-        auto flag_of = [&](int b) __attribute__((always_inline)) {
-            return __hip_atomic_load(P.flow_done + (size_t)(P.flow_phase - 1) * P.flow_bmax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        const bool fdep = flow && P.flow_phase > 0;
-        if constexpr (CHAIN) { if (fdep && n_my > 0) fv = flag_of(geo_of(tile_of(0)).b); }
         for (int q = 0; q < n_my; ++q) {
             const Geo gq = geo_of(tile_of(q));
             if (gq.combo != cur_combo) { lookup(gq); cur_combo = gq.combo; }        // uniform; a few times per workgroup
-            if constexpr (CHAIN) {
-                if (fdep && fv < (uint32_t)P.flow_need) {
-                    // (ONE lane per wave polls, with a long sleep: 256 workgroups x 4 waves x 64 lanes re-reading flags is memory
-                    // traffic of its own -- MI355X_MICROARCH.md "polling-cost")
-                    uint32_t n = 0;
-                    if ((ptid & 63) == 0) {
-                        while (flag_of(gq.b) < (uint32_t)P.flow_need) {
-                            __builtin_amdgcn_s_sleep(32);
-                            if ((++n & 15u) == 0 && __hip_atomic_load(P.flow_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                            if (n > P.flow_spin) { __hip_atomic_store(P.flow_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
             for (int ch = 0; ch < nchunks; ++ch) {
                 issue(gq, ch, val, ymv, okm);
-                if constexpr (CHAIN) { if (ch == 0 && fdep && q + 1 < n_my) fv = flag_of(geo_of(tile_of(q + 1)).b); }
                 commit(gq, ch, val, ymv, okm);
             }
         }
@@ -625,11 +484,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     constexpr bool DIRECT = (MODE == MODE_ZERO || EDGE) && KS == 3;   // data gradient: interior cells go straight to the sources
     constexpr int RING = EDGE ? 0 : 1;          // width of the ring around the sources' cells on the output grid (gather form: none)
     int g = 0;
-#ifdef DLWPCS_TIMELINE
-    int tli = 0;
-    long long *tlp = (P.dbg && tid == 0 && by == 0) ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
-#endif
-    TL_MARK();
     int abase[MT];
     int cur_combo = -1, cur_v = -1;
     // EDGE: per (face, band).  A lane owns pixel l31 of each of the wave's MT M tiles.  For a border cell the plan record
@@ -970,9 +824,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 // waited for the stores of the previous slice (measured: 43.8 us against 26.1 us unmasked, 32 -> 32 at N = 48)
                 v.x = on ? vm.x : v.x; v.y = on ? vm.y : v.y; v.z = on ? vm.z : v.z; v.w = on ? vm.w : v.w;
             }
-#ifdef DLWPCS_TIMELINE
-            if (P.abl & 1) boff = ST_SKIP;          // ablation: no global stores
-#endif
             if constexpr (decltype(ud_tag)::value) {
                 // gather form, whole 32-channel n tiles per source: the destination is the same for every lane of the pass
                 bst128(v, dsel[nt], boff);
@@ -994,7 +845,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     };
     auto epilogue_lines = [&](const Geo &gq, const auto &A, auto mta_tag) {
         constexpr int MTA = decltype(mta_tag)::value;       // M tiles this wave has in this tile (ILV), else MT
-        TL_MARK();
         if constexpr (MOUT) {
             // Every mask value is waited for HERE, before the first store of the epilogue: with loads and stores both in flight
             // hipcc cannot count (gfx9 has one vmcnt for both and they complete out of order), so each later use of a mask
@@ -1049,11 +899,9 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         else if (P.act != DLWPCS_ACT_LEAKY_CLIP) run(std::integral_constant<int, 2>{}, std::false_type{});
         else if (fast_act) run(std::integral_constant<int, 1>{}, std::false_type{});
         else run(std::integral_constant<int, 0>{}, std::false_type{});
-        TL_MARK();
     };
     // fallback (odd channel counts, or no LDS room for the patches): quads / scalars straight from the accumulators
     auto epilogue_plain = [&](const Geo &gq) {
-        TL_MARK();
         T *outp = reinterpret_cast<T *>(P.out) + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
         const bool wide = (P.Cout & 3) == 0;
 #pragma unroll
@@ -1085,7 +933,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 }
             }
         }
-        TL_MARK();
     };
 
     // ---- one chunk of MFMAs out of LDS buffer g & 1 (between two barriers: fragment reads + MFMAs only)
@@ -1195,22 +1042,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     };
 
     const bool lines = P.patches && (P.Cout % (16 / ES)) == 0;
-    // FLOW: this wave's arrival for the PREVIOUS tile is posted behind the matrix phase of the current one: its stores have long
-    // left by then, the wait costs nothing (posting right behind the epilogue would put a store round trip into every tile)
-    int arrive_b = -1;
-    auto flow_arrive = [&]() __attribute__((always_inline)) {
-        if constexpr (CHAIN) {
-            if (flow && arrive_b >= 0) {
-#ifndef DLWPCS_FLOW_NOWAIT          // (timing experiment only: arrivals without waiting for the stores -- results are then unordered)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-                if (lane == 0)
-                    __hip_atomic_fetch_add(P.flow_done + (size_t)P.flow_phase * P.flow_bmax + arrive_b, 1u, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                arrive_b = -1;
-            }
-        }
-    };
     for (int q = 0; q < n_my; ++q) {
         const Geo gq = geo_of(tile_of(q));
         setup(gq);
@@ -1218,14 +1049,12 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         // (ILV: how many of its M tiles this wave has in this tile: M tile j of the tile's ceil(npix / 32) belongs to wave j % WM)
         const int my_mt = ilv ? max(0, min(MT, (((gq.npix + 31) >> 5) - wm + WM - 1) / WM)) : MT;
         for (int ch = 0; ch < nchunks; ++ch, ++g) {
-            TL_MARK();
             // B_g: chunk g has been written by the producers.  A RAW barrier behind an explicit LDS wait: __syncthreads() makes
             // hipcc drain vmcnt(0) first, i.e. wait for the previous tile's epilogue stores to be acknowledged and -- MOUT -- for
             // the mask values requested a moment ago (measured on the 32 -> 32 data gradient at N = 48: 43.8 us masked against
             // 26.1 plain, nearly all of it this wait).  The consumers only owe the producers their LDS reads.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            TL_MARK();
             if constexpr (ILV_OK) {
                 if (my_mt >= MT) mma_chunk(ch, std::integral_constant<int, MT>{});
                 else if (my_mt == 2) mma_chunk(ch, std::integral_constant<int, 2>{});
@@ -1239,7 +1068,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 mma_chunk(ch, std::integral_constant<int, MT>{});
             }
         }
-        flow_arrive();
         if (lines) {
             if constexpr (ILV_OK) {
                 if (my_mt >= MT) epilogue_lines(gq, acc, std::integral_constant<int, MT>{});
@@ -1251,9 +1079,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         } else {
             epilogue_plain(gq);
         }
-        arrive_b = gq.b;
     }
-    flow_arrive();
 }
 
 // the per-layer launch: one workgroup per CU, workers laid out XCD-aware over the tile list
@@ -1261,8 +1087,8 @@ template <typename T, int KS, int KC, int MT, int NT, int WM, int WN, int VW, in
           bool EDGE = false>
 __global__ void __launch_bounds__(2 * 64 * WM * WN) conv_mfma_ws_kernel(const ConvKParams P, const ConvEdgeArgs E) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv_ws_body<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8, MOUT, false, EDGE>(P, smem, xcd_remap(blockIdx.x, gridDim.x),
-                                                                                    (int)gridDim.x, (int)blockIdx.y, 0, E);
+    conv_ws_body<T, KS, KC, MT, NT, WM, WN, VW, MODE, MASK, TAIL8, MOUT, EDGE>(P, smem, xcd_remap(blockIdx.x, gridDim.x), (int)gridDim.x,
+                                                                             (int)blockIdx.y, E);
 }
 
 }  // namespace dlwpcs

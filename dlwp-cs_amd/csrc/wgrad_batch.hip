@@ -113,16 +113,6 @@ struct WbRedPtrs {
 // One segment.  Called by all 512 threads of the workgroup; threads 256.. are the producers.  Both halves execute
 // n_items + 3 workgroup barriers.
 // ------------------------------------------------------------------------------------------------------------------
-// development only (-DDLWPCS_WB_TIMING): s_memtime accounting of one producer and one consumer thread per workgroup,
-// dbg[worker][role][8] (cycles): producer {issue, wait + LDS writes, barrier, epilogue, items}, consumer {barrier, mma, epilogue}
-#ifdef DLWPCS_WB_TIMING
-#define WB_T(var) const long long var = __builtin_amdgcn_s_memtime()
-#define WB_ACC(slot, a, b) do { tacc[slot] += (b) - (a); } while (0)
-#else
-#define WB_T(var) do { } while (0)
-#define WB_ACC(slot, a, b) do { } while (0)
-#endif
-
 // Consumer schedule of one K slab: the 2 * TAPS + 2 transpose reads of the NEXT slab interleaved with the TAPS MFMAs of this
 // one (an in-order wave can issue ~5 other instructions in the shadow of a 32x32x16 MFMA; all reads first, then all MFMAs --
 // the schedule of wgrad_bf16_kernel -- measured ~600 cycles per slab of 9 MFMAs, twice the matrix time).
@@ -232,10 +222,6 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
         float bsum[DV];
 #pragma unroll
         for (int u = 0; u < DV; ++u) bsum[u] = 0.f;
-#ifdef DLWPCS_WB_TIMING
-        long long *tdbg = (dbg && ptid == 0) ? dbg + ((size_t)blockIdx.x * 2 + 0) * 8 : nullptr;
-        long long tacc[4] = {0, 0, 0, 0};
-#endif
         // (Round 3, measured and dropped: src / dz / table reach this noinline function as GENERIC pointers, so every load below is
         // a FLAT instruction, which counts in lgkmcnt too -- the LDS wait in commit() therefore also waits for the loads of the
         // next item.  Casting them to the global address space (global_load, the producers really two items ahead) measured
@@ -326,43 +312,23 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
             // B_k: item k is in LDS.  RAW barrier behind an explicit LDS wait (a __syncthreads() would drain vmcnt(0), i.e. wait
             // for the loads of item k + 1 that were issued a moment ago)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            WB_T(tq0);
             __builtin_amdgcn_s_barrier();
-            WB_T(tq1);
-            WB_ACC(2, tq0, tq1);
-#ifdef DLWPCS_WB_TIMING
-            tacc[1] -= tq1 - tq0;
-#endif
         };
-#ifdef DLWPCS_WB_TIMING
-        if (tdbg) tdbg[4] += n_my;
-#endif
         {
             Stage A, B;
             Item i0 = item_of(0), i1 = item_of(1);          // item_of clamps: prefetches past the end re-read the last item
-            WB_T(ta);
             issue(i0, A);
-            WB_T(tb);
-            WB_ACC(0, ta, tb);
             for (int k = 0; k < n_my; k += 2) {
                 const Item i2 = item_of(k + 2);
-                WB_T(t0);
                 issue(i1, B);
-                WB_T(t1);
                 commit(i0, k, A);
-                WB_T(t2);
-                WB_ACC(0, t0, t1); WB_ACC(1, t1, t2);
                 if (k + 1 >= n_my) break;
                 const Item i3 = item_of(k + 3);
                 issue(i2, A);
-                WB_T(t3);
                 commit(i1, k + 1, B);
-                WB_T(t4);
-                WB_ACC(0, t2, t3); WB_ACC(1, t3, t4);
                 i0 = i2; i1 = i3;
             }
         }
-        WB_T(te0);
         // ---- bias partial: thread (vector qd, 256 / QDT pixel phases) holds sums of DV channels -> fixed-order sum
         __syncthreads();                // E1: consumers are done with the buffers
         float *red = reinterpret_cast<float *>(smem) + RED_FLOATS;   // behind the consumers' reduction slots
@@ -383,11 +349,6 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
             slot[TAPS * (32 * CT) * (32 * NT) + ptid] = sum;
         }
         __syncthreads();                // E3: the next segment may overwrite the buffers
-        WB_T(te1);
-        WB_ACC(3, te0, te1);
-#ifdef DLWPCS_WB_TIMING
-        if (tdbg) { for (int u = 0; u < 4; ++u) tdbg[u] += tacc[u]; }
-#endif
         return;
     }
 
@@ -409,16 +370,8 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
     const int nslab = pix_cap / 16;             // K slabs (16 pixels) per item
     const int S = (((nslab + NPH - 1) / NPH) + 1) & ~1;   // slabs per consumer wave, rounded up to even (extras add zero)
     const int ct = wave % CT, nt = (wave / CT) % NT, ph = wave / (CT * NT);
-#ifdef DLWPCS_WB_TIMING
-    long long *tdbg = (dbg && tid == 0) ? dbg + ((size_t)blockIdx.x * 2 + 1) * 8 : nullptr;
-    long long tacc[3] = {0, 0, 0};
-    long long tprev = __builtin_amdgcn_s_memtime();
-#endif
     for (int k = 0; k < n_my; ++k) {
         __syncthreads();                        // B_k
-#ifdef DLWPCS_WB_TIMING
-        { const long long tn = __builtin_amdgcn_s_memtime(); WB_ACC(0, tprev, tn); tprev = tn; }
-#endif
         const char *lds_x0 = smem + (k & 1) * buf_bytes, *lds_dy = lds_x0 + x_bytes + nt * dzplane_bytes;
         const char *lds_x = lds_x0 + ct * plane_bytes;
         const Item it = item_of(k);
@@ -455,9 +408,6 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
             for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fa[1][tap], fb[1]);
             WB_SCHED();
         }
-#ifdef DLWPCS_WB_TIMING
-        { const long long tn = __builtin_amdgcn_s_memtime(); WB_ACC(1, tprev, tn); tprev = tn; }
-#endif
     }
     __syncthreads();                            // E1: all consumers finished reading the last buffer
     // Cross-wave reduction, one LDS round (see wgrad_bf16_kernel): the NPH waves of a (ci tile, co tile) hold K-split sums
@@ -506,10 +456,6 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
         }
     }
     __syncthreads();                            // E3
-#ifdef DLWPCS_WB_TIMING
-    { const long long tn = __builtin_amdgcn_s_memtime(); WB_ACC(2, tprev, tn); }
-    if (tdbg) { for (int u = 0; u < 3; ++u) tdbg[u] += tacc[u]; }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -828,13 +774,7 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
     const WbSeg *segs = reinterpret_cast<const WbSeg *>(plan + H->off_segs);
     const int w = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int s0 = (int)H->seg_start[w], s1 = (int)H->seg_start[w + 1];
-#ifdef DLWPCS_WB_SEGTIME
-    long long seg_t = __builtin_amdgcn_s_memtime();      // development: dbg[segment] = constant-clock ticks the segment took
-#endif
     for (int s = s0; s < s1; ++s) {
-#ifdef DLWPCS_WB_SEGTIME
-        if (s > s0 && dbg && threadIdx.x == 0) { const long long t = __builtin_amdgcn_s_memtime(); dbg[s - 1] = t - seg_t; seg_t = t; }
-#endif
         const WbSeg &sg = segs[s];
         const WbLayer &L = layers[sg.layer];
         const void *a0 = ptrs.src0[sg.layer], *a1 = ptrs.src1[sg.layer], *dz = ptrs.dz[sg.layer], *yy = ptrs.y[sg.layer];
@@ -879,9 +819,6 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
             default:          wb_segment<1, 8, 4, 1, 1, 2>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
         }
     }
-#ifdef DLWPCS_WB_SEGTIME
-    if (s1 > s0 && dbg && threadIdx.x == 0) dbg[s1 - 1] = __builtin_amdgcn_s_memtime() - seg_t;
-#endif
     // optimizer fused into the reduction that follows: the step counter {t, ticket} moves on here (last worker to finish)
     if (adam_state != nullptr && threadIdx.x == 0) {
         const int done = atomicAdd(adam_state + 1, 1);
@@ -1202,12 +1139,7 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
         // (barrier, first fragments), ~6500 for a 1x1 kernel whose few MFMAs no longer hide the producers; act' on load adds
         // ~7.5 per pixel.  The chains are cut at equal cost: a layer whose items run x % over the
         // model makes the whole launch x % longer.
-        static double cm[4] = {-1, 0, 0, 0};
-        if (cm[0] < 0) {
-            const char *e = getenv("DLWPCS_WB_COST_F32");
-            cm[0] = 73.0; cm[1] = 4300.0; cm[2] = 6500.0; cm[3] = 7.5;
-            if (e) sscanf(e, "%lf,%lf,%lf,%lf", &cm[0], &cm[1], &cm[2], &cm[3]);
-        }
+        const double cm[4] = {73.0, 4300.0, 6500.0, 7.5};
         const int nsteps = L.pix_cap / 2, S = (ceil_div(nsteps, 4) + 1) & ~1;
         const double cost = (double)S * TAPS * cm[0] + (KS == 1 ? cm[2] : cm[1]) + (mask ? cm[3] * pix : 0.0);
         G.cost_item[0] = G.cost_item[1] = cost;
@@ -1222,12 +1154,8 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
     // shapes of the U-Net, +-7 %): when the producers set the period an item costs ~3300 cycles plus its bytes at 23 B/clk
     // (plus ~45 per 4-B load instruction of a thread); when the consumers do, ~530 cycles per 16-pixel slab of 9 taps (260
     // for a 1x1 kernel; the slab count per wave is rounded up to even) plus ~1200.
-    static double fix = -1, bpc = -1, slab3 = -1, slab1 = -1, ld4 = -1, cfix = -1;
-    if (fix < 0) {
-        const char *e = getenv("DLWPCS_WB_COST");
-        fix = 3300.0; bpc = 23.0; slab3 = 530.0; slab1 = 260.0; ld4 = 45.0; cfix = 1200.0;
-        if (e) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &fix, &bpc, &slab3, &slab1, &ld4, &cfix);
-    }
+    // (round 4: every one of the six constants, the segment overhead and the worker count varied against the step -- these are the optimum)
+    const double fix = 3300.0, bpc = 23.0, slab3 = 530.0, slab1 = 260.0, ld4 = 45.0, cfix = 1200.0;
     const int nslab = L.pix_cap / 16;
     const int S = ((ceil_div(nslab, nph)) + 1) & ~1;
     const double mma = (double)S * (KS == 3 ? slab3 : slab1) + cfix;
@@ -1246,11 +1174,7 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
     return DLWPCS_OK;
 }
 
-static double wb_seg_overhead() {
-    static double v = -1;
-    if (v < 0) { const char *e = getenv("DLWPCS_WB_SEG"); v = e ? atof(e) : 20000.0; }
-    return v;
-}
+static double wb_seg_overhead() { return 20000.0; }
 
 struct WbPlanOut {
     WbHeader H;
@@ -1367,11 +1291,7 @@ static int wb_build(const dlwpcs_wgrad_item *items, int n, int n_workers, WbPlan
     return DLWPCS_OK;
 }
 
-static int wb_workers() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DLWPCS_WB_WORKERS"); v = e ? atoi(e) : 256; if (v < 1 || v > 256) v = 256; }
-    return v;
-}
+static int wb_workers() { return 256; }
 
 // upper bound of the plan size that does not depend on where the cuts fall: every group is cut at most once per worker
 static size_t wb_plan_bound(int n_groups, int n_layers, int n_workers) {
@@ -1539,9 +1459,6 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
     if (!apply_only) {
         if (prof_enabled()) pidx = prof_begin("wgrad_batch_kernel", flops, bytes, s);
         long long *dbg = nullptr;
-#if defined(DLWPCS_WB_TIMING) || defined(DLWPCS_WB_SEGTIME)
-        { const char *e = getenv("DLWPCS_DBG_PTR"); dbg = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
-#endif
         hipLaunchKernelGGL(wgrad_batch_kernel, dim3(H->n_workers), dim3(512), lds, s, (const char *)plan_dev, ptrs, (float *)workspace, dbg,
                            adam_state);
         if (pidx >= 0) prof_end(pidx, s);

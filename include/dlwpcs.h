@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DLWPCS_VERSION 104            /* 0.1.4: dlwpcs_wgrad_batch_apply (data-parallel step tail), dlwpcs_conv_chain* */
+#define DLWPCS_VERSION 105            /* 0.1.5: dlwpcs_comm_* / dlwpcs_allreduce_f32, gather-form data gradient by default; the chain launch is gone */
 
 /* error codes */
 #define DLWPCS_OK             0
@@ -327,36 +327,6 @@ int dlwpcs_wgrad_batch_adam_tail(const dlwpcs_wgrad_item *items, int n_items, co
 int dlwpcs_wgrad_batch_apply(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                              float *p, float *g, float *m, float *v, size_t n, int32_t *state_dev, const float *hyper_dev,
                              const struct dlwpcs_loss_tail *tail, const dlwpcs_pack_item *pack_items_host, dlwpcs_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------------------------- *
- * Multi-layer persistent convolution chain (round 4, csrc/conv_chain.hip): consecutive fused convolutions of a forward pass --
- * pad -> CubeSphereConv2D -> ReLU [-> AveragePooling3D as a second output], Azure/train_cs.py:277-305 -- as ONE launch.  The
- * layers are phases of a persistent kernel; the batch is cut into (up to 8) sample groups whose workgroups meet at a GROUP
- * barrier between phases (a layer's halo couples the faces of one sample only, DLWP/custom.py:1198-1308, so groups never wait
- * for each other).  Same kernel body, same tiles, same arithmetic order as dlwpcs_conv_fwd[_pool]: bit-identical results.
- *   items: the layers in execution order, DLWPCS_BF16, 3x3 with halo, pre-packed operands (dlwpcs_pack_batch outputs); item k
- *          may read the outputs of any item < k (and tensors that exist before the launch); y_pooled as for dlwpcs_conv_fwd_pool
- *          -- a layer whose tiling cannot pool in its epilogue makes the whole call DLWPCS_E_UNSUPPORTED (the caller then launches
- *          layer by layer), like every shape without a chain phase (dlwpcs_conv_chain_supported asks without launching).
- *   sync_dev: DLWPCS_CHAIN_SYNC_BYTES of device memory, zeroed ONCE by the caller (hipMemset) and left alone: the barrier words
- *          of the launch (they return to zero at its end).  One buffer per stream; launches on a stream are serial anyway.
- * The launch needs its 256 workgroups co-resident (one per CU).  A barrier that does not complete within ~1 s (the device is
- * shared with another process) ABORTS the launch: every workgroup leaves and word [8 * 64] of sync_dev is set --
- * dlwpcs_conv_chain_status reports it (blocking copy); results of that launch are undefined, and the buffer must be zeroed again.
- * ------------------------------------------------------------------------------------------------------------- */
-#define DLWPCS_CHAIN_MAX 11
-#define DLWPCS_CHAIN_SYNC_BYTES 65536
-typedef struct dlwpcs_chain_item {
-    dlwpcs_conv_desc d;
-    const void *src0, *src1;        /* as for dlwpcs_conv_fwd */
-    const void *wpk_fwd, *bias_pk;  /* dlwpcs_pack_batch outputs (bias_pk NULL: no bias) */
-    void *y, *y_pooled;             /* y_pooled NULL: no pooled second output */
-    const int32_t *table_dev;       /* halo table of face size d.N, padding 1 */
-} dlwpcs_chain_item;
-size_t dlwpcs_conv_chain_sync_bytes(void);
-int dlwpcs_conv_chain_supported(const dlwpcs_chain_item *items, int n_items);
-int dlwpcs_conv_chain_fwd(const dlwpcs_chain_item *items, int n_items, void *sync_dev, dlwpcs_stream_t stream);
-int dlwpcs_conv_chain_status(const void *sync_dev, int *aborted);
 
 /* ------------------------------------------------------------------------------------------------------------- *
  * Generic (any kernel size / stride / dilation / 'same') per-face convolution on an ALREADY PADDED channels_last

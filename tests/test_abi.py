@@ -52,7 +52,7 @@ def test_ctypes_prototypes_cover_header(native):
 
 def test_version_and_error_channel(native):
     lib = native.lib()
-    assert lib.dlwpcs_version() == 104
+    assert lib.dlwpcs_version() == 105
     out = np.zeros(4, dtype=np.int32)
     rc = lib.dlwpcs_halo_table(0, 1, out.ctypes.data)
     assert rc == -1

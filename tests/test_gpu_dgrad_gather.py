@@ -144,7 +144,7 @@ def test_gather_form_is_reproducible_bit_for_bit():
 
 @pytest.mark.parametrize('N', [16, 48])
 def test_unet2_training_in_gather_form(N):
-    """A bf16 `unet2` trains through the gather-form data gradients (DLWP.ops.DGRAD_GATHER): no ring fix-up / inverse-gather launch
+    """A bf16 `unet2` trains through the gather-form data gradients (engine option dgrad_gather): no ring fix-up / inverse-gather launch
     on the levels the form serves, the same loss and update direction as the padded-grid path, eager steps and hipGraph replays."""
     from DLWP import ops
     from DLWP.keras import backend
@@ -156,10 +156,10 @@ def test_unet2_training_in_gather_form(N):
     x = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     t = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
     w0, out = None, []
-    saved = ops.DGRAD_GATHER
+    import os
     try:
         for on in (False, True):
-            ops.DGRAD_GATHER = on
+            os.environ['DLWPCS_OPTIONS'] = 'dgrad_gather=%d' % int(on)
             backend.set_compute_dtype('bfloat16')
             try:
                 np.random.seed(5)
@@ -175,7 +175,7 @@ def test_unet2_training_in_gather_form(N):
             torch.cuda.synchronize()
             out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
     finally:
-        ops.DGRAD_GATHER = saved
+        os.environ.pop('DLWPCS_OPTIONS', None)
     (p_off, s_off), (p_on, s_on) = out
     flat0 = np.concatenate([w.ravel() for w in w0])
     d_off, d_on = p_off - flat0, p_on - flat0

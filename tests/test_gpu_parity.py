@@ -37,7 +37,7 @@ def to_dev(a):
 
 def test_native_library_loaded():
     from DLWP import _native as nat
-    assert nat.lib().dlwpcs_version() == 104
+    assert nat.lib().dlwpcs_version() == 105
     # the loaded shared object is the in-tree one
     assert os.path.samefile(nat.LIB_PATH, os.path.join(os.path.dirname(nat.__file__), '..', 'lib', 'libdlwpcs.so'))
 

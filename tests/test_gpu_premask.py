@@ -199,8 +199,7 @@ def test_unet2_training_with_and_without_the_convention(graphs):
     t = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
     w0, out = None, []
     for on in ('0', '1'):
-        os.environ['DLWPCS_PREMASK'] = on
-        os.environ['DLWPCS_WGRAD_BATCH'] = on
+        os.environ['DLWPCS_OPTIONS'] = 'premask=%s,wgrad_batch=%s' % (on, on)
         try:
             backend.set_compute_dtype('bfloat16')
             try:
@@ -221,8 +220,7 @@ def test_unet2_training_with_and_without_the_convention(graphs):
             torch.cuda.synchronize()
             out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
         finally:
-            os.environ.pop('DLWPCS_PREMASK', None)
-            os.environ.pop('DLWPCS_WGRAD_BATCH', None)
+            os.environ.pop('DLWPCS_OPTIONS', None)
     (p_off, s_off), (p_on, s_on) = out
     # Adam's first steps move every weight by ~lr regardless of the gradient's size: compare the UPDATES
     d_off, d_on = p_off - np.concatenate([w.ravel() for w in w0]), p_on - np.concatenate([w.ravel() for w in w0])
@@ -243,7 +241,7 @@ def test_optimizer_fused_into_the_reduction_gives_the_same_bits():
     t = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
     w0, out = None, []
     for fuse in ('0', '1'):
-        os.environ['DLWPCS_FUSE_ADAM'] = fuse
+        os.environ['DLWPCS_OPTIONS'] = 'fuse_adam=' + fuse
         try:
             backend.set_compute_dtype('bfloat16')
             try:
@@ -263,7 +261,7 @@ def test_optimizer_fused_into_the_reduction_gives_the_same_bits():
             assert float(model._flat_grads.abs().max()) == 0.0
             out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
         finally:
-            os.environ.pop('DLWPCS_FUSE_ADAM', None)
+            os.environ.pop('DLWPCS_OPTIONS', None)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
 
@@ -316,7 +314,7 @@ def test_ring_fix_folded_into_the_pooling_adjoint(B, N, Cin, Cout):
 
 
 def test_unet2_training_with_the_ring_folded_gives_the_same_bits():
-    """DLWPCS_FOLD_RING on/off on a bf16 unet2 (eager warm-up, capture, replays): two ring fix-up launches less, same weights"""
+    """engine option fold_ring on/off on a bf16 unet2 (eager warm-up, capture, replays): two ring fix-up launches less, same weights"""
     from DLWP.keras import backend
     from DLWP.model.cs_unet import build_cs_model
     from DLWP import _native as nat
@@ -328,7 +326,7 @@ def test_unet2_training_with_the_ring_folded_gives_the_same_bits():
     t = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
     w0, out = None, []
     for fold in ('0', '1'):
-        os.environ['DLWPCS_FOLD_RING'] = fold
+        os.environ['DLWPCS_OPTIONS'] = 'fold_ring=' + fold
         try:
             backend.set_compute_dtype('bfloat16')
             try:
@@ -346,7 +344,7 @@ def test_unet2_training_with_the_ring_folded_gives_the_same_bits():
             torch.cuda.synchronize()
             out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
         finally:
-            os.environ.pop('DLWPCS_FOLD_RING', None)
+            os.environ.pop('DLWPCS_OPTIONS', None)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
 
@@ -391,7 +389,7 @@ def test_pooling_as_a_second_output_of_the_convolution(dtype, B, N, C0, C1, up0,
 
 
 def test_unet2_training_with_the_pooling_fused_gives_the_same_bits():
-    """DLWPCS_FUSE_POOL on/off on a bf16 unet2 at N = 48 (where the epilogue can pool): no pooling launches in the forward pass,
+    """engine option fuse_pool on/off on a bf16 unet2 at N = 48 (where the epilogue can pool): no pooling launches in the forward pass,
     same weights"""
     from DLWP.keras import backend
     from DLWP.model.cs_unet import build_cs_model
@@ -405,7 +403,7 @@ def test_unet2_training_with_the_pooling_fused_gives_the_same_bits():
     w0, out = None, []
     lib = nat.lib()
     for fuse in ('0', '1'):
-        os.environ['DLWPCS_FUSE_POOL'] = fuse
+        os.environ['DLWPCS_OPTIONS'] = 'fuse_pool=' + fuse
         try:
             backend.set_compute_dtype('bfloat16')
             try:
@@ -428,7 +426,7 @@ def test_unet2_training_with_the_pooling_fused_gives_the_same_bits():
             lib.dlwpcs_prof_reset()
             out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
         finally:
-            os.environ.pop('DLWPCS_FUSE_POOL', None)
+            os.environ.pop('DLWPCS_OPTIONS', None)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
 
@@ -465,13 +463,13 @@ def test_rollout_with_padded_state_gives_the_same_series():
     series = []
     xh = x.float().cpu().numpy()
     for flag in ('0', '1'):
-        os.environ['DLWPCS_PADDED_IO'] = flag
+        os.environ['DLWPCS_OPTIONS'] = 'padded_io=' + flag
         try:
             out = np.full((3, B, 6, N, N, C), np.nan, dtype=np.float32)
             model.rollout_on_device(xh, 3, 1, out)
             series.append(out)
         finally:
-            os.environ.pop('DLWPCS_PADDED_IO', None)
+            os.environ.pop('DLWPCS_OPTIONS', None)
     assert np.array_equal(series[0], series[1])
     assert np.array_equal(series[0][-1], outs[0])
 
@@ -482,7 +480,7 @@ def _packed_snapshot(model, dev):
 
 
 def test_packed_operands_refreshed_by_the_optimizer_launch():
-    """DLWPCS_FUSE_PACK: hipGraph-replayed steps start without the packing launch, the reduction + optimizer launch writes the
+    """engine option fuse_pack: hipGraph-replayed steps start without the packing launch, the reduction + optimizer launch writes the
     updated parameters into the packed bf16 operands.  (1) after replays the packed buffers equal what dlwpcs_pack_batch makes
     of the current parameters, bit for bit; (2) the same weights as with the packing launch, also when eager steps (another
     batch size: an optimizer launch of its own) and set_weights come between replays"""
@@ -498,7 +496,7 @@ def test_packed_operands_refreshed_by_the_optimizer_launch():
     (x4, t4), (x2, t2) = mk(4), mk(2)
     w0, out = None, []
     for fuse in ('0', '1'):
-        os.environ['DLWPCS_FUSE_PACK'] = fuse
+        os.environ['DLWPCS_OPTIONS'] = 'fuse_pack=' + fuse
         try:
             backend.set_compute_dtype('bfloat16')
             try:
@@ -534,6 +532,6 @@ def test_packed_operands_refreshed_by_the_optimizer_launch():
             torch.cuda.synchronize()
             out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
         finally:
-            os.environ.pop('DLWPCS_FUSE_PACK', None)
+            os.environ.pop('DLWPCS_OPTIONS', None)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])

@@ -33,7 +33,7 @@ def _flat(model):
 
 def _fit(staged, x, y, C=3, **kw):
     _dev()
-    os.environ['DLWPCS_HOST_STAGING'] = '1' if staged else '0'
+    os.environ['DLWPCS_OPTIONS'] = 'host_staging=%d' % (1 if staged else 0)
     try:
         m = _model(C)
         np.random.seed(11)                       # the epoch shuffles
@@ -41,7 +41,7 @@ def _fit(staged, x, y, C=3, **kw):
         torch.cuda.synchronize()
         return _flat(m), h.history
     finally:
-        os.environ.pop('DLWPCS_HOST_STAGING', None)
+        os.environ.pop('DLWPCS_OPTIONS', None)
 
 
 @pytest.mark.parametrize('shuffle', [False, True])
@@ -111,11 +111,11 @@ def test_staged_predict_equals_plain_predict(dtype):
     x = rng.standard_normal((23, 6, 8, 8, 3))           # float64, ragged last batch
     res = []
     for staged in ('1', '0'):
-        os.environ['DLWPCS_HOST_STAGING'] = staged
+        os.environ['DLWPCS_OPTIONS'] = 'host_staging=' + staged
         try:
             res.append(m.predict(x, batch_size=4))
         finally:
-            os.environ.pop('DLWPCS_HOST_STAGING', None)
+            os.environ.pop('DLWPCS_OPTIONS', None)
     assert res[0].shape == (23, 6, 8, 8, 3) and res[0].dtype == np.float32
     assert np.array_equal(res[0], res[1])
 
@@ -128,11 +128,11 @@ def test_staged_evaluate_equals_plain_evaluate():
     m = _model(3)
     res = []
     for staged in ('1', '0'):
-        os.environ['DLWPCS_HOST_STAGING'] = staged
+        os.environ['DLWPCS_OPTIONS'] = 'host_staging=' + staged
         try:
             res.append(m.evaluate(x, y, batch_size=4, verbose=0))
         finally:
-            os.environ.pop('DLWPCS_HOST_STAGING', None)
+            os.environ.pop('DLWPCS_OPTIONS', None)
     assert res[0] == res[1]
 
 

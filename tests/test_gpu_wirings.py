@@ -213,12 +213,12 @@ def test_channels_first_unet2_runs_channels_last_inside():
     assert np.array_equal(np.array(h_cl.history['mean_absolute_error']), np.array(h_cf.history['mean_absolute_error']))
     for a, b in zip(m_cl.get_weights(), m_cf.get_weights()):
         assert np.array_equal(a, b)
-    # DLWPCS_CF_MODEL=0 semantics (per-layer transposes) stay available: same numbers
-    os.environ['DLWPCS_CF_MODEL'] = '0'
+    # engine option cf_model=0 semantics (per-layer transposes) stay available: same numbers
+    os.environ['DLWPCS_OPTIONS'] = 'cf_model=0'
     try:
         m_old = build('channels_first', N, cin, cout, base)
     finally:
-        os.environ.pop('DLWPCS_CF_MODEL', None)
+        os.environ.pop('DLWPCS_OPTIONS', None)
     assert not m_old._cf_model
     m_old.set_weights(m_cf.get_weights())
     assert np.array_equal(m_old.predict(x_cf), m_cf.predict(x_cf))

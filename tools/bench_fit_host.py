@@ -28,7 +28,7 @@ for shuffle in (False, True):
     print('host-fed fit, shuffle=%s: %.1f steps/s = %.0f samples/s (%.2f ms per step; batch = %.1f MB of fp32 x + y)'
           % (shuffle, steps / dt, steps * 32 / dt, 1e3 * dt / steps, 2 * x[:32].nbytes / 1e6))
 for stg in ('1', '0'):
-    os.environ['DLWPCS_HOST_STAGING'] = stg
+    os.environ['DLWPCS_OPTIONS'] = 'host_staging=' + stg
     model.predict(x[:64], batch_size=32)
     torch.cuda.synchronize()
     t0 = time.time()
