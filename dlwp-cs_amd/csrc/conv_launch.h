@@ -56,6 +56,8 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     const bool halfrows = !rowpairs && 32 * MT == P.No && WM == 4 && WN == 1 && pix == 4 * P.No && P.No % 4 == 0;
     bool pool = MODE != MODE_ZERO && P.pool_out != nullptr && P.No % 2 == 0 && (rowpairs || halfrows) &&
                 face_pix % pix == 0 && P.Cout % 32 == 0 && P.Cout % (16 / ES) == 0;
+    // (gather-form data gradient: the "pooled" output is the 2 x 2 sum of an upsampled source's channels -- whole n tiles of it)
+    if (EDGE) pool = pool && !MOUT && ES == 2 && P.dsplit > 0 && P.dsplit % 32 == 0;
     const size_t buf = in_b + w_b;
     size_t patch_b = (size_t)(WM * WN) * 32 * (32 * ES + 16);
     if (pool && 2 * buf + patch_b * MT <= 160 * 1024) patch_b *= MT; else pool = false;
@@ -76,11 +78,11 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
         P.d0 = P.d1 = nullptr;
     }
     if (EDGE) {
-        // The producers stage ONE weight-id triple per tile beside the nine taps (the top row's, or the bottom row's when the tile holds
-        // the face's last row; the polar faces' two triples are equal): a tile must not hold both edge rows of a face.  A tiling that
-        // does is refused and the caller keeps the padded-grid path (faces of <= 16 x 16 cells with the 384-pixel tiles).
-        if (P.No < 8) return fail(DLWPCS_E_UNSUPPORTED, "conv: gather-form data gradient needs N >= 8");
-        if (P.nblk_face < 2 || pix < P.No)
+        // The producers stage ONE weight-id triple per tile behind the nine taps (the top row's, or the bottom row's when the tile
+        // holds the face's last row; the polar faces' two triples are equal): a tile must not hold both edge rows of a face.  Faces
+        // that fit into one tile (N <= 16) keep the padded-grid path: served in gather form -- both triples staged, or two half-face
+        // tiles -- they measured 29-46 us against 23-25 (EXPERIMENTS.md).
+        if (P.nblk_face < 2)
             return fail(DLWPCS_E_UNSUPPORTED, "conv: gather-form data gradient: a tile holds both edge rows of a face (N=%d)", P.No);
     }
     if (lds > 160 * 1024)
@@ -182,7 +184,11 @@ static int launch_conv(const ConvKParams &P, const Work &W, hipStream_t s) {
         // (not the forward pass on faces of <= 320 pixels: 64 -> 128 at N = 12 measured 13.4 us with the 160-pixel tiling, 14.9 split)
         if ((tune_bits() & TUNE_CONV_SPLIT_N) && (face_pix > 320 || MODE == MODE_ZERO))
             return launch_conv_cfg<T, KS, K2, 3, 1, 2, 2, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
-        if (face_pix <= 320) return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
+        if (face_pix <= 320) {
+            // (gather form: one wave over the whole face would hold both edge rows -- dispatch_conv_edge takes the 4-wave M split)
+            if constexpr (EDGE) return fail(DLWPCS_E_UNSUPPORTED, "conv: gather-form data gradient: one-wave tiling of a small face");
+            else return launch_conv_cfg<T, KS, K1, 5, 1, 1, 4, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
+        }
         return launch_conv_cfg<T, KS, K1, 3, 1, 1, 4, VW, MODE, MASK, false, MOUT, EDGE>(P, W, s);
     }
 }

@@ -1828,6 +1828,10 @@ static int conv_bwd_data_impl(const dlwpcs_conv_desc *d, const void *dy, const v
         G.d0 = (dsrc0 && !d->up0) ? dsrc0 : nullptr;
         G.d1 = (dsrc1 && d->C1 > 0) ? dsrc1 : nullptr;
         G.m0 = G.d0 ? m0 : nullptr; G.m1 = G.d1 ? m1 : nullptr;
+        // an upsampled source 0: its gradient = the 2 x 2 block sums of its channels' gradient, written by the kernel's epilogue as
+        // a second output (masked there too) where the tiling allows (g_usum) -- else through the workspace + one window-sum launch
+        int g_usum = 0;
+        G.pool_out = (dsrc0 && d->up0) ? dsrc0 : nullptr; G.pool_mask = G.pool_out ? m0 : nullptr; G.pool_done = &g_usum;
         int g_direct = 0, g_mask = 0;
         G.direct_done = &g_direct; G.mask_done = &g_mask;
         G.dry_run = 1;
@@ -1838,8 +1842,8 @@ static int conv_bwd_data_impl(const dlwpcs_conv_desc *d, const void *dy, const v
             G.dry_run = 0;
             grc = dispatch_conv(d->dtype, d->ksize, 8, G, conv_work(d), s);
             if (grc) return grc;
-            bool todo0 = m0 != nullptr && !(G.d0 && (g_mask & 1)), todo1 = m1 != nullptr && !(G.d1 && (g_mask & 2));
-            if (dsrc0 && !G.d0) {
+            bool todo0 = m0 != nullptr && !(G.d0 && (g_mask & 1)) && !g_usum, todo1 = m1 != nullptr && !(G.d1 && (g_mask & 2));
+            if (dsrc0 && !G.d0 && !g_usum) {
                 int masked = 0;
                 grc = launch_src_grad(dxv, dsrc0, nullptr, d->B, d->N, Cin, 0, d->C0, d->up0, 0, d->dtype, s, m0, m_alpha, m_vmax, &masked);
                 if (grc) return grc;

@@ -52,6 +52,11 @@ struct ConvKParams {
     // kernel does it.
     void *pool_out;
     int *pool_done;
+    // EDGE (data gradient in gather form) with an UPSAMPLED source 0 (UpSampling3D in front of the convolution, Azure/train_cs.py:292,
+    // 298): the gradient of that source is the 2 x 2 block SUM of the gradient of its channels on the fine grid.  The same second-
+    // output machinery writes it -- pool_out = the source's gradient (B,6,No/2,No/2,dsplit), scale 1 instead of 1/4, times
+    // act'(pool_mask) where pool_mask (the source itself) is given -- and the n tiles of that source store nothing on the fine grid.
+    const void *pool_mask;
     int colsplit;               // pooled output, faces whose row is exactly one wave's 32 * MT pixels (N = 96): see launch_conv_cfg
     int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
     int tile_rows_max;          // rows reserved in LDS
@@ -151,10 +156,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     constexpr int NTB = NT * WN;
     constexpr int NCT = 64 * WM * WN;               // consumer threads == producer threads
     constexpr int GF4 = TAPS * 64;                  // 16-B entries per (variant, n tile, operand group) of the packed operands
-    // EDGE: three more tap slots per operand group in the LDS weight area -- the substitute fragments of the tile's weight-id triple
-    constexpr int TAPSW = EDGE ? TAPS + 3 : TAPS;
-    constexpr int GF4L = TAPSW * 64;
-    constexpr int WF4 = NTB * KCG * TAPSW * 64;     // 16-B entries per weight chunk
+    // LDS weight area of a chunk: [n tile][operand group][tap][64 lanes] 16-B entries -- and, EDGE, behind it the three substitute
+    // fragments of the gather form (the weight-id triple of the tile's edge row), [slot][n tile][operand group][64]
+    constexpr int WF4M = NTB * KCG * TAPS * 64;     // 16-B entries of the nine taps
+    constexpr int XF4 = NTB * KCG * 64;             // ... of one substitute slot
+    constexpr int WF4 = EDGE ? WF4M + 3 * XF4 : WF4M;
     constexpr int ITS = 3 * KC / VW;                // input vectors per producer thread per chunk (3*NCT pixels)
     constexpr int ITW = (WF4 + NCT - 1) / NCT;
     static_assert(NCT % Q == 0, "thread -> channel-vector mapping must not depend on the item");
@@ -343,29 +349,29 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         };
         // weight fragments of (face variant v, chunk ch) -> registers -> the weight area of LDS buffer b
         auto load_w = [&](int v, int fcls, int ch, uint4 (&wv)[ITW]) __attribute__((always_inline)) {
-            // EDGE: slot TAPS + k of an operand group = fragment (variant, tap) = weight id k of the tile's triple (E.wids, -1: none)
+            // EDGE: substitute slot sl = fragment (variant, tap) = weight id sl of the tile's triple (E.wids [face][top | bottom row][3], -1: none)
             int wid[ITW];
             if constexpr (EDGE) {
 #pragma unroll
                 for (int u = 0; u < ITW; ++u) {
-                    const int w = min(ptid + u * NCT, WF4 - 1) % GF4L;
-                    wid[u] = (int)E.wids[fcls * 3 + max(w / 64 - TAPS, 0)];
+                    const int sl = max(min(ptid + u * NCT, WF4 - 1) - WF4M, 0) / XF4;
+                    wid[u] = (int)E.wids[fcls * 3 + sl];
                 }
             }
 #pragma unroll
             for (int u = 0; u < ITW; ++u) {
                 const int idx = min(ptid + u * NCT, WF4 - 1);
-                const int gg = idx / GF4L, w = idx % GF4L;
+                const bool sub = EDGE && idx >= WF4M;
+                const int gg = sub ? ((idx - WF4M) % XF4) / 64 : idx / GF4, w = sub ? (idx & 63) : idx % GF4;
                 const int ntl = gg / KCG, cgl = gg % KCG;
                 const int ntile = nt0 + ntl, cg = ch * KCG + cgl;
                 bool ok = ntile < P.NTtot && cg < P.CG;
                 int vv = v, ww = w;
                 if constexpr (EDGE) {
-                    const bool sub = w >= GF4;
                     const int id = max(wid[u], 0);
                     ok = ok && (!sub || wid[u] >= 0);
                     vv = sub ? id / 9 : v;
-                    ww = sub ? (id % 9) * 64 + (w & 63) : w;
+                    ww = sub ? (id % 9) * 64 + w : w;
                 }
                 wv[u] = vsel(ok, wsrc[ok ? (((size_t)vv * P.NTtot + ntile) * P.CG + cg) * GF4 + ww : 0]);
             }
@@ -460,7 +466,9 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     }
 
     // ============================================= consumers =============================================
-    const int lane = tid & 63, wave = tid >> 6;
+    // (wave index as a SCALAR: values derived from it -- n tile, per-wave buffer descriptors -- are then uniform for the compiler too;
+    // a descriptor it cannot prove uniform costs a waterfall loop around every store)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
     // NOTE: no s_setprio(1) here: a prioritised wave waiting for the busy matrix pipe still wins its SIMD's issue
@@ -533,12 +541,18 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 sel = in0 ? 1u : 2u;
             }
         }
+        if constexpr (EDGE) { if (P.pool_out != nullptr && !MOUT && c < P.dsplit) return ST_SKIP; }     // (that source gets the 2 x 2 sums only)
         return (mm < gq.npix && c < P.Cout) ? (uint32_t)off * ES : ST_SKIP;
     };
 
     constexpr int PROW = 32 * ES + 16;          // patch row: one pixel's 32 channels + pad
     // pooling as a second output: one patch per M tile of the wave (all of them are read back once the wave's rows are complete)
-    const bool pooling = MODE != MODE_ZERO && !EDGE && P.pool_out != nullptr;      // (EDGE is a data gradient: nothing to pool)
+    // (MOUT instantiations of the gather form have no registers to spare for it: an upsampled source beside directly masked ones
+    // takes the workspace + window-sum launch)
+    const bool pooling = MODE != MODE_ZERO && !(EDGE && MOUT) && P.pool_out != nullptr;
+    const int pool_cs = EDGE ? P.dsplit : P.Cout;                       // channels of the pooled output
+    // EDGE: does n tile nt of this wave belong to the upsampled source (pooled sum only) or to the other one (fine stores only)?
+    auto pools_nt = [&](int nt) { return !EDGE || (nt0 + wn * NT + nt) * 32 < P.dsplit; };
     char *const patch0 = smem + patch_base + wave * (32 * PROW) * (pooling ? MT : 1);
     const int patch_step = pooling ? 32 * PROW : 0;
     // ---- pooled second output.  The wave's MT * 32 pixels are whole pairs of tile rows: pooled pixel pp of the wave is the
@@ -564,8 +578,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int c = (nt0 + wn * NT + nt) * 32 + q * (16 / ES);
-                const bool ok = item / LPP < MT * 8 && tile_pix(i00) < gq.npix && c < P.Cout;
-                pgo[nt][ps] = ok ? (uint32_t)((((gq.f * hN + (oy >> 1)) * hN + (ox >> 1)) * P.Cout + c) * ES) : ST_SKIP;
+                const bool ok = item / LPP < MT * 8 && tile_pix(i00) < gq.npix && c < pool_cs;
+                pgo[nt][ps] = ok ? (uint32_t)((((gq.f * hN + (oy >> 1)) * hN + (ox >> 1)) * pool_cs + c) * ES) : ST_SKIP;
             }
         }
     };
@@ -767,6 +781,23 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                     }
         }
     };
+    uint4 ypm[EDGE && !MOUT ? NT : 1][EDGE && !MOUT ? PNP : 1];      // EDGE: act' operands of the pooled sums (the upsampled source's own values)
+    auto pool_mask_load = [&](const Geo &gq) {
+        if constexpr (EDGE && !MOUT) {
+            if (pooling && P.pool_mask != nullptr) {
+                const int ppix = 6 * (P.No >> 1) * (P.No >> 1);
+                const rsrc_t rm = make_rsrc(reinterpret_cast<const T *>(P.pool_mask) + (size_t)gq.b * ppix * pool_cs, (uint32_t)(ppix * pool_cs * ES));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int ps = 0; ps < PNP; ++ps) {
+                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rm, pgo[nt][ps], 0, 0);
+                        ypm[nt][ps] = make_uint4(a.x, a.y, a.z, a.w);
+                    }
+            }
+        }
+    };
+    const float pool_scale = EDGE ? 1.f : 0.25f;
     auto pool_pass = [&](int nt, rsrc_t d_pool) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -777,17 +808,20 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             const uint4 d = *reinterpret_cast<const uint4 *>(patch0 + plds1[ps] + PROW);
             uint4 o;
             if constexpr (ES == 4) {
-                auto avg = [](uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
-                    return __float_as_uint(((__uint_as_float(x) + __uint_as_float(y)) + (__uint_as_float(z) + __uint_as_float(w))) * 0.25f);
+                auto avg = [&](uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+                    return __float_as_uint(((__uint_as_float(x) + __uint_as_float(y)) + (__uint_as_float(z) + __uint_as_float(w))) * pool_scale);
                 };
                 o = make_uint4(avg(a.x, b.x, c.x, d.x), avg(a.y, b.y, c.y, d.y), avg(a.z, b.z, c.z, d.z), avg(a.w, b.w, c.w, d.w));
             } else {
-                auto avg2 = [](uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
-                    const float lo = ((bf_lo(x) + bf_lo(y)) + (bf_lo(z) + bf_lo(w))) * 0.25f;
-                    const float hi = ((bf_hi(x) + bf_hi(y)) + (bf_hi(z) + bf_hi(w))) * 0.25f;
+                auto avg2 = [&](uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+                    const float lo = ((bf_lo(x) + bf_lo(y)) + (bf_lo(z) + bf_lo(w))) * pool_scale;
+                    const float hi = ((bf_hi(x) + bf_hi(y)) + (bf_hi(z) + bf_hi(w))) * pool_scale;
                     return f2bf2(lo, hi);
                 };
                 o = make_uint4(avg2(a.x, b.x, c.x, d.x), avg2(a.y, b.y, c.y, d.y), avg2(a.z, b.z, c.z, d.z), avg2(a.w, b.w, c.w, d.w));
+            }
+            if constexpr (EDGE && !MOUT && ES == 2) {
+                if (P.pool_mask != nullptr) vmask_pk(o, ypm[nt][ps], P.m_alpha, P.m_thr1);      // (uniform)
             }
             bst128(o, d_pool, pgo[nt][ps]);
         }
@@ -840,8 +874,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     };
     auto pool_of = [&](const Geo &gq) {
         const int ppix = 6 * (P.No >> 1) * (P.No >> 1);
-        return make_rsrc(pooling ? reinterpret_cast<T *>(P.pool_out) + (size_t)gq.b * ppix * P.Cout : nullptr,
-                         (uint32_t)(ppix * P.Cout * ES));
+        return make_rsrc(pooling ? reinterpret_cast<T *>(P.pool_out) + (size_t)gq.b * ppix * pool_cs : nullptr,
+                         (uint32_t)(ppix * pool_cs * ES));
     };
     auto epilogue_lines = [&](const Geo &gq, const auto &A, auto mta_tag) {
         constexpr int MTA = decltype(mta_tag)::value;       // M tiles this wave has in this tile (ILV), else MT
@@ -857,6 +891,13 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 #pragma unroll
                     for (int ps = 0; ps < NPS; ++ps)
                         asm volatile("" : "+v"(ymq[nt][mt][ps].x), "+v"(ymq[nt][mt][ps].y), "+v"(ymq[nt][mt][ps].z), "+v"(ymq[nt][mt][ps].w));
+        }
+        if constexpr (EDGE && !MOUT) {      // (the pooled sums' mask operands: waited for once, like the MOUT values above)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int ps = 0; ps < PNP; ++ps)
+                    asm volatile("" : "+v"(ypm[nt][ps].x), "+v"(ypm[nt][ps].y), "+v"(ypm[nt][ps].z), "+v"(ypm[nt][ps].w));
         }
         const rsrc_t d_out = out_of(gq);
         const rsrc_t d_0 = DIRECT ? d0_of(gq) : d_out, d_1 = DIRECT ? d1_of(gq) : d_out;
@@ -885,9 +926,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         auto run = [&](auto tag, auto ud_tag) {
 #pragma unroll
             for (int i = 0; i < NSLICE; ++i) {
-                if ((i / SPP) % MT < MTA) epi_slice(tag, ud_tag, i, gq, d_out, d_0, d_1, dsel, on_u, A);   // (compile-time: the loop is unrolled)
+                // (EDGE, an n tile of the upsampled source: its patches are filled, nothing is stored on the fine grid)
+                const bool sum_only = EDGE && i % SPP >= 4 && pooling && pools_nt((i / SPP) / MT);
+                if ((i / SPP) % MT < MTA && !sum_only) epi_slice(tag, ud_tag, i, gq, d_out, d_0, d_1, dsel, on_u, A);   // (compile-time: the loop is unrolled)
                 if constexpr (MODE != MODE_ZERO) {
-                    if ((i + 1) % (MT * SPP) == 0 && pooling) pool_pass(i / (MT * SPP), d_pool);
+                    if ((i + 1) % (MT * SPP) == 0 && pooling && pools_nt(i / (MT * SPP))) pool_pass(i / (MT * SPP), d_pool);
                 }
             }
         };
@@ -953,7 +996,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 bw[nt] = *reinterpret_cast<const uint4 *>(
-                    lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPSW + tap) * 2 + half) * 512 + l31 * 16);
+                    lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 512 + l31 * 16);
         };
         load_frag(0, fa[0], fb[0]);
         // (the groups of all sched_group_barriers of the unrolled block form ONE pipeline, filled in program order: without a group
@@ -985,6 +1028,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         constexpr int NSETS = decltype(two_tag)::value ? 2 : 1;
         constexpr int NX = NSETS * 3 * KCG;
         const char *lds_in = smem + (g & 1) * in_step, *lds_w = smem + w_base + (P.wstat ? ch : (g & 1)) * w_step;
+        const char *lds_x = lds_w + WF4M * 16;                          // the substitute fragments
         // (the packed records are redefined per chunk -- empty asm, in place -- so that their decoding stays INSIDE the chunk: hoisted
         // out of the tile loop, the 24 masked bases and 18 operand addresses are 40 more live registers, i.e. spills -- and a spill
         // reloaded in the epilogue is a scratch load behind s_waitcnt vmcnt(0), i.e. behind the acknowledgement of every store
@@ -1011,7 +1055,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     bw[nt] = *reinterpret_cast<const uint4 *>(
-                        lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPSW + tap) * 2 + half) * 512 + l31 * 16);
+                        lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPS + tap) * 2 + half) * 512 + l31 * 16);
             } else {
                 const int x = step - NSTEP, j = x / KCG, cgl = x % KCG;       // j = set * 3 + k
 #pragma unroll
@@ -1022,7 +1066,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)         // the substitute fragment: tap slot TAPS + k of the weight area
                     bw[nt] = *reinterpret_cast<const uint4 *>(
-                        lds_w + ((((wn * NT + nt) * KCG + cgl) * TAPSW + TAPS + j % 3) * 2 + half) * 512 + l31 * 16);
+                        lds_x + (((j % 3) * NTB * KCG + (wn * NT + nt) * KCG + cgl) * 2 + half) * 512 + l31 * 16);
             }
         };
         load_frag(0, fa[0], fb[0]);
@@ -1046,6 +1090,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         const Geo gq = geo_of(tile_of(q));
         setup(gq);
         mask_load(gq);
+        pool_mask_load(gq);
         // (ILV: how many of its M tiles this wave has in this tile: M tile j of the tile's ceil(npix / 32) belongs to wave j % WM)
         const int my_mt = ilv ? max(0, min(MT, (((gq.npix + 31) >> 5) - wm + WM - 1) / WM)) : MT;
         for (int ch = 0; ch < nchunks; ++ch, ++g) {
