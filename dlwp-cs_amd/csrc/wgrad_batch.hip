@@ -201,6 +201,10 @@ __device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const Wb
         it.nitems = (ylast - it.y0 + KS) * L.W2 * QXT;
         return it;
     };
+    // (the workspace pointer arrives in vector registers -- a noinline call -- and a buffer descriptor built from it is not
+    // uniform for the compiler: every store of the epilogue sat in a waterfall loop)
+    ws = reinterpret_cast<float *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)ws >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)ws));
     float *slot = ws + sg.slot_off;
 
     if (tid >= NCT) {
@@ -539,6 +543,8 @@ __device__ __attribute__((noinline)) void wb_segment_f32(const WbLayer &Lg, cons
         it.nitems = ((ylast - it.y0 + KS) * L.W2) << lqx;
         return it;
     };
+    ws = reinterpret_cast<float *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)ws >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)ws));      // (see wb_segment)
     float *slot = ws + sg.slot_off;
 
     if (tid >= NCT) {
