@@ -102,6 +102,8 @@ PROTOTYPES = {
                                                                                  c_void_p]),
     'dlwpcs_conv_fwd_pool': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                                                       c_void_p]),
+    'dlwpcs_conv_fwd_head': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [ctypes.POINTER(ConvDesc)] + [c_void_p] * 6 +
+                             [c_size_t, ctypes.POINTER(c_int), c_void_p]),
     'dlwpcs_conv_bwd_data': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 5 + [c_void_p, c_void_p, c_void_p,
                                                                                       c_void_p, c_size_t, c_void_p]),
     'dlwpcs_conv_bwd_data_masked': (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_void_p] * 4 + [c_float, c_float] +

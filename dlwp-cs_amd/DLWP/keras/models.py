@@ -92,6 +92,8 @@ class Model(object):
         self._stager = None                 # pinned-memory / copy-stream feed of fit() on host arrays (keras/staging.py)
         # training step: output layer + loss + loss gradient + the layer's data gradient as one launch (ops.head_mse)
         self.fuse_head_loss = option('fuse_head')
+        # inference: the pointwise output layer inside the epilogue of the convolution in front of it (ops.cs_conv_head)
+        self.fold_head = option('fold_head')
         # True: the caller feeds every step through the SAME device tensors (e.g. a generator that assembles each batch in
         # place): the captured graphs read them directly instead of copying each batch into private static buffers
         self.static_batch_buffers = False
@@ -224,6 +226,22 @@ class Model(object):
             self._padded_io_ok = (len(rd) == 1 and rd[0][0] == 'fused_conv' and rd[0][3] == u and rd[0][4] is None
                                   and not rd[0][5] and u not in out_uids and not self._cf_model)
         self._plan_premask(steps, out_uids)
+        # inference: a fused convolution whose only reader is a pointwise CubeSphereConv2D (the U-Net's output layer,
+        # Azure/train_cs.py:300-305) can take that layer into its epilogue (ops.cs_conv_head): step index -> the head's step index
+        self._head_fold = {}
+        for i, st in enumerate(steps):
+            if st[0] != 'fused_conv' or st[1] in out_uids:
+                continue
+            rd = [j for j, s2 in enumerate(steps)
+                  if (s2[0] == 'fused_conv' and st[1] in (s2[3], s2[4])) or (s2[0] == 'pool_skip' and s2[3] == st[1])
+                  or (s2[0] == 'layer' and st[1] in s2[3])]
+            if len(rd) != 1 or steps[rd[0]][0] != 'layer':
+                continue
+            hl = steps[rd[0]][2]
+            if (isinstance(hl, CubeSphereConv2D) and len(steps[rd[0]][3]) == 1 and tuple(hl.kernel_size) == (1, 1)
+                    and hl.activation is None and not hl.independent_north_pole and not st[2].independent_north_pole
+                    and st[2].filters == 32 and self._runs_channels_last(hl) and not self._cf_model):
+                self._head_fold[i] = rd[0]
         # model outputs that no other node consumes (candidates for the fused head + loss step) and appear once
         uids = [o.uid for o in self.outputs]
         self._sole_outputs = {u for u in uids if not consumers.get(u) and uids.count(u) == 1}
@@ -403,7 +421,10 @@ class Model(object):
         cut = getattr(self, '_record_cut', None)
         self._cut_tensors = []
         ops._POOLED.clear()
+        folded = set()                       # head steps served by the epilogue of the convolution in front of them
         for i, st in enumerate(self._plan):
+            if i in folded:
+                continue
             if cut is not None and i == cut:
                 # split backward pass (two-bucket exchange): the tensors alive here that a step from here on READS -- the
                 # first half of the backward pass stops at them (an aliased skip tensor is its alias by now)
@@ -417,6 +438,19 @@ class Model(object):
                         self._cut_tensors.append(v)
             if st[0] == 'fused_conv':
                 _, out_uid, lay, s0, s1, up0, act, alpha, vmax = st
+                j = self._head_fold.get(i) if self.fold_head else None
+                if j is not None and fuse_targets is None and not torch.is_grad_enabled():
+                    hl, h_uid = self._plan[j][2], self._plan[j][1]
+                    padded = bool(getattr(self, '_padded_io', False) and h_uid in self._sole_outputs and hl.filters % 8 != 0)
+                    if (lay._is_mfma_config() and hl._is_mfma_config() and hl.built and lay.built and ops.cs_conv_head_applicable(
+                            values[s0], None if s1 is None else values[s1], lay.equatorial_kernel, hl.equatorial_kernel, padded)):
+                        values[h_uid] = ops.cs_conv_head(values[s0], lay.equatorial_kernel, lay.equatorial_bias,
+                                                         hl.equatorial_kernel, hl.equatorial_bias,
+                                                         src1=None if s1 is None else values[s1], up0=up0,
+                                                         flip_north_pole=lay.flip_north_pole, act=act, alpha=alpha, vmax=vmax,
+                                                         out_padded=padded)
+                        folded.add(j)
+                        continue
                 m0, m1 = self._src_mask[i]
                 values[out_uid] = lay.fused_call(values[s0], None if s1 is None else values[s1], up0=up0, halo=True,
                                                  act=act, alpha=alpha, vmax=vmax,

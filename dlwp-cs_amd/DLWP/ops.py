@@ -778,6 +778,60 @@ def cs_conv(src0, w_eq, w_pol, w_np=None, b_eq=None, b_pol=None, b_np=None, src1
                          bool(dy_premasked), bool(defer_ring0), bool(want_pool), bool(out_padded))
 
 
+def cs_conv_head_applicable(src0, src1, w_eq, head_w_eq, out_padded):
+    """True when dlwpcs_conv_fwd_head can serve (last 3x3 layer, pointwise head) of an inference pass: bf16 device tensors, both
+    layers' operands packed for this pass (PREPACKED), 32 channels between them and head rows of 32 channels."""
+    if torch.is_grad_enabled() or not src0.is_cuda or src0.dtype != torch.bfloat16:
+        return False
+    pk, hk = PREPACKED.get(id(w_eq)), PREPACKED.get(id(head_w_eq))
+    if pk is None or hk is None or pk[0] != nat.BF16 or hk[0] != nat.BF16:
+        return False
+    cout2 = head_w_eq.shape[3]
+    rows = (cout2 + 7) // 8 * 8 if out_padded else cout2
+    c0, c1 = src0.shape[-1], (src1.shape[-1] if src1 is not None else 0)
+    if c0 % 8 or c1 % 8 or c0 + c1 != w_eq.shape[2]:
+        return False
+    return (tuple(w_eq.shape[:2]) == (3, 3) and w_eq.shape[3] == 32 and tuple(head_w_eq.shape[:3]) == (1, 1, 32) and rows == 32
+            and cout2 % 2 == 0 and cout2 >= 8)
+
+
+def cs_conv_head(src0, w_eq, b_eq, head_w_eq, head_b_eq, src1=None, up0=False, flip_north_pole=True, act=nat.ACT_NONE,
+                 alpha=0.0, vmax=0.0, out_padded=False):
+    """Inference: y_head = conv1x1(act(conv3x3(halo_pad(concat(up?(src0), src1))) + b)) + b_head through dlwpcs_conv_fwd_head --
+    the pointwise output layer folded into the epilogue of the convolution in front of it (Azure/train_cs.py:300-305).  The
+    weights are identified by the layers' equatorial kernels (their packed operands of this pass: PREPACKED).  No autograd."""
+    require_device(src0, 'cs_conv_head')
+    src0 = _c(src0)
+    B = src0.shape[0]
+    N = src0.shape[2] * (2 if up0 else 1)
+    C0, C1 = src0.shape[4], 0
+    if src1 is not None:
+        src1 = _c(src1)
+        C1 = src1.shape[4]
+    Cout, cout2 = w_eq.shape[3], head_w_eq.shape[3]
+    pk, hk = PREPACKED[id(w_eq)], PREPACKED[id(head_w_eq)]
+    d = _make_desc(B, N, C0, C1, Cout, 3, True, up0, flip_north_pole, act, alpha, vmax, nat.BF16, 0)
+    d.flags |= nat.CONV_PREPACKED
+    dh = _make_desc(B, N, Cout, 0, cout2, 1, False, False, flip_north_pole, nat.ACT_NONE, 0.0, 0.0, nat.BF16, 0)
+    dh.flags |= nat.CONV_PREPACKED | (nat.CONV_OUT_PADDED if out_padded else 0)
+    rows = (cout2 + 7) // 8 * 8 if out_padded else cout2
+    y = torch.empty((B, 6, N, N, Cout), dtype=src0.dtype, device=src0.device)
+    yh = torch.empty((B, 6, N, N, rows), dtype=src0.dtype, device=src0.device)
+    table = nat.halo_tables(N, 1, src0.device)[0]
+    nbytes = max(lib().dlwpcs_conv_workspace_bytes(ctypes.byref(d)), lib().dlwpcs_conv_workspace_bytes(ctypes.byref(dh)))
+    ws = _workspace(nbytes, src0.device)
+    fused = ctypes.c_int(0)
+    check(lib().dlwpcs_conv_fwd_head(ctypes.byref(d), ptr(src0), ptr(src1), ptr(pk[1]), ptr(pk[2]) if b_eq is not None else 0,
+                                     ctypes.byref(dh), ptr(hk[1]), ptr(hk[2]) if head_b_eq is not None else 0, ptr(y), ptr(yh),
+                                     ptr(table), ptr(ws), ws.numel(), ctypes.byref(fused), stream_ptr()), 'dlwpcs_conv_fwd_head')
+    global HEAD_FOLDED
+    HEAD_FOLDED = bool(fused.value)
+    return yh
+
+
+HEAD_FOLDED = False     # (what the last cs_conv_head call did: tests / diagnostics)
+
+
 # ------------------------------------------------------------------------------------------------------------------ #
 # Generic per-face convolution for the off-hot-path layer options (strides, dilation, 'same')
 # ------------------------------------------------------------------------------------------------------------------ #

@@ -70,6 +70,14 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
         lds = 2 * in_b + nchunks * w_b + patch_b;
     } else if (lds > 160 * 1024) { lds = 2 * buf; P.patches = 0; pool = false; } // large faces: direct quad stores instead
     if (!pool) P.pool_out = nullptr;
+    // pointwise output layer folded into the epilogue: bf16, the layer's 32 output channels = ONE n tile of ONE wave column, the
+    // line-store epilogue (its rows are the head's rows: 32 channels), no pooled second output
+    {
+        const bool head = P.head_w != nullptr && P.head_out != nullptr && ES == 2 && NT == 1 && WN == 1 && !EDGE && !MOUT && !MASK &&
+                          MODE != MODE_ZERO && P.Cout == 32 && P.patches && !pool;
+        if (head) P.out = P.head_out; else P.head_w = nullptr;
+        if (P.head_done) *P.head_done = head ? 1 : 0;
+    }
     P.colsplit = (pool && halfrows) ? 1 : 0;
     if (P.pool_done) *P.pool_done = pool ? 1 : 0;
     if ((MODE == MODE_ZERO || EDGE) && KS == 3 && P.patches && P.Cout % (16 / ES) == 0 && P.dsplit % (16 / ES) == 0) {

@@ -1629,11 +1629,14 @@ static int head_mse_impl(const dlwpcs_conv_desc *d, const void *x, const void *w
     return check_launch("head_mse_step");
 }
 
+// the pointwise output layer behind the convolution, folded into its epilogue where the tiling allows (dlwpcs_conv_fwd_head)
+struct ConvHeadArgs { const void *wpk; const float *bias; void *out; int *done; };
 static int conv_fwd_impl(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
                          const void *w_eq, const void *w_pol, const void *w_np,
                          const void *b_eq, const void *b_pol, const void *b_np,
                          void *y, const int32_t *table_dev,
-                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream, void *y_pooled, int *pool_done);
+                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream, void *y_pooled, int *pool_done,
+                         const ConvHeadArgs *head = nullptr);
 
 extern "C" int dlwpcs_conv_fwd(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
                                const void *w_eq, const void *w_pol, const void *w_np,
@@ -1661,11 +1664,47 @@ extern "C" int dlwpcs_conv_fwd_pool(const dlwpcs_conv_desc *d, const void *src0,
     return dlwpcs_avgpool2_fwd(y, y_pooled, d->B, d->N, d->Cout, d->dtype, stream);
 }
 
+// Convolution + the pointwise output layer behind it (inference: the U-Net's last 3x3 layer and its 1x1 head,
+// Azure/train_cs.py:300-305), see include/dlwpcs.h.
+extern "C" int dlwpcs_conv_fwd_head(const dlwpcs_conv_desc *d, const void *src0, const void *src1, const void *wpk_fwd,
+                                    const void *bias_pk, const dlwpcs_conv_desc *dh, const void *head_wpk_fwd,
+                                    const void *head_bias_pk, void *y, void *y_head, const int32_t *table_dev,
+                                    void *workspace, size_t workspace_bytes, int *fused, dlwpcs_stream_t stream) {
+    if (fused) *fused = 0;
+    int rc = validate(d, "conv_fwd_head");
+    if (rc) return rc;
+    rc = validate(dh, "conv_fwd_head (head)");
+    if (rc) return rc;
+    if (!wpk_fwd || !head_wpk_fwd || !y || !y_head) return fail(DLWPCS_E_INVALID, "conv_fwd_head: null pointer");
+    if (!(d->flags & DLWPCS_CONV_PREPACKED) || !(dh->flags & DLWPCS_CONV_PREPACKED))
+        return fail(DLWPCS_E_INVALID, "conv_fwd_head: both layers take dlwpcs_pack_batch operands (DLWPCS_CONV_PREPACKED)");
+    const int No = out_size(d);
+    if (dh->B != d->B || dh->N != No || dh->C0 != d->Cout || dh->dtype != d->dtype)
+        return fail(DLWPCS_E_INVALID, "conv_fwd_head: the head (B=%d N=%d C_in=%d) does not consume the layer's output (B=%d N=%d C=%d)",
+                    dh->B, dh->N, dh->C0, d->B, No, d->Cout);
+    if (d->flags & DLWPCS_CONV_OUT_PADDED) return fail(DLWPCS_E_INVALID, "conv_fwd_head: DLWPCS_CONV_OUT_PADDED belongs to the head's descriptor");
+    if (d->B == 0) return DLWPCS_OK;
+    // folded: bf16 pointwise head without activation whose stored rows are 32 channels (C_out = 32, or padded to 32)
+    const int head_rows = (dh->flags & DLWPCS_CONV_OUT_PADDED) ? (dh->Cout + 7) / 8 * 8 : dh->Cout;
+    const bool can = pw_applies(dh) && dh->act == DLWPCS_ACT_NONE && dh->c0_valid == 0 && head_rows == 32 && d->Cout == 32 &&
+                     d->dtype == DLWPCS_BF16 && d->ksize == 3;
+    int done = 0;
+    ConvHeadArgs H{head_wpk_fwd, (const float *)head_bias_pk, y_head, &done};
+    rc = conv_fwd_impl(d, src0, src1, wpk_fwd, nullptr, nullptr, bias_pk, nullptr, nullptr, y, table_dev, workspace, workspace_bytes,
+                       stream, nullptr, nullptr, can ? &H : nullptr);
+    if (rc) return rc;
+    if (done) { if (fused) *fused = 1; return DLWPCS_OK; }
+    // the tiling of this shape cannot fold the head: its own launch on y, same contract as dlwpcs_conv_fwd
+    return conv_fwd_impl(dh, y, nullptr, head_wpk_fwd, nullptr, nullptr, head_bias_pk, nullptr, nullptr, y_head, nullptr, workspace,
+                         workspace_bytes, stream, nullptr, nullptr);
+}
+
 static int conv_fwd_impl(const dlwpcs_conv_desc *d, const void *src0, const void *src1,
                          const void *w_eq, const void *w_pol, const void *w_np,
                          const void *b_eq, const void *b_pol, const void *b_np,
                          void *y, const int32_t *table_dev,
-                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream, void *y_pooled, int *pool_done) {
+                         void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream, void *y_pooled, int *pool_done,
+                         const ConvHeadArgs *head) {
     int rc = validate(d, "conv_fwd");
     if (rc) return rc;
     if (!src0 || !w_eq || (!w_pol && !(d->flags & DLWPCS_CONV_PREPACKED)) || !y || !workspace)
@@ -1698,6 +1737,7 @@ static int conv_fwd_impl(const dlwpcs_conv_desc *d, const void *src0, const void
     P.mode = d->halo ? MODE_HALO : MODE_DIRECT;
     P.act = d->act; P.alpha = d->alpha; P.vmax = d->vmax;
     P.pool_out = y_pooled; P.pool_done = pool_done;
+    if (head) { P.head_w = head->wpk; P.head_b = head->bias; P.head_out = head->out; P.head_done = head->done; }
     if ((d->flags & DLWPCS_CONV_OUT_PADDED) && !pw_applies(d))
         return fail(DLWPCS_E_UNSUPPORTED, "conv_fwd: DLWPCS_CONV_OUT_PADDED serves the bf16 pointwise output layer only");
     if (pw_applies(d)) {

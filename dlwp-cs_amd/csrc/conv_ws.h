@@ -58,6 +58,16 @@ struct ConvKParams {
     // act'(pool_mask) where pool_mask (the source itself) is given -- and the n tiles of that source store nothing on the fine grid.
     const void *pool_mask;
     int colsplit;               // pooled output, faces whose row is exactly one wave's 32 * MT pixels (N = 96): see launch_conv_cfg
+    // Forward pass with the POINTWISE OUTPUT LAYER behind it folded into the epilogue (inference: the last 3x3 convolution of the
+    // U-Net + the 1x1 head, Azure/train_cs.py:300-305): head_w / head_b are the head's dlwpcs_pack_batch operands (forward
+    // fragments [3][4 k groups of 8][32 columns][8] bf16, bias [3][32] fp32, zero beyond its C_out); the tile's activated
+    // 32-channel result, rounded to bf16 exactly as it would have been stored, is the B operand of two more MFMAs straight out of
+    // the accumulators and what is stored (to head_out, rows of 32 channels) is the head's result.  bf16, 32 output channels, one
+    // n tile per wave.  head_done: HOST pointer, set to 1 when the launched kernel does it (else `out` gets the layer's own output).
+    const void *head_w;
+    const float *head_b;
+    void *head_out;
+    int *head_done;
     int tune;                   // scheduling tunables (tune_bits(): DLWPCS_TUNE, default set below)
     int tile_rows_max;          // rows reserved in LDS
     int ntiles;                 // B * 6 * nblk_face (persistent kernel)
@@ -514,6 +524,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     uint32_t ewp[EDGE ? (MT + 3) / 4 : 1];
     uint32_t e_any = 0, e_two = 0;
     float4 bq[NT][4];
+    // pointwise output layer folded into the epilogue (P.head_w): the head's two A fragments (K = 16 channels each) and its bias quads
+    // in the D layout, per face variant like the layer's own bias quads
+    constexpr bool HEAD_OK = ES == 2 && NT == 1 && WN == 1 && !EDGE && !MOUT && !MASK && MODE != MODE_ZERO;
+    uint4 hfrag[HEAD_OK ? 2 : 1];
+    float4 hbq[HEAD_OK ? 4 : 1];
     // store pass (nt, mt, ps) of this lane: byte offset of its 16 B inside ONE sample of the destination (ST_SKIP: nothing to
     // store) and, data gradient in direct mode, which destination (2 bits each: 0 = out, 1 = d0, 2 = d1).  Like the LDS
     // addresses they depend on the (face, band) only, not on the sample.
@@ -679,6 +694,27 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 #pragma unroll
                 for (int jq = 0; jq < 4; ++jq)
                     asm volatile("" : "+v"(bq[nt][jq].x), "+v"(bq[nt][jq].y), "+v"(bq[nt][jq].z), "+v"(bq[nt][jq].w));
+            if constexpr (HEAD_OK) {
+                if (P.head_w != nullptr) {      // (uniform)
+                    // MFMA step s of the head contracts the channels this lane's accumulator quads 2s and 2s + 1 hold: 16 s + 4 half +
+                    // (0..3) and 16 s + 8 + 4 half + (0..3) -- the half-entries [4 half, 4 half + 4) of k groups 2s and 2s + 1 of
+                    // output channel l31 in the packed forward fragments
+                    const uint2 *hw = reinterpret_cast<const uint2 *>(P.head_w) + (size_t)gq.v * 256 + l31 * 2 + half;
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const uint2 lo = hw[(2 * st) * 64], hi = hw[(2 * st + 1) * 64];
+                        hfrag[st] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    }
+#pragma unroll
+                    for (int jq = 0; jq < 4; ++jq)
+                        hbq[jq] = P.head_b ? *reinterpret_cast<const float4 *>(P.head_b + (size_t)gq.v * 32 + 8 * jq + 4 * half)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) asm volatile("" : "+v"(hfrag[st].x), "+v"(hfrag[st].y), "+v"(hfrag[st].z), "+v"(hfrag[st].w));
+#pragma unroll
+                    for (int jq = 0; jq < 4; ++jq) asm volatile("" : "+v"(hbq[jq].x), "+v"(hbq[jq].y), "+v"(hbq[jq].z), "+v"(hbq[jq].w));
+                }
+            }
         }
         // the accumulators start at the bias (row = output channel in the MFMA's D[co][pixel] layout): no add in the epilogue
 #pragma unroll
@@ -741,6 +777,30 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             v4.z = act_leaky_clip(v4.z, e_alpha, e_vmax); v4.w = act_leaky_clip(v4.w, e_alpha, e_vmax);
         }
         return v4;
+    };
+    // pointwise output layer folded in: acc[mt][0] <- W_head * bf16(act(acc[mt][0])) + b_head, in place (the epilogue then stores it
+    // without an activation).  The activated values are rounded to bf16 as the stand-alone layer would have stored them.
+    const bool headed = HEAD_OK && P.head_w != nullptr;
+    auto head_apply = [&](auto fast_tag) {
+        if constexpr (HEAD_OK) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                uint4 bf[2];
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const float4 lo = quad(fast_tag, acc[mt][0], 2 * st), hi = quad(fast_tag, acc[mt][0], 2 * st + 1);
+                    bf[st] = make_uint4(f2bf2(lo.x, lo.y), f2bf2(lo.z, lo.w), f2bf2(hi.x, hi.y), f2bf2(hi.z, hi.w));
+                }
+                f32x16 a2;
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq) {
+                    a2[4 * jq] = hbq[jq].x; a2[4 * jq + 1] = hbq[jq].y; a2[4 * jq + 2] = hbq[jq].z; a2[4 * jq + 3] = hbq[jq].w;
+                }
+                frag_mma<T>(a2, hfrag[0], bf[0]);
+                frag_mma<T>(a2, hfrag[1], bf[1]);
+                acc[mt][0] = a2;
+            }
+        }
     };
     // per-sample buffer descriptors of the destinations (uniform): write-through stores, see common.h
     auto out_of = [&](const Geo &gq) {
@@ -939,7 +999,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             else run(std::integral_constant<int, 2>{}, std::false_type{});
         }
         else if constexpr (DIRECT) run(std::integral_constant<int, 2>{}, std::false_type{});
-        else if (P.act != DLWPCS_ACT_LEAKY_CLIP) run(std::integral_constant<int, 2>{}, std::false_type{});
+        else if (P.act != DLWPCS_ACT_LEAKY_CLIP || headed) run(std::integral_constant<int, 2>{}, std::false_type{});
         else if (fast_act) run(std::integral_constant<int, 1>{}, std::false_type{});
         else run(std::integral_constant<int, 0>{}, std::false_type{});
     };
@@ -1111,6 +1171,12 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 else mma_chunk_edge(gq, ch, std::true_type{});
             } else {
                 mma_chunk(ch, std::integral_constant<int, MT>{});
+            }
+        }
+        if constexpr (HEAD_OK) {
+            if (headed) {       // (uniform; launch_conv_cfg grants it with the line-store epilogue only)
+                if (fast_act) head_apply(std::integral_constant<int, 1>{});
+                else head_apply(std::integral_constant<int, 0>{});
             }
         }
         if (lines) {

@@ -149,8 +149,17 @@ template <typename T> __device__ __forceinline__ T load_uniform(const T &g) {
     return out;
 }
 
+// (experiment switch, side builds only: DLWPCS_WB_ONLY = 1 compiles the kernel with the plain bf16 segment bodies alone, inlined)
+#ifndef DLWPCS_WB_ONLY
+#define DLWPCS_WB_ONLY 0
+#endif
+#if DLWPCS_WB_ONLY
+#define WB_SEG_ATTR __forceinline__
+#else
+#define WB_SEG_ATTR __attribute__((noinline))
+#endif
 template <int KS, int XV, int QX, int CT, int NT, int DV, bool MASK = false>
-__device__ __attribute__((noinline)) void wb_segment(const WbLayer &Lg, const WbSeg &sgg, const void *src0, const void *src1,
+__device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, const void *src0, const void *src1,
                                            const void *dzp, const void *yp, const int32_t *table, float *ws, char *smem,
                                            long long *dbg) {
     const WbLayer L = load_uniform(Lg);
@@ -785,6 +794,7 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
         const WbLayer &L = layers[sg.layer];
         const void *a0 = ptrs.src0[sg.layer], *a1 = ptrs.src1[sg.layer], *dz = ptrs.dz[sg.layer], *yy = ptrs.y[sg.layer];
         const int32_t *tb = ptrs.table[sg.layer];
+#if DLWPCS_WB_ONLY == 0
         if (L.variant >= WB_V_F32_3) {
             switch (L.variant) {
             case WB_V_F32_1: wb_segment_f32<1, false>(L, sg, a0, a1, dz, yy, tb, ws, smem); break;
@@ -814,6 +824,7 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
             }
             continue;
         }
+#endif
         switch (L.variant) {
             case WB_V_3_8_22: wb_segment<3, 8, 4, 2, 2, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
             case WB_V_3_8_21: wb_segment<3, 8, 4, 2, 1, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;

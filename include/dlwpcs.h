@@ -197,6 +197,21 @@ int dlwpcs_conv_fwd_pool(const dlwpcs_conv_desc *d, const void *src0, const void
                          const void *b_eq, const void *b_pol, const void *b_np,
                          void *y, void *y_pooled, const int32_t *table_dev,
                          void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream);
+/* Inference: dlwpcs_conv_fwd of layer `d` + the POINTWISE OUTPUT LAYER `dh` behind it (the U-Net's last 3x3 CubeSphereConv2D
+ * and its 1x1 head, Azure/train_cs.py:300-305; reference layer: DLWP/custom.py:921-1002 with kernel_size 1) -- y_head =
+ * conv1x1(act(conv(...)))).  Both layers take dlwpcs_pack_batch operands (DLWPCS_CONV_PREPACKED in both descriptors: wpk_fwd /
+ * bias_pk and head_wpk_fwd / head_bias_pk; a bias pointer may be NULL).  Where the tiling allows -- bf16, 32 output channels of
+ * `d`, a head without activation whose stored rows are 32 channels (C_out = 32, or 25..31 with DLWPCS_CONV_OUT_PADDED in dh->flags:
+ * the rollout's 26 = 13 variables x 2 steps) -- the head is FOLDED INTO THE EPILOGUE of the convolution: the tile's activated
+ * result, rounded to bf16 as it would have been stored, is contracted with the head's fragments straight out of the accumulators,
+ * y is never written (113 MB written + 113 MB read back per pass at C96, batch 32, and a launch) and *fused = 1.  Otherwise the
+ * two launches of dlwpcs_conv_fwd run (y holds the layer's output, *fused = 0).  y must be a valid (B,6,No,No,Cout) buffer either
+ * way; fused may be NULL.  The folded result differs from the two-launch one only by the summation order inside the head's MFMA
+ * (fp32 accumulation in both). */
+int dlwpcs_conv_fwd_head(const dlwpcs_conv_desc *d, const void *src0, const void *src1, const void *wpk_fwd,
+                         const void *bias_pk, const dlwpcs_conv_desc *dh, const void *head_wpk_fwd,
+                         const void *head_bias_pk, void *y, void *y_head, const int32_t *table_dev,
+                         void *workspace, size_t workspace_bytes, int *fused, dlwpcs_stream_t stream);
 
 /* Gradients w.r.t. the sources.  dy: gradient w.r.t. the (post-activation) output y; y: the saved forward output
  * (needed when act != NONE: dz = dy * act'(.) is applied on load), NULL otherwise.

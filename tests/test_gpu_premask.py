@@ -449,6 +449,18 @@ def test_rollout_with_padded_state_gives_the_same_series():
         backend.set_compute_dtype('float32')
     x = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     outs = []
+    # (fold_head=0: the padded state would otherwise take its head through the epilogue of the last convolution, another summation
+    # order inside the head's MFMA -- tests/test_gpu_head_fold.py compares that form; here the two layouts must give the same bits)
+    os.environ['DLWPCS_OPTIONS'] = 'fold_head=0'
+    try:
+        np.random.seed(3)
+        backend.set_compute_dtype('bfloat16')
+        try:
+            model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=32)
+        finally:
+            backend.set_compute_dtype('float32')
+    finally:
+        os.environ.pop('DLWPCS_OPTIONS', None)
     for padded in (False, True):
         s = x
         for i in range(3):
