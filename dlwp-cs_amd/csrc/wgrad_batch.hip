@@ -20,6 +20,7 @@
 //   * wb_reduce_kernel adds the few partial sums per (layer, group, class) in a fixed order (no atomics: bitwise
 //     reproducible), applies the weight-group map / north-pole row reversal and accumulates into the fp32 gradients.
 // Tensor addresses travel BY VALUE in the kernel arguments (a captured hipGraph keeps them); the plan holds geometry only.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -149,15 +150,9 @@ template <typename T> __device__ __forceinline__ T load_uniform(const T &g) {
     return out;
 }
 
-// (experiment switch, side builds only: DLWPCS_WB_ONLY = 1 compiles the kernel with the plain bf16 segment bodies alone, inlined)
-#ifndef DLWPCS_WB_ONLY
-#define DLWPCS_WB_ONLY 0
-#endif
-#if DLWPCS_WB_ONLY
-#define WB_SEG_ATTR __forceinline__
-#else
+// (noinline on purpose: the kernel carries 22 segment bodies; forced inline -- even of the 8 plain bf16 bodies alone -- hipcc spills
+// 266 VGPRs and the launch takes 237 instead of 150 us, EXPERIMENTS.md)
 #define WB_SEG_ATTR __attribute__((noinline))
-#endif
 template <int KS, int XV, int QX, int CT, int NT, int DV, bool MASK = false>
 __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, const void *src0, const void *src1,
                                            const void *dzp, const void *yp, const int32_t *table, float *ws, char *smem,
@@ -220,13 +215,7 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
         // =========================================== producers ===========================================
         const int ptid = tid - NCT;
         const int qd = ptid % QDT;                              // this thread's dZ vector inside a pixel: fixed
-        const int cx = sg.cit * 32 * CT + (ptid % QXT) * XV;    // this thread's X channels: fixed as well
-        const bool cx_ok = cx < L.Cin;
-        const bool from0 = cx < L.C0;
         const int g0 = L.up0 ? (L.Nin >> 1) : L.Nin;
-        const int cs = from0 ? cx : cx - L.C0;
-        const int cstride = from0 ? L.C0 : L.C1;
-        const bool up = from0 && L.up0;
         const int M = L.Nin + KS - 1;
         const int co = sg.cot * 32 * NT + (qd / QD) * 32 + (qd % QD) * DV;
         const bool co_ok = co < L.Cout;
@@ -235,72 +224,148 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
         float bsum[DV];
 #pragma unroll
         for (int u = 0; u < DV; ++u) bsum[u] = 0.f;
-        // (Round 3, measured and dropped: src / dz / table reach this noinline function as GENERIC pointers, so every load below is
-        // a FLAT instruction, which counts in lgkmcnt too -- the LDS wait in commit() therefore also waits for the loads of the
-        // next item.  Casting them to the global address space (global_load, the producers really two items ahead) measured
-        // 159 against 156 us; fetching the table entries of rebuild() branch-free, all in flight at once, 152 against 150 us.
-        // The kernel is bound by its consumers; producer LDS writes that land in their MFMA phase cost more than the waiting.)
-        int xoff[IT_X];
+        // ---- producer pipeline (round 5).  What rounds 3-4 shipped kept ONE item's loads in flight per CU: FLAT loads count in
+        // lgkmcnt too, so the LDS wait in front of the barrier also waited for the loads of the next item that had been issued a
+        // moment before, and hipcc put vmcnt(0) in front of every issue (read off the ISA; the per-item cost the plan's model was
+        // fitted to -- ~3300 cycles + bytes at 23 B/clk -- IS one exposed memory round trip per item).  Now: BUFFER loads (vmcnt
+        // only; a lane without work passes an offset beyond num_records and gets zeros: no select, no clamp, no 64-bit address
+        // arithmetic per load; the sample / band base lives in the scalar descriptor), two register stages, and the loads of item
+        // k + 2 are issued right AFTER item k has gone to LDS: two items in flight, each with a whole period to land.
+        auto uni_ptr = [](const void *q) {      // (pointer arguments of a noinline call arrive in vector registers)
+            return reinterpret_cast<const char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)q >> 32)) << 32) |
+                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)q));
+        };
+        const char *const x0_u = uni_ptr(src0), *const x1_u = uni_ptr(src1);
+        const char *const dz_u = uni_ptr(dzp), *const y_u = uni_ptr(yp);
+        const int32_t *const table_u = reinterpret_cast<const int32_t *>(uni_ptr(table));
+        const uint32_t s0_bytes = (uint32_t)((size_t)6 * g0 * g0 * L.C0 * 2), s1_bytes = (uint32_t)((size_t)6 * L.Nin * L.Nin * L.C1 * 2);
+        // Thread -> element map of THIS pipeline: load i of a thread serves channel plane i % CT (32 channels each), element
+        // ptid + (i / CT) * 256 of that plane's QX vectors per tile pixel -- the plane, and with it the SOURCE of the concatenation
+        // (which buffer descriptor), is the same for every lane of a load instruction (the first pipeline gave every thread one fixed
+        // plane: a worker whose 64 channels span both sources -- 32 up-sampled + 32 skip channels -- would need two loads per vector).
+        constexpr int ITP = IT_X / CT;          // loads per thread and plane
+        static_assert(IT_X % CT == 0 && NCT % QX == 0, "plane-major load map");
+        const int qx = ptid % QX;               // this thread's vector inside a pixel of a plane: fixed
+        // per plane: which source (uniform), stride / channel offset / upsampling of that source.  Plain records picked with
+        // compile-time plane indices (small arrays captured by the lambdas below went to scratch memory: a stack load and a
+        // vmcnt(0) in front of every use).
+        // (a worker with a plane that holds channels of BOTH sources -- C0 no multiple of 32 -- keeps per-thread sources: two loads per
+        // vector, one of them with the skip offset; no U-Net layer)
+        struct Plane { int cs, stride; bool all0, up, ok, f0; };
+        bool straddle = false;
+        auto mkplane = [&](int pl) {
+            Plane q;
+            const int c_lo = sg.cit * 32 * CT + pl * 32, c_hi = min(c_lo + 32, L.Cin);
+            const int cxp = c_lo + qx * XV;                     // (per thread)
+            q.all0 = c_hi <= L.C0;
+            straddle |= c_lo < L.C0 && c_hi > L.C0;
+            q.ok = cxp < L.Cin;
+            q.f0 = cxp < L.C0;                                  // this thread's source (what counts in a straddling plane)
+            q.cs = q.f0 ? cxp : cxp - L.C0;
+            q.stride = q.f0 ? L.C0 : L.C1;
+            q.up = q.f0 && L.up0;
+            return q;
+        };
+        const Plane P0 = mkplane(0), P1 = mkplane(CT - 1);
+        auto nit_plane = [&](const Item &it) { return it.nitems / CT; };
+        uint32_t xoff[IT_X];                    // BYTE offsets inside one sample of the load's source; 0xffffffff: nothing to load
         int cur_combo = -1;
+        // (the table entries of a rebuild are fetched with ALL loads in flight at once: a uniform branch per entry -- `if (L.halo)` --
+        // made them eight serialised memory round trips, vmcnt(0) behind each)
+        const rsrc_t rt = make_rsrc(table_u, L.halo ? (uint32_t)(6 * M * M * 4) : 0u);
         auto rebuild = [&](const Item &it) {
+            const int nitp = nit_plane(it);
+            int tbl[ITP];
 #pragma unroll
-            for (int i = 0; i < IT_X; ++i) {
-                const int e = min(ptid + i * NCT, it.nitems - 1);
-                const int pix = e / QXT;
+            for (int j = 0; j < ITP; ++j) {
+                const int e = min(ptid + j * NCT, nitp - 1);
+                const int pix = e / QX;
+                const int ty = __umulhi((uint32_t)pix, L.magicW2);
+                const int tx = pix - ty * L.W2;
+                tbl[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(rt, (uint32_t)(((it.f * M + it.y0 + ty) * M + tx) * 4), 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < ITP; ++j) {
+                const int e = min(ptid + j * NCT, nitp - 1);
+                const int pix = e / QX;
                 const int ty = __umulhi((uint32_t)pix, L.magicW2);
                 const int tx = pix - ty * L.W2;
                 const int iy = it.y0 + ty;
-                int ii;                                              // flat cell on the Nin grid
-                if (L.halo) ii = table[(it.f * M + iy) * M + tx];
-                else ii = (it.f * L.Nin + iy) * L.Nin + tx;
+                const int ii = L.halo ? tbl[j] : (it.f * L.Nin + iy) * L.Nin + tx;      // flat cell on the Nin grid
                 const int r = __umulhi((uint32_t)ii, L.magicN);      // row face*Nin + y of the Nin grid -> row r/2 of Nin/2
                 const int pix_up = (r >> 1) * g0 + ((ii - r * L.Nin) >> 1);
-                const int spix = up ? pix_up : ii;
-                xoff[i] = (cx_ok && ptid + i * NCT < it.nitems) ? spix * cstride + cs : -1;
+                {
+                    const int spix = P0.up ? pix_up : ii;
+                    xoff[j * CT] = (P0.ok && ptid + j * NCT < nitp) ? (uint32_t)(spix * P0.stride + P0.cs) * 2u : 0xffffffffu;
+                }
+                if constexpr (CT == 2) {
+                    const int spix = P1.up ? pix_up : ii;
+                    xoff[j * CT + 1] = (P1.ok && ptid + j * NCT < nitp) ? (uint32_t)(spix * P1.stride + P1.cs) * 2u : 0xffffffffu;
+                }
             }
             cur_combo = it.combo;
         };
-        int doff[IT_DY];
+        uint32_t doff[IT_DY];                   // BYTE offsets from the item's first dZ row
 #pragma unroll
-        for (int i = 0; i < IT_DY; ++i) doff[i] = ((ptid + i * NCT) / QDT) * L.Cout + co;
-        const size_t sample_elems = from0 ? (size_t)6 * g0 * g0 * L.C0 : (size_t)6 * L.Nin * L.Nin * L.C1;
-        const bf16_t *src_base = reinterpret_cast<const bf16_t *>(from0 ? src0 : src1);
-        // two register sets, prefetch distance 2 (see wgrad_bf16_kernel)
+        for (int i = 0; i < IT_DY; ++i) doff[i] = co_ok ? (uint32_t)(((ptid + i * NCT) / QDT) * L.Cout + co) * 2u : 0xffffffffu;
         struct Stage {
             XVec xv[IT_X];
             DVec dv[IT_DY], yv[MASK ? IT_DY : 1];
-            bool xok[IT_X], dok[IT_DY];
         };
-        auto issue = [&](const Item &it, Stage &st) {
-            if (it.combo != cur_combo) rebuild(it);                 // uniform, a few times per segment
-            const bf16_t *sb = src_base + (size_t)it.b * sample_elems;
-#pragma unroll
-            for (int i = 0; i < IT_X; ++i) {
-                const int o = xoff[i];
-                st.xv[i] = *reinterpret_cast<const XVec *>(sb + (uint32_t)max(o, 0));
-                st.xok[i] = o >= 0;
+        auto bld = [](rsrc_t r, uint32_t off, auto &dst) __attribute__((always_inline)) {
+            typedef std::remove_reference_t<decltype(dst)> V;
+            if constexpr (sizeof(V) == 16) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+                dst = make_uint4(q.x, q.y, q.z, q.w);
+            } else {
+                dst = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
             }
-            const size_t rowbase = (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * L.Cout;
-            const bf16_t *dzb = reinterpret_cast<const bf16_t *>(dzp) + rowbase;
-            const bf16_t *yb = MASK ? reinterpret_cast<const bf16_t *>(yp) + rowbase : nullptr;
-            const int dlim = it.npix * L.Cout;                      // slot valid <=> its pixel < npix
+        };
+        // `live` (uniform): an item index past the segment's end loads nothing (descriptors of zero bytes)
+        auto issue = [&](const Item &it, Stage &st, bool live) {
+            if (live && it.combo != cur_combo) rebuild(it);         // uniform, a few times per segment
+            const rsrc_t r0 = make_rsrc(x0_u + (size_t)it.b * s0_bytes, live ? s0_bytes : 0u);
+            const rsrc_t r1 = make_rsrc(x1_u ? x1_u + (size_t)it.b * s1_bytes : nullptr, live ? s1_bytes : 0u);
+            if (!straddle) {
+                // one descriptor per plane, chosen as SCALARS (base + size): no branch between the loads
+                const rsrc_t rp0 = make_rsrc(P0.all0 ? x0_u + (size_t)it.b * s0_bytes : (x1_u ? x1_u + (size_t)it.b * s1_bytes : nullptr),
+                                             live ? (P0.all0 ? s0_bytes : s1_bytes) : 0u);
+                const rsrc_t rp1 = make_rsrc(P1.all0 ? x0_u + (size_t)it.b * s0_bytes : (x1_u ? x1_u + (size_t)it.b * s1_bytes : nullptr),
+                                             live ? (P1.all0 ? s0_bytes : s1_bytes) : 0u);
 #pragma unroll
-            for (int i = 0; i < IT_DY; ++i) {
-                const bool ok = co_ok && doff[i] < dlim;
-                const uint32_t o = ok ? (uint32_t)doff[i] : 0u;
-                st.dv[i] = *reinterpret_cast<const DVec *>(dzb + o);
-                if (MASK) st.yv[i] = *reinterpret_cast<const DVec *>(yb + o);
-                st.dok[i] = ok;
+                for (int i = 0; i < IT_X; ++i) {
+                    if (i % CT == 0) bld(rp0, xoff[i], st.xv[i]);       // (compile-time: the loop is unrolled)
+                    else bld(rp1, xoff[i], st.xv[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < IT_X; ++i) {
+                    XVec a, b;
+                    const bool f0 = i % CT == 0 ? P0.f0 : P1.f0;        // this thread's source in plane i % CT
+                    bld(r0, f0 ? xoff[i] : 0xffffffffu, a);
+                    bld(r1, f0 ? 0xffffffffu : xoff[i], b);
+                    st.xv[i] = a | b;
+                }
+            }
+            const size_t rowbase = (((size_t)it.b * 6 + it.f) * face_pix + it.m0) * L.Cout * 2;
+            const uint32_t dbytes = live ? (uint32_t)(it.npix * L.Cout * 2) : 0u;     // slot valid <=> its pixel < npix
+            const rsrc_t rd = make_rsrc(dz_u + rowbase, dbytes);
+#pragma unroll
+            for (int i = 0; i < IT_DY; ++i) bld(rd, doff[i], st.dv[i]);
+            if constexpr (MASK) {
+                const rsrc_t ry = make_rsrc(y_u + rowbase, dbytes);
+#pragma unroll
+                for (int i = 0; i < IT_DY; ++i) bld(ry, doff[i], st.yv[i]);
             }
         };
         auto commit = [&](const Item &it, int k, Stage &st) {
             char *buf = smem + (k & 1) * buf_bytes;
+            const int nitp = nit_plane(it);
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
-                const int e = ptid + i * NCT;
-                if (e < it.nitems)
-                    *reinterpret_cast<XVec *>(buf + ((ptid % QXT) / QX) * plane_bytes + (size_t)(e / QXT) * PB +
-                                              ((ptid % QXT) % QX) * (XV * 2)) = vsel(st.xok[i], st.xv[i]);
+                const int e = ptid + (i / CT) * NCT;
+                if (e < nitp)
+                    *reinterpret_cast<XVec *>(buf + (i % CT) * plane_bytes + (size_t)(e / QX) * PB + qx * (XV * 2)) = st.xv[i];
             }
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
@@ -309,7 +374,7 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
                     if constexpr (DV == 8) vmask_pk(st.dv[i], st.yv[i], L.alpha, mthr1);
                     else vmask(st.dv[i], st.yv[i], L.alpha, L.vmax);
                 }
-                const DVec v = vsel(st.dok[i], st.dv[i]);
+                const DVec v = st.dv[i];
                 if (e < pix_cap * QDT)
                     *reinterpret_cast<DVec *>(buf + x_bytes + (qd / QD) * dzplane_bytes + (size_t)(e / QDT) * PB +
                                               (qd % QD) * (DV * 2)) = v;
@@ -323,24 +388,28 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
                 }
             }
             // B_k: item k is in LDS.  RAW barrier behind an explicit LDS wait (a __syncthreads() would drain vmcnt(0), i.e. wait
-            // for the loads of item k + 1 that were issued a moment ago)
+            // for the loads of item k + 1 that are in flight)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         };
         {
             Stage A, B;
-            Item i0 = item_of(0), i1 = item_of(1);          // item_of clamps: prefetches past the end re-read the last item
-            issue(i0, A);
-            for (int k = 0; k < n_my; k += 2) {
-                const Item i2 = item_of(k + 2);
-                issue(i1, B);
+            Item i0 = item_of(0), i1 = item_of(1);          // (item_of clamps; an index past the end is issued dead)
+            issue(i0, A, true);
+            issue(i1, B, 1 < n_my);
+            // (whole pairs in the loop, an odd last item behind it: with `if (k + 1 >= n_my) break` in the middle of the body hipcc moved
+            // the exit check -- and a vmcnt(0) for a value its exit path reads -- between the X loads and the dZ loads of an issue)
+            const int npair = n_my >> 1;
+            for (int pr = 0; pr < npair; ++pr) {
+                const int k = 2 * pr;
                 commit(i0, k, A);
-                if (k + 1 >= n_my) break;
-                const Item i3 = item_of(k + 3);
-                issue(i2, A);
+                i0 = item_of(k + 2);
+                issue(i0, A, k + 2 < n_my);
                 commit(i1, k + 1, B);
-                i0 = i2; i1 = i3;
+                i1 = item_of(k + 3);
+                issue(i1, B, k + 3 < n_my);
             }
+            if (n_my & 1) commit(i0, n_my - 1, A);
         }
         // ---- bias partial: thread (vector qd, 256 / QDT pixel phases) holds sums of DV channels -> fixed-order sum
         __syncthreads();                // E1: consumers are done with the buffers
@@ -794,7 +863,6 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
         const WbLayer &L = layers[sg.layer];
         const void *a0 = ptrs.src0[sg.layer], *a1 = ptrs.src1[sg.layer], *dz = ptrs.dz[sg.layer], *yy = ptrs.y[sg.layer];
         const int32_t *tb = ptrs.table[sg.layer];
-#if DLWPCS_WB_ONLY == 0
         if (L.variant >= WB_V_F32_3) {
             switch (L.variant) {
             case WB_V_F32_1: wb_segment_f32<1, false>(L, sg, a0, a1, dz, yy, tb, ws, smem); break;
@@ -824,7 +892,6 @@ __global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict
             }
             continue;
         }
-#endif
         switch (L.variant) {
             case WB_V_3_8_22: wb_segment<3, 8, 4, 2, 2, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
             case WB_V_3_8_21: wb_segment<3, 8, 4, 2, 1, 8>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
@@ -1172,7 +1239,10 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
     // (plus ~45 per 4-B load instruction of a thread); when the consumers do, ~530 cycles per 16-pixel slab of 9 taps (260
     // for a 1x1 kernel; the slab count per wave is rounded up to even) plus ~1200.
     // (round 4: every one of the six constants, the segment overhead and the worker count varied against the step -- these are the optimum)
-    const double fix = 3300.0, bpc = 23.0, slab3 = 530.0, slab1 = 260.0, ld4 = 45.0, cfix = 1200.0;
+    double fix = 3300.0, bpc = 23.0, slab3 = 530.0, slab1 = 260.0, ld4 = 45.0, cfix = 1200.0;
+#ifdef DLWPCS_WB_TUNE_ENV       // (side builds only: the six constants from the environment, tools/wb_sweep.sh)
+    if (const char *e = getenv("DLWPCS_WB_COST")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &fix, &bpc, &slab3, &slab1, &ld4, &cfix);
+#endif
     const int nslab = L.pix_cap / 16;
     const int S = ((ceil_div(nslab, nph)) + 1) & ~1;
     const double mma = (double)S * (KS == 3 ? slab3 : slab1) + cfix;
@@ -1191,7 +1261,12 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
     return DLWPCS_OK;
 }
 
-static double wb_seg_overhead() { return 20000.0; }
+static double wb_seg_overhead() {
+#ifdef DLWPCS_WB_TUNE_ENV
+    if (const char *e = getenv("DLWPCS_WB_SEG")) return atof(e);
+#endif
+    return 20000.0;
+}
 
 struct WbPlanOut {
     WbHeader H;

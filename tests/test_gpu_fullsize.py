@@ -289,22 +289,46 @@ def test_cfg3_gradient_is_linear_in_the_batch(dtype, tol):
 
 
 def test_cfg5_rollout_full_size_bf16():
-    """Config 5: unet2 C96, 26 channels, bf16, batch 32, predict_timeseries: step 1 equals predict(), step s+1 equals
-    predict(step s) (device-resident state == host round trip), and samples are independent of their batch."""
+    """Config 5: unet2 C96, 26 channels, bf16, batch 32, predict_timeseries.  (1) engine option fold_head=0 (the output layer a
+    launch of its own, as predict() runs it): step 1 equals predict(), step s+1 equals predict(step s) bit for bit (device-resident
+    state == host round trip).  (2) default options (the rollout's padded state takes the output layer through the epilogue of the
+    last convolution, dlwpcs_conv_fwd_head: another summation order inside the head's MFMA): the first application within ONE bf16
+    rounding step of predict() and against the fp64 oracle; samples are independent of their batch."""
+    import os
     from DLWP.model import DLWPFunctional
+    from DLWP import ops
     rng = np.random.default_rng(505)
     x = rng.standard_normal((B_FULL, 6, 96, 96, 26)).astype(np.float32)
-    model, convs = _build_unet2(96, 26, 26, 32, 'bfloat16')
+    os.environ['DLWPCS_OPTIONS'] = 'fold_head=0'
+    try:
+        model0, convs0 = _build_unet2(96, 26, 26, 32, 'bfloat16')
+    finally:
+        os.environ.pop('DLWPCS_OPTIONS', None)
+    weights = model0.get_weights()
     dlwp = DLWPFunctional(is_convolutional=True, time_dim=2)
-    dlwp.build_model(model, loss='mse', optimizer='adam')
+    dlwp.build_model(model0, loss='mse', optimizer='adam')
     # the full configuration: 40 forecast steps = 20 model applications at batch 32 (26 channels = 13 variables x 2 steps)
     series = dlwp.predict_timeseries(x, 40, keep_time_dim=True)
     assert series.shape[0] == 20 and np.isfinite(series).all()
     series = series.reshape((20, B_FULL, 6, 96, 96, 26))
     state = x
     for s in range(20):
-        state = model.predict(state, batch_size=B_FULL)
+        state = model0.predict(state, batch_size=B_FULL)
         assert np.array_equal(series[s], state), s
+    first0 = series[0].copy()
+    del series, state, dlwp, model0
+    # default options: the same weights, the head folded into the last convolution
+    model, convs = _build_unet2(96, 26, 26, 32, 'bfloat16')
+    model.set_weights(weights)
+    dlwp = DLWPFunctional(is_convolutional=True, time_dim=2)
+    dlwp.build_model(model, loss='mse', optimizer='adam')
+    ops.HEAD_FOLDED = False
+    series = dlwp.predict_timeseries(x, 4, keep_time_dim=True).reshape((2, B_FULL, 6, 96, 96, 26))
+    assert ops.HEAD_FOLDED, 'the rollout takes its output layer through dlwpcs_conv_fwd_head'
+    assert np.isfinite(series).all()
+    scale = np.abs(first0).max()
+    assert np.abs(series[0] - first0).max() <= 2.0 ** -8 * scale
+    assert np.array_equal(model.predict(x, batch_size=B_FULL), first0)          # (predict() writes 26-channel rows: never folded)
     # oracle on one sample, first application (bf16 activations: 1e-2 of the output range)
     params = [{n: torch.tensor(w, dtype=torch.float64) for n, w in
                zip(('equatorial_kernel', 'polar_kernel', 'equatorial_bias', 'polar_bias'), lay.get_weights())}
