@@ -231,6 +231,10 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
         // only; a lane without work passes an offset beyond num_records and gets zeros: no select, no clamp, no 64-bit address
         // arithmetic per load; the sample / band base lives in the scalar descriptor), two register stages, and the loads of item
         // k + 2 are issued right AFTER item k has gone to LDS: two items in flight, each with a whole period to land.
+        // (Measured and dropped, EXPERIMENTS.md: a third stage -- 146.8 against 145.4 us, depth no longer limits the launch; BAND-minor
+        // item order with the halo-table entries of every item fetched one issue ahead -- FETCH_SIZE -9 % (vertically adjacent bands
+        // share two halo rows through the L2) but 175-186 against 141 us: the per-item offset arithmetic, eight more loads and ~30
+        // more registers per thread -- spills in the widest variants -- cost more than the bytes give.)
         auto uni_ptr = [](const void *q) {      // (pointer arguments of a noinline call arrive in vector registers)
             return reinterpret_cast<const char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)q >> 32)) << 32) |
                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)q));
@@ -1239,6 +1243,8 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
     // (plus ~45 per 4-B load instruction of a thread); when the consumers do, ~530 cycles per 16-pixel slab of 9 taps (260
     // for a 1x1 kernel; the slab count per wave is rounded up to even) plus ~1200.
     // (round 4: every one of the six constants, the segment overhead and the worker count varied against the step -- these are the optimum)
+    // (round 5, new producers: re-swept on a side build -- 136-142 us over a flat, noisy landscape around these values; settings that
+    // measured 3 us better in the micro-benchmark left workers without a segment: kept)
     double fix = 3300.0, bpc = 23.0, slab3 = 530.0, slab1 = 260.0, ld4 = 45.0, cfix = 1200.0;
 #ifdef DLWPCS_WB_TUNE_ENV       // (side builds only: the six constants from the environment, tools/wb_sweep.sh)
     if (const char *e = getenv("DLWPCS_WB_COST")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &fix, &bpc, &slab3, &slab1, &ld4, &cfix);
