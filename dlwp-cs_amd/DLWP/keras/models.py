@@ -155,6 +155,9 @@ class Model(object):
             lay = t.layer
             if isinstance(lay, InputLayer):
                 return len(t.shape) == 5
+            if isinstance(lay, CubeSphereConv2D) and lay.activation is not None \
+                    and getattr(lay.activation, '_dlwp_name', None) != 'relu':
+                return False        # a user's callable may depend on the axis order (softmax): such a graph keeps its own layout
             if isinstance(lay, (CubeSpherePadding2D, CubeSphereConv2D, AveragePooling3D, UpSampling3D)):
                 return lay.data_format == 'channels_first'
             if isinstance(lay, Concatenate):
