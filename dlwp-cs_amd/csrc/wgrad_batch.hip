@@ -487,11 +487,11 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
         for (int si = 0; si < S; si += 2) {
             frag(si + 1, fa[1], fb[1]);
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fa[0][tap], fb[0]);
+            for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fb[0], fa[0][tap]);
             WB_SCHED();
             frag(si + 2, fa[0], fb[0]);
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fa[1][tap], fb[1]);
+            for (int tap = 0; tap < TAPS; ++tap) frag_mma<bf16_t>(acc[tap], fb[1], fa[1][tap]);
             WB_SCHED();
         }
     }
@@ -530,14 +530,25 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
                     }
                 }
             }
-            const uint32_t row0 = (uint32_t)(((t * (32 * CT) + ct * 32 + 4 * half) * (32 * NT) + nt * 32 + l31) * 4);
+            // The MFMAs ran as D[co][ci] (dZ as the A operand, X as the B operand: the two operand layouts are the same function of
+            // (lane, register), so the roles swap with the arguments): a lane owns input channel l31 and, per register quad, FOUR
+            // CONSECUTIVE output channels 8 q + 4 half + (0..3) -- four 16-B stores into the slot's [tap][ci][co] rows instead of sixteen
+            // 4-B ones per tap.  (The launch's WRITE_SIZE -- 62 MB for 23 MB of partial sums -- did not move with it: what the counter
+            // sees besides the slots are the callee-saved registers every noinline segment call parks in scratch memory, 71 dwords x 512
+            // threads x ~290 calls = 42 MB written and read back per launch.)
+            const uint32_t row0 = (uint32_t)(((t * (32 * CT) + ct * 32 + l31) * (32 * NT) + nt * 32 + 4 * half) * 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sum;
-                if (NPH == 4) sum = (v[0][r] + v[1][r]) + (v[2][r] + v[3][r]);
-                else if (NPH == 2) sum = v[0][r] + v[1][r];
-                else sum = v[0][r];
-                bst32(__float_as_uint(sum), pr, row0 + (uint32_t)(((r & 3) + 8 * (r >> 2)) * (32 * NT) * 4));
+            for (int q = 0; q < 4; ++q) {
+                float sum[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 4 * q + u;
+                    if (NPH == 4) sum[u] = (v[0][r] + v[1][r]) + (v[2][r] + v[3][r]);
+                    else if (NPH == 2) sum[u] = v[0][r] + v[1][r];
+                    else sum[u] = v[0][r];
+                }
+                bst128(make_uint4(__float_as_uint(sum[0]), __float_as_uint(sum[1]), __float_as_uint(sum[2]), __float_as_uint(sum[3])), pr,
+                       row0 + (uint32_t)(8 * q * 4));
             }
         }
     }
