@@ -59,7 +59,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 N_SIMD = 1024                      # 256 CUs x 4 SIMDs
 N_XCC = 8
 PEAK_CLOCK_MHZ = 2400.0
-PMC_GROUPS = (('FETCH_SIZE',), ('WRITE_SIZE',), ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'))
+# one rocprofv3 pass per group.  The guide's counter budget per block: TCC holds 4 (FETCH_SIZE costs 3, WRITE_SIZE 2: never both in one
+# pass), SQ 8, GRBM 2, independent of each other -- WRITE_SIZE shares its pass with the SQ / GRBM counters (two passes per workload
+# instead of three: a pass is ~25 s of process start-up under the profiler)
+PMC_GROUPS = (('FETCH_SIZE',), ('WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'))
 # peaks MEASURED on an MI355X box with tools/peaks.hip (profiles/r01_peaks.txt): register-resident MFMA chains, streaming
 # read / write / copy kernels -- what a perfect kernel reaches on this hardware, next to the datasheet numbers above
 MEASURED_PEAKS = {'bf16_mfma_tflops': 2460.0, 'fp32_mfma_tflops': 156.0, 'hbm_read_gbs': 6400.0, 'hbm_write_gbs': 5200.0,
@@ -222,26 +225,42 @@ def collect_pmc_live(args, dtype, timeout_s=240, groups=None):
     tmp = tempfile.mkdtemp(prefix='dlwpcs_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
     try:
-        groups = groups or PMC_GROUPS
-        for i, group in enumerate(groups):
+        groups_in = groups
+        groups = list(groups or PMC_GROUPS)
+        errors = []
+        i = 0
+        while groups:
+            group = groups.pop(0)
             d = os.path.join(tmp, 'pass%d' % i)
+            i += 1
             cmd = [exe, '--kernel-trace', '--pmc'] + list(group) + ['-d', d, '-o', 'p', '--output-format', 'csv', '--',
                    sys.executable, os.path.abspath(__file__), '--pmc-child', '--workload', args.workload, '--dtype', dtype,
                    '--batch', str(args.batch), '--face', str(args.face), '--channels', str(args.channels),
                    '--base', str(args.base)]
+            err = None
             try:
                 r = subprocess.run(cmd, env=env, cwd='/tmp', capture_output=True, text=True, timeout=timeout_s)
+                if r.returncode != 0:
+                    err = 'rocprofv3 pass (%s) failed (rc %d): %s' % (' '.join(group), r.returncode, (r.stderr or '')[-200:].replace('\n', ' '))
             except subprocess.TimeoutExpired:
-                return None, 'rocprofv3 pass %d timed out' % i
-            if r.returncode != 0:
-                return None, 'rocprofv3 pass %d failed (rc %d): %s' % (i, r.returncode, (r.stderr or '')[-200:].replace('\n', ' '))
+                err = 'rocprofv3 pass (%s) timed out' % ' '.join(group)
+            if err is not None:
+                # a group of several hardware blocks that the profiler refuses is retried block by block; a failed pass costs its
+                # own counters only (the kernels it would have covered are listed in roofline.pmc_missing)
+                if len(group) > 1 and 'WRITE_SIZE' in group:
+                    groups = [('WRITE_SIZE',), tuple(c for c in group if c != 'WRITE_SIZE')] + groups
+                else:
+                    errors.append(err)
+                continue
             for k, cs in parse_pmc_dir(d).items():
                 merged.setdefault(k, {}).update(cs)
+        if not merged:
+            return None, '; '.join(errors) or 'no counter records'
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     recs = {k: pmc_record(v) for k, v in merged.items()}
-    return {k: v for k, v in recs.items() if v}, 'live rocprofv3 --kernel-trace --pmc passes (%s), 3 eager steps each' % (
-        ' | '.join(' '.join(g) for g in groups))
+    return {k: v for k, v in recs.items() if v}, 'live rocprofv3 --kernel-trace --pmc passes (%s), 3 eager steps each%s' % (
+        ' | '.join(' '.join(g) for g in (groups_in or PMC_GROUPS)), ('; FAILED: ' + '; '.join(errors)) if errors else '')
 
 
 def newest_committed_pmc(workload, dtype):
