@@ -118,6 +118,8 @@ CASES = [
     (2, 48, 32, 0, 0, 32, 3, 1),      # 32 x 32, 384-pixel items
     (3, 10, 16, 0, 0, 24, 3, 1),      # ... partial channel tiles, ragged band
     (2, 20, 40, 8, 0, 48, 3, 1),      # ... 48 input channels from two sources (two ci groups of 32)
+    (2, 24, 40, 24, 0, 64, 3, 1),     # 64 x 64 per worker, the second 32-channel plane holds channels of BOTH sources
+    (2, 24, 32, 32, 0, 32, 3, 1),     # 64 x 32, one plane per source, no upsampling
     (2, 48, 14, 0, 0, 32, 3, 1),      # 4-B X vectors: the 14-channel network input
     (1, 16, 26, 0, 0, 32, 3, 1),      # ... 26 channels
     (2, 48, 32, 0, 0, 14, 1, 0),      # 1x1 head, 14 outputs (4-B dZ vectors)
