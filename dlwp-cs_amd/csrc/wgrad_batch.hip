@@ -153,6 +153,27 @@ template <typename T> __device__ __forceinline__ T load_uniform(const T &g) {
 // (noinline on purpose: the kernel carries 22 segment bodies; forced inline -- even of the 8 plain bf16 bodies alone -- hipcc spills
 // 266 VGPRs and the launch takes 237 instead of 150 us, EXPERIMENTS.md)
 #define WB_SEG_ATTR __attribute__((noinline))
+#ifndef DLWPCS_WB_PRODUCER_PRIO
+#define DLWPCS_WB_PRODUCER_PRIO 0
+#endif
+// (side builds only, -DDLWPCS_WB_TL=1, tools/wb_timeline.py: s_memtime marks of the first workers' first producer / consumer wave into
+// a library-owned buffer -- [worker][kind][TL_MAX] words (time << 4 | tag), cursor per (worker, kind) behind them)
+#ifdef DLWPCS_WB_TL
+// phase SUMS in registers, one store per segment (per-mark stores were FLAT stores: hipcc answered them with vmcnt(0) in front of the
+// next LDS write, and the "LDS write" phase of the first timeline was really a wait for every load in flight)
+constexpr int TL_WORKERS = 256, TL_MAX = 8;
+#define WB_TL_DECL(kind_) \
+    const bool tl_on = dbg != nullptr && (threadIdx.x & 255) == 0; \
+    long long *tl_base = dbg + ((size_t)blockIdx.x * 2 + (kind_)) * TL_MAX; \
+    long long tl_a[TL_MAX] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+    long long tl_prev = (long long)__builtin_amdgcn_s_memtime();
+#define WB_TL(bucket_) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); tl_a[bucket_] += t_ - tl_prev; tl_prev = t_; } while (0)
+#define WB_TL_END() do { if (tl_on) { _Pragma("unroll") for (int q_ = 0; q_ < TL_MAX; ++q_) tl_base[q_] += tl_a[q_]; } } while (0)
+#else
+#define WB_TL_DECL(kind_)
+#define WB_TL(tag_)
+#define WB_TL_END()
+#endif
 template <int KS, int XV, int QX, int CT, int NT, int DV, bool MASK = false>
 __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, const void *src0, const void *src1,
                                            const void *dzp, const void *yp, const int32_t *table, float *ws, char *smem,
@@ -178,10 +199,15 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
     static_assert(NCT % QXT == 0 && NCT % QDT == 0, "thread -> channel-vector maps must not depend on the item");
 
     const int pix_cap = L.pix_cap;
-    const int plane_bytes = L.tile_rows_max * L.W2 * PB;
-    const int x_bytes = CT * plane_bytes;
-    const int dzplane_bytes = pix_cap * PB;
-    const int buf_bytes = x_bytes + NT * dzplane_bytes;
+    // LDS planes are as large as the producers' SLOTS (not as the layer's tile): every staged vector has a home, so the producers'
+    // LDS writes are unconditional stores at compile-time offsets -- no bounds test, no exec mask, no address arithmetic per write
+    // (time-neutral against bounds-tested writes -- tools/wb_timeline.py: the writes + bias sums of an item take a producer wave ~1800
+    // cycles either way, a fifth of it the bias sums -- but the producers' code is a third shorter)
+    constexpr int XCAP_PIX = (IT_X / CT) * NCT / QX;        // tile pixels a plane can hold
+    constexpr int plane_bytes = XCAP_PIX * PB;
+    constexpr int x_bytes = CT * plane_bytes;
+    constexpr int dzplane_bytes = CAP_PIX * PB;
+    constexpr int buf_bytes = x_bytes + NT * dzplane_bytes;
 
     const int nfaces = sg.cls == 0 ? 4 : 1, fbase = sg.cls == 0 ? 0 : (sg.cls == 1 ? 4 : 5);
     const int n_my = sg.t_last - sg.t_first;
@@ -214,6 +240,10 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
     if (tid >= NCT) {
         // =========================================== producers ===========================================
         const int ptid = tid - NCT;
+        // (s_setprio for the producer waves, as the per-layer kernels and the convolution do it: measured here, priority 2 makes the
+        // launch 3 % SLOWER -- the consumers beside them compute 15 % longer, the producers' phases do not shrink.  Default 0.)
+        if (DLWPCS_WB_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(DLWPCS_WB_PRODUCER_PRIO);
+        WB_TL_DECL(0)
         const int qd = ptid % QDT;                              // this thread's dZ vector inside a pixel: fixed
         const int g0 = L.up0 ? (L.Nin >> 1) : L.Nin;
         const int M = L.Nin + KS - 1;
@@ -364,24 +394,25 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
         };
         auto commit = [&](const Item &it, int k, Stage &st) {
             char *buf = smem + (k & 1) * buf_bytes;
-            const int nitp = nit_plane(it);
+            WB_TL(0);                                           // bucket 0: set-up + issue of the loads since the last barrier
+#ifdef DLWPCS_WB_TL
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(IT_X + IT_DY + (MASK ? IT_DY : 0)) : "memory");    // this stage's data (the other stage's loads stay in flight)
+            WB_TL(1);                                           // bucket 1: wait for the stage's data
+#endif
+            // (slots beyond the item's cells hold zeros: their loads were issued with the out-of-range offset)
+            char *const xbase = buf + (ptid / QX) * PB + qx * (XV * 2);
 #pragma unroll
-            for (int i = 0; i < IT_X; ++i) {
-                const int e = ptid + (i / CT) * NCT;
-                if (e < nitp)
-                    *reinterpret_cast<XVec *>(buf + (i % CT) * plane_bytes + (size_t)(e / QX) * PB + qx * (XV * 2)) = st.xv[i];
-            }
+            for (int i = 0; i < IT_X; ++i)
+                *reinterpret_cast<XVec *>(xbase + (i % CT) * plane_bytes + (i / CT) * (NCT / QX) * PB) = st.xv[i];
+            char *const dbase = buf + x_bytes + (qd / QD) * dzplane_bytes + (ptid / QDT) * PB + (qd % QD) * (DV * 2);
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
-                const int e = ptid + i * NCT;
                 if constexpr (MASK) {                                       // dz = dy * act'(y), rounded to bf16 like a stored dz
                     if constexpr (DV == 8) vmask_pk(st.dv[i], st.yv[i], L.alpha, mthr1);
                     else vmask(st.dv[i], st.yv[i], L.alpha, L.vmax);
                 }
                 const DVec v = st.dv[i];
-                if (e < pix_cap * QDT)
-                    *reinterpret_cast<DVec *>(buf + x_bytes + (qd / QD) * dzplane_bytes + (size_t)(e / QDT) * PB +
-                                              (qd % QD) * (DV * 2)) = v;
+                *reinterpret_cast<DVec *>(dbase + i * (NCT / QDT) * PB) = v;
                 if (want_bias) {
                     if constexpr (DV == 8) {
                         bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
@@ -394,7 +425,9 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
             // B_k: item k is in LDS.  RAW barrier behind an explicit LDS wait (a __syncthreads() would drain vmcnt(0), i.e. wait
             // for the loads of item k + 1 that are in flight)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WB_TL(2);                                           // bucket 2: LDS writes (+ bias sums)
             __builtin_amdgcn_s_barrier();
+            WB_TL(3);                                           // bucket 3: barrier
         };
         {
             Stage A, B;
@@ -435,6 +468,8 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
             slot[TAPS * (32 * CT) * (32 * NT) + ptid] = sum;
         }
         __syncthreads();                // E3: the next segment may overwrite the buffers
+        WB_TL(4);                                               // bucket 4: segment epilogue
+        WB_TL_END();
         return;
     }
 
@@ -442,6 +477,7 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
     const int lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int li = lane & 15;
+    WB_TL_DECL(1)
     const int choff = ((((lane >> 4) & 1) * 16) + (li & 3) * 4) * 2;   // byte offset of this lane's 4 contiguous channels
     const int prow = li >> 2;                                            // which of the 4 pixels of a transpose block
     f32x16 acc[TAPS];
@@ -457,7 +493,9 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
     const int S = (((nslab + NPH - 1) / NPH) + 1) & ~1;   // slabs per consumer wave, rounded up to even (extras add zero)
     const int ct = wave % CT, nt = (wave / CT) % NT, ph = wave / (CT * NT);
     for (int k = 0; k < n_my; ++k) {
+        WB_TL(1);                               // bucket 1: fragment reads + MFMAs of the previous item (+ set-up)
         __syncthreads();                        // B_k
+        WB_TL(0);                               // bucket 0: wait at B_k
         const char *lds_x0 = smem + (k & 1) * buf_bytes, *lds_dy = lds_x0 + x_bytes + nt * dzplane_bytes;
         const char *lds_x = lds_x0 + ct * plane_bytes;
         const Item it = item_of(k);
@@ -472,10 +510,13 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
                 const int gm = it.m0 + min(m, it.npix - 1);
                 const int oy = __umulhi((uint32_t)gm, L.magicNo);
                 xaddr[jj] = ((oy - it.y0) * L.W2 + (gm - oy * L.No)) * PB + choff;
-                daddr[jj] = m * PB + choff;
+                // a slab past the item's pixels reads its dZ fragment 8 MB beyond the allocation: zeros (dlwpcs_lds_oob_probe).  As a
+                // select on the LOADED fragment the masking put a wait for these two reads -- issued a moment before -- into every
+                // slab: one exposed LDS round trip per 9 MFMAs
+                daddr[jj] = m * PB + choff + (live ? 0 : (1 << 23));
             }
             const uint2 b0 = lds_tr16(lds_dy + daddr[0]), b1 = lds_tr16(lds_dy + daddr[1]);
-            bq = vsel(live, make_uint4(b0.x, b0.y, b1.x, b1.y));
+            bq = make_uint4(b0.x, b0.y, b1.x, b1.y);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 const uint2 a0 = lds_tr16(lds_x + xaddr[0] + tapoff[tap]), a1 = lds_tr16(lds_x + xaddr[1] + tapoff[tap]);
@@ -495,6 +536,7 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
             WB_SCHED();
         }
     }
+    WB_TL(1);
     __syncthreads();                            // E1: all consumers finished reading the last buffer
     // Cross-wave reduction, one LDS round (see wgrad_bf16_kernel): the NPH waves of a (ci tile, co tile) hold K-split sums
     // of the same (taps, 32, 32) block; tap t belongs to the wave of phase t % NPH, the others park theirs in LDS.
@@ -553,6 +595,8 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
         }
     }
     __syncthreads();                            // E3
+    WB_TL(2);                                   // bucket 2: segment epilogue (reduction, partial sums)
+    WB_TL_END();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1244,7 +1288,7 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
         G.cost_item[0] = G.cost_item[1] = cost;
         return DLWPCS_OK;
     }
-    const size_t buf = (size_t)CT * rows * W2 * 64 + (size_t)NT * L.pix_cap * 64;
+    const size_t buf = (size_t)CT * cap_tile_px * 64 + (size_t)NT * cap_pix * 64;      // planes as large as the producers' slots (wb_segment)
     const int nph = 4 / (CT * NT), rslots = TAPS - TAPS / nph;
     const size_t need = ((size_t)4 * rslots * 1024 + 2048) * 4;
     G.lds = 2 * buf > need ? 2 * buf : need;
@@ -1401,6 +1445,9 @@ static int wb_build(const dlwpcs_wgrad_item *items, int n, int n_workers, WbPlan
 }
 
 static int wb_workers() { return 256; }
+#ifdef DLWPCS_WB_TL
+static long long *g_tl_last = nullptr;
+#endif
 
 // upper bound of the plan size that does not depend on where the cuts fall: every group is cut at most once per worker
 static size_t wb_plan_bound(int n_groups, int n_layers, int n_workers) {
@@ -1568,6 +1615,16 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
     if (!apply_only) {
         if (prof_enabled()) pidx = prof_begin("wgrad_batch_kernel", flops, bytes, s);
         long long *dbg = nullptr;
+#ifdef DLWPCS_WB_TL
+        {
+            static long long *g_tl = nullptr;
+            const size_t nb = (size_t)TL_WORKERS * 2 * TL_MAX * sizeof(long long);
+            if (!g_tl && hipMalloc((void **)&g_tl, nb) != hipSuccess) g_tl = nullptr;
+            if (g_tl) (void)hipMemsetAsync(g_tl, 0, nb, s);
+            dbg = g_tl;
+            g_tl_last = g_tl;
+        }
+#endif
         hipLaunchKernelGGL(wgrad_batch_kernel, dim3(H->n_workers), dim3(512), lds, s, (const char *)plan_dev, ptrs, (float *)workspace, dbg,
                            adam_state);
         if (pidx >= 0) prof_end(pidx, s);
@@ -1618,3 +1675,13 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
     }
     return check_launch("wgrad_batch_reduce");
 }
+
+#ifdef DLWPCS_WB_TL
+// side builds only: the timeline of the last dlwpcs_wgrad_batch launch -> host (tools/wb_timeline.py)
+extern "C" int dlwpcs_wb_timeline(long long *host, size_t words) {
+    const size_t have = (size_t)dlwpcs::TL_WORKERS * 2 * dlwpcs::TL_MAX;
+    if (!dlwpcs::g_tl_last || words < have) return -1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(host, dlwpcs::g_tl_last, have * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? (int)have : -2;
+}
+#endif
