@@ -525,6 +525,10 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
         };
         uint4 fa[2][TAPS], fb[2];
         frag(0, fa[0], fb[0]);
+#ifdef DLWPCS_WB_TL
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WB_TL(3);                               // bucket 3: item set-up + the first slab's fragments (of bucket 1's time otherwise)
+#endif
         for (int si = 0; si < S; si += 2) {
             frag(si + 1, fa[1], fb[1]);
 #pragma unroll

@@ -60,11 +60,11 @@ def main():
     arr = np.frombuffer(buf, dtype=np.int64).reshape(TLW, 2, TLM).astype(np.float64)
     prod, cons = arr[:, 0], arr[:, 1]
     names_p = ['issue', 'wait_data', 'lds_write', 'barrier', 'epilogue']
-    names_c = ['barrier', 'compute', 'epilogue']
+    names_c = ['barrier', 'compute', 'epilogue', 'first_frag']
     print('phase sums per workgroup (s_memtime ticks of its first producer / first consumer wave, the last launch), mean over the 256 '
           'workgroups [min .. max]:')
     tot_p = prod[:, :5].sum(axis=1)
-    tot_c = cons[:, :3].sum(axis=1)
+    tot_c = cons[:, :4].sum(axis=1)
     print('  producer total %8.0f [%8.0f .. %8.0f]' % (tot_p.mean(), tot_p.min(), tot_p.max()))
     for i, nm in enumerate(names_p):
         v = prod[:, i]
