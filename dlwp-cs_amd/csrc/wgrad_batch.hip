@@ -1301,10 +1301,10 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
     // shapes of the U-Net, +-7 %): when the producers set the period an item costs ~3300 cycles plus its bytes at 23 B/clk
     // (plus ~45 per 4-B load instruction of a thread); when the consumers do, ~530 cycles per 16-pixel slab of 9 taps (260
     // for a 1x1 kernel; the slab count per wave is rounded up to even) plus ~1200.
-    // (round 4: every one of the six constants, the segment overhead and the worker count varied against the step -- these are the optimum)
-    // (round 5, new producers: re-swept on a side build -- 136-142 us over a flat, noisy landscape around these values; settings that
-    // measured 3 us better in the micro-benchmark left workers without a segment: kept)
-    double fix = 3300.0, bpc = 23.0, slab3 = 530.0, slab1 = 260.0, ld4 = 45.0, cfix = 1200.0;
+    // (round 5: re-swept for the new producers on a side build, tools/wb_sweep.sh, three runs per setting, twice: bytes cheaper -- 35
+    // instead of 23 B/clk --, a slab and the consumers' fixed part dearer -- 570 / 2000 instead of 530 / 1200: 145.4-147.0 against
+    // 152.7-156.4 us on the same box, step 0.653 -> 0.644 ms; settings that left a worker without a segment were not considered)
+    double fix = 3300.0, bpc = 35.0, slab3 = 570.0, slab1 = 260.0, ld4 = 45.0, cfix = 2000.0;
 #ifdef DLWPCS_WB_TUNE_ENV       // (side builds only: the six constants from the environment, tools/wb_sweep.sh)
     if (const char *e = getenv("DLWPCS_WB_COST")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &fix, &bpc, &slab3, &slab1, &ld4, &cfix);
 #endif
