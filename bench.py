@@ -435,6 +435,34 @@ def allreduce_probe(model, world, reps=20):
     return float(el.item()) * 1e6
 
 
+def replicas_in_sync(model, world):
+    """N > 1: after the warm-up steps (eager, captured, replayed -- every one of them exchanged gradients) the replicas' parameters
+    must be IDENTICAL on every rank: MAX and MIN over the ranks of two checksums of the flat parameter buffer agree.  A collective
+    that summed nothing, summed a subset or ran as a fallback on some ranks fails here, before the timed region.  Every rank calls it."""
+    if world <= 1 or model._flat_params is None:
+        return None
+    from DLWP import parallel as _par
+    p = model._flat_params.double()
+    cs = torch.stack([p.sum(), p.abs().sum(), (p * torch.arange(1, p.numel() + 1, device=p.device, dtype=torch.float64)).sum()])
+    hi, lo = cs.clone(), cs.clone()
+    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    same = bool(torch.equal(hi, lo))
+    native = _par.native_comm() is not None
+    asked = bool(_par.NATIVE_COMM)
+    info = {'replicas_identical_after_warmup': same,
+            'collective': 'dlwpcs_allreduce_f32 (library-owned RCCL communicator, compute stream, a node of the step graph)'
+            if native else 'torch.distributed.all_reduce (ProcessGroupNCCL stream)',
+            'native_comm_requested': asked, 'native_comm_status': _par.native_comm_status()}
+    if not same:
+        raise RuntimeError('bench.py: the replicas diverged during warm-up (%s): the gradient exchange is broken; refusing to time it'
+                           % info['collective'])
+    if torch.distributed.get_backend() == 'nccl' and asked and not native:
+        sys.stderr.write('bench.py: WARNING: the library-owned communicator was asked for and is NOT in use (%s); '
+                         'torch.distributed.all_reduce serves the timed region\n' % info['native_comm_status'])
+    return info
+
+
 def time_without_exchange(st, timed, per_block):
     """Seconds per step of the SAME step form with the all-reduce calls turned into no-ops (the collective is captured inside
     the step graph, so the graphs are captured anew for this and once more afterwards)."""
@@ -589,6 +617,7 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
             model._seen_batch.clear()
             for _ in range(4):
                 run_step(st)
+    sync = replicas_in_sync(model, world) if st['train'] else None
     k_elapsed = timed(args.steps)             # the contract's window: exactly K steps
     est = k_elapsed / args.steps
     per_block = max(args.steps, int(np.ceil(args.min_block_s / max(est, 1e-9))))
@@ -665,6 +694,7 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
         result['exchange'] = {'allreduce_us': None if ar_us is None else round(ar_us, 1),
                               'bytes': int(model._flat_grads.numel() * 4) if st['train'] else 0,
                               'backend': torch.distributed.get_backend(), 'rccl_ranks': torch.distributed.get_world_size(),
+                              **(sync or {}),
                               'buckets': 2 if (st['train'] and getattr(model, '_did_split', False)) else 1,
                               'bucket_trials_ms_per_step': None if not bucket_trials else
                               {str(k): round(1e3 * v, 4) for k, v in bucket_trials.items()},
@@ -881,6 +911,12 @@ def main():
     from DLWP.keras import backend
     backend.set_device('cuda:%d' % local_rank)
     single = world == 1
+    if world > 1:
+        # the exchange this run ASKS for: the library-owned RCCL communicator on the compute stream (opt-in in the product, see
+        # DLWP/parallel.py; DLWPCS_BENCH_NATIVE_RCCL=0: torch.distributed.all_reduce).  What actually served the timed region is
+        # written into the line (exchange.collective) and checked against the request there.
+        from DLWP import parallel as _par
+        _par.enable_native_comm(os.environ.get('DLWPCS_BENCH_NATIVE_RCCL', '1') == '1')
     result = measure(args, args.dtype, rank, world, with_roofline=not args.no_roofline,
                      with_pmc=single and not args.no_pmc)
     if world > 1:

@@ -273,12 +273,49 @@ def dgrad_gather_plan_host(N):
 
 
 _gather_ok = set()
+_lds_probe = {}
+
+
+def _run_lds_oob_probe(device):
+    """One dlwpcs_lds_oob_probe launch on `device`: the number of non-zero words the device returned for LDS reads beyond a
+    workgroup's allocation (0 on gfx950)."""
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        nz = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        check(lib().dlwpcs_lds_oob_probe(nz.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), 'dlwpcs_lds_oob_probe')
+        return int(nz.item())
+
+
+def _capturing():
+    return torch.cuda.is_current_stream_capturing()
+
+
+def lds_oob_reads_zero(device):
+    """Does this device return zeros for LDS reads beyond the workgroup's allocation?  The gather-form data gradient (conv_ws.h,
+    EDGE) and the batched weight gradient's slab tails (wgrad_batch.hip) mask operands by ADDRESS on that property; one probe
+    launch per device at first use decides it (never inside a graph capture: the answer is read back), a failing device gets
+    a warning and the padded-grid data gradient / per-layer weight gradients."""
+    key = str(torch.device(device))
+    hit = _lds_probe.get(key)
+    if hit is None:
+        if _capturing():
+            raise NativeError('lds_oob_reads_zero(%s): first use inside a graph capture (run one eager step first)' % key)
+        bad = _run_lds_oob_probe(device)
+        hit = bad == 0
+        if not hit:
+            import warnings
+            warnings.warn('%s: LDS reads beyond the allocation returned %d non-zero words (dlwpcs_lds_oob_probe): the gather-form '
+                          'data gradient and the batched weight gradient are switched off on this device (padded-grid / '
+                          'per-layer kernels serve)' % (key, bad))
+        _lds_probe[key] = hit
+    return hit
 
 
 def dgrad_gather_ready(N, p, device):
-    """True when halo_tables(N, p, device)[1] is a dlwpcs_dgrad_gather_plan buffer (CONV_DGRAD_GATHER may be set)."""
+    """True when halo_tables(N, p, device)[1] is a dlwpcs_dgrad_gather_plan buffer AND the device passed the LDS out-of-range
+    probe (CONV_DGRAD_GATHER may be set)."""
     halo_tables(N, p, device)
-    return (int(N), int(p), str(device)) in _gather_ok
+    return (int(N), int(p), str(device)) in _gather_ok and lds_oob_reads_zero(device)
 
 
 def halo_tables(N, p, device):

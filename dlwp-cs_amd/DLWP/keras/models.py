@@ -24,6 +24,7 @@ import torch
 
 from .. import ops, parallel
 from ..options import option
+from .. import _native as _nat
 from .._native import ACT_LEAKY_CLIP, ACT_NONE
 from . import backend, callbacks as cbks, optimizers, staging
 from .engine import KTensor, Layer
@@ -104,6 +105,7 @@ class Model(object):
         self._graphs = {}
         self._infer_graphs = {}         # rollout_passes_on_device: captured chains of forward passes
         self._rollout_series = {}       # rollout_on_device: the device buffer a batch's series is written to
+        self.rollout_keep_bytes = 4 << 30   # ... kept between calls (with its captured chain) up to this size
         self._seen_batch = {}
         self._toposort()
         self._build_plan()
@@ -625,6 +627,8 @@ class Model(object):
         self._seen_batch.clear()
         self._world = parallel.world()[1]
         parallel.broadcast_parameters(self._flat_params)     # identical replicas: rank 0's initial weights everywhere
+        if parallel.exchange_wanted() and self._flat_params.is_cuda:
+            parallel.native_comm()      # (opt-in; agreed on by every rank HERE, outside any capture: see DLWP/parallel.py)
         self._compiled = True
 
     def _metric_names(self):
@@ -709,6 +713,10 @@ class Model(object):
         stats tensor (StopIteration.value)."""
         self._update_done = False
         self._did_split = False
+        if train and self.batch_wgrad and inputs and inputs[0].is_cuda and not _nat.lds_oob_reads_zero(inputs[0].device):
+            # the batched weight gradient masks slab tails by LDS address (wgrad_batch.hip): a device that failed the probe
+            # (warned once by _native) takes the per-layer weight-gradient kernels
+            self.batch_wgrad = False
         if len(targets) != len(self.outputs):
             raise ValueError('Error when checking model target: expected %d target arrays, got %d'
                              % (len(self.outputs), len(targets)))
@@ -1164,6 +1172,7 @@ class Model(object):
         cbl = cbks.CallbackList([history] + list(callbacks or []), self, params)
         self.history = history
         self.stop_training = False
+        self.release_rollout_buffers()      # (a rollout's series buffer + captured chain: up to rollout_keep_bytes of HBM)
         cbl.call('on_train_begin', None)
         dev = backend.device()
         for epoch in range(initial_epoch, epochs):
@@ -1369,6 +1378,8 @@ class Model(object):
             if not graphs_ok:
                 return chain(state, True)
             g = self._infer_graphs.get(key)
+            if g is False:
+                return chain(state, True)                           # (this chain could not be captured: eager, like round 4)
             if g is None:
                 n = self._seen_batch.get(key, 0)
                 self._seen_batch[key] = n + 1
@@ -1385,6 +1396,16 @@ class Model(object):
                     mode = 'thread_local' if parallel.group_alive() else 'global'
                     with torch.cuda.graph(graph, capture_error_mode=mode):
                         out = chain(sin, False)
+                except Exception as exc:
+                    # a plan step that cannot be captured (a generic layer with a host synchronisation, a user Lambda, a table
+                    # uploaded at first use): the model keeps working the way it did without graphs
+                    import warnings
+                    warnings.warn('capturing the rollout into a hipGraph failed (%s: %s); this rollout shape runs eagerly'
+                                  % (type(exc).__name__, exc))
+                    del graph
+                    torch.cuda.synchronize()
+                    self._infer_graphs[key] = False
+                    return chain(state, True)
                 finally:
                     if gc_was_enabled:
                         gc.enable()
@@ -1417,13 +1438,24 @@ class Model(object):
                 skey = ((steps * n_steps,) + tuple(state.shape), str(state.device))
                 series = self._rollout_series.get(skey)
                 if series is None:
-                    self._rollout_series.clear()                    # (one shape at a time: a C96 series of 40 steps is 18 GB)
+                    self.release_rollout_buffers()                  # (one shape at a time: a C96 series of 40 steps is 18 GB)
                     series = self._rollout_series[skey] = torch.empty(skey[0], dtype=torch.float32, device=state.device)
-                if verbose > 0 and s == 0:
-                    for t in range(steps):
-                        print('Prediction step %d/%d' % (t + 1, steps))
+                if verbose > 0:
+                    # (the chain is one graph replay: the steps of a batch finish together)
+                    print('Prediction steps 1-%d/%d (samples %d-%d of %d)' % (steps, steps, s + 1, min(s + bs, n), n))
                 self.rollout_passes_on_device(state, steps, series=series, n_steps=n_steps)
                 out_series[:, s:s + bs] = series.cpu().numpy()
+            if self._rollout_series and next(iter(self._rollout_series.values())).numel() * 4 > self.rollout_keep_bytes:
+                self.release_rollout_buffers()                      # a large series does not outlive the call (a fit() may follow)
+
+    def release_rollout_buffers(self):
+        """Free the device buffers rollouts keep between calls: the series buffer and every captured chain that writes into it
+        (its graph keeps a private activation pool alive)."""
+        live = {t.data_ptr() for t in self._rollout_series.values()}
+        for k in [k for k in self._infer_graphs if k[0] == 'rollout' and k[-1] is not None and k[-1][0] in live]:
+            del self._infer_graphs[k]
+            self._seen_batch.pop(k, None)
+        self._rollout_series.clear()
 
     def _input_roles(self):
         """(main, [solar...], constants | None) indices into self.inputs: by the names the reference scripts use

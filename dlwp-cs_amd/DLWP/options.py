@@ -28,19 +28,37 @@ DEFAULTS = {
 }
 
 
+_parsed = {}
+
+
+def _parse(env):
+    """{name: bool} of one DLWPCS_OPTIONS string (cached per distinct string: option() sits on eager hot paths)."""
+    hit = _parsed.get(env)
+    if hit is None:
+        hit = {}
+        for item in env.split(','):
+            item = item.strip()
+            if not item:
+                continue
+            k, _, v = item.partition('=')
+            k = k.strip()
+            if k not in DEFAULTS:
+                raise KeyError('DLWPCS_OPTIONS: unknown engine option %r (known: %s)' % (k, ', '.join(sorted(DEFAULTS))))
+            hit[k] = v.strip() not in ('0', 'false', 'False', 'off', '')
+        if len(_parsed) > 64:
+            _parsed.clear()
+        _parsed[env] = hit
+    return hit
+
+
 def option(name):
     """Current value of engine option `name` (DLWPCS_OPTIONS overrides the default)."""
     if name not in DEFAULTS:
         raise KeyError('unknown engine option %r (known: %s)' % (name, ', '.join(sorted(DEFAULTS))))
-    val = DEFAULTS[name]
-    for item in os.environ.get('DLWPCS_OPTIONS', '').split(','):
-        item = item.strip()
-        if not item:
-            continue
-        k, _, v = item.partition('=')
-        k = k.strip()
-        if k not in DEFAULTS:
-            raise KeyError('DLWPCS_OPTIONS: unknown engine option %r (known: %s)' % (k, ', '.join(sorted(DEFAULTS))))
-        if k == name:
-            val = v.strip() not in ('0', 'false', 'False', 'off', '')
-    return val
+    return _parse(os.environ.get('DLWPCS_OPTIONS', '')).get(name, DEFAULTS[name])
+
+
+def snapshot():
+    """Every option's current value (a Model keeps one from its construction: its captured graphs belong to that configuration)."""
+    over = _parse(os.environ.get('DLWPCS_OPTIONS', ''))
+    return {k: over.get(k, v) for k, v in DEFAULTS.items()}

@@ -22,65 +22,125 @@ def broadcast_parameters(flat_params, src=0):
 
 
 # ---------------------------------------------------------------------------------------------------------------------- #
-# The library's own RCCL communicator (include/dlwpcs.h: dlwpcs_comm_* / dlwpcs_allreduce_f32; round 5): the step's one exchange
-# is enqueued on the COMPUTE stream through the C ABI, so that in a captured training step it is a plain node of the step's graph
-# (torch's ProcessGroupNCCL runs its collectives on a stream of its own: a fork / join around the collective, 17 us per step in
-# the captured form).  Created on first use -- a collective over the torch process group, which carries the 128-byte unique id
-# and the ranks' agreement that every one of them has a communicator (else nobody uses it: torch's all-reduce serves).
-# DLWPCS_NATIVE_RCCL=0 turns it off.
+# The library's own RCCL communicator (include/dlwpcs.h: dlwpcs_comm_* / dlwpcs_allreduce_f32): the step's one exchange enqueued
+# on the COMPUTE stream through the C ABI, so that in a captured training step it is a plain node of the step's graph (torch's
+# ProcessGroupNCCL runs its collectives on a stream of its own: a fork / join around the collective, 17 us per captured step).
+#
+# OPT-IN (enable_native_comm(True) or DLWPCS_NATIVE_RCCL=1): it has never run on more than one GPU -- torch's all_reduce is the
+# default exchange until a run with >= 2 ranks has been seen.  Whoever opts in gets a communicator that
+#   * is agreed on by EVERY rank (the request itself is part of the agreement: a rank that did not opt in, could not load RCCL or
+#     could not create its communicator moves ALL ranks to torch's all_reduce -- no subset of ranks can wait for the others),
+#   * has summed a test vector over the ranks and found n(n+1)/2 everywhere before it is handed out,
+#   * belongs to ONE process group: a new init_process_group() releases it and the next call creates a fresh one,
+#   * is never created inside a graph capture (the agreement reads flags back): a capture that comes first takes torch's path.
 # ---------------------------------------------------------------------------------------------------------------------- #
-_native = {'tried': False, 'comm': None}
+NATIVE_COMM = None      # None: DLWPCS_NATIVE_RCCL decides (default off); True / False: enable_native_comm()
+_native = {'tried': False, 'comm': None, 'group': None, 'why': 'not requested'}
+
+
+def enable_native_comm(on=True):
+    """Ask for (or refuse) the library-owned RCCL communicator for the gradient exchange; every rank must make the same call before
+    its first training step (ranks that disagree all end up on torch's all_reduce).  Overrides DLWPCS_NATIVE_RCCL."""
+    global NATIVE_COMM
+    NATIVE_COMM = None if on is None else bool(on)
+    if _native['tried']:
+        native_comm_release()           # the next native_comm() call decides anew (a collective: every rank makes this call)
+
+
+def _native_wanted():
+    import os
+    if NATIVE_COMM is not None:
+        return NATIVE_COMM
+    return os.environ.get('DLWPCS_NATIVE_RCCL', '0') == '1'
+
+
+def _group_token():
+    """The default process group OBJECT (identity = this init_process_group() call), None outside one."""
+    try:
+        return dist.distributed_c10d._get_default_group() if group_alive() else None
+    except Exception:
+        return None
+
+
+def _min_over_ranks(ok, dev, n):
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    if n > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
 
 
 def native_comm():
-    """ctypes handle of the library-owned communicator of this process group, or None.  Collective on first call."""
+    """ctypes handle of the library-owned communicator of the CURRENT process group, or None (not asked for, not possible, not
+    agreed on; native_comm_status() says which).  Collective on the first call per process group: every rank calls it at the same
+    point (Model.compile does)."""
     import os
+    token = _group_token()
+    if _native['tried'] and _native['group'] is not token:
+        native_comm_release(stale=True)                 # the group it was created over is gone (destroy + init again)
     if _native['tried']:
         return _native['comm']
-    if not (group_alive() and dist.get_backend() == 'nccl' and torch.cuda.is_available()):
+    if token is None or dist.get_backend() != 'nccl' or not torch.cuda.is_available():
         return None
-    _native['tried'] = True
-    if os.environ.get('DLWPCS_NATIVE_RCCL', '1') == '0':
-        return None
+    if torch.cuda.is_current_stream_capturing():
+        return None                                     # (not remembered: the first call outside a capture decides)
+    _native['tried'], _native['group'] = True, token
     import ctypes
     from . import _native as nat
     lib = nat.lib()
     rank, n = dist.get_rank(), dist.get_world_size()
     dev = torch.device('cuda', torch.cuda.current_device())
     path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
-    ok = os.path.exists(path) and lib.dlwpcs_comm_load(path.encode()) == 0
+    want = _native_wanted()
+    ok = want and os.path.exists(path) and lib.dlwpcs_comm_load(path.encode()) == 0
     idbuf = (ctypes.c_char * 128)()
     if rank == 0 and ok:
         ok = lib.dlwpcs_comm_unique_id(idbuf) == 0
-    # the id travels as a device tensor over the existing group (every rank takes part, whatever its own `ok` says)
+    # the id travels as a device tensor over the existing group; EVERY rank takes part in both collectives whatever its own
+    # `want` / `ok` says -- the request is agreed on like everything else
     idt = torch.frombuffer(bytearray(bytes(idbuf)), dtype=torch.uint8).to(dev)
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     if n > 1:
         dist.broadcast(idt, src=0)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if not _min_over_ranks(ok, dev, n):
+        _native['why'] = ('not requested (enable_native_comm / DLWPCS_NATIVE_RCCL=1)' if not want else
+                          'RCCL could not be loaded or a rank did not ask for it')
+        return None
     comm = ctypes.c_void_p()
-    if int(flag.item()):
-        raw = bytes(idt.cpu().numpy().tobytes())
-        ok = lib.dlwpcs_comm_init(ctypes.byref(comm), raw, rank, n) == 0
-    else:
-        ok = False
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-    if n > 1:
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()):
-        _native['comm'] = comm
-    elif ok:
+    raw = bytes(idt.cpu().numpy().tobytes())
+    ok = lib.dlwpcs_comm_init(ctypes.byref(comm), raw, rank, n) == 0
+    if not _min_over_ranks(ok, dev, n):
+        if ok:
+            lib.dlwpcs_comm_destroy(comm)
+        _native['why'] = 'a rank could not create its communicator: %s' % (lib.dlwpcs_last_error() or b'').decode()
+        return None
+    # real sums before anybody trusts it: rank r contributes r + 1 in every slot
+    probe = torch.full((4099,), float(rank + 1), dtype=torch.float32, device=dev)
+    rc = lib.dlwpcs_allreduce_f32(comm, probe.data_ptr(), probe.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ok = rc == 0 and bool((probe == float(n * (n + 1) // 2)).all().item())
+    if not _min_over_ranks(ok, dev, n):
         lib.dlwpcs_comm_destroy(comm)
-    return _native['comm']
+        _native['why'] = 'the test sum over %d ranks came back wrong on a rank' % n
+        import warnings
+        warnings.warn('DLWP.parallel: the library-owned RCCL communicator failed its test sum; torch.distributed.all_reduce serves')
+        return None
+    _native['comm'], _native['why'] = comm, 'ok (%d ranks, test sum verified)' % n
+    return comm
 
 
-def native_comm_release():
-    """Destroy the library-owned communicator (before the process group it was created over goes away)."""
+def native_comm_status():
+    """Why native_comm() answers what it answers (bench.py writes it into its JSON line)."""
+    return _native['why']
+
+
+def native_comm_release(stale=False):
+    """Destroy the library-owned communicator (before the process group it was created over goes away; native_comm() does it
+    itself when it finds a new group)."""
     if _native['comm'] is not None:
         from . import _native as nat
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         nat.lib().dlwpcs_comm_destroy(_native['comm'])
-    _native['comm'], _native['tried'] = None, False
+    _native.update(comm=None, tried=False, group=None, why='released' if not stale else 'not requested')
 
 
 def allreduce_gradients(flat_grads):

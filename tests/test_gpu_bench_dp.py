@@ -30,6 +30,9 @@ def test_bench_two_ranks_share_one_gpu():
     ex = r['exchange']
     assert ex['rccl_ranks'] == 2 and ex['backend'] == 'gloo' and ex['allreduce_us'] > 0 and ex['bytes'] > 0
     assert ex['buckets'] in (1, 2) and set(ex['bucket_trials_ms_per_step']) == {'1', '2'}
+    # the line says which collective served and that the replicas were identical after the warm-up steps (gloo here: torch's)
+    assert ex['replicas_identical_after_warmup'] is True and ex['collective'].startswith('torch.distributed.all_reduce')
+    assert ex['native_comm_requested'] is True
     assert ex['exposed_us'] is not None and ex['ms_per_step_without_exchange'] > 0
     assert len(r['timing']['block_ms_per_step']) == 3 and r['ms_per_step'] > 0
 
@@ -66,8 +69,15 @@ assert dist.get_backend() == 'nccl'
 g = torch.arange(673628, dtype=torch.float32, device='cuda')
 ref = g.clone()
 os.environ['DLWPCS_EXCHANGE_FORCE'] = '1'
-# the library-owned communicator (dlwpcs_comm_*): created over the torch group, its all-reduce runs on the CURRENT stream ...
-assert parallel.native_comm() is not None
+# torch's all_reduce is the default exchange; the library-owned communicator (dlwpcs_comm_*) is opt-in ...
+assert parallel.native_comm() is None and 'not requested' in parallel.native_comm_status()
+parallel.allreduce_gradients(g)
+torch.cuda.synchronize()
+assert torch.equal(g, ref)
+# ... created over the torch group once every rank asked for it and its test sum came back right; its all-reduce runs on the
+# CURRENT stream ...
+parallel.enable_native_comm(True)
+assert parallel.native_comm() is not None and 'test sum verified' in parallel.native_comm_status()
 scale = parallel.allreduce_gradients(g)
 parallel.broadcast_parameters(g)
 torch.cuda.synchronize()
@@ -93,13 +103,38 @@ for _ in range(3):
 torch.cuda.synchronize()
 assert torch.equal(g, ref)
 del gr
-# torch's own all_reduce serves when the library's communicator is switched off
-parallel.native_comm_release()
-os.environ['DLWPCS_NATIVE_RCCL'] = '0'
+# torch's own all_reduce serves again when the request is withdrawn; the environment variable asks like the call does
+parallel.enable_native_comm(False)
 assert parallel.native_comm() is None
 parallel.allreduce_gradients(g)
 torch.cuda.synchronize()
 assert torch.equal(g, ref)
+parallel.enable_native_comm(None)
+os.environ['DLWPCS_NATIVE_RCCL'] = '1'
+c1 = parallel.native_comm()
+assert c1 is not None
+# a first call inside a capture of a fresh state creates nothing (the agreement reads flags back) and decides nothing
+parallel.native_comm_release()
+gr = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr, capture_error_mode='thread_local'):
+    assert parallel.native_comm() is None
+    parallel.allreduce_gradients(g)
+gr.replay()
+torch.cuda.synchronize()
+assert torch.equal(g, ref)
+del gr
+assert parallel.native_comm() is not None
+# the communicator belongs to ONE process group: destroy + init again -> the stale one is released, a fresh one is created
+old_group = parallel._native['group']
+dist.destroy_process_group()
+assert parallel.native_comm() is None
+dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29534', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+c2 = parallel.native_comm()
+assert c2 is not None and parallel._native['group'] is not old_group
+parallel.allreduce_gradients(g)
+torch.cuda.synchronize()
+assert torch.equal(g, ref)
+os.environ.pop('DLWPCS_NATIVE_RCCL')
 os.environ.pop('DLWPCS_EXCHANGE_FORCE')
 # the captured form of the step: all-reduce between two graph replays
 s = torch.cuda.Stream()
@@ -150,7 +185,12 @@ def train(buckets, w0=None):
 w0, plain, _ = train(1)
 dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29541', rank=0, world_size=1, device_id=dev)
 os.environ['DLWPCS_EXCHANGE_FORCE'] = '1'
+from DLWP import parallel as _par
+_, one_t, _m = train(1, w0)                       # default exchange: torch.distributed.all_reduce
+assert _par.native_comm() is None and np.array_equal(plain, one_t)
+_par.enable_native_comm(True)                     # opt-in: the library-owned communicator
 _, one, m1 = train(1, w0)
+assert _par.native_comm() is not None
 _, two, m2 = train(2, w0)
 g = next(iter(m2._graphs.values()))
 assert g['bwd_b'] is not None and g['update'] is not None and m2._did_split
@@ -212,11 +252,14 @@ for pol, N, C, base in cases:
     plain[pol] = (x, t) + train(pol, N, C, base, x, t)[:3]
 dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29547', rank=0, world_size=1, device_id=dev)
 os.environ['DLWPCS_EXCHANGE_FORCE'] = '1'
+from DLWP import parallel as _par
 for pol, N, C, base in cases:
     x, t, w0, ref, lref = plain[pol]
-    for one_graph in ('1', '0'):
+    for one_graph, native in (('1', True), ('1', False), ('0', True)):
         os.environ['DLWPCS_DP_ONE_GRAPH'] = one_graph
+        _par.enable_native_comm(native)           # (the library's communicator on the compute stream | torch's all_reduce)
         _, got, lgot, m = train(pol, N, C, base, x, t, w0)
+        assert (_par.native_comm() is not None) == native
         g = next(iter(m._graphs.values()))
         assert (g['update'] is None) == (one_graph == '1'), (pol, one_graph)
         assert np.array_equal(ref, got), (pol, one_graph, np.abs(ref - got).max())
