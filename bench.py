@@ -79,12 +79,31 @@ def conv_plan(workload, c_in, c_out, base):
     return enc + [(2, 4 * b, 2 * b, 3), (2, 2 * b, b, 3), (1, 2 * b, b, 3), (1, b, b, 3), (1, b, c_out, 1)]
 
 
+# --workload unet2x2: the model every reference CS script trains (Azure/train_cs.py:99-104,391-430): 4 variables x 2 time steps,
+# insolation as a fifth input field per time step, two constant fields, integration_steps = 2 with shared weights
+X2_VARS, X2_ITS, X2_CONST, X2_STEPS = 4, 2, 2, 2
+
+
+def x2_channels():
+    """(main-input channels, CNN input channels, output channels) of the production model"""
+    c_main = (X2_VARS + 1) * X2_ITS
+    return c_main, c_main + X2_CONST, X2_VARS * X2_ITS
+
+
 def flops_per_sample(workload, N, c_in, c_out, base):
+    if workload == 'unet2x2':
+        _, ci, co = x2_channels()
+        return X2_STEPS * flops_per_sample('unet2', N, ci, co, base)
     wl = 'unet2' if workload == 'rollout' else workload
     return sum(2.0 * 6 * (N // r) ** 2 * k * k * ci * co for (r, ci, co, k) in conv_plan(wl, c_in, c_out, base))
 
 
 def build_model(workload, N, c_in, c_out, base):
+    if workload == 'unet2x2':
+        from DLWP.model.cs_unet import build_cs_model
+        c_main, _, co = x2_channels()
+        return build_cs_model((6, N, N, c_main), co, 'unet2', base_filter_number=base, integration_steps=X2_STEPS,
+                              io_time_steps=X2_ITS, insolation_shape=(X2_ITS, 6, N, N, 1), constants_shape=(6, N, N, X2_CONST))
     from DLWP.model.cs_unet import CubeSphereNet
     from DLWP.keras.layers import Input
     from DLWP.keras.models import Model
@@ -313,13 +332,23 @@ def prepare(args, dtype, rank):
     adt = torch.bfloat16 if dtype == 'bf16' else torch.float32
     rng = np.random.default_rng(1000 + rank)
     dev = backend.device()
-    dx = [torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(adt)]
+    def rnd(*shape):
+        return torch.tensor(rng.standard_normal(shape), dtype=torch.float32, device=dev)
+    if args.workload == 'unet2x2':
+        c_main, _, co = x2_channels()
+        # [main_input, solar_1, constants] as the reference's generator yields them (Azure/train_cs.py:191-194,392-396)
+        dx = [rnd(B, 6, N, N, c_main).to(adt), rnd(B, X2_ITS, 6, N, N, 1).to(adt), rnd(B, 6, N, N, X2_CONST).to(adt)]
+        st = {'model': model, 'dx': dx, 'dev': dev, 'train': True}
+        model.compile(optimizer='adam', loss='mse', loss_weights=[1. / X2_STEPS] * X2_STEPS, metrics=['mae'])
+        st['dt'] = [rnd(B, 6, N, N, co) for _ in range(X2_STEPS)]
+        return st
+    dx = [rnd(B, 6, N, N, C).to(adt)]
     st = {'model': model, 'dx': dx, 'dev': dev, 'train': args.workload != 'rollout'}
     if st['train']:
         model.compile(optimizer='adam', loss='mse')
         with torch.no_grad():
             oshape = model.predict_on_device(dx[0][:1]).shape[1:]
-        st['dt'] = [torch.tensor(rng.standard_normal((B,) + tuple(oshape)), dtype=torch.float32, device=dev)]
+        st['dt'] = [rnd(*((B,) + tuple(oshape)))]
     else:
         st['n_fwd'] = args.rollout_steps // 2          # time_dim = 2: one forward pass per two forecast steps
     return st
@@ -667,6 +696,12 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
         metric, unit = 'cubed-sphere samples/sec (fwd+bwd)', 'samples/s'
         what = '%s C%d: x (%d,6,%d,%d,%d) per GPU, %d out channels, base %d, MSE + Adam, fwd+bwd+update, %s' % (
             args.workload, N, B, N, N, C, C if args.workload == 'unet2' else 2 * base, base, prec)
+        if args.workload == 'unet2x2':
+            c_main, ci, co = x2_channels()
+            what = ('unet2x2 C%d (the reference scripts\' production model, Azure/train_cs.py:99-104,391-430): integration_steps = %d with '
+                    'shared weights, inputs main (%d,6,%d,%d,%d) + solar_1 (%d,%d,6,%d,%d,1) + constants (%d,6,%d,%d,%d) per GPU -> the CNN '
+                    'sees %d channels, %d outputs of %d channels, base %d, loss_weights [1/%d]*%d, MSE + MAE + Adam, fwd+bwd+update, %s'
+                    % (N, X2_STEPS, B, N, N, c_main, B, X2_ITS, N, N, B, N, N, X2_CONST, ci, X2_STEPS, co, base, X2_STEPS, X2_STEPS, prec))
         flops_step = 3 * fps * B
     else:
         metric, unit = 'cubed-sphere rollouts/sec (%d-step, inference)' % args.rollout_steps, 'rollouts/s'
@@ -829,7 +864,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='unet2', choices=['unet2', 'encoder6', 'rollout'])
+    ap.add_argument('--workload', default='unet2', choices=['unet2', 'encoder6', 'rollout', 'unet2x2'])
     ap.add_argument('--batch', type=int, default=32, help='samples per GPU per step')
     ap.add_argument('--face', type=int, default=None, help='cube face size (48; rollout: 96)')
     ap.add_argument('--channels', type=int, default=None,
@@ -860,7 +895,7 @@ def main():
     if args.face is None:
         args.face = 96 if args.workload == 'rollout' else 48
     if args.channels is None:
-        args.channels = 26 if args.workload == 'rollout' else 14
+        args.channels = 26 if args.workload == 'rollout' else (x2_channels()[1] if args.workload == 'unet2x2' else 14)
 
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner through C stdio when
     # a communicator is created, flushed at process exit): file descriptor 1 is pointed at stderr for the life of the process and
@@ -932,7 +967,8 @@ def main():
         # BASELINE configs 2 and 5, timed by the same clock in the same run (their own lines: --workload encoder6 / rollout)
         import copy
         result['configs'] = {}
-        for key, wl, ch, face, dt in (('cfg2_encoder6_f32', 'encoder6', 7, 48, 'f32'), ('cfg5_rollout_bf16', 'rollout', 26, 96, 'bf16')):
+        for key, wl, ch, face, dt in (('cfg2_encoder6_f32', 'encoder6', 7, 48, 'f32'), ('cfg5_rollout_bf16', 'rollout', 26, 96, 'bf16'),
+                                      ('production_unet2x2_bf16', 'unet2x2', 12, 48, 'bf16')):
             a2 = copy.copy(args)
             a2.workload, a2.channels, a2.face, a2.dtype = wl, ch, face, dt
             a2.blocks, a2.min_block_s, a2.steps, a2.warmup, a2.pmc_out = 3, 0.3, (20 if wl == 'rollout' else 100), 5, None
@@ -949,7 +985,7 @@ def main():
                                                            'traffic_vs_algorithmic', 'hbm_gbs', 'mfma_busy', 'pmc_source', 'pmc_error', 'pmc_missing')
                                    if k in rf2}
             result['configs'][key] = ent
-    if rank == 0 and single and not args.no_cpu_baseline:
+    if rank == 0 and single and not args.no_cpu_baseline and args.workload != 'unet2x2':     # (the port times single-input networks)
         result['cpu_baseline'] = cpu_baseline(args.workload, args.face, args.channels, args.channels, args.base, args.batch)
     if rank == 0:
         line = json.dumps(result) + '\n'

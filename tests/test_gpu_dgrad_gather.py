@@ -196,47 +196,56 @@ def test_lds_reads_beyond_the_allocation_return_zero():
 
 def test_a_device_that_fails_the_probe_trains_on_the_fallback_kernels(monkeypatch):
     """DLWP._native.lds_oob_reads_zero gates the gather form and the batched weight gradient: with the probe's answer forced to
-    'non-zero words' a bf16 `unet2` step runs the padded-grid data gradient + per-layer weight gradients (one warning) and moves the
-    weights the way the default kernels do."""
+    'non-zero words' a bf16 `unet2` step runs the padded-grid data gradient + per-layer weight gradients (one warning) -- BITWISE the
+    step of the engine options dgrad_gather=0,wgrad_batch=0 (the same kernels, chosen by the gate instead of by hand) -- and moves
+    the weights the way the default kernels do."""
+    import os
     import warnings
     from DLWP import _native as nat
     from DLWP.keras import backend
     from DLWP.model.cs_unet import build_cs_model
     dev = _dev()
     backend.set_device('cuda:0')
-    N, C, B = 24, 14, 2
+    N, C, B = 24, 14, 4
     rng = np.random.default_rng(11)
     x = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     t = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
     w0, out = None, []
-    for fail in (False, True):
+    try:
+        for mode in ('default', 'probe_fails', 'options_off'):
+            monkeypatch.setattr(nat, '_lds_probe', {})
+            monkeypatch.setattr(nat, '_run_lds_oob_probe', (lambda device: 3) if mode == 'probe_fails' else (lambda device: 0))
+            os.environ['DLWPCS_OPTIONS'] = 'dgrad_gather=0,wgrad_batch=0' if mode == 'options_off' else ''
+            backend.set_compute_dtype('bfloat16')
+            try:
+                np.random.seed(5)
+                model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=32)
+            finally:
+                backend.set_compute_dtype('float32')
+            model.compile(optimizer='adam', loss='mse', metrics=['mae'])
+            if w0 is None:
+                w0 = model.get_weights()
+            model.set_weights(w0)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter('always')
+                for _ in range(4):
+                    stats = model.train_on_device_batch([x], [t])
+                torch.cuda.synchronize()
+            warned = [m for m in w if 'dlwpcs_lds_oob_probe' in str(m.message)]
+            assert len(warned) == (1 if mode == 'probe_fails' else 0)
+            assert model.batch_wgrad == (mode == 'default')
+            if mode != 'options_off':
+                assert nat.dgrad_gather_ready(N, 1, dev) == (mode == 'default')
+            out.append((np.concatenate([p.ravel() for p in model.get_weights()]), stats.cpu().numpy().copy()))
+    finally:
+        os.environ.pop('DLWPCS_OPTIONS', None)
         monkeypatch.setattr(nat, '_lds_probe', {})
-        if fail:
-            monkeypatch.setattr(nat, '_run_lds_oob_probe', lambda device: 3)
-        backend.set_compute_dtype('bfloat16')
-        try:
-            np.random.seed(5)
-            model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=32)
-        finally:
-            backend.set_compute_dtype('float32')
-        model.compile(optimizer='adam', loss='mse', metrics=['mae'])
-        if w0 is None:
-            w0 = model.get_weights()
-        model.set_weights(w0)
-        with warnings.catch_warnings(record=True) as w:
-            warnings.simplefilter('always')
-            for _ in range(4):
-                stats = model.train_on_device_batch([x], [t])
-            torch.cuda.synchronize()
-        warned = [m for m in w if 'dlwpcs_lds_oob_probe' in str(m.message)]
-        assert len(warned) == (1 if fail else 0)
-        assert model.batch_wgrad == (not fail)
-        assert nat.dgrad_gather_ready(N, 1, dev) == (not fail)
-        out.append((np.concatenate([p.ravel() for p in model.get_weights()]), stats.cpu().numpy().copy()))
-    monkeypatch.setattr(nat, '_lds_probe', {})
-    (p_ok, s_ok), (p_fb, s_fb) = out
+    (p_ok, s_ok), (p_fb, s_fb), (p_off, s_off) = out
+    assert np.array_equal(p_fb, p_off) and np.array_equal(s_fb, s_off)
     flat0 = np.concatenate([p.ravel() for p in w0])
     a, b = p_ok - flat0, p_fb - flat0
     cos = float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b)))
-    assert np.isfinite(p_fb).all() and cos > 0.99, cos
+    # (four Adam steps normalise every entry's update to ~lr: entries whose gradient is bf16 noise flip freely, the direction of the
+    # rest must agree; the loss after the steps pins the size)
+    assert np.isfinite(p_fb).all() and cos > 0.9, cos
     assert abs(s_fb[0, 0] - s_ok[0, 0]) <= 5e-3 * abs(s_ok[0, 0])

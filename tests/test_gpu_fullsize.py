@@ -488,3 +488,68 @@ def test_cfg2_encoder6_full_batch_fp32():
     orc.mse_loss(orc.encoder6_forward(torch.tensor(x[:8], dtype=torch.float64), prm), torch.tensor(t[:8], dtype=torch.float64)).backward()
     for g, name in zip(got, ('equatorial_kernel', 'polar_kernel', 'equatorial_bias', 'polar_bias')):
         assert rel_err(g, prm[0][name].grad.numpy()) < RTOL, name
+
+
+# ---------------------------------------------------------------------------------------------------------------------- #
+# The model every reference CS script trains (Azure/train_cs.py:99-104,391-430): integration_steps = 2 with shared weights,
+# inputs [main_input, solar_1, constants], two outputs, loss_weights [1/2, 1/2] -- at its own size (C48, base 32).
+# ---------------------------------------------------------------------------------------------------------------------- #
+def _production_oracle(main, solar, const, params, its):
+    """fp64 restatement of complete_model() (Azure/train_cs.py:391-408) on the oracle's unet2: channels are time-major, the
+    insolation of the second step's input time steps becomes the last channel of every time step, the constants ride behind."""
+    o1 = orc.unet2_forward(torch.cat([main, const], dim=-1), params)
+    B, F, N = o1.shape[0], o1.shape[1], o1.shape[2]
+    xo = o1.reshape(B, F, N, N, its, -1)
+    xo = torch.cat([xo, solar.permute(0, 2, 3, 4, 1, 5)], dim=-1).reshape(B, F, N, N, -1)
+    o2 = orc.unet2_forward(torch.cat([xo, const], dim=-1), params)
+    return o1, o2
+
+
+@pytest.mark.parametrize('dtype,tol_loss,tol_grad', [('float32', 1e-5, 1e-5), ('bfloat16', 1e-2, 3e-2)])
+def test_production_model_training_step_matches_oracle(dtype, tol_loss, tol_grad):
+    """unet2 x 2 (4 variables x 2 time steps + insolation + 2 constants -> the CNN sees 12 channels, 8 out; every layer applied
+    twice with shared weights) at C48 / base 32, batch 2: the training step's loss and every kernel / bias gradient against fp64
+    autograd of the oracle (bf16: on the bf16-rounded inputs and kernels the device consumes; tolerances as for config 3)."""
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    rng = np.random.default_rng(707)
+    N, V, ITS, K, B, base = 48, 4, 2, 2, 2, 32
+    c_main, c_out = (V + 1) * ITS, V * ITS
+    main = rng.standard_normal((B, 6, N, N, c_main)).astype(np.float32)
+    solar = rng.standard_normal((B, ITS, 6, N, N, 1)).astype(np.float32)
+    const = rng.standard_normal((B, 6, N, N, K)).astype(np.float32)
+    t1 = rng.standard_normal((B, 6, N, N, c_out)).astype(np.float32)
+    t2 = rng.standard_normal((B, 6, N, N, c_out)).astype(np.float32)
+    backend.set_compute_dtype(dtype)
+    try:
+        model = build_cs_model((6, N, N, c_main), c_out, 'unet2', base_filter_number=base, integration_steps=2, io_time_steps=ITS,
+                               insolation_shape=(ITS, 6, N, N, 1), constants_shape=(6, N, N, K))
+    finally:
+        backend.set_compute_dtype('float32')
+    model.compile(optimizer='adam', loss='mse', loss_weights=[0.5, 0.5], metrics=['mae'])
+    model.use_graphs = False
+    net = model.cs_net
+    convs = [net.conv_2d_1, net.conv_2d_1_2, net.conv_2d_2, net.conv_2d_2_2, net.conv_2d_5_2, net.conv_2d_5,
+             net.conv_2d_6_2, net.conv_2d_6, net.conv_2d_7, net.conv_2d_7_2, net.conv_2d_8]
+    params = orc.make_unet2_params(c_main + K, c_out, base=base, seed=11)
+    _set_params(convs, params)
+    hist = model.fit([main, solar, const], [t1, t2], batch_size=B, epochs=1, verbose=0, shuffle=False)
+    names = ('equatorial_kernel', 'polar_kernel', 'equatorial_bias', 'polar_bias')
+    if dtype == 'bfloat16':
+        rd = lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64)
+    else:
+        rd = lambda a: torch.tensor(a, dtype=torch.float64)
+    pr = [{n: (rd(v.numpy()) if 'kernel' in n else v.double().clone()).requires_grad_(True) for n, v in prm.items()} for prm in params]
+    o1, o2 = _production_oracle(rd(main), rd(solar), rd(const), pr, ITS)
+    loss = 0.5 * orc.mse_loss(o1, torch.tensor(t1, dtype=torch.float64)) + 0.5 * orc.mse_loss(o2, torch.tensor(t2, dtype=torch.float64))
+    loss.backward()
+    l_dev = hist.history['loss'][0]
+    assert abs(l_dev - loss.item()) < tol_loss * max(1.0, abs(loss.item())), (l_dev, loss.item())
+    g_dev = _flat_grad(convs)
+    g_ref = np.concatenate([prm[n].grad.numpy().ravel() for prm in pr for n in names])
+    cos = float(np.dot(g_dev, g_ref) / (np.linalg.norm(g_dev) * np.linalg.norm(g_ref)))
+    errs = [rel_err(w.grad.to(torch.float64).cpu().numpy(), prm[n].grad.numpy()) for lay, prm in zip(convs, pr) for w, n in zip(lay.weights, names)]
+    print('production model (%s) step vs oracle: loss %.6g / %.6g, cos %.7f, worst per-tensor gradient error %.3g'
+          % (dtype, l_dev, loss.item(), cos, max(errs)))
+    assert cos >= 0.9999, cos
+    assert max(errs) <= tol_grad, errs
