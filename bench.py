@@ -208,6 +208,8 @@ def parse_pmc_dir(d, segments=1):
                 if run == 2:
                     seg += 1
             continue
+        if '__amd_rocclr_fillBuffer' in k and run:      # (the probe's own memset node sits between two separator launches)
+            continue
         run = 0
         if 0 <= seg < segments:
             a = out[seg].setdefault(k, {}).setdefault(cname, [0, 0.0])
@@ -296,7 +298,11 @@ def collect_pmc_plan(plan, timeout_s=900, groups=None):
                 else:
                     errors.append(err)
                 continue
-            for seg, per_kernel in zip(merged, parse_pmc_dir(d, segments=len(plan))):
+            parsed = parse_pmc_dir(d, segments=len(plan))
+            if not any(parsed):
+                errors.append('rocprofv3 pass (%s): no counter rows behind a separator (rc 0); child said: %s'
+                              % (' '.join(group), ((r.stderr or '') + (r.stdout or ''))[-400:].replace('\n', ' ')))
+            for seg, per_kernel in zip(merged, parsed):
                 for k, cs in per_kernel.items():
                     seg.setdefault(k, {}).update(cs)
     finally:

@@ -831,7 +831,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int ps = 0; ps < NPS; ++ps) {
-                        const uint32_t boff = soff[nt][mt][ps], sel = (ssel >> (2 * ((nt * MT + mt) * NPS + ps))) & 3u;
+                        uint32_t boff = soff[nt][mt][ps];
+                        const uint32_t sel = (ssel >> (2 * ((nt * MT + mt) * NPS + ps))) & 3u;
+#ifdef DLWPCS_ABL_MASK8     // (side builds only: what would an 8x smaller mask tensor be worth?  wrong numbers, right traffic)
+                        if (boff != ST_SKIP) boff = (boff >> 3) & ~15u;
+#endif
                         u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r0, sel == 1 ? boff : ST_SKIP, 0, 0);
                         if (P.m1 != nullptr) {      // (uniform; a skip connection that is masked directly -- not in the U-Nets)
                             const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r1, sel == 2 ? boff : ST_SKIP, 0, 0);

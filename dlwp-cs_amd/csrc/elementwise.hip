@@ -416,7 +416,11 @@ __global__ void __launch_bounds__(256) avgpool2_bwd_masked_kernel(const V *__res
         auto sk = vzero<VT<V>::N>();
         if (dskip) sk = VT<V>::ld(dskip + e);
         auto mm = vzero<VT<V>::N>();
+#ifdef DLWPCS_ABL_MASK8
+        if (m) mm = VT<V>::ld(m + (e >> 3));
+#else
         if (m) mm = VT<V>::ld(m + e);
+#endif
         if (border) {
             const V *base = ring + b * (size_t)(6 * Mo * Mo) * CTV + choffV + cv;
             auto rs = vzero<VT<V>::N>();
