@@ -121,8 +121,6 @@ PROTOTYPES = {
                                         c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     'dlwpcs_wgrad_batch_adam_tail': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'dlwpcs_wgrad_batch_adam_fold': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
-                                             c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dlwpcs_wgrad_batch_apply': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dlwpcs_gconv_fwd': (c_int, [ctypes.POINTER(GConvDesc)] + [c_void_p] * 9),

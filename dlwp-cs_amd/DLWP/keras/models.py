@@ -1208,9 +1208,6 @@ class Model(object):
             finally:
                 feed.close()
             logs = dict(zip(names, self._assemble_logs(sums, count)))
-            if ops.wgrad_fold_faults():        # (the host is synchronised here anyway: the epoch's sums were just read back)
-                raise RuntimeError('a one-launch weight-gradient + optimizer step gave up at its grid barrier (a workgroup never became '
-                                   'resident): its update was skipped.  Set DLWPCS_OPTIONS=fold_reduce=0 on this device.')
             if validation_data is not None:
                 vals = self._evaluate_impl(validation_data, None, batch_size, validation_steps)
                 logs.update({'val_' + k: v for k, v in zip(names, vals)})

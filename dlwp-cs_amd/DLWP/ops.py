@@ -298,25 +298,6 @@ def _wb_items(entries):
     return arr, tuple(key)
 
 
-_wb_sync = {}
-
-
-def _wb_sync_words(dev):
-    """{arrivals, sense, fault, -} of dlwpcs_wgrad_batch_adam_fold's grid barrier: zero-initialised once, self-resetting; one set per
-    (device, stream) so that two steps in flight on different streams never share it."""
-    key = (str(dev), stream_ptr())
-    t = _wb_sync.get(key)
-    if t is None:
-        t = _wb_sync[key] = torch.zeros(4, dtype=torch.int32, device=dev)
-    return t
-
-
-def wgrad_fold_faults():
-    """Launches of the one-launch weight-gradient + optimizer step that gave up at their grid barrier (a worker never became
-    resident): their parameters were left untouched.  Host synchronisation; DLWP.keras.Model.fit asks once per epoch."""
-    return sum(int(t[2].item()) for t in _wb_sync.values())
-
-
 def wgrad_batch(entries, adam=None, packs=None):
     """entries: [(ConvDesc, src0, src1 | None, dz, halo table | None, (dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np)[, y])] with
     fp32 gradient tensors that are ACCUMULATED into (None where the layer has no such parameter).  dz is the gradient
@@ -336,16 +317,6 @@ def wgrad_batch(entries, adam=None, packs=None):
             tail = None
             if len(_pending_tail) == 1:
                 tail, keep = _pending_tail.pop()            # the step's loss is finished by this launch
-            if option('fold_reduce') and nat.lds_oob_reads_zero(dev):
-                # ONE launch: the workers meet at a grid barrier and run the reduction + optimizer themselves (the library falls back
-                # to two launches where a layer is applied twice)
-                pk_arr = _pack_array(packs[lo:lo + len(chunk)]) if packs is not None else None
-                check(lib().dlwpcs_wgrad_batch_adam_fold(arr, len(chunk), host, ptr(plan_dev), ptr(ws), ws.numel(), ptr(p), ptr(g),
-                                                         ptr(m), ptr(v), g.numel(), ptr(state), ptr(hyper),
-                                                         ctypes.byref(tail) if tail is not None else None, pk_arr,
-                                                         ptr(_wb_sync_words(dev)), stream_ptr()),
-                      'dlwpcs_wgrad_batch_adam_fold')
-                continue
             if tail is not None or packs is not None:
                 pk_arr = _pack_array(packs[lo:lo + len(chunk)]) if packs is not None else None
                 check(lib().dlwpcs_wgrad_batch_adam_tail(arr, len(chunk), host, ptr(plan_dev), ptr(ws), ws.numel(), ptr(p), ptr(g),

@@ -10,7 +10,6 @@ is asked for, so a test can set it around the construction of a model).  Everyth
   fuse_pack       ... which also refreshes the packed bf16 operands: replayed steps start without packing     (Model.fuse_pack)
   fuse_head       output layer + loss + loss gradient + the layer's data gradient as one launch               (Model.fuse_head_loss)
   fold_loss_tail  the loss's last reduction stage inside the step's last launch                               (Model.fold_loss_tail)
-  fold_reduce     ... and that launch IS the weight-gradient launch: reduction + optimizer behind a grid barrier             (ops)
   fuse_pool       2x2 average pooling written by the epilogue of the convolution in front of it               (Model.fuse_pool)
   fold_ring       (padded-grid data gradient) a pooled tensor's ring fix-up inside the pooling adjoint        (Model.fold_ring)
   cf_model        channels_first models run channels_last inside, one transpose per input / output            (Model)
@@ -24,7 +23,7 @@ import os
 
 DEFAULTS = {
     'graphs': True, 'premask': True, 'wgrad_batch': True, 'fuse_adam': True, 'fuse_pack': True, 'fuse_head': True,
-    'fold_loss_tail': True, 'fold_reduce': True, 'fuse_pool': True, 'fold_ring': True, 'cf_model': True, 'padded_io': True, 'host_staging': True,
+    'fold_loss_tail': True, 'fuse_pool': True, 'fold_ring': True, 'cf_model': True, 'padded_io': True, 'host_staging': True,
     'dgrad_gather': True, 'fold_head': True, 'check_finite': False,
 }
 

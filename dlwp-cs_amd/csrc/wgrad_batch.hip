@@ -29,7 +29,7 @@
 
 namespace dlwpcs {
 static const int g_wb_tags[] = {prof_register_tag("wgrad_batch_kernel"), prof_register_tag("wb_reduce_kernel"),
-                                prof_register_tag("wb_reduce_kernel(apply)"), prof_register_tag("wgrad_batch_fold_kernel")};
+                                prof_register_tag("wb_reduce_kernel(apply)")};
 
 
 constexpr int WB_MAX_LAYERS = DLWPCS_WGRAD_BATCH_MAX;
@@ -913,9 +913,9 @@ __device__ __attribute__((noinline)) void wb_segment_f32(const WbLayer &Lg, cons
     __syncthreads();                    // E3
 }
 
-// the chain of segments of this workgroup (all 512 threads)
-__device__ __forceinline__ void wb_run_chain(const char *__restrict__ plan, const WbPtrs &ptrs, float *__restrict__ ws, long long *dbg,
-                                             char *smem) {
+__global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict__ plan, const WbPtrs ptrs, float *__restrict__ ws,
+                                                          long long *dbg, int32_t *adam_state) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const WbHeader *H = reinterpret_cast<const WbHeader *>(plan);
     const WbLayer *layers = reinterpret_cast<const WbLayer *>(plan + H->off_layers);
     const WbSeg *segs = reinterpret_cast<const WbSeg *>(plan + H->off_segs);
@@ -966,12 +966,6 @@ __device__ __forceinline__ void wb_run_chain(const char *__restrict__ plan, cons
             default:          wb_segment<1, 8, 4, 1, 1, 2>(L, sg, a0, a1, dz, yy, tb, ws, smem, dbg); break;
         }
     }
-}
-
-__global__ void __launch_bounds__(512) wgrad_batch_kernel(const char *__restrict__ plan, const WbPtrs ptrs, float *__restrict__ ws,
-                                                          long long *dbg, int32_t *adam_state) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    wb_run_chain(plan, ptrs, ws, dbg, smem);
     // optimizer fused into the reduction that follows: the step counter {t, ticket} moves on here (last worker to finish)
     if (adam_state != nullptr && threadIdx.x == 0) {
         const int done = atomicAdd(adam_state + 1, 1);
@@ -991,20 +985,17 @@ constexpr int WB_RED_OUT = 64, WB_RED_THREADS = 3 * WB_RED_OUT;
 template <int VEC, bool ALIGNED>
 __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGroup *__restrict__ groups, const float *__restrict__ ws,
                                                float *dw_eq, float *dw_pol, float *dw_np, float *db_eq, float *db_pol,
-                                               float *db_np, int block, const WbAdam &A, const WbRedPack &K, const int tid,
-                                               float *red_lds, const int t_step) {
-    // tid: 0 .. WB_RED_THREADS - 1 inside the reduction team; red_lds: WB_RED_OUT * 4 floats of LDS of that team; t_step: the step
-    // counter the optimizer computes with (the caller read it: from A.state behind a kernel boundary, or behind the grid barrier)
+                                               float *db_np, int block, const WbAdam &A, const WbRedPack &K) {
     typedef float VT __attribute__((ext_vector_type(VEC)));
     constexpr bool VECIO = ALIGNED || VEC == 1;         // (the four flat buffers share their 16-B alignment)
     float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gscale = 1.f;
     if (A.on) {
         b1 = A.hyper[1]; b2 = A.hyper[2]; eps = A.hyper[3]; gscale = A.hyper[4];
-        lr_t = adam_lr_t(A.hyper[0], b1, b2, (float)t_step);
+        lr_t = adam_lr_t(A.hyper[0], b1, b2, (float)(A.state[0] + A.apply_only));
     }
     const int KS = L.KS, TAPS = KS * KS, Cin = L.Cin, Cout = L.Cout;
     const int nW = TAPS * Cin * Cout;
-    const int o = tid % WB_RED_OUT, c = tid / WB_RED_OUT;
+    const int o = (int)threadIdx.x % WB_RED_OUT, c = (int)threadIdx.x / WB_RED_OUT;
     const int e = (block * WB_RED_OUT + o) * VEC;
     const bool is_w = e < nW, is_b = !is_w && L.want_bias && e < nW + Cout;
     const int TC = L.TC, TN = L.TN;
@@ -1062,7 +1053,7 @@ __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGrou
 #pragma unroll 8
         for (int j = 0; j < g.count; ++j) s += *reinterpret_cast<const VT *>(p + (size_t)j * g.stride);
     }
-    VT *red = reinterpret_cast<VT *>(red_lds);
+    __shared__ VT red[WB_RED_OUT];
     if (c == 2) red[o] = s;
     __syncthreads();
     if (dst == nullptr) return;
@@ -1153,9 +1144,6 @@ __device__ __forceinline__ void wb_reduce_body(const WbRedLayer &L, const WbGrou
 __global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__ plan, const WbRedPtrs R, const float *__restrict__ ws,
                                                         const WbAdam A, const dlwpcs_loss_tail tail, uint32_t red_blocks,
                                                         const WbPackArgs PK) {
-    __shared__ __attribute__((aligned(16))) float red_lds[WB_RED_OUT * 4];
-    const int t_step = A.on ? A.state[0] + A.apply_only : 0;
-    const int tid = (int)threadIdx.x;
     if (blockIdx.x >= red_blocks) {
         loss_stage2_body(tail.partial, tail.loss_out, tail.nblocks, tail.inv_n, tail.weight, tail.overwrite);
     } else if (threadIdx.x < WB_RED_THREADS) {
@@ -1170,11 +1158,11 @@ __global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__
             const bool al = ((((uintptr_t)R.dw_eq[l] | (uintptr_t)R.dw_pol[l] | (uintptr_t)R.dw_np[l] | (uintptr_t)R.db_eq[l] |
                                (uintptr_t)R.db_pol[l] | (uintptr_t)R.db_np[l]) & 15) == 0);
             if (L.Cout % 4 == 0 && al)
-                wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l], tid, red_lds, t_step);
+                wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
             else if (L.Cout % 4 == 0)       // (the plan sized this layer's workgroups for 4 outputs per thread)
-                wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l], tid, red_lds, t_step);
+                wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
             else
-                wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l], tid, red_lds, t_step);
+                wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
         }
     }
     // apply-only form: the step counter moves on when the last workgroup is through (every workgroup read state[0] before it
@@ -1186,140 +1174,6 @@ __global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__
             int32_t *st = const_cast<int32_t *>(A.state);
             const int done = atomicAdd(st + 1, 1);
             if (done == (int)gridDim.x - 1) { st[1] = 0; st[0] += 1; }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Round 6: weight gradients AND their reduction / optimizer step as ONE launch (dlwpcs_wgrad_batch_adam_fold).
-// wgrad_batch_kernel | wb_reduce_kernel was two launches because the reduction of a (layer, group, class) needs the partial sums
-// of every worker that held a piece of it.  All 256 workers of the launch are resident at once (one workgroup per CU: the LDS
-// request admits no second one, the grid is <= the CU count), so they can meet at a grid barrier instead of a kernel boundary:
-//   chain of segments (partial sums: write-through stores)  ->  every wave drains, one lane: agent-scope release, arrive
-//   -> last arriver moves the step counter, flips the barrier's sense  ->  one lane per workgroup: agent-scope acquire
-//   -> the reduction blocks (the code of wb_reduce_kernel, same order of additions: same bits), dealt round-robin over the workers,
-//      two teams of 192 threads per workgroup; worker 0 finishes the loss.
-// What it saves is the second launch's boundary and cold start (16.8 us eager, 19.8 inside the step graph, for ~35 MB).  The
-// barrier is sense-reversing and self-resetting ({count, sense} in sync[0..1], zero-initialised ONCE by the caller); a spin that
-// exceeds ~2 s (a worker that never became resident) sets sync[2] and the launch ends WITHOUT touching the parameters.
-// Placement-independent by construction (cdna_hip_programming.md Guideline 16): visibility comes from release / acquire at agent
-// scope, never from which XCD a worker ran on.
-// ------------------------------------------------------------------------------------------------------------------
-struct WbFold {
-    // destinations as float offsets into A.g (0xffffffff: none): the fused optimizer requires them inside the flat gradient buffer
-    uint32_t dw_eq[WB_MAX_LAYERS], dw_pol[WB_MAX_LAYERS], dw_np[WB_MAX_LAYERS];
-    uint32_t db_eq[WB_MAX_LAYERS], db_pol[WB_MAX_LAYERS], db_np[WB_MAX_LAYERS];
-    bf16_t *wf[WB_MAX_LAYERS], *wb[WB_MAX_LAYERS];      // packed operands (nullptr: no fused packing)
-    float *bp[WB_MAX_LAYERS];
-    WbAdam A;
-    dlwpcs_loss_tail tail;
-    uint32_t red_blocks, has_tail;
-    int32_t *sync;                                      // {arrivals, sense, fault, -}
-};
-
-typedef __attribute__((address_space(1))) int32_t gi32;
-
-__device__ __forceinline__ bool wb_grid_barrier(int32_t *sync, int32_t *step_word, int *ok_s) {
-    // (ok_s: one word of the DYNAMIC LDS region -- a static __shared__ variable would shift its base off 16-B alignment)
-    // every wave of the workgroup has its stores out (the partial sums are write-through; the bias partials are plain stores)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        gi32 *cnt = (gi32 *)sync, *sns = (gi32 *)(sync + 1), *flt = (gi32 *)(sync + 2);
-        const int sense = __hip_atomic_load(sns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // BEFORE arriving
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 1;
-        if (old == (int)gridDim.x - 1) {
-            // last arriver: the step counter moves on (what the end ticket of wgrad_batch_kernel does), the barrier resets and opens
-            __hip_atomic_store((gi32 *)step_word, __hip_atomic_load((gi32 *)step_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(sns, sense ^ 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            while (__hip_atomic_load(sns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sense) {
-                __builtin_amdgcn_s_sleep(8);
-                if (__builtin_amdgcn_s_memtime() - t0 > 200000000ull) {            // ~2 s of the 100 MHz counter: somebody is not resident
-                    __hip_atomic_store(flt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (__hip_atomic_load(flt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ok = 0;
-        *ok_s = ok;
-    }
-    __syncthreads();
-    const bool ok_all = *ok_s != 0;
-    __syncthreads();                    // (the word is free again)
-    return ok_all;
-}
-
-__global__ void __launch_bounds__(512) wgrad_batch_fold_kernel(const char *__restrict__ plan, const WbPtrs ptrs, float *__restrict__ ws,
-                                                               long long *dbg, const WbFold F) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    wb_run_chain(plan, ptrs, ws, dbg, smem);
-    int32_t *state = const_cast<int32_t *>(F.A.state);
-    if (!wb_grid_barrier(F.sync, state, reinterpret_cast<int *>(smem))) return;
-    // ---- the reduction, dealt over the workers: block b of wb_reduce_kernel's grid -> worker b % n, team (b / n) & 1
-    const WbHeader *H = reinterpret_cast<const WbHeader *>(plan);
-    const WbLayer *layers = reinterpret_cast<const WbLayer *>(plan + H->off_layers);
-    const WbGroup *groups = reinterpret_cast<const WbGroup *>(plan + H->off_groups);
-    const int t_step = __hip_atomic_load((gi32 *)state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (never the scalar cache)
-    const int team = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255;
-    float *red_lds = reinterpret_cast<float *>(smem) + team * (WB_RED_OUT * 4);
-    const uint32_t n = gridDim.x, w = blockIdx.x;
-    const uint32_t rounds = (F.red_blocks + 2 * n - 1) / (2 * n);
-    const int n_layers = (int)H->n_layers;
-    for (uint32_t it = 0; it < rounds; ++it) {
-        const uint32_t b = w + (2 * it + (uint32_t)team) * n;
-        if (b < F.red_blocks && tid < WB_RED_THREADS) {
-            int l = 0;
-#pragma unroll
-            for (int k = 1; k < WB_MAX_LAYERS; ++k) l += (k < n_layers && b >= H->red_first[k]) ? 1 : 0;
-            const WbLayer Lp = load_uniform(layers[l]);
-            const WbRedLayer L{Lp.KS, Lp.cin_logical, Lp.Cout, Lp.want_bias, 32 * Lp.CT, 32 * Lp.NT, Lp.ncot, Lp.group_base, Lp.flip};
-            const int blk = (int)(b - H->red_first[l]);
-            auto dst = [&](uint32_t off) { return off == 0xffffffffu ? (float *)nullptr : F.A.g + off; };
-            float *dw_eq = dst(F.dw_eq[l]), *dw_pol = dst(F.dw_pol[l]), *dw_np = dst(F.dw_np[l]);
-            float *db_eq = dst(F.db_eq[l]), *db_pol = dst(F.db_pol[l]), *db_np = dst(F.db_np[l]);
-            const bool f32 = Lp.variant >= WB_V_F32_3;
-            const int cgw = f32 ? 8 : 16;
-            const WbRedPack K{F.wf[l], F.wb[l], F.bp[l], (Lp.cin_logical + cgw - 1) / cgw, (Lp.Cout + 31) / 32, (Lp.Cout + cgw - 1) / cgw,
-                              (Lp.cin_logical + 31) / 32, f32 ? 1 : 0};
-            const bool al = ((((uintptr_t)dw_eq | (uintptr_t)dw_pol | (uintptr_t)dw_np | (uintptr_t)db_eq | (uintptr_t)db_pol |
-                               (uintptr_t)db_np) & 15) == 0);
-            if (L.Cout % 4 == 0 && al) wb_reduce_body<4, true>(L, groups, ws, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, blk, F.A, K, tid, red_lds, t_step);
-            else if (L.Cout % 4 == 0) wb_reduce_body<4, false>(L, groups, ws, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, blk, F.A, K, tid, red_lds, t_step);
-            else wb_reduce_body<1, true>(L, groups, ws, dw_eq, dw_pol, dw_np, db_eq, db_pol, db_np, blk, F.A, K, tid, red_lds, t_step);
-        } else {
-            __syncthreads();            // (the one barrier of wb_reduce_body: every wave of the workgroup counts)
-        }
-    }
-    // the loss's second reduction stage: worker 0, its first 256 threads (loss_stage2_body with dynamic LDS)
-    if (F.has_tail && blockIdx.x == 0) {
-        __syncthreads();
-        double *s_sq = reinterpret_cast<double *>(smem), *s_ab = s_sq + 256;
-        const int t = (int)threadIdx.x;
-        if (t < 256) {
-            double sq = 0.0, ab = 0.0;
-            for (int i = t; i < F.tail.nblocks; i += 256) { sq += F.tail.partial[2 * i]; ab += F.tail.partial[2 * i + 1]; }
-            s_sq[t] = sq; s_ab[t] = ab;
-        }
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if (t < st) { s_sq[t] += s_sq[t + st]; s_ab[t] += s_ab[t + st]; }
-            __syncthreads();
-        }
-        if (t == 0) {
-            const float l0 = (float)(s_sq[0] * F.tail.inv_n) * F.tail.weight, l1 = (float)(s_ab[0] * F.tail.inv_n);
-            F.tail.loss_out[0] = F.tail.overwrite ? l0 : F.tail.loss_out[0] + l0;
-            F.tail.loss_out[1] = F.tail.overwrite ? l1 : F.tail.loss_out[1] + l1;
         }
     }
 }
@@ -1595,16 +1449,6 @@ static int wb_build(const dlwpcs_wgrad_item *items, int n, int n_workers, WbPlan
 }
 
 static int wb_workers() { return 256; }
-// workgroups of the batched kernel that are resident at once: one per CU (its LDS request admits no second one)
-static int wb_resident_workers() {
-    static int n = -1;
-    if (n < 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-        n = cus;
-    }
-    return n;
-}
 #ifdef DLWPCS_WB_TL
 static long long *g_tl_last = nullptr;
 #endif
@@ -1655,7 +1499,7 @@ extern "C" int dlwpcs_wgrad_batch_plan(const dlwpcs_wgrad_item *items, int n_ite
 
 static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                             void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream,
-                            const dlwpcs_loss_tail *tail = nullptr, const dlwpcs_pack_item *pack_host = nullptr, int32_t *sync_dev = nullptr);
+                            const dlwpcs_loss_tail *tail = nullptr, const dlwpcs_pack_item *pack_host = nullptr);
 
 extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                   void *workspace, size_t workspace_bytes, dlwpcs_stream_t stream) {
@@ -1666,7 +1510,7 @@ extern "C" int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, c
 static int wgrad_batch_adam_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                  void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
                                  int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream, const dlwpcs_loss_tail *tail,
-                                 const dlwpcs_pack_item *pack_host, int32_t *sync_dev = nullptr);
+                                 const dlwpcs_pack_item *pack_host);
 
 extern "C" int dlwpcs_wgrad_batch_adam(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                        void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
@@ -1685,21 +1529,10 @@ extern "C" int dlwpcs_wgrad_batch_adam_tail(const dlwpcs_wgrad_item *items, int 
                                  stream, tail, pack_items_host);
 }
 
-extern "C" int dlwpcs_wgrad_batch_adam_fold(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
-                                            void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
-                                            int32_t *state_dev, const float *hyper_dev, const dlwpcs_loss_tail *tail,
-                                            const dlwpcs_pack_item *pack_items_host, int32_t *sync_dev, dlwpcs_stream_t stream) {
-    if (tail && (!tail->partial || !tail->loss_out || tail->nblocks < 1))
-        return fail(DLWPCS_E_INVALID, "wgrad_batch_adam_fold: bad loss tail");
-    if (!sync_dev) return fail(DLWPCS_E_INVALID, "wgrad_batch_adam_fold: null sync_dev");
-    return wgrad_batch_adam_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, p, g, m, v, n, state_dev, hyper_dev,
-                                 stream, tail, pack_items_host, sync_dev);
-}
-
 static int wgrad_batch_adam_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                                  void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
                                  int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream, const dlwpcs_loss_tail *tail,
-                                 const dlwpcs_pack_item *pack_host, int32_t *sync_dev) {
+                                 const dlwpcs_pack_item *pack_host) {
     if (!items || !p || !g || !m || !v || !state_dev || !hyper_dev) return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: null pointer");
     // every destination must lie inside g, no destination may be named twice (a layer applied twice takes the unfused path)
     for (int l = 0; l < n_items; ++l) {
@@ -1713,7 +1546,7 @@ static int wgrad_batch_adam_impl(const dlwpcs_wgrad_item *items, int n_items, co
     }
     WbAdam A{};
     A.p = p; A.g = g; A.m = m; A.v = v; A.state = state_dev; A.hyper = hyper_dev; A.on = 1;
-    return wgrad_batch_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, A, state_dev, stream, tail, pack_host, sync_dev);
+    return wgrad_batch_impl(items, n_items, plan_host, plan_dev, workspace, workspace_bytes, A, state_dev, stream, tail, pack_host);
 }
 
 extern "C" int dlwpcs_wgrad_batch_apply(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
@@ -1737,7 +1570,7 @@ extern "C" int dlwpcs_wgrad_batch_apply(const dlwpcs_wgrad_item *items, int n_it
 
 static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                             void *workspace, size_t workspace_bytes, const WbAdam &adam, int32_t *adam_state, dlwpcs_stream_t stream,
-                            const dlwpcs_loss_tail *tail, const dlwpcs_pack_item *pack_host, int32_t *sync_dev) {
+                            const dlwpcs_loss_tail *tail, const dlwpcs_pack_item *pack_host) {
     const bool apply_only = adam.apply_only != 0;
     if (!items || !plan_host || !plan_dev || (!workspace && !apply_only)) return fail(DLWPCS_E_INVALID, "wgrad_batch: null pointer");
     const WbHeader *H = (const WbHeader *)plan_host;
@@ -1783,52 +1616,6 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
     }
     int pidx = -1;
     int rc = DLWPCS_OK;
-    // the packed operands the fused optimizer refreshes (validated once, used by either form of the reduction)
-    WbPackArgs PK{};
-    if (pack_host && adam.on) {
-        for (int l = 0; l < n_items; ++l) {
-            const dlwpcs_pack_item &pk = pack_host[l];
-            const WbLayer &L = layers[l];
-            // the packed operands must belong to the parameters this item's gradients update
-            const float *pw = adam.p + ((const float *)items[l].dw_eq - adam.g);
-            const bool pf32 = items[l].d.dtype == DLWPCS_F32;
-            if (pk.dtype != items[l].d.dtype || pk.ksize != L.KS || pk.Cin != L.cin_logical || pk.Cout != L.Cout ||
-                (const float *)pk.w_eq != pw || !pk.wpk_fwd || !pk.wpk_bwd || (pk.flip_north_pole != 0) != (L.flip != 0) ||
-                (L.want_bias && !pk.bias_pk))
-                return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: pack item %d does not describe the layer of gradient item %d", l, l);
-            WbRedPack &K = PK.l[l];
-            K.wf = (bf16_t *)pk.wpk_fwd; K.wb = (bf16_t *)pk.wpk_bwd; K.bp = (float *)pk.bias_pk;
-            const int cgw = pf32 ? 8 : 16;
-            K.CGf = (pk.Cin + cgw - 1) / cgw; K.NTf = (pk.Cout + 31) / 32;
-            K.CGb = (pk.Cout + cgw - 1) / cgw; K.NTb = (pk.Cin + 31) / 32;
-            K.f32 = pf32 ? 1 : 0;
-        }
-    }
-    // ONE launch (round 6) where the reduction is a single round with the optimizer inside and the caller gave the barrier's words
-    bool shared_dst = false;
-    for (int l = 0; l < n_items; ++l)
-        for (int k = 0; k < l; ++k) shared_dst |= items[k].dw_eq == items[l].dw_eq;
-    if (sync_dev && adam.on && !apply_only && !shared_dst && (int)H->n_workers <= wb_resident_workers()) {
-        WbFold F{};
-        auto off = [&](const void *q) { return q ? (uint32_t)((const float *)q - adam.g) : 0xffffffffu; };
-        for (int l = 0; l < n_items; ++l) {
-            F.dw_eq[l] = off(items[l].dw_eq); F.dw_pol[l] = off(items[l].dw_pol); F.dw_np[l] = off(items[l].dw_np);
-            F.db_eq[l] = off(items[l].db_eq); F.db_pol[l] = off(items[l].db_pol); F.db_np[l] = off(items[l].db_np);
-            F.wf[l] = PK.l[l].wf; F.wb[l] = PK.l[l].wb; F.bp[l] = PK.l[l].bp;
-        }
-        F.A = adam;
-        if (tail) { F.tail = *tail; F.has_tail = 1; }
-        F.red_blocks = H->red_first[WB_MAX_LAYERS];
-        F.sync = sync_dev;
-        hipError_t e = hipFuncSetAttribute((const void *)wgrad_batch_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(lds > 8192 ? lds : 8192));
-        if (e != hipSuccess) return fail(DLWPCS_E_LAUNCH, "wgrad_batch_fold: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        if (prof_enabled()) pidx = prof_begin("wgrad_batch_fold_kernel", flops, bytes + (double)H->ws_floats * 4.0, s);
-        hipLaunchKernelGGL(wgrad_batch_fold_kernel, dim3(H->n_workers), dim3(512), lds > 8192 ? lds : 8192, s, (const char *)plan_dev, ptrs,
-                           (float *)workspace, (long long *)nullptr, F);
-        if (pidx >= 0) prof_end(pidx, s);
-        return check_launch("wgrad_batch_fold");
-    }
     if (!apply_only) {
         if (prof_enabled()) pidx = prof_begin("wgrad_batch_kernel", flops, bytes, s);
         long long *dbg = nullptr;
@@ -1865,6 +1652,26 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
         const uint32_t rb = H->red_first[WB_MAX_LAYERS];
         dlwpcs_loss_tail tl{};
         if (tail) tl = *tail;
+        WbPackArgs PK{};
+        if (pack_host && adam.on) {
+            for (int l = 0; l < n_items; ++l) {
+                const dlwpcs_pack_item &pk = pack_host[l];
+                const WbLayer &L = layers[l];
+                // the packed operands must belong to the parameters this item's gradients update
+                const float *pw = adam.p + ((const float *)items[l].dw_eq - adam.g);
+                const bool pf32 = items[l].d.dtype == DLWPCS_F32;
+                if (pk.dtype != items[l].d.dtype || pk.ksize != L.KS || pk.Cin != L.cin_logical || pk.Cout != L.Cout ||
+                    (const float *)pk.w_eq != pw || !pk.wpk_fwd || !pk.wpk_bwd || (pk.flip_north_pole != 0) != (L.flip != 0) ||
+                    (L.want_bias && !pk.bias_pk))
+                    return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: pack item %d does not describe the layer of gradient item %d", l, l);
+                WbRedPack &K = PK.l[l];
+                K.wf = (bf16_t *)pk.wpk_fwd; K.wb = (bf16_t *)pk.wpk_bwd; K.bp = (float *)pk.bias_pk;
+                const int cgw = pf32 ? 8 : 16;
+                K.CGf = (pk.Cin + cgw - 1) / cgw; K.NTf = (pk.Cout + 31) / 32;
+                K.CGb = (pk.Cout + cgw - 1) / cgw; K.NTb = (pk.Cin + 31) / 32;
+                K.f32 = pf32 ? 1 : 0;
+            }
+        }
         hipLaunchKernelGGL(wb_reduce_kernel, dim3(rb + (tail ? 1u : 0u)), dim3(tail ? 256 : WB_RED_THREADS), 0, s,
                            (const char *)plan_dev, R, (const float *)workspace, adam, tl, rb, PK);
         if (pidx >= 0) prof_end(pidx, s);

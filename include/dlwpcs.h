@@ -332,19 +332,6 @@ int dlwpcs_wgrad_batch_adam_tail(const dlwpcs_wgrad_item *items, int n_items, co
                                  int32_t *state_dev, const float *hyper_dev, const struct dlwpcs_loss_tail *tail,
                                  const dlwpcs_pack_item *pack_items_host, dlwpcs_stream_t stream);
 
-/* Round 6: the same step as ONE launch.  dlwpcs_wgrad_batch_adam_tail is two (wgrad_batch_kernel | wb_reduce_kernel) because the
- * reduction of a (layer, group, class) needs the partial sums of every worker that held a piece of it; here the workers of the launch
- * (all resident at once: one workgroup per CU) meet at a grid barrier -- agent-scope release / acquire, sense-reversing, self-resetting
- * -- and run the reduction blocks, the optimizer, the packed operands and the loss tail themselves: the same additions in the same
- * order, the same bits.  sync_dev: FOUR device int32 {arrivals, sense, fault, -}, zero-initialised ONCE by the caller and not shared
- * with a launch in flight on another stream; a worker that waits ~2 s at the barrier sets fault and the launch ends without touching
- * p / m / v / g (never a hang).  Where the form does not apply (a layer applied twice, fewer CUs than workers) the call runs the two
- * launches of dlwpcs_wgrad_batch_adam_tail. */
-int dlwpcs_wgrad_batch_adam_fold(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
-                                 void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
-                                 int32_t *state_dev, const float *hyper_dev, const struct dlwpcs_loss_tail *tail,
-                                 const dlwpcs_pack_item *pack_items_host, int32_t *sync_dev, dlwpcs_stream_t stream);
-
 /* The data-parallel form of the step's last launch (reference counterpart: the multi-GPU model of DLWP/model/models.py:369-374,
  * one optimizer step on the gradient of the GLOBAL batch): dlwpcs_wgrad_batch leaves the finished local gradients in g, the
  * caller sums g over the ranks (RCCL all-reduce of the flat buffer), and this ONE launch then does what dlwpcs_wgrad_batch_adam_tail

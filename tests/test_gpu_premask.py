@@ -266,82 +266,6 @@ def test_optimizer_fused_into_the_reduction_gives_the_same_bits():
     assert np.array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize('dtype,N', [('bfloat16', 16), ('bfloat16', 48), ('float32', 24)])
-def test_reduction_and_optimizer_inside_the_weight_gradient_launch_give_the_same_bits(dtype, N):
-    """dlwpcs_wgrad_batch_adam_fold (engine option fold_reduce, round 6): the workers of the batched weight-gradient launch meet at a
-    grid barrier and run the reduction, Adam, the packed operands and the loss tail themselves -- one launch instead of two.  Same
-    additions in the same order: parameters, optimizer state and the step's statistics are BITWISE those of the two-launch form,
-    over eager steps and hipGraph replays, in both dtypes; the barrier's words are back at {0, sense} and no fault was raised."""
-    from DLWP import ops
-    from DLWP.keras import backend
-    from DLWP.model.cs_unet import build_cs_model
-    dev = _dev()
-    backend.set_device('cuda:0')
-    C, B = 14, 4
-    rng = np.random.default_rng(N)
-    x = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
-    if dtype == 'bfloat16':
-        x = x.to(torch.bfloat16)
-    t = torch.tensor(rng.standard_normal((B, 6, N, N, C)), dtype=torch.float32, device=dev)
-    w0, out, counts = None, [], []
-    for fold in ('0', '1'):
-        os.environ['DLWPCS_OPTIONS'] = 'fold_reduce=' + fold
-        os.environ['DLWPCS_KEEP_GRAPH'] = '1'
-        try:
-            backend.set_compute_dtype(dtype)
-            try:
-                np.random.seed(5)
-                model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=32)
-            finally:
-                backend.set_compute_dtype('float32')
-            model.compile(optimizer='adam', loss='mse', metrics=['mae'])
-            if w0 is None:
-                w0 = model.get_weights()
-            model.set_weights(w0)
-            stats = []
-            for _ in range(7):                      # eager warm-up, capture, five replays
-                stats.append(model.train_on_device_batch([x], [t]).clone())
-            torch.cuda.synchronize()
-            assert model._update_done and model.optimizer.iterations == 7
-            assert float(model._flat_grads.abs().max()) == 0.0
-            g = next(iter(model._graphs.values()))
-            assert g['update'] is None                  # one graph per step
-            counts.append(_graph_kernel_nodes(g['fwd_bwd']))
-            out.append((model._flat_params.detach().cpu().numpy().copy(), model.optimizer._m.cpu().numpy().copy(),
-                        model.optimizer._v.cpu().numpy().copy(), torch.stack(stats).cpu().numpy()))
-        finally:
-            os.environ.pop('DLWPCS_OPTIONS', None)
-            os.environ.pop('DLWPCS_KEEP_GRAPH', None)
-    for a, b in zip(out[0], out[1]):
-        assert np.array_equal(a, b)
-    if None not in counts:
-        assert counts[1] == counts[0] - 1, counts      # the reduction is no launch of its own any more
-    assert ops.wgrad_fold_faults() == 0
-    for words in ops._wb_sync.values():
-        assert int(words[0].item()) == 0 and int(words[2].item()) == 0
-
-
-def _graph_kernel_nodes(cuda_graph):
-    """number of kernel nodes of a captured hipGraph (DLWPCS_KEEP_GRAPH=1), None where torch does not hand out the raw graph"""
-    import ctypes
-    try:
-        raw = cuda_graph.raw_cuda_graph()
-    except Exception:
-        return None
-    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
-    n = ctypes.c_size_t(0)
-    if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
-        return None
-    nodes = (ctypes.c_void_p * n.value)()
-    hip.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n))
-    k = 0
-    for nd in nodes:
-        ty = ctypes.c_int(-1)
-        hip.hipGraphNodeGetType(ctypes.c_void_p(nd), ctypes.byref(ty))
-        k += 1 if ty.value == 0 else 0
-    return k
-
-
 @pytest.mark.parametrize('B,N,Cin,Cout', [(2, 24, 32, 64), (3, 12, 64, 128), (2, 16, 32, 32)])
 def test_ring_fix_folded_into_the_pooling_adjoint(B, N, Cin, Cout):
     """dlwpcs_conv_bwd_data_masked with DLWPCS_CONV_DEFER_RING0 + dlwpcs_avgpool2_bwd_ring against the same call with its own
