@@ -298,7 +298,7 @@ def collect_pmc_plan(plan, timeout_s=900, groups=None):
                 else:
                     errors.append(err)
                 continue
-            parsed = parse_pmc_dir(d, segments=len(plan))
+            parsed = parse_pmc_dir(d, segments=2 * len(plan))[1::2]      # (even segments: the workloads' first-use steps)
             if not any(parsed):
                 errors.append('rocprofv3 pass (%s): no counter rows behind a separator (rc 0); child said: %s'
                               % (' '.join(group), ((r.stderr or '') + (r.stdout or ''))[-400:].replace('\n', ' ')))
@@ -365,10 +365,14 @@ def pmc_child(args):
         a.rollout_steps = ent.get('rollout_steps', 40)
         state = prepare(a, a.dtype, rank=0)
         state['model'].use_graphs = False
-        run_step(state)                     # (first use: table uploads, workspace growth -- in front of the separator)
+        def separator():
+            for _ in range(2):
+                nat.check(nat.lib().dlwpcs_lds_oob_probe(nz.data_ptr(), torch.cuda.current_stream().cuda_stream), 'separator')
+        # two segments per workload: [separator] first-use step (table uploads, workspace growth, packing: nobody's) [separator] 3 steps
+        separator()
+        run_step(state)
         torch.cuda.synchronize()
-        for _ in range(2):
-            nat.check(nat.lib().dlwpcs_lds_oob_probe(nz.data_ptr(), torch.cuda.current_stream().cuda_stream), 'separator')
+        separator()
         for _ in range(3):
             run_step(state)
         torch.cuda.synchronize()

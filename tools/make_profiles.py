@@ -87,7 +87,9 @@ def main():
     for wl, name, title in (('encoder6', 'encoder6_b32', '`python bench.py --workload encoder6 --channels 7 --dtype f32` (BASELINE config 2), '
                                                           'hipGraph-replayed steps'),
                             ('rollout', 'rollout_b32', '`python bench.py --workload rollout` (BASELINE config 5: one step = one 40-step '
-                                                        'rollout = 20 forward passes), eager launches')):
+                                                        'rollout = 20 forward passes), eager launches'),
+                            ('unet2x2', 'unet2x2_b32', '`python bench.py --workload unet2x2` (the reference scripts\' production model: '
+                                                        'integration_steps 2, solar + constants inputs), hipGraph-replayed steps')):
         d2 = os.path.join(R, 'gpurun_out', 'prof_%s_%s' % (TAG, wl))
         if glob.glob(os.path.join(d2, '**', '*kernel_trace.csv'), recursive=True):
             t2 = step_summaries(d2, ((None, 'rocprofv3 --kernel-trace --stats of ' + title),))
