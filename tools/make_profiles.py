@@ -57,6 +57,11 @@ def step_summaries(pdir, modes):
     # a training step ENDS with its optimizer launch (the weight-gradient reduction + Adam, or the Adam kernel); a rollout (no
     # optimizer) starts at its weight-packing launch
     ends = [i + 1 for i, r in enumerate(rows) if 'wb_reduce_kernel' in r['Kernel_Name'] or 'adam_fused_kernel' in r['Kernel_Name']]
+    # (a step with ONE batched weight-gradient launch is cut there instead: a model whose layers are applied twice -- unet2x2 -- runs
+    # two reduction launches and an optimizer launch behind it; the cut is rotated against the step, the per-step sums are not)
+    wb = [i + 1 for i, r in enumerate(rows) if 'wgrad_batch_kernel' in r['Kernel_Name']]
+    if len(wb) > 2:
+        ends = wb
     idx = ends if len(ends) > 2 else [i for i, r in enumerate(rows) if 'pack_batch_kernel' in r['Kernel_Name']]
     steps = []
     for a, b in zip(idx[:-1], idx[1:]):
