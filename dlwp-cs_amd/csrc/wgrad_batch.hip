@@ -1319,6 +1319,12 @@ static int wb_geometry(const dlwpcs_conv_desc *d, bool want_bias, bool has_np, b
         const double dbytes = (double)pix * (d->Cout < 32 * NT ? d->Cout : 32 * NT) * 2.0 * (mask ? 2.0 : 1.0);
         double ld = fix + (xbytes + dbytes) / bpc;
         if (x4) ld += ld4 * ((double)rows * W2 * (variant == WB_V_3_2_8 ? 8 : 16) / 256.0);
+        // a plane that holds channels of BOTH sources of a concatenation (C0 no multiple of 32: the 10 + 2 channel input of the
+        // reference scripts' production model) takes two loads per vector, one of them a no-op (wb_segment, `straddle`): measured
+        // 42.5 us for that layer alone against 35.2 for the same 12 channels in one source -- and 183 against 131 us for the whole
+        // list while the plan priced it like a single-source layer (its workers ran long, everybody else waited): priced at four times
+        // its load term now
+        if (x4 && d->C1 > 0 && d->C0 % 32 != 0) ld = 4.0 * ld - 3.0 * fix;      // (swept 1 .. 6 on that list: 188 / 166 / 152 / 150 / 152 / 150 us)
         if (d4) ld += ld4 * ((double)pix * 8 / 256.0);
         if (mask) ld += 190.0 * ((double)pix * 4 * NT / 256.0);     // act' arithmetic + the second load stream (measured: 5.85 k -> 7.9 k)
         G.cost_item[last] = ld > mma ? ld : mma;

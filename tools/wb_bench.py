@@ -26,11 +26,15 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--layers', default='')
+    ap.add_argument('--spec', default='', help="layer list instead of unet2's: 'N,C0,C1,up0,Cout,k,halo;...'")
     ap.add_argument('--mask', default='', help='layers (of the full list) whose item carries y: act\' applied on load')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     lib = nat.lib()
     B = args.batch
+    global UNET2
+    if args.spec:
+        UNET2 = [tuple(int(v) for v in item.split(',')) for item in args.spec.split(';')]
     sel = [int(v) for v in args.layers.split(',')] if args.layers else range(len(UNET2))
     entries = []
     keep = []
