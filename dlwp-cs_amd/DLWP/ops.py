@@ -179,13 +179,13 @@ def flush_wgrad_batch(adam=None, pack_lookup=None):
 
 
 def _wb_covers(entries, n_elems):
-    """do the gradient tensors of `entries` cover n_elems parameter elements, each exactly once?"""
+    """do the gradient tensors of `entries` cover n_elems parameter elements?  A layer applied more than once (integration_steps
+    = 2 in the reference scripts) names its tensors once per application: the library reduces such items in successive launches
+    and lets the optimizer consume a tensor in the launch of its last item."""
     seen, covered = set(), 0
     for ent in entries:
         for t in ent[5]:
-            if t is not None:
-                if t.data_ptr() in seen:
-                    return False
+            if t is not None and t.data_ptr() not in seen:
                 seen.add(t.data_ptr())
                 covered += t.numel()
     return covered == n_elems

@@ -106,6 +106,8 @@ struct WbRedPtrs {
     float *db_eq[WB_MAX_LAYERS], *db_pol[WB_MAX_LAYERS], *db_np[WB_MAX_LAYERS];
     uint32_t first[WB_MAX_LAYERS + 1];
     uint32_t live;                               // bit l: layer l is reduced by this launch
+    uint32_t adam;                               // bit l: ... and this launch is the LAST one that adds to its destination: the fused
+                                                 // optimizer consumes it here (a layer applied twice: its first item only accumulates)
     uint32_t n_layers, off_groups;
     WbRedLayer lay[WB_MAX_LAYERS];
 };
@@ -1154,15 +1156,17 @@ __global__ void __launch_bounds__(256) wb_reduce_kernel(const char *__restrict__
         for (int k = 1; k < WB_MAX_LAYERS; ++k) l += (k < (int)R.n_layers && b >= R.first[k]) ? 1 : 0;
         if ((R.live >> l) & 1u) {
             const WbRedLayer L = R.lay[l];          // (block-uniform index into the kernel arguments: scalar loads)
+            WbAdam Al = A;
+            if (!((R.adam >> l) & 1u)) Al.on = 0;
             const int blk = (int)(b - R.first[l]);
             const bool al = ((((uintptr_t)R.dw_eq[l] | (uintptr_t)R.dw_pol[l] | (uintptr_t)R.dw_np[l] | (uintptr_t)R.db_eq[l] |
                                (uintptr_t)R.db_pol[l] | (uintptr_t)R.db_np[l]) & 15) == 0);
             if (L.Cout % 4 == 0 && al)
-                wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
+                wb_reduce_body<4, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, Al, PK.l[l]);
             else if (L.Cout % 4 == 0)       // (the plan sized this layer's workgroups for 4 outputs per thread)
-                wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
+                wb_reduce_body<4, false>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, Al, PK.l[l]);
             else
-                wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, A, PK.l[l]);
+                wb_reduce_body<1, true>(L, groups, ws, R.dw_eq[l], R.dw_pol[l], R.dw_np[l], R.db_eq[l], R.db_pol[l], R.db_np[l], blk, Al, PK.l[l]);
         }
     }
     // apply-only form: the step counter moves on when the last workgroup is through (every workgroup read state[0] before it
@@ -1546,9 +1550,13 @@ static int wgrad_batch_adam_impl(const dlwpcs_wgrad_item *items, int n_items, co
         for (int k = 0; k < 6; ++k)
             if (ds[k] && ((const float *)ds[k] < g || (const float *)ds[k] >= g + n))
                 return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: item %d: gradient tensor outside the flat gradient buffer", l);
+        // (items that share their gradients -- a layer applied twice, integration_steps = 2 in the reference scripts -- are reduced in
+        // successive launches; the optimizer consumes a destination in the launch of its LAST item, see wgrad_batch_impl)
         for (int k = 0; k < l; ++k)
-            if (items[k].dw_eq == items[l].dw_eq)
-                return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch_adam: items %d and %d share their gradients (use dlwpcs_wgrad_batch + dlwpcs_adam_step_dev)", k, l);
+            if (items[k].dw_eq == items[l].dw_eq &&
+                (items[k].dw_pol != items[l].dw_pol || items[k].dw_np != items[l].dw_np || items[k].db_eq != items[l].db_eq ||
+                 items[k].db_pol != items[l].db_pol || items[k].db_np != items[l].db_np))
+                return fail(DLWPCS_E_INVALID, "wgrad_batch_adam: items %d and %d share some of their gradient tensors but not all", k, l);
     }
     WbAdam A{};
     A.p = p; A.g = g; A.m = m; A.v = v; A.state = state_dev; A.hyper = hyper_dev; A.on = 1;
@@ -1565,9 +1573,6 @@ extern "C" int dlwpcs_wgrad_batch_apply(const dlwpcs_wgrad_item *items, int n_it
         for (int k = 0; k < 6; ++k)
             if (ds[k] && ((const float *)ds[k] < g || (const float *)ds[k] >= g + n))
                 return fail(DLWPCS_E_INVALID, "wgrad_batch_apply: item %d: gradient tensor outside the flat gradient buffer", l);
-        for (int k = 0; k < l; ++k)
-            if (items[k].dw_eq == items[l].dw_eq)
-                return fail(DLWPCS_E_UNSUPPORTED, "wgrad_batch_apply: items %d and %d share their gradients", k, l);
     }
     WbAdam A{};
     A.p = p; A.g = g; A.m = m; A.v = v; A.state = state_dev; A.hyper = hyper_dev; A.on = 1; A.apply_only = 1;
@@ -1643,6 +1648,14 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
     }
     // reduction rounds: items that share their destination (a layer applied twice) go into successive launches
     uint32_t pending = n_items >= 32 ? 0xffffffffu : ((1u << n_items) - 1u);
+    // last[l]: no later item adds to the destination of item l
+    uint32_t last = 0;
+    for (int l = 0; l < n_items; ++l) {
+        bool later = false;
+        for (int k = l + 1; k < n_items; ++k) later |= items[k].dw_eq == items[l].dw_eq;
+        if (!later) last |= 1u << l;
+    }
+    if (apply_only) pending &= last;            // (nothing is added: every destination is consumed once)
     while (pending) {
         uint32_t live = 0;
         for (int l = 0; l < n_items; ++l) {
@@ -1653,6 +1666,8 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
             if (!clash) live |= 1u << l;
         }
         R.live = live;
+        R.adam = live & last;
+        const bool final_round = (pending & ~live) == 0;
         pidx = -1;
         if (prof_enabled()) pidx = prof_begin(apply_only ? "wb_reduce_kernel(apply)" : "wb_reduce_kernel", 0.0, (double)H->ws_floats * 4.0, s);
         const uint32_t rb = H->red_first[WB_MAX_LAYERS];
@@ -1678,7 +1693,8 @@ static int wgrad_batch_impl(const dlwpcs_wgrad_item *items, int n_items, const v
                 K.f32 = pf32 ? 1 : 0;
             }
         }
-        hipLaunchKernelGGL(wb_reduce_kernel, dim3(rb + (tail ? 1u : 0u)), dim3(tail ? 256 : WB_RED_THREADS), 0, s,
+        const bool with_tail = tail && final_round;     // (the loss is finished once, by the step's last launch)
+        hipLaunchKernelGGL(wb_reduce_kernel, dim3(rb + (with_tail ? 1u : 0u)), dim3(with_tail ? 256 : WB_RED_THREADS), 0, s,
                            (const char *)plan_dev, R, (const float *)workspace, adam, tl, rb, PK);
         if (pidx >= 0) prof_end(pidx, s);
         pending &= ~live;

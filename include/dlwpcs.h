@@ -315,7 +315,9 @@ int dlwpcs_wgrad_batch(const dlwpcs_wgrad_item *items, int n_items, const void *
  * item covers are NOT updated (alignment padding; a caller with parameters outside the items uses dlwpcs_wgrad_batch +
  * dlwpcs_adam_step_dev instead).  state_dev = {t - 1, ticket} as for dlwpcs_adam_step_fused (the weight-gradient launch
  * increments t, the reduction reads it), hyper_dev = {lr, beta1, beta2, eps, grad_scale}.  Items that share their gradient
- * tensors (a layer applied twice) are rejected with DLWPCS_E_UNSUPPORTED. */
+ * tensors (a layer applied twice: integration_steps = 2, /root/reference/Azure/train_cs.py:391-408) must share ALL of them; they are
+ * reduced in successive launches and the optimizer consumes a tensor in the launch of its LAST item (round 6; rounds 3-5 rejected
+ * such lists with DLWPCS_E_UNSUPPORTED and the caller ran reduction, optimizer and operand packing as launches of their own). */
 int dlwpcs_wgrad_batch_adam(const dlwpcs_wgrad_item *items, int n_items, const void *plan_host, const void *plan_dev,
                             void *workspace, size_t workspace_bytes, float *p, float *g, float *m, float *v, size_t n,
                             int32_t *state_dev, const float *hyper_dev, dlwpcs_stream_t stream);

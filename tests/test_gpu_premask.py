@@ -266,6 +266,53 @@ def test_optimizer_fused_into_the_reduction_gives_the_same_bits():
     assert np.array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize('dtype', ['bfloat16', 'float32'])
+def test_optimizer_fused_into_the_reduction_with_layers_applied_twice(dtype):
+    """The reference scripts' production wiring (integration_steps = 2, shared weights, solar + constants inputs,
+    /root/reference/Azure/train_cs.py:391-430): every layer names its gradient tensors twice.  The fused optimizer consumes a tensor in
+    the reduction launch of its LAST item; parameters and statistics are bitwise those of reduction + dlwpcs_adam_step_dev."""
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    dev = _dev()
+    backend.set_device('cuda:0')
+    N, V, ITS, K, B, base = 16, 4, 2, 2, 4, 8
+    c_main, c_out = (V + 1) * ITS, V * ITS
+    rng = np.random.default_rng(3)
+    adt = torch.bfloat16 if dtype == 'bfloat16' else torch.float32
+    mk = lambda *sh: torch.tensor(rng.standard_normal(sh), dtype=torch.float32, device=dev)
+    xs = [mk(B, 6, N, N, c_main).to(adt), mk(B, ITS, 6, N, N, 1).to(adt), mk(B, 6, N, N, K).to(adt)]
+    ts = [mk(B, 6, N, N, c_out), mk(B, 6, N, N, c_out)]
+    w0, out = None, []
+    for fuse in ('0', '1'):
+        os.environ['DLWPCS_OPTIONS'] = 'fuse_adam=' + fuse
+        try:
+            backend.set_compute_dtype(dtype)
+            try:
+                np.random.seed(5)
+                model = build_cs_model((6, N, N, c_main), c_out, 'unet2', base_filter_number=base, integration_steps=2, io_time_steps=ITS,
+                                       insolation_shape=(ITS, 6, N, N, 1), constants_shape=(6, N, N, K))
+            finally:
+                backend.set_compute_dtype('float32')
+            model.compile(optimizer='adam', loss='mse', loss_weights=[0.5, 0.5], metrics=['mae'])
+            if w0 is None:
+                w0 = model.get_weights()
+            model.set_weights(w0)
+            for _ in range(5):                      # eager warm-up, capture, three replays
+                stats = model.train_on_device_batch(xs, ts)
+            torch.cuda.synchronize()
+            # (fp32: the 10 + 2 channel first layer has no batched fp32 kernel -- a 16-B vector would straddle the sources -- so the
+            # list does not cover every parameter and the optimizer stays a launch of its own: same numbers either way)
+            assert model._update_done == (fuse == '1' and dtype == 'bfloat16')
+            assert model.optimizer.iterations == 5
+            assert float(model._flat_grads.abs().max()) == 0.0
+            out.append((np.concatenate([w.ravel() for w in model.get_weights()]), stats.cpu().numpy().copy()))
+        finally:
+            os.environ.pop('DLWPCS_OPTIONS', None)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.abs(out[0][0] - np.concatenate([w.ravel() for w in w0])).max() > 0
+
+
 @pytest.mark.parametrize('B,N,Cin,Cout', [(2, 24, 32, 64), (3, 12, 64, 128), (2, 16, 32, 32)])
 def test_ring_fix_folded_into_the_pooling_adjoint(B, N, Cin, Cout):
     """dlwpcs_conv_bwd_data_masked with DLWPCS_CONV_DEFER_RING0 + dlwpcs_avgpool2_bwd_ring against the same call with its own
