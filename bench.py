@@ -91,7 +91,7 @@ def x2_channels():
 
 
 def flops_per_sample(workload, N, c_in, c_out, base):
-    if workload == 'unet2x2':
+    if workload in ('unet2x2', 'rollout_x2'):
         _, ci, co = x2_channels()
         return X2_STEPS * flops_per_sample('unet2', N, ci, co, base)
     wl = 'unet2' if workload == 'rollout' else workload
@@ -99,7 +99,7 @@ def flops_per_sample(workload, N, c_in, c_out, base):
 
 
 def build_model(workload, N, c_in, c_out, base):
-    if workload == 'unet2x2':
+    if workload in ('unet2x2', 'rollout_x2'):
         from DLWP.model.cs_unet import build_cs_model
         c_main, _, co = x2_channels()
         return build_cs_model((6, N, N, c_main), co, 'unet2', base_filter_number=base, integration_steps=X2_STEPS,
@@ -401,6 +401,15 @@ def prepare(args, dtype, rank):
     dev = backend.device()
     def rnd(*shape):
         return torch.tensor(rng.standard_normal(shape), dtype=torch.float32, device=dev)
+    if args.workload == 'rollout_x2':
+        # the production model's forecast as TimeSeriesEstimator.predict runs it (DLWP/model/extensions.py:252-308 in the reference):
+        # the whole two-output model applied `seq` times on its own last output, insolation re-injected from an HBM-resident array
+        c_main, _, co = x2_channels()
+        dx = [rnd(B, 6, N, N, c_main).to(adt), rnd(B, X2_ITS, 6, N, N, 1).to(adt), rnd(B, 6, N, N, X2_CONST).to(adt)]
+        seq = max(1, args.rollout_steps // (X2_ITS * X2_STEPS))
+        rows = seq * X2_ITS * X2_STEPS + B + 4
+        return {'model': model, 'dx': dx, 'dev': dev, 'train': False, 'x2roll': True, 'seq': seq, 'n_fwd': seq * X2_STEPS,
+                'sol': torch.rand((rows, 6, N, N), dtype=torch.float32, device=dev), 'start': np.arange(B, dtype=np.int64) % 4}
     if args.workload == 'unet2x2':
         c_main, _, co = x2_channels()
         # [main_input, solar_1, constants] as the reference's generator yields them (Azure/train_cs.py:191-194,392-396)
@@ -424,6 +433,9 @@ def prepare(args, dtype, rank):
 def run_step(st):
     if st['train']:
         st['model'].train_on_device_batch(st['dx'], st['dt'])
+        return
+    if st.get('x2roll'):
+        st['last'] = st['model'].rollout_with_forcing(st['dx'], st['seq'], insolation=st['sol'], start_index=st['start'], io_time_steps=X2_ITS)
         return
     # one "step" = one 40-step rollout of the batch, state resident in HBM: the chain of forward passes the product's
     # predict_timeseries runs (Model.rollout_passes_on_device: one hipGraph replay per rollout when graphs are on; from the second
@@ -775,6 +787,12 @@ def measure(args, dtype, rank, world, with_roofline, with_pmc, pmc_groups=None):
         what = 'unet2 C%d: state (%d,6,%d,%d,%d) per GPU, %d-step rollout = %d forward passes with the state in HBM ' \
                '(independent replicas, no communication), %s' % (N, B, N, N, C, args.rollout_steps, st['n_fwd'], prec)
         flops_step = fps * B * st['n_fwd']
+        if st.get('x2roll'):
+            what = ('unet2x2 C%d (the reference scripts\' production model) forecast as TimeSeriesEstimator.predict runs it: batch %d, %d forecast '
+                    'steps = %d applications of the two-output model (%d network passes) on its own last output, insolation re-injected '
+                    'from an HBM-resident array, state never leaves HBM (Model.rollout_with_forcing), %s'
+                    % (N, B, st['seq'] * X2_ITS * X2_STEPS, st['seq'], st['n_fwd'], prec))
+            flops_step = fps * B * st['seq']
     value = B * world / step_s
     result = {
         'metric': metric, 'value': round(value, 2), 'unit': unit,
@@ -931,7 +949,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='unet2', choices=['unet2', 'encoder6', 'rollout', 'unet2x2'])
+    ap.add_argument('--workload', default='unet2', choices=['unet2', 'encoder6', 'rollout', 'unet2x2', 'rollout_x2'])
     ap.add_argument('--batch', type=int, default=32, help='samples per GPU per step')
     ap.add_argument('--face', type=int, default=None, help='cube face size (48; rollout: 96)')
     ap.add_argument('--channels', type=int, default=None,
@@ -963,7 +981,7 @@ def main():
     if args.face is None:
         args.face = 96 if args.workload == 'rollout' else 48
     if args.channels is None:
-        args.channels = 26 if args.workload == 'rollout' else (x2_channels()[1] if args.workload == 'unet2x2' else 14)
+        args.channels = 26 if args.workload == 'rollout' else (x2_channels()[1] if args.workload in ('unet2x2', 'rollout_x2') else 14)
 
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner through C stdio when
     # a communicator is created, flushed at process exit): file descriptor 1 is pointed at stderr for the life of the process and
@@ -1019,10 +1037,11 @@ def main():
     cfg_runs = []
     if single and not args.no_configs and args.workload == 'unet2':
         for key, wl, ch, face, dt in (('cfg2_encoder6_f32', 'encoder6', 7, 48, 'f32'), ('cfg5_rollout_bf16', 'rollout', 26, 96, 'bf16'),
-                                      ('production_unet2x2_bf16', 'unet2x2', x2_channels()[1], 48, 'bf16')):
+                                      ('production_unet2x2_bf16', 'unet2x2', x2_channels()[1], 48, 'bf16'),
+                                      ('production_rollout_bf16', 'rollout_x2', x2_channels()[1], 48, 'bf16')):
             a2 = copy.copy(args)
             a2.workload, a2.channels, a2.face, a2.dtype = wl, ch, face, dt
-            a2.blocks, a2.min_block_s, a2.steps, a2.warmup, a2.pmc_out = 3, 0.3, (20 if wl == 'rollout' else 100), 5, None
+            a2.blocks, a2.min_block_s, a2.steps, a2.warmup, a2.pmc_out = 3, 0.3, (20 if 'rollout' in wl else 100), 5, None
             cfg_runs.append((key, a2, dt))
     if single and not args.no_pmc and not args.no_roofline:
         # every counter pass of this line up front: ONE rocprofv3 process per counter group runs all workloads (round 5: one per group
@@ -1042,7 +1061,7 @@ def main():
                      with_pmc=single and not args.no_pmc)
     if world > 1:
         torch.distributed.barrier()
-    if single and not args.no_dp_form and args.workload != 'rollout':
+    if single and not args.no_dp_form and 'rollout' not in args.workload:
         result['dp_form'] = dp_form_probe(args, args.dtype, result['ms_per_step'])
     if single and not args.no_companion:
         other = 'f32' if args.dtype == 'bf16' else 'bf16'
@@ -1066,7 +1085,7 @@ def main():
                                                            'traffic_vs_algorithmic', 'hbm_gbs', 'mfma_busy', 'pmc_source', 'pmc_error', 'pmc_missing')
                                    if k in rf2}
             result['configs'][key] = ent
-    if rank == 0 and single and not args.no_cpu_baseline and args.workload != 'unet2x2':     # (the port times single-input networks)
+    if rank == 0 and single and not args.no_cpu_baseline and args.workload not in ('unet2x2', 'rollout_x2'):     # (the port times single-input networks)
         result['cpu_baseline'] = cpu_baseline(args.workload, args.face, args.channels, args.channels, args.base, args.batch)
     if rank == 0:
         line = json.dumps(result) + '\n'

@@ -130,6 +130,57 @@ def _oracle_sequence_model(params, n_out):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [('float32', 1e-5), ('bfloat16', 2e-2)])
+def test_production_model_rollout_full_size(dtype, tol):
+    """The forecast of the model the reference scripts train, at ITS OWN SIZE (C48, base 32, 4 variables x 2 time steps + insolation +
+    2 constants, integration_steps = 2; /root/reference/Azure/train_cs.py:99-104,391-421) through TimeSeriesEstimator's device-resident
+    rollout (/root/reference/DLWP/model/extensions.py:252-308): 3 sequence steps = 6 applications of the network on its own output with
+    the forcing re-injected, two samples, against the fp64 oracle network unrolled by hand through the oracle's restatement of the
+    reference loop.  fp32: 1e-5 of the forecast's range (observed 9e-7, six networks deep); bf16: 2e-2 (observed 7e-3; activations rounded 66 layers deep)."""
+    assert torch.cuda.is_available()
+    from DLWP.keras import backend
+    backend.set_device('cuda:0')
+    from DLWP.model import DLWPFunctional, TimeSeriesEstimator
+    from DLWP.model.cs_unet import build_cs_model
+    from DLWP.model.generators import ArrayDataGenerator
+    Nf, Vf, Kf, Tf, n_out, base = 48, 4, 2, 30, 2, 32
+    rng = np.random.default_rng(77)
+    arr = rng.standard_normal((Tf, Vf, 6, Nf, Nf)).astype(np.float32)
+    sol = rng.random((Tf, 6, Nf, Nf)).astype(np.float32)
+    const = rng.standard_normal((Kf, 6, Nf, Nf)).astype(np.float32)
+    dlwp = DLWPFunctional(is_convolutional=True, time_dim=ITS)
+    gen = ArrayDataGenerator(dlwp, arr, rank=3, batch_size=2, input_time_steps=ITS, output_time_steps=ITS, sequence=n_out,
+                             insolation_array=sol, constants=const, channels_last=True)
+    backend.set_compute_dtype(dtype)
+    try:
+        np.random.seed(3)
+        model = build_cs_model(gen.convolution_shape, ITS * Vf, 'unet2', base_filter_number=base, integration_steps=n_out,
+                               io_time_steps=ITS, insolation_shape=gen.insolation_shape, constants_shape=(6, Nf, Nf, Kf))
+    finally:
+        backend.set_compute_dtype('float32')
+    dlwp.build_model(model, loss='mse', optimizer='adam')
+    params = orc.make_unet2_params(ITS * (Vf + 1) + Kf, ITS * Vf, base=base, seed=19)
+    net = model.cs_net
+    convs = [net.conv_2d_1, net.conv_2d_1_2, net.conv_2d_2, net.conv_2d_2_2, net.conv_2d_5_2, net.conv_2d_5,
+             net.conv_2d_6_2, net.conv_2d_6, net.conv_2d_7, net.conv_2d_7_2, net.conv_2d_8]
+    for lay, prm in zip(convs, params):
+        lay.set_weights([prm['equatorial_kernel'].numpy(), prm['polar_kernel'].numpy(),
+                         prm['equatorial_bias'].numpy(), prm['polar_bias'].numpy()])
+    est = TimeSeriesEstimator(dlwp, gen)
+    samples = np.array([2, 7])
+    steps = 12                                           # 3 sequence steps of 2 x 2 time steps
+    fc = est.predict(steps, samples=samples)
+    assert fc.values.shape == (steps, 2, 6, Nf, Nf, Vf) and fc.values.dtype == np.float32
+    p, _ = gen.generate(samples)
+    ref, f_hour = orc.estimator_rollout_ref(_oracle_sequence_model(params, n_out), p, steps, lambda rows: sol[rows], samples,
+                                            n_out, ITS, ITS, ITS, constants=const.transpose(1, 2, 3, 0))
+    err = np.abs(fc.values - ref).max() / np.abs(ref).max()
+    print('production-model rollout at C48 (%s): max error / range = %.3g' % (dtype, err))
+    assert err < tol, err
+    assert np.array_equal(fc.coords['f_hour'], f_hour.astype(np.float64))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
 def test_estimator_device_rollout_matches_oracle_and_host_loop(dtype):
     assert torch.cuda.is_available()
