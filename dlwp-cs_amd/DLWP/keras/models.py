@@ -899,7 +899,8 @@ class Model(object):
         """
         if not self._compiled:
             raise RuntimeError('You must compile your model before training/testing. Use `model.compile(...)`.')
-        key = tuple(tuple(t.shape) for t in inputs + targets)
+        # (the engine options in force are part of the key: a step captured under one DLWPCS_OPTIONS string is not replayed under another)
+        key = tuple(tuple(t.shape) for t in inputs + targets) + (os.environ.get('DLWPCS_OPTIONS', ''),)
         if not self.use_graphs or self._weight_rules():
             return self._train_step_eager(inputs, targets)
         g = self._graphs.get(key)
@@ -1373,7 +1374,8 @@ class Model(object):
             return x
 
         graphs_ok = (self.use_graphs and state.is_cuda and passes > 0)
-        key = ('rollout', shape0, str(state.dtype), passes, n_steps, None if series is None else (series.data_ptr(), tuple(series.shape)))
+        key = ('rollout', shape0, str(state.dtype), passes, n_steps, os.environ.get('DLWPCS_OPTIONS', ''),
+               None if series is None else (series.data_ptr(), tuple(series.shape)))
         with torch.no_grad():
             if not graphs_ok:
                 return chain(state, True)
