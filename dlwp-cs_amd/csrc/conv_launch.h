@@ -33,17 +33,28 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     constexpr int ES = sizeof(T), CGW = 32 / ES;
     constexpr int BM = 32 * MT * WM, NTB = NT * WN, NTHREADS = 64 * WM * WN;
     const int face_pix = P.No * P.No;
-    const int pix = tile_pixels(BM, P.No);
+    // column blocks (conv_ws.h): forward pass with the halo gather on wide faces -- two strips when that doubles the rows of a band
+    P.ncol = 1;
+    if (MODE == MODE_HALO && !EDGE && KS == 3 && (tune_bits() & TUNE_CONV_STRIPS) && P.No >= 64 && P.No % 2 == 0 && P.Cout % (16 / ES) == 0) {
+        const int wt = P.No / 2, rows2 = BM / wt, rows1 = BM / P.No;
+        // whole rows of the strip, bands that tile it evenly, and at least twice the rows of a full-width band
+        if (BM % wt == 0 && rows2 <= P.No && P.No % rows2 == 0 && rows1 >= 1 && rows2 >= 2 * rows1) P.ncol = 2;
+    }
+    P.Wt = P.No / P.ncol;
+    const int strip_pix = P.No * P.Wt;
+    const int pix = P.ncol > 1 ? (BM / P.Wt) * P.Wt : tile_pixels(BM, P.No);
     P.pix_per_block = pix;
-    P.nblk_face = ceil_div(face_pix, pix);
-    P.W2 = P.No + KS - 1;
+    P.nblk_face = ceil_div(strip_pix, pix);
+    P.W2 = P.Wt + KS - 1;
     P.magicW2 = div_magic(P.W2);
+    P.magicWt = div_magic(P.Wt);
+    P.magicNcol = P.ncol > 1 ? div_magic(P.ncol) : 0;
     P.magicNo = div_magic(P.No);
     P.magicN = div_magic(P.Nin);
     P.magicB = P.B > 1 ? div_magic(P.B) : 0;
     P.magicNblk = P.nblk_face > 1 ? div_magic(P.nblk_face) : 0;
-    P.tile_rows_max = tile_rows_for(pix, P.No) + (KS - 1);
-    P.ntiles = P.B * 6 * P.nblk_face;
+    P.tile_rows_max = tile_rows_for(pix, P.Wt) + (KS - 1);
+    P.ntiles = P.B * 6 * P.ncol * P.nblk_face;
     P.split_gb = P.split_fb = 0;
     P.tune = tune_bits();
     const size_t in_b = (size_t)P.tile_rows_max * P.W2 * (KC * ES + 16), w_b = (size_t)NTB * (KC / CGW) * (KS * KS + (EDGE ? 3 : 0)) * 1024;
@@ -52,10 +63,10 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     // with a launch of its own (pool_done stays 0)
     // (... or, faces whose row is exactly one wave's 32 * MT pixels -- N = 96 -- with four consumer waves on a 4-row tile: the
     // waves take half-rows of two rows each instead, P.colsplit)
-    const bool rowpairs = (32 * MT) % (2 * P.No) == 0 && pix % (2 * P.No) == 0;
-    const bool halfrows = !rowpairs && 32 * MT == P.No && WM == 4 && WN == 1 && pix == 4 * P.No && P.No % 4 == 0;
-    bool pool = MODE != MODE_ZERO && P.pool_out != nullptr && P.No % 2 == 0 && (rowpairs || halfrows) &&
-                face_pix % pix == 0 && P.Cout % 32 == 0 && P.Cout % (16 / ES) == 0;
+    const bool rowpairs = (32 * MT) % (2 * P.Wt) == 0 && pix % (2 * P.Wt) == 0;
+    const bool halfrows = !rowpairs && 32 * MT == P.Wt && WM == 4 && WN == 1 && pix == 4 * P.Wt && P.Wt % 4 == 0;
+    bool pool = MODE != MODE_ZERO && P.pool_out != nullptr && P.No % 2 == 0 && P.Wt % 2 == 0 && (rowpairs || halfrows) &&
+                strip_pix % pix == 0 && P.Cout % 32 == 0 && P.Cout % (16 / ES) == 0;
     // (gather-form data gradient: the "pooled" output is the 2 x 2 sum of an upsampled source's channels -- whole n tiles of it)
     if (EDGE) pool = pool && !MOUT && ES == 2 && P.dsplit > 0 && P.dsplit % 32 == 0;
     const size_t buf = in_b + w_b;
@@ -95,6 +106,8 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     }
     if (lds > 160 * 1024)
         return fail(DLWPCS_E_UNSUPPORTED, "conv: LDS tile of %zu bytes exceeds 160 KiB (face size %d)", lds, P.No);
+    if (P.ncol > 1 && !P.patches)
+        return fail(DLWPCS_E_UNSUPPORTED, "conv: internal: column strips need the line-store epilogue (face size %d)", P.No);
     if (P.tile_rows_max > 32)
         return fail(DLWPCS_E_UNSUPPORTED, "conv: %d tile rows exceed the producers' 5-bit row field", P.tile_rows_max);
     if ((size_t)P.tile_rows_max * P.W2 > (size_t)3 * NTHREADS)

@@ -73,6 +73,13 @@ struct ConvKParams {
     int ntiles;                 // B * 6 * nblk_face (persistent kernel)
     int split_gb, split_fb;     // ILV cost split (launch_conv_cfg): the LAST split_gb workers take all the short tiles (the last band
                                 // of every face) and split_fb of the full ones, the others the remaining full tiles; 0: plain split
+    // COLUMN BLOCKS (round 6; forward pass on wide faces): a face of No x No cells is cut into ncol strips of Wt = No / ncol columns and
+    // a tile is a band of rows of ONE strip -- at N = 96 a 384-pixel tile is 8 rows x 48 columns (fetches 10 x 50 cells: 1.30 x) instead
+    // of 4 rows x 96 (6 x 98: 1.53 x, and the counters say the L2 absorbs none of it).  Everything inside a tile (band geometry, LDS
+    // addresses, the waves' pixel ownership, W2 = Wt + KS - 1) is that of a face of width Wt; the strip's first column x0 enters where
+    // global addresses are formed (halo-table lookup, store / pooled-store offsets).  ncol = 1, Wt = No: the layout of rounds 1-5.
+    int Wt, ncol;
+    uint32_t magicWt, magicNcol;
 };
 
 // EDGE instantiations: `P.table` is the forward halo table inside a dlwpcs_dgrad_gather_plan buffer, `src` its border-cell records
@@ -97,12 +104,13 @@ struct ConvEdgeArgs { const int32_t *src; int8_t wids[36]; };
 //      kernel; default 3)
 // 512: data-gradient kernel: M tiles of a tile dealt to the consumer waves round-robin, short tiles skip the M tiles they do not
 //      have, tile list split by cost (see ILV in the kernel)
+//1024: forward kernel on faces of >= 64 cells: tiles are bands of a column strip (ConvKParams::ncol)
 enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_SPLIT_N = 16,
-       TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64, TUNE_CONV_STAGGER = 256, TUNE_CONV_ILV = 512 };
+       TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64, TUNE_CONV_STAGGER = 256, TUNE_CONV_ILV = 512, TUNE_CONV_STRIPS = 1024 };
 static int tune_bits() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_WG_PRODUCER_PRIO | TUNE_CONV_PRODUCER_PRIO | TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT |
-                               TUNE_CONV_STAGGER | TUNE_CONV_ILV | (3 << 12));
+                               TUNE_CONV_STAGGER | TUNE_CONV_ILV | TUNE_CONV_STRIPS | (3 << 12));
                  }
     return v;
 }
@@ -189,6 +197,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     const bool is_producer = tid >= NCT;
     const int nt0 = by * NTB;
     const int face_pix = P.No * P.No;
+    const int strip_pix = P.No * P.Wt;              // cells of one column strip (= face_pix without column blocks)
     const int g0 = P.up0 ? (P.Nin >> 1) : P.Nin;
     const int nchunks = (P.CG + KCG - 1) / KCG;
 
@@ -253,18 +262,20 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
 #pragma unroll 1
         for (int i = 0; i < ((P.tune >> 12) & 63); ++i) __builtin_amdgcn_s_sleep(16);
     }
-    struct Geo { int b, f, v, combo, m0, npix, y0, nitems, fcls; };
+    struct Geo { int b, f, v, combo, m0, npix, y0, nitems, fcls, x0; };
     auto geo_of = [&](int t) __attribute__((always_inline)) {
         Geo gq;
         gq.combo = P.magicB ? __umulhi((uint32_t)t, P.magicB) : t;                      // t / B   (magic 0 <=> divisor 1)
         gq.b = t - gq.combo * P.B;
-        gq.f = P.magicNblk ? __umulhi((uint32_t)gq.combo, P.magicNblk) : gq.combo;     // combo / nblk_face
-        const int blk = gq.combo - gq.f * P.nblk_face;
+        const int fs = P.magicNblk ? __umulhi((uint32_t)gq.combo, P.magicNblk) : gq.combo;      // combo / nblk_face = face * ncol + strip
+        const int blk = gq.combo - fs * P.nblk_face;
+        gq.f = P.magicNcol ? __umulhi((uint32_t)fs, P.magicNcol) : fs;                  // (magic 0 <=> one strip)
+        gq.x0 = (fs - gq.f * P.ncol) * P.Wt;
         gq.v = gq.f < 4 ? 0 : (gq.f == 4 ? 1 : 2);
-        gq.m0 = blk * P.pix_per_block;
-        gq.npix = min(P.pix_per_block, face_pix - gq.m0);
-        gq.y0 = __umulhi((uint32_t)gq.m0, P.magicNo);
-        const int ylast = __umulhi((uint32_t)(gq.m0 + gq.npix - 1), P.magicNo);
+        gq.m0 = blk * P.pix_per_block;                                                  // (flat in the strip: rows of Wt cells)
+        gq.npix = min(P.pix_per_block, strip_pix - gq.m0);
+        gq.y0 = __umulhi((uint32_t)gq.m0, P.magicWt);
+        const int ylast = __umulhi((uint32_t)(gq.m0 + gq.npix - 1), P.magicWt);
         gq.nitems = (ylast - gq.y0 + KS) * P.W2 * Q;
         gq.fcls = 2 * gq.f + (ylast == P.No - 1 ? 1 : 0);     // EDGE: which weight-id triple (face; the tile holds the face's last row)
         return gq;
@@ -307,7 +318,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             return (r >> 1) * g0 + ((ii - r * P.Nin) >> 1);
         };
         auto lookup = [&](const Geo &gq) __attribute__((always_inline)) {
-            const int base = (gq.f * rstride + gq.y0) * rstride - OFF;
+            const int base = (gq.f * rstride + gq.y0) * rstride + gq.x0 - OFF;
 #pragma unroll
             for (int i = 0; i < ITS; ++i) {
                 const int sc = slot_c[i];
@@ -490,9 +501,9 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // 2 x 2 pooling blocks again.
     auto tile_pix = [&](int loc) __attribute__((always_inline)) {
         const int lin = ilv ? (((loc >> 5) * WM + wm) * 32 + (loc & 31)) : wm * MT * 32 + loc;
-        const int hN = P.No >> 1;
+        const int hN = P.Wt >> 1;
         const int r = loc >= hN ? 1 : 0;
-        const int cs = (2 * (wm >> 1) + r) * P.No + (wm & 1) * hN + (loc - r * hN);
+        const int cs = (2 * (wm >> 1) + r) * P.Wt + (wm & 1) * hN + (loc - r * hN);
         return P.colsplit ? cs : lin;
     };
     f32x16 acc[MT][NT];
@@ -541,11 +552,12 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
         const int mm = tile_pix(mt * 32 + px);
         const int c = (nt0 + wn * NT + nt) * 32 + q * (16 / ES);
         const int gm = gq.m0 + mm;
-        int off = (gq.f * face_pix + gm) * P.Cout + c;
+        const int sy = __umulhi((uint32_t)gm, P.magicWt), sx = gm - sy * P.Wt;      // row / column inside the strip
+        int off = (gq.f * face_pix + sy * P.No + gq.x0 + sx) * P.Cout + c;
         sel = 0;
         if constexpr (DIRECT) {
-            // direct mode: an interior cell of the padded gradient IS cell (oy-1, ox-1) of the source
-            const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
+            // direct mode: an interior cell of the padded gradient IS cell (oy-1, ox-1) of the source  (never with column blocks)
+            const int oy = sy, ox = sx;
             const int Ns = P.No - 2 * RING;
             const bool in0 = c < P.dsplit;
             const bool have = (in0 ? P.d0 : P.d1) != nullptr;
@@ -579,7 +591,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     uint32_t plds0[PNP], plds1[PNP], pgo[NT][PNP];  // LDS offsets of i00 / i00 + No, byte offset in one sample of pool_out
     auto pool_setup = [&](const Geo &gq) {
         const int hN = P.No >> 1;
-        const int Wl = P.colsplit ? hN : P.No, hW = Wl >> 1;        // the wave's pixels as rows of Wl (local, row-major)
+        const int Wl = P.colsplit ? (P.Wt >> 1) : P.Wt, hW = Wl >> 1;   // the wave's pixels as rows of Wl (local, row-major)
 #pragma unroll
         for (int ps = 0; ps < PNP; ++ps) {
             const int item = ps * 64 + lane;
@@ -589,7 +601,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
             plds0[ps] = (uint32_t)((i00 >> 5) * (32 * PROW) + (i00 & 31) * PROW + q * 16);
             plds1[ps] = (uint32_t)((i10 >> 5) * (32 * PROW) + (i10 & 31) * PROW + q * 16);
             const int gm = gq.m0 + tile_pix(i00);
-            const int oy = __umulhi((uint32_t)gm, P.magicNo), ox = gm - oy * P.No;
+            const int oy = __umulhi((uint32_t)gm, P.magicWt), ox = gq.x0 + (gm - oy * P.Wt);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int c = (nt0 + wn * NT + nt) * 32 + q * (16 / ES);
@@ -609,8 +621,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
                 int base = 0;
                 if (m < gq.npix) {
                     const int gm = gq.m0 + m;
-                    const int oy = __umulhi((uint32_t)gm, P.magicNo);
-                    const int ox = gm - oy * P.No;
+                    const int oy = __umulhi((uint32_t)gm, P.magicWt);
+                    const int ox = gm - oy * P.Wt;
                     base = ((oy - gq.y0) * P.W2 + ox) * RB;
                 }
                 abase[mt] = base + half * 16;
@@ -1009,7 +1021,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     };
     // fallback (odd channel counts, or no LDS room for the patches): quads / scalars straight from the accumulators
     auto epilogue_plain = [&](const Geo &gq) {
-        T *outp = reinterpret_cast<T *>(P.out) + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;
+        T *outp = reinterpret_cast<T *>(P.out) + ((size_t)gq.b * 6 + gq.f) * face_pix * P.Cout;      // (never with column blocks)
         const bool wide = (P.Cout & 3) == 0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
