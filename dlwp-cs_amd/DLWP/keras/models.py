@@ -1454,8 +1454,8 @@ class Model(object):
         """Free the device buffers rollouts keep between calls: the series buffer and every captured chain that writes into it
         (its graph keeps a private activation pool alive)."""
         live = {t.data_ptr() for t in self._rollout_series.values()}
-        for k in [k for k in self._infer_graphs if k[0] == 'rollout' and k[-1] is not None and k[-1][0] in live]:
-            del self._infer_graphs[k]
+        for k in [k for k in self._infer_graphs if (k[0] == 'rollout' and k[-1] is not None and k[-1][0] in live) or k[0] == 'forcing']:
+            del self._infer_graphs[k]           # (a forced rollout's graph owns its series, insolation and input buffers)
             self._seen_batch.pop(k, None)
         self._rollout_series.clear()
 
@@ -1536,31 +1536,86 @@ class Model(object):
                 steps_ar = np.arange(its, dtype=np.int64)
             elif c_main != c_out or i_solar:
                 raise ValueError('rollout_with_forcing: without insolation the last output must have the main input\'s shape')
+            if insolation is not None and len(i_solar) != n_out - 1:
+                raise ValueError('rollout_with_forcing: %d solar inputs for %d outputs' % (len(i_solar), n_out))
+            # every gather index of the rollout in ONE device tensor, uploaded before the first launch: rows start + (s+1)*its*n_out +
+            # m*its + (0..its-1) for sequence step s, output m (extensions.py:277-287) -- the loop below then never touches the host
+            idx_all = None
+            if insolation is not None and sequence_steps > 1:
+                rows = (start[None, None, :, None] + ((np.arange(1, sequence_steps) * its * n_out)[:, None, None, None]
+                                                      + (np.arange(n_out) * its)[None, :, None, None] + steps_ar[None, None, None, :]))
+                idx_all = torch.from_numpy(np.ascontiguousarray(rows.reshape(sequence_steps - 1, n_out, B * its).astype(np.int32))).to(dev)
+
+            def chain(cur, sol, idx_all, series, repack_first, zero):
+                cur = list(cur)
+                for s in range(sequence_steps):
+                    res = self._forward(cur, repack=(repack_first and s == 0))      # weights are fixed during a rollout
+                    for k in range(n_out):
+                        series[s, k].copy_(res[k])
+                    if s + 1 == sequence_steps:
+                        break
+                    if insolation is None:
+                        cur[i_main] = res[-1]
+                        continue
+                    nxt = []
+                    for m in range(n_out):
+                        buf = torch.empty((B, its) + space + (1,), dtype=cdt, device=dev)
+                        ops.batch_gather(sol, idx_all[s, m], zero, buf.view((B * its,) + space + (1,)), 1, 0, 1, 0, 1, True)
+                        nxt.append(buf)
+                    cur[i_main] = ops.state_repack(res[-1], nxt[0], its)
+                    for m, i in enumerate(i_solar):
+                        cur[i] = nxt[m + 1]
+
+            if verbose > 0:
+                print('Time steps 1-%d/%d (one chain of launches: the steps of a batch finish together)' % (sequence_steps, sequence_steps))
+            # With use_graphs the whole chain is ONE hipGraph from the second call with the same shapes on (as rollout_passes_on_device):
+            # inputs, insolation rows and gather indices are copied into the graph's static buffers, the series it returns lives in the
+            # graph's pool and is overwritten by the next call with the same key (TimeSeriesEstimator downloads it at once).
+            key = ('forcing', tuple(tuple(t.shape) for t in cur), str(cur[i_main].dtype), sequence_steps,
+                   None if insolation is None else tuple(sol.shape), os.environ.get('DLWPCS_OPTIONS', ''))
+            g = self._infer_graphs.get(key) if (self.use_graphs and cur[i_main].is_cuda) else False
+            if g is None:
+                n = self._seen_batch.get(key, 0)
+                self._seen_batch[key] = n + 1
+                if n > 0:
+                    self._ensure_packed(dev)
+                    sin = [torch.empty_like(t).copy_(t) for t in cur]
+                    ssol = None if insolation is None else torch.empty_like(sol).copy_(sol)
+                    sidx = None if idx_all is None else torch.empty_like(idx_all).copy_(idx_all)
+                    sser = torch.empty((sequence_steps, n_out, B) + space + (c_out,), dtype=torch.float32, device=dev)
+                    szero = torch.zeros(1, dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize()
+                    graph = _new_graph()
+                    gc_was_enabled = gc.isenabled()
+                    gc.collect()
+                    gc.disable()
+                    try:
+                        mode = 'thread_local' if parallel.group_alive() else 'global'
+                        with torch.cuda.graph(graph, capture_error_mode=mode):
+                            chain(sin, ssol, sidx, sser, False, szero)
+                        g = self._infer_graphs[key] = {'graph': graph, 'in': sin, 'sol': ssol, 'idx': sidx, 'series': sser, 'zero': szero}
+                    except Exception as exc:
+                        import warnings
+                        warnings.warn('capturing the forced rollout into a hipGraph failed (%s: %s); this rollout shape runs eagerly'
+                                      % (type(exc).__name__, exc))
+                        del graph
+                        torch.cuda.synchronize()
+                        g = self._infer_graphs[key] = False
+                    finally:
+                        if gc_was_enabled:
+                            gc.enable()
+            if g:
+                for dst, src in zip(g['in'], cur):
+                    dst.copy_(src, non_blocking=True)
+                if g['sol'] is not None:
+                    g['sol'].copy_(sol, non_blocking=True)
+                if g['idx'] is not None:
+                    g['idx'].copy_(idx_all, non_blocking=True)
+                self._ensure_packed(dev)                                        # (a launch only if something changed the parameters)
+                g['graph'].replay()
+                return g['series']
             series = torch.empty((sequence_steps, n_out, B) + space + (c_out,), dtype=torch.float32, device=dev)
-            for s in range(sequence_steps):
-                if verbose > 0:
-                    print('Time step %d/%d' % (s + 1, sequence_steps))
-                res = self._forward(cur, repack=(s == 0))                           # weights are fixed during a rollout
-                for k in range(n_out):
-                    series[s, k].copy_(res[k])
-                if s + 1 == sequence_steps:
-                    break
-                if insolation is None:
-                    cur[i_main] = res[-1]
-                    continue
-                # known forcing of the next application: time rows start + (s+1)*its*n_out + n + m*its  (extensions.py:277-287)
-                nxt = []
-                for m in range(n_out):
-                    rows = (start[:, None] + (s + 1) * its * n_out + m * its + steps_ar[None, :]).reshape(-1)
-                    idx = torch.from_numpy(rows.astype(np.int32)).to(dev)
-                    buf = torch.empty((B, its) + space + (1,), dtype=cdt, device=dev)
-                    ops.batch_gather(sol, idx, zero, buf.view((B * its,) + space + (1,)), 1, 0, 1, 0, 1, True)
-                    nxt.append(buf)
-                cur[i_main] = ops.state_repack(res[-1], nxt[0], its)
-                if len(i_solar) != n_out - 1:
-                    raise ValueError('rollout_with_forcing: %d solar inputs for %d outputs' % (len(i_solar), n_out))
-                for m, i in enumerate(i_solar):
-                    cur[i] = nxt[m + 1]
+            chain(cur, sol if insolation is not None else None, idx_all, series, True, zero if insolation is not None else None)
         return series
 
     def reset_states(self):

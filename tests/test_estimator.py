@@ -231,6 +231,16 @@ def test_estimator_device_rollout_matches_oracle_and_host_loop(dtype):
     fk = est.predict(steps, samples=samples, keep_time_dim=True)
     assert fk.dims[:3] == ('f_hour', 'time', 'time_step') and fk.values.shape == (6, 4, ITS, 6, N, N, V)
     assert np.array_equal(fk.values[0, :, 0], fc.values[0])
+    # from the second call on the whole forced rollout is ONE hipGraph replay (inputs, insolation rows and gather indices copied into
+    # the graph's static buffers): other samples through the captured chain == the same chain launched eagerly, bit for bit
+    assert any(k[0] == 'forcing' and g for k, g in model._infer_graphs.items())
+    s2 = np.array([2, 3, 5, 8])
+    a = est.predict(steps, samples=s2).values.copy()
+    a2 = est.predict(steps, samples=samples).values.copy()
+    model.use_graphs = False
+    b = est.predict(steps, samples=s2).values
+    assert np.array_equal(a, b) and np.array_equal(a2, fc.values)
+    assert not np.array_equal(a, a2)
 
 
 # --------------------------------------------------------------------------------------------------------------------- #
