@@ -15,6 +15,7 @@ is asked for, so a test can set it around the construction of a model).  Everyth
   cf_model        channels_first models run channels_last inside, one transpose per input / output            (Model)
   padded_io       bf16 rollouts with C % 8 != 0 keep their state padded to C + pad channels between passes    (Model)
   host_staging    fit() / predict() on host arrays stage batches in pinned memory on a copy stream            (Model)
+  resident_data   fit() over several epochs keeps the arrays it uploaded during the first one in HBM            (Model)
   fold_head       inference: the pointwise output layer inside the epilogue of the convolution in front of it  (Model)
   dgrad_gather    bf16 data gradients in gather form (no halo ring, no fix-up launches); 0: padded grid        (ops)
   check_finite    fit() raises on a non-finite loss                                                            (Model.check_finite)
@@ -23,7 +24,7 @@ import os
 
 DEFAULTS = {
     'graphs': True, 'premask': True, 'wgrad_batch': True, 'fuse_adam': True, 'fuse_pack': True, 'fuse_head': True,
-    'fold_loss_tail': True, 'fuse_pool': True, 'fold_ring': True, 'cf_model': True, 'padded_io': True, 'host_staging': True,
+    'fold_loss_tail': True, 'fuse_pool': True, 'fold_ring': True, 'cf_model': True, 'padded_io': True, 'host_staging': True, 'resident_data': True,
     'dgrad_gather': True, 'fold_head': True, 'check_finite': False,
 }
 

@@ -179,3 +179,43 @@ def test_device_generator_in_another_dtype_trains_like_the_host_path():
         res.append(np.asarray(p))
     assert np.array_equal(res[0], res[2])
     assert np.array_equal(res[1], res[3])
+
+
+def test_multi_epoch_fit_keeps_the_data_in_hbm_and_trains_the_same():
+    """fit() on host arrays over several epochs (engine option resident_data): the first epoch's uploads are kept in device buffers,
+    later epochs gather their batches out of HBM.  Same shuffles (one numpy draw per epoch either way), same batches, same kernels:
+    the weights after three shuffled epochs are bitwise those of the all-host-fed run; the second epoch on does not touch the link."""
+    import os
+    from DLWP.keras import backend
+    from DLWP.model.cs_unet import build_cs_model
+    backend.set_device('cuda:0')
+    N, C, n = 16, 6, 40                          # 40 samples, batches of 16: a ragged last batch
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((n, 6, N, N, C)).astype(np.float32)
+    y = rng.standard_normal((n, 6, N, N, C)).astype(np.float32)
+    out = []
+    for on in ('0', '1'):
+        os.environ['DLWPCS_OPTIONS'] = 'resident_data=' + on
+        try:
+            backend.set_compute_dtype('bfloat16')
+            try:
+                np.random.seed(5)
+                model = build_cs_model((6, N, N, C), C, 'unet2', base_filter_number=8)
+            finally:
+                backend.set_compute_dtype('float32')
+            model.compile(optimizer='adam', loss='mse', metrics=['mae'])
+            np.random.seed(11)
+            hist = model.fit(x, y, batch_size=16, epochs=3, verbose=0, shuffle=True)
+            torch.cuda.synchronize()
+            res = model._last_resident
+            assert (res is not None and res['state'] == 'ready' and res['bufs'] is None) == (on == '1')
+            out.append((np.concatenate([w.ravel() for w in model.get_weights()]), np.array(hist.history['loss'])))
+        finally:
+            os.environ.pop('DLWPCS_OPTIONS', None)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    # one epoch, or a bounded number of steps per epoch: nothing to keep
+    model.fit(x, y, batch_size=16, epochs=1, verbose=0)
+    assert model._last_resident is None
+    model.fit(x, y, batch_size=16, epochs=3, steps_per_epoch=2, verbose=0)
+    assert model._last_resident is None
