@@ -620,6 +620,51 @@ __global__ void __launch_bounds__(256) batch_gather_cl_kernel(const float *__res
     }
 }
 
+// The same for the common case "the gathered channels ARE the output row" (c_off = 0, c_stride = nv, Ctot = n_steps * nv; S % 4 == 0,
+// 16-B aligned array rows): a workgroup moves 256 pixels x all channels -- 16-B loads (1 KB contiguous per wave and channel row
+// instead of 256 B), and the tile's 256 x nch outputs are ONE contiguous block of `out`, written as 16-B vectors.  Round 6: the two
+// gathers of a generator-fed training step took 26 us each (1.2-1.9 TB/s); they are what a step fed by the HBM-resident
+// ArrayDataGenerator costs beyond the step itself.
+template <typename OT>
+__global__ void __launch_bounds__(256) batch_gather_cl_rows_kernel(const float *__restrict__ array, size_t S, int V,
+                                                                   const int32_t *__restrict__ samples,
+                                                                   const int32_t *__restrict__ var_idx, int nv, int n_steps,
+                                                                   int t_off, int t_stride, OT *__restrict__ out) {
+    extern __shared__ float tile[];                 // [nch][257]
+    const int nch = n_steps * nv;
+    const size_t s0 = (size_t)blockIdx.x * 256;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long t0 = (long)samples[b] + t_off;
+    const int npx = (int)(S - s0 < 256 ? S - s0 : 256);             // (a multiple of 4)
+    for (int cc = w; cc < nch; cc += 4) {
+        const int n = cc / nv, j = cc - n * nv;
+        const float *src = array + ((size_t)(t0 + (long)n * t_stride) * V + var_idx[j]) * S + s0;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane * 4 < npx) v = *reinterpret_cast<const float4 *>(src + lane * 4);
+        float *t = tile + cc * 257 + lane * 4;
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+    __syncthreads();
+    constexpr int EV = 16 / (int)sizeof(OT);        // output elements per 16-B store: 8 bf16 / 4 fp32
+    const int total = npx * nch;                    // (a multiple of EV: npx % 4 == 0, and bf16 rows need nch % 2 == 0 -- host)
+    OT *dst = out + ((size_t)b * S + s0) * nch;
+    for (int e0 = threadIdx.x * EV; e0 < total; e0 += 256 * EV) {
+        int px = e0 / nch, cc = e0 - px * nch;
+        float v[EV];
+#pragma unroll
+        for (int k = 0; k < EV; ++k) {
+            v[k] = tile[cc * 257 + px];
+            if (++cc == nch) { cc = 0; ++px; }
+        }
+        if constexpr (sizeof(OT) == 2) {
+            *reinterpret_cast<uint4 *>(dst + e0) = make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+        } else {
+            *reinterpret_cast<float4 *>(dst + e0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 template <typename OT>
 __global__ void __launch_bounds__(256) batch_gather_cf_kernel(const float *__restrict__ array, size_t S, int V,
                                                               const int32_t *__restrict__ samples,
@@ -1294,6 +1339,20 @@ extern "C" int dlwpcs_batch_gather(const void *array, int64_t T, int V, int64_t 
     if (channels_last) {
         const size_t lds = (size_t)nch * 65 * sizeof(float);
         if (lds > 64 * 1024) return fail(DLWPCS_E_UNSUPPORTED, "batch_gather: %d gathered channels exceed the LDS tile", nch);
+        // whole output rows, 16-B aligned on both sides: the 256-pixel vector kernel
+        const size_t lds_rows = (size_t)nch * 257 * sizeof(float);
+        const int ev = dtype == DLWPCS_BF16 ? 8 : 4;
+        if (c_off == 0 && c_stride == nv && Ctot == nch && S % 4 == 0 && (4 * nch) % ev == 0 && lds_rows <= 64 * 1024 &&
+            ((uintptr_t)array & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+            dim3 grid_r((unsigned)((S + 255) / 256), (unsigned)B);
+            if (dtype == DLWPCS_BF16)
+                hipLaunchKernelGGL(batch_gather_cl_rows_kernel<bf16_t>, grid_r, dim3(256), lds_rows, s, (const float *)array, (size_t)S, V,
+                                   samples_dev, var_idx_dev, nv, n_steps, t_off, t_stride, (bf16_t *)out);
+            else
+                hipLaunchKernelGGL(batch_gather_cl_rows_kernel<float>, grid_r, dim3(256), lds_rows, s, (const float *)array, (size_t)S, V,
+                                   samples_dev, var_idx_dev, nv, n_steps, t_off, t_stride, (float *)out);
+            return check_launch("batch_gather");
+        }
         dim3 grid((unsigned)((S + 63) / 64), (unsigned)B);
         if (dtype == DLWPCS_BF16)
             hipLaunchKernelGGL(batch_gather_cl_kernel<bf16_t>, grid, dim3(256), lds, s, (const float *)array, (size_t)S, V,

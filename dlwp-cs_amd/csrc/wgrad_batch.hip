@@ -487,43 +487,71 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    int tapoff[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) tapoff[t] = ((t / KS) * L.W2 + (t % KS)) * PB;
-
     const int nslab = pix_cap / 16;             // K slabs (16 pixels) per item
     const int S = (((nslab + NPH - 1) / NPH) + 1) & ~1;   // slabs per consumer wave, rounded up to even (extras add zero)
-    const int ct = wave % CT, nt = (wave / CT) % NT, ph = wave / (CT * NT);
+    // (the wave index as a SCALAR: which plane, which slabs and whether a slab is alive are then scalar selects, not v_cndmasks)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int ct = wave_u % CT, nt = (wave_u / CT) % NT, ph = wave_u / (CT * NT);
+    // Addresses carried from slab to slab by ADDITIONS (round 6).  A lane's pixel advances by 16 * NPH per slab of its wave; through
+    // round 5 every slab recomputed (row, column) of its two pixels from the flat index -- v_mul_hi / v_mul_lo / v_mad_u64 per pixel,
+    // 12 quarter-rate instructions per pair of slabs on the SIMD the producer wave shares (the loop ran ~1030 cycles per 18 MFMAs =
+    // 576 cycles of matrix pipe).  Now two divisions per lane and ITEM; per slab the column advances by (16 * NPH) % No with at most one
+    // wrap, the tile address by a constant plus W2 - No pixels per wrap.  No clamp to the item's last pixel either: pixels of the
+    // 16-pixel round-up and of a band's missing rows hold zeros in the dZ plane (their loads were issued out of range), their X
+    // address stays inside the tile plane (rows the producers wrote as zeros).
+    constexpr int DSTEP = 16 * NPH;
+    const int stq = (int)__umulhi((uint32_t)DSTEP, L.magicNo), str = DSTEP - stq * L.No;
+    const int stepA = (stq * L.W2 + str) * PB, wrapA = (L.W2 - L.No) * PB, rowB = L.W2 * PB;
+    const int mlane = 16 * ph + 8 * half + prow;        // this lane's pixel of its wave's first slab (jj = 0; jj = 1: + 4)
     for (int k = 0; k < n_my; ++k) {
         WB_TL(1);                               // bucket 1: fragment reads + MFMAs of the previous item (+ set-up)
         __syncthreads();                        // B_k
         WB_TL(0);                               // bucket 0: wait at B_k
-        const char *lds_x0 = smem + (k & 1) * buf_bytes, *lds_dy = lds_x0 + x_bytes + nt * dzplane_bytes;
-        const char *lds_x = lds_x0 + ct * plane_bytes;
+        const int buf0 = (k & 1) * buf_bytes;
         const Item it = item_of(k);
+        const int x0 = it.m0 - it.y0 * L.No;    // first pixel's column (0: bands are whole rows wherever a face row fits an item)
+        int xa[2], ox[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int g = x0 + mlane + 4 * jj;
+            const int oy = __umulhi((uint32_t)g, L.magicNo);
+            ox[jj] = g - oy * L.No;
+            xa[jj] = buf0 + ct * plane_bytes + (oy * L.W2 + ox[jj]) * PB + choff;
+        }
+        int da = buf0 + x_bytes + nt * dzplane_bytes + mlane * PB + choff;
+        // frag(si) must be called for si = 0, 1, 2, ... in order: it reads slab si at the carried addresses and moves them on
         auto frag = [&](int si, uint4 (&a)[TAPS], uint4 &bq) {
             const int s = ph + NPH * si;
-            const int sc = min(s, nslab - 1);
-            const bool live = s < nslab;
-            int xaddr[2], daddr[2];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int m = 16 * sc + 8 * half + 4 * jj + prow;
-                const int gm = it.m0 + min(m, it.npix - 1);
-                const int oy = __umulhi((uint32_t)gm, L.magicNo);
-                xaddr[jj] = ((oy - it.y0) * L.W2 + (gm - oy * L.No)) * PB + choff;
-                // a slab past the item's pixels reads its dZ fragment 8 MB beyond the allocation: zeros (dlwpcs_lds_oob_probe).  As a
-                // select on the LOADED fragment the masking put a wait for these two reads -- issued a moment before -- into every
-                // slab: one exposed LDS round trip per 9 MFMAs
-                daddr[jj] = m * PB + choff + (live ? 0 : (1 << 23));
-            }
-            const uint2 b0 = lds_tr16(lds_dy + daddr[0]), b1 = lds_tr16(lds_dy + daddr[1]);
+            // a slab past the item's pixels reads its dZ fragment 8 MB beyond the allocation: zeros (dlwpcs_lds_oob_probe).  As a
+            // select on the LOADED fragment the masking put a wait for these two reads -- issued a moment before -- into every
+            // slab: one exposed LDS round trip per 9 MFMAs
+            const char *pd = smem + da + (s < nslab ? 0 : (1 << 23));
+            const uint2 b0 = lds_tr16(pd), b1 = lds_tr16(pd + 4 * PB);
             bq = make_uint4(b0.x, b0.y, b1.x, b1.y);
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const uint2 a0 = lds_tr16(lds_x + xaddr[0] + tapoff[tap]), a1 = lds_tr16(lds_x + xaddr[1] + tapoff[tap]);
-                a[tap] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            for (int ky = 0; ky < KS; ++ky) {
+                const char *p0 = smem + xa[0] + ky * rowB, *p1 = smem + xa[1] + ky * rowB;
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+#ifdef DLWPCS_WB_ABL_DS         // (side builds only: wrong numbers -- one X fragment per slab / per tap row instead of nine)
+                    if (DLWPCS_WB_ABL_DS == 1 && (ky | kx)) { a[ky * KS + kx] = a[0]; continue; }
+                    if (DLWPCS_WB_ABL_DS == 3 && kx) { a[ky * KS + kx] = a[ky * KS]; continue; }
+#endif
+                    const uint2 a0 = lds_tr16(p0 + kx * PB), a1 = lds_tr16(p1 + kx * PB);
+                    a[ky * KS + kx] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                }
             }
+            // on to the wave's next slab (frozen once that one is dead: the X address never leaves the tile plane)
+            const bool nl = s + NPH < nslab;
+            const int sr = nl ? str : 0, sa = nl ? stepA : 0;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int o = ox[jj] + sr;
+                const bool w = o >= L.No;
+                ox[jj] = w ? o - L.No : o;
+                xa[jj] += sa + (w ? wrapA : 0);
+            }
+            da += DSTEP * PB;
         };
         uint4 fa[2][TAPS], fb[2];
         frag(0, fa[0], fb[0]);
