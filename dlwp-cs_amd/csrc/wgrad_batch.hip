@@ -350,6 +350,9 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
         };
         auto bld = [](rsrc_t r, uint32_t off, auto &dst) __attribute__((always_inline)) {
             typedef std::remove_reference_t<decltype(dst)> V;
+#ifdef DLWPCS_WB_ABL_P          // (side builds only, wrong numbers: 2 = no global loads)
+            if (DLWPCS_WB_ABL_P & 2) { memset(&dst, 0, sizeof(V)); asm volatile("" : "+v"(*reinterpret_cast<uint32_t *>(&dst))); return; }
+#endif
             if constexpr (sizeof(V) == 16) {
                 const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
                 dst = make_uint4(q.x, q.y, q.z, q.w);
@@ -404,8 +407,12 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
             // (slots beyond the item's cells hold zeros: their loads were issued with the out-of-range offset)
             char *const xbase = buf + (ptid / QX) * PB + qx * (XV * 2);
 #pragma unroll
-            for (int i = 0; i < IT_X; ++i)
+            for (int i = 0; i < IT_X; ++i) {
+#ifdef DLWPCS_WB_ABL_P          // (1 = no LDS writes: the data is waited for, then dropped)
+                if (DLWPCS_WB_ABL_P & 1) { asm volatile("" :: "v"(*reinterpret_cast<uint32_t *>(&st.xv[i]))); continue; }
+#endif
                 *reinterpret_cast<XVec *>(xbase + (i % CT) * plane_bytes + (i / CT) * (NCT / QX) * PB) = st.xv[i];
+            }
             char *const dbase = buf + x_bytes + (qd / QD) * dzplane_bytes + (ptid / QDT) * PB + (qd % QD) * (DV * 2);
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
@@ -414,7 +421,14 @@ __device__ WB_SEG_ATTR void wb_segment(const WbLayer &Lg, const WbSeg &sgg, cons
                     else vmask(st.dv[i], st.yv[i], L.alpha, L.vmax);
                 }
                 const DVec v = st.dv[i];
+#ifdef DLWPCS_WB_ABL_P
+                if (DLWPCS_WB_ABL_P & 1) { asm volatile("" :: "v"(*reinterpret_cast<const uint32_t *>(&v))); }
+                else
+#endif
                 *reinterpret_cast<DVec *>(dbase + i * (NCT / QDT) * PB) = v;
+#ifdef DLWPCS_WB_ABL_P
+                if (DLWPCS_WB_ABL_P & 4) continue;      // (4 = no bias sums)
+#endif
                 if (want_bias) {
                     if constexpr (DV == 8) {
                         bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
@@ -724,6 +738,7 @@ __device__ __attribute__((noinline)) void wb_segment_f32(const WbLayer &Lg, cons
         const int qx = ptid & ((1 << lqx) - 1), qd = ptid & ((1 << lqd) - 1);
         const int nit_x = (((L.tile_rows_max * L.W2) << lqx) + NCT - 1) / NCT;         // (uniform: iterations that carry work)
         const int nit_d = ((pix_cap << lqd) + NCT - 1) / NCT;
+        const int x_cap = (L.tile_rows_max * L.W2) << lqx;
         const int cx = sg.cit * 32 + qx * 4;
         const bool cx_ok = cx < L.Cin;
         const bool hi_ok = cx + 2 < L.Cin;      // (H2: the vector is two 8-B halves, the upper one may lie past the last channel)
@@ -819,7 +834,8 @@ __device__ __attribute__((noinline)) void wb_segment_f32(const WbLayer &Lg, cons
 #pragma unroll
             for (int i = 0; i < IT_X; ++i) {
                 const int e = ptid + i * NCT;
-                if (i < nit_x && e < cur.nitems) *reinterpret_cast<float4 *>(buf + (e >> lqx) * XS + qx * 4) = vsel(xok[i], xv[i]);
+                // (every slot of the tile, zeros beyond the item's cells: the consumers' capped addresses may read them, see pb_max)
+                if (i < nit_x && e < x_cap) *reinterpret_cast<float4 *>(buf + (e >> lqx) * XS + qx * 4) = vsel(xok[i], xv[i]);
             }
 #pragma unroll
             for (int i = 0; i < IT_DY; ++i) {
@@ -860,54 +876,57 @@ __device__ __attribute__((noinline)) void wb_segment_f32(const WbLayer &Lg, cons
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int nsteps = pix_cap / 2;
     const int S = (((nsteps + 3) / 4) + 1) & ~1;
+    // Addresses carried from step to step by additions (round 6, as in wb_segment): a lane's pixel advances by 8 per step of its wave.
+    // A v_mfma_f32_32x32x2_f32 takes 64 cycles and the fitted period was 73: the ~13 VALU instructions per step (three of them
+    // quarter-rate: v_mul_hi, v_mul_lo, v_mad) issue BETWEEN the MFMAs of an in-order wave, they do not hide behind them.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int stq = (int)__umulhi(8u, L.magicNo), str = 8 - stq * L.No;
+    const int stepA = (stq * L.W2 + str) * XS, wrapA = (L.W2 - L.No) * XS;
+    // (the X address is capped at the tile's last window: pixels of the round-up to even / of a band's missing rows have dZ = 0, and the
+    // producers write every slot of the tile -- zeros beyond the item's cells --, so what they read there is finite)
+    const int pb_max = ((L.tile_rows_max - KS) * L.W2 + (L.W2 - KS)) * XS + l31;
     for (int k = 0; k < n_my; ++k) {
         __syncthreads();                // B_k
         const float *lds_x = smem + (k & 1) * buf_floats, *lds_dy = lds_x + x_floats;
         const Item it = item_of(k);
-        // Pixel pair `si` of this wave: the LDS offset of its X value under tap (0, 0) and of its dZ value.  The addresses of
-        // step si + 2 are computed, and the 10 reads of step si + 1 issued, in the shadow of the 9 MFMAs of step si: an in-order
-        // wave that first issues all reads, then all MFMAs leaves the matrix pipe idle while it does the address arithmetic
-        // (measured, nine 3x3 layers of unet2 at B = 32: 816 us that way, ... us interleaved; 440 us is the pipe's own time).
-        struct Addr { int pb, db; bool on; };
-        auto addr = [&](int si) {
-            const int s = wave + 4 * si;
-            const int kk = min(2 * s + half, pix_cap - 1);
-            const int gm = it.m0 + min(kk, it.npix - 1);
-            const int oy = __umulhi((uint32_t)gm, L.magicNo);
-            Addr A;
-            A.pb = ((oy - it.y0) * L.W2 + (gm - oy * L.No)) * XS + l31;
-            A.db = kk * 32 + l31;
-            A.on = s < nsteps;
-            return A;
-        };
-        auto frag = [&](const Addr &A, float (&a)[TAPS], float &bq) {
-#ifdef WB_F32_ABL
-            if (WB_F32_ABL & 4) {
-                bq = __int_as_float(A.db);
+        // Pixel pair `si` of this wave: the LDS offset of its X value under tap (0, 0) and of its dZ value.  The 10 reads of step
+        // si + 1 are issued in the shadow of the 9 MFMAs of step si: an in-order wave that first issues all reads, then all MFMAs
+        // leaves the matrix pipe idle (measured, nine 3x3 layers of unet2 at B = 32: 816 us that way; 440 us is the pipe's own time).
+        const int kk0 = 2 * wave_u + half;
+        int ox, pb, db = kk0 * 32 + l31;
+        {
+            const int g = it.m0 - it.y0 * L.No + kk0;
+            const int oy = __umulhi((uint32_t)g, L.magicNo);
+            ox = g - oy * L.No;
+            pb = (oy * L.W2 + ox) * XS + l31;
+        }
+        // frag(si) must be called for si = 0, 1, 2, ... in order: it reads step si at the carried addresses and moves them on
+        auto frag = [&](int si, float (&a)[TAPS], float &bq) {
+            const int s = wave_u + 4 * si;
+            // (a step past the item's pixel pairs reads its dZ value 8 MB beyond the allocation: zero -- dlwpcs_lds_oob_probe)
+            bq = lds_dy[db + (s < nsteps ? 0 : (1 << 21))];
+            const int p = min(pb, pb_max);
 #pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) a[tap] = __int_as_float(A.pb + tap);
-                return;
-            }
-#endif
-            const float bv = lds_dy[A.db];
-            bq = A.on ? bv : 0.f;
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) a[tap] = lds_x[A.pb + ((tap / KS) * L.W2 + (tap % KS)) * XS];
+            for (int tap = 0; tap < TAPS; ++tap) a[tap] = lds_x[p + ((tap / KS) * L.W2 + (tap % KS)) * XS];
+            const bool nl = s + 4 < nsteps;
+            const int sr = nl ? str : 0, sa = nl ? stepA : 0;
+            const int o = ox + sr;
+            const bool w = o >= L.No;
+            ox = w ? o - L.No : o;
+            pb += sa + (w ? wrapA : 0);
+            db += 8 * 32;
         };
         float fa[2][TAPS], fb[2];
-        Addr A0 = addr(0), A1 = addr(1);
-        frag(A0, fa[0], fb[0]);
+        frag(0, fa[0], fb[0]);
 #ifdef WB_F32_ABL
         if (WB_F32_ABL & 1) continue;
 #endif
         for (int si = 0; si < S; si += 2) {
-            frag(A1, fa[1], fb[1]);
-            A0 = addr(si + 2);
+            frag(si + 1, fa[1], fb[1]);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][tap], fb[0], acc[tap], 0, 0, 0);
             WB_F32_SCHED();
-            frag(A0, fa[0], fb[0]);
-            A1 = addr(si + 3);
+            frag(si + 2, fa[0], fb[0]);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][tap], fb[1], acc[tap], 0, 0, 0);
             WB_F32_SCHED();
