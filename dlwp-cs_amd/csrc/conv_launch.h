@@ -21,6 +21,34 @@ static int tile_pixels(int BM, int No) {
     return pix;
 }
 
+// ILV (conv_ws.h): cost of the most expensive tile list when `gx` workers share the 6 * B * ceil(face_pix / pix) tiles of a launch, a
+// tile of mn M tiles costing 2 x ceil(mn / WM) + 1.  split = false: the plain contiguous split (some worker has ceil(ntiles / gx) full
+// tiles).  split = true: the M tiles dealt round-robin and, where the last tile of a face is cheaper than the others, the best cost
+// split (*gb workers take all the short tiles + *fb full ones; 0 / 0: the plain split is as good).
+static long ilv_cost(int pix, int face_pix, int B, int gx, int WM, int *gb, int *fb, bool split, int c2 = 2) {
+    auto cost = [&](int npix) { const int mn = (npix + 31) / 32; return 4 * ceil_div(mn, WM) + c2; };       // (in half units)
+    const int nbl = ceil_div(face_pix, pix), cF = cost(pix), cL = cost(face_pix - (nbl - 1) * pix);
+    const long ntiles = 6l * B * nbl;
+    const long plain = (long)ceil_div((int)ntiles, gx) * cF;       // (some workgroup has that many tiles, full ones in general)
+    if (gb) *gb = 0;
+    if (fb) *fb = 0;
+    if (!split || cL >= cF || nbl < 2) return plain;
+    const long F = 6l * (nbl - 1) * B, S = 6l * B;
+    long best = plain;
+    for (int GB = 1; GB < gx; ++GB) {
+        const int GA = gx - GB;
+        // FB full tiles for the B group: as many as keep a B list (ceil(FB / GB) full + ceil(S / GB) short) under the A lists
+        const long sB = ceil_div((int)S, GB) * (long)cL;
+        for (long mB = 0; mB <= ceil_div((int)F, gx) + 1; ++mB) {
+            const long FB = mB * GB < F ? mB * GB : F, FA = F - FB;
+            const long cA = (long)ceil_div((int)FA, GA) * cF, cB = mB * cF + sB;
+            const long mx = cA > cB ? cA : cB;
+            if (mx < best) { best = mx; if (gb) *gb = GB; if (fb) *fb = (int)FB; }
+        }
+    }
+    return best;
+}
+
 // the gather-form plan of the data-gradient launch in flight on this thread (conv_bwd_data_impl sets it around its dispatch_conv;
 // every other launch passes the empty record: the kernels that read it are the EDGE instantiations only)
 extern thread_local ConvEdgeArgs g_edge_args;
@@ -42,7 +70,25 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     }
     P.Wt = P.No / P.ncol;
     const int strip_pix = P.No * P.Wt;
-    const int pix = P.ncol > 1 ? (BM / P.Wt) * P.Wt : tile_pixels(BM, P.No);
+    int pix = P.ncol > 1 ? (BM / P.Wt) * P.Wt : tile_pixels(BM, P.No);
+    // fp32 forward pass (MFMA-bound: a tile costs its M tiles): tiles of k x WM M tiles, k = 1 .. MT, dealt to the waves round-robin
+    // (ILV) with the tile list cut by cost -- whichever setting has the cheapest longest list; the plain tiling unless one beats it
+    P.ilv_fwd = 0;
+    int fwd_gb = 0, fwd_fb = 0;
+    const int gy_ = ceil_div(P.NTtot, NTB);
+    const int gx_ = 256 / gy_ < 1 ? 1 : 256 / gy_;
+    if (MODE == MODE_HALO && !EDGE && KS == 3 && MT == 3 && sizeof(T) == 4 && (tune_bits() & TUNE_CONV_ILV) && (tune_bits() & TUNE_CONV_ILV_FWD) &&
+        P.ncol == 1 && P.pool_out == nullptr && gx_ > 1) {
+        static const int c2 = getenv("DLWPCS_ILV_C2") ? atoi(getenv("DLWPCS_ILV_C2")) : 2;       // (fixed cost of a tile in half M-tile rounds)
+        long best = ilv_cost(pix, face_pix, P.B, gx_, WM, nullptr, nullptr, false, c2);
+        for (int k = MT; k >= 1; --k) {
+            const int cand = 32 * WM * k;
+            if (cand >= face_pix) continue;
+            int gb = 0, fb = 0;
+            const long c = ilv_cost(cand, face_pix, P.B, gx_, WM, &gb, &fb, true, c2);
+            if (c < best) { best = c; pix = cand; P.ilv_fwd = 1; fwd_gb = gb; fwd_fb = fb; }
+        }
+    }
     P.pix_per_block = pix;
     P.nblk_face = ceil_div(strip_pix, pix);
     P.W2 = P.Wt + KS - 1;
@@ -137,28 +183,9 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     // ILV cost split (conv_ws.h): data gradient, MT = 3, the last band of a face shorter than the others.  Tile cost = 2 x rounds of
     // M tiles per consumer wave + 1.  Choose how many workers (GB) take the short tiles + FB full ones so that the most expensive
     // list is as cheap as possible; keep the plain split unless that beats it.
-    if (MODE == MODE_ZERO && MT == 3 && sizeof(T) == 4 && (P.tune & TUNE_CONV_ILV) && P.nblk_face > 1 && gx > 1) {
-        auto cost = [&](int npix) { const int mn = (npix + 31) / 32; return 2 * ceil_div(mn, WM) + 1; };
-        const int nbl = P.nblk_face, cF = cost(pix), cL = cost(face_pix - (nbl - 1) * pix);
-        if (cL < cF) {
-            const long F = 6l * (nbl - 1) * P.B, S = 6l * P.B;
-            const long plain = (long)ceil_div(P.ntiles, gx) * cF;       // (some workgroup has that many tiles, full ones in general)
-            long best = plain;
-            int best_gb = 0, best_fb = 0;
-            for (int GB = 1; GB < gx; ++GB) {
-                const int GA = gx - GB;
-                // FB full tiles for the B group: as many as keep a B list (ceil(FB / GB) full + ceil(S / GB) short) under the A lists
-                const long sB = ceil_div((int)S, GB) * (long)cL;
-                for (long mB = 0; mB <= ceil_div((int)F, gx) + 1; ++mB) {
-                    const long FB = mB * GB < F ? mB * GB : F, FA = F - FB;
-                    const long cA = (long)ceil_div((int)FA, GA) * cF, cB = mB * cF + sB;
-                    const long mx = cA > cB ? cA : cB;
-                    if (mx < best) { best = mx; best_gb = GB; best_fb = (int)FB; }
-                }
-            }
-            P.split_gb = best_gb; P.split_fb = best_fb;
-        }
-    }
+    if (MODE == MODE_ZERO && MT == 3 && sizeof(T) == 4 && (P.tune & TUNE_CONV_ILV) && P.nblk_face > 1 && gx > 1)
+        (void)ilv_cost(pix, face_pix, P.B, gx, WM, &P.split_gb, &P.split_fb, true);
+    if (P.ilv_fwd) { P.split_gb = fwd_gb; P.split_fb = fwd_fb; }
     if (P.dry_run) return DLWPCS_OK;
     int pidx = -1;
     // (the tag carries every template argument, as rocprofv3 / nm -C print the instantiation: bench.py joins its PMC records on this

@@ -80,6 +80,7 @@ struct ConvKParams {
     // global addresses are formed (halo-table lookup, store / pooled-store offsets).  ncol = 1, Wt = No: the layout of rounds 1-5.
     int Wt, ncol;
     uint32_t magicWt, magicNcol;
+    int ilv_fwd;                // fp32 forward pass: M tiles dealt round-robin + cost split (ILV in the kernel), chosen by launch_conv_cfg
 };
 
 // EDGE instantiations: `P.table` is the forward halo table inside a dlwpcs_dgrad_gather_plan buffer, `src` its border-cell records
@@ -105,12 +106,14 @@ struct ConvEdgeArgs { const int32_t *src; int8_t wids[36]; };
 // 512: data-gradient kernel: M tiles of a tile dealt to the consumer waves round-robin, short tiles skip the M tiles they do not
 //      have, tile list split by cost (see ILV in the kernel)
 //1024: forward kernel on faces of >= 64 cells: tiles are bands of a column strip (ConvKParams::ncol)
+//2048: fp32 forward kernel: tiles of fewer M tiles, dealt round-robin, tile list split by cost where that shortens the longest list (ConvKParams::ilv_fwd)
 enum { TUNE_WG_PRODUCER_PRIO = 1, TUNE_CONV_PRODUCER_PRIO = 2, TUNE_CONV_WEIGHTS_STAY = 4, TUNE_CONV_SPLIT_N = 16,
-       TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64, TUNE_CONV_STAGGER = 256, TUNE_CONV_ILV = 512, TUNE_CONV_STRIPS = 1024 };
+       TUNE_CONV_SPLIT2_BWD = 32, TUNE_CONV_WSTAT = 64, TUNE_CONV_STAGGER = 256, TUNE_CONV_ILV = 512, TUNE_CONV_STRIPS = 1024,
+       TUNE_CONV_ILV_FWD = 2048 };
 static int tune_bits() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("DLWPCS_TUNE"); v = e ? atoi(e) : (TUNE_WG_PRODUCER_PRIO | TUNE_CONV_PRODUCER_PRIO | TUNE_CONV_WEIGHTS_STAY | TUNE_CONV_SPLIT_N | TUNE_CONV_SPLIT2_BWD | TUNE_CONV_WSTAT |
-                               TUNE_CONV_STAGGER | TUNE_CONV_ILV | TUNE_CONV_STRIPS | (3 << 12));
+                               TUNE_CONV_STAGGER | TUNE_CONV_ILV | TUNE_CONV_STRIPS | TUNE_CONV_ILV_FWD | (3 << 12));
                  }
     return v;
 }
@@ -215,8 +218,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvKParams &P, char *smem, c
     // fp32 only: there a tile's time is its MFMA work and the cost split pays (unet2 fp32 step 3.278 -> 3.189 ms, same box); the bf16
     // kernels are bandwidth-bound in steady state -- their launch time did not move with the split (25.2 -> 25.0 us) and the step lost
     // the staggered start's 2-3 us -- so they keep the plain map.
-    constexpr bool ILV_OK = MODE == MODE_ZERO && MT == 3 && sizeof(T) == 4;
-    const bool ilv = ILV_OK && (P.tune & TUNE_CONV_ILV) != 0;
+    // (round 6: the fp32 FORWARD pass too, where launch_conv_cfg found tiles of fewer M tiles + the cost split worthwhile -- P.ilv_fwd:
+    // 576 tiles of 192 pixels at N = 24 are 2.25 per workgroup = three rounds of three M tiles per wave where tiles of 128 pixels, two
+    // M tiles per wave, come out at seven; never with the pooled second output, whose waves own whole pairs of rows)
+    constexpr bool ILV_OK = (MODE == MODE_ZERO || (MODE == MODE_HALO && !EDGE && KS == 3)) && MT == 3 && sizeof(T) == 4;
+    const bool ilv = ILV_OK && (P.tune & TUNE_CONV_ILV) != 0 && (MODE == MODE_ZERO || P.ilv_fwd != 0);
     // The tile list of this worker: n_my tiles, tile_of(q) = the q-th.  Plain split: one contiguous range of the (face, band)-major,
     // sample-minor list.  Cost split (P.split_gb > 0; the host found it worthwhile): per face the list is (nbl - 1) * B FULL tiles and
     // then B SHORT ones (the last band).  Workers [0, GA) share the full tiles [0, F - split_fb) of the "full list" evenly, workers

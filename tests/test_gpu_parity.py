@@ -321,6 +321,51 @@ np.savez(sys.argv[1], **out)
         assert np.array_equal(res[0][k], res[1][k]), k
 
 
+def test_fp32_forward_tile_interleave_is_bitwise_neutral(tmp_path):
+    """Round 6 (TUNE_CONV_ILV_FWD, csrc/conv_launch.h): the exact-fp32 FORWARD pass takes tiles of fewer M tiles, dealt to the consumer
+    waves round-robin, with the tile list cut by cost, where that shortens the longest list (N = 24, 64 channels: 128-pixel tiles that
+    are no whole rows).  Outputs AND input gradients bitwise equal with the bit on (default) and off; face sizes with and without a
+    short last tile, one and two sources, an up-sampled source, pooled second output (which keeps the plain tiling)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%r, 'dlwp-cs_amd'))
+import numpy as np, torch
+from DLWP import ops
+from DLWP._native import ACT_LEAKY_CLIP
+dev = torch.device('cuda', 0)
+out = {}
+for name, (B, N, C0, C1, Cout, up0) in {'a': (32, 24, 32, 0, 64, False), 'b': (5, 24, 64, 0, 64, False), 'c': (3, 48, 32, 0, 32, False),
+                                        'd': (4, 20, 64, 64, 64, True), 'e': (2, 36, 16, 16, 64, False), 'f': (7, 12, 64, 0, 128, False),
+                                        'g': (3, 28, 64, 0, 96, False)}.items():
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + N)
+    n0 = N // 2 if up0 else N
+    x0 = torch.randn(B, 6, n0, n0, C0, device=dev, generator=g).requires_grad_(True)
+    x1 = torch.randn(B, 6, N, N, C1, device=dev, generator=g).requires_grad_(True) if C1 else None
+    w = [torch.randn(3, 3, C0 + C1, Cout, device=dev, generator=g) * 0.1 for _ in range(2)]
+    b = [torch.randn(Cout, device=dev, generator=g) * 0.1 for _ in range(2)]
+    y = ops.cs_conv(x0, w[0], w[1], None, b[0], b[1], None, src1=x1, ksize=3, halo=True, up0=up0, act=ACT_LEAKY_CLIP, alpha=0.1, vmax=10.0)
+    gy = torch.randn(y.shape, device=dev, generator=g)
+    y.backward(gy)
+    out[name + 'y'] = y.detach().cpu().numpy()
+    out[name + '0'] = x0.grad.cpu().numpy()
+np.savez(sys.argv[1], **out)
+''' % root
+    res = []
+    for tune in ('16247', '14199'):          # default bits with / without TUNE_CONV_ILV_FWD (2048)
+        f = str(tmp_path / ('fw_%s.npz' % tune))
+        r = subprocess.run([sys.executable, '-c', code, f], cwd=root, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, DLWPCS_TUNE=tune))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(f))
+    assert sorted(res[0].files) == sorted(res[1].files) and len(res[0].files) == 14
+    for k in res[0].files:
+        assert np.isfinite(res[0][k]).all() and np.abs(res[0][k]).max() > 0
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
 def test_conv_cfg1_golden(golden_dir):
     """BASELINE config 1 against the vector produced by the reference layers."""
     from DLWP import ops
