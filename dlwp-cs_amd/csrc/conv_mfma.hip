@@ -1022,6 +1022,10 @@ struct PwParams {
     int groups_per_face;     // N * N / 16
     int Cout;
     float alpha, vmax;
+    // data gradient, pre-masked gradients (round 6): dx *= act'(mask; m_alpha, m_vmax), mask (pix, 32) = the layer's input, the output of
+    // an activated layer -- inside the launch instead of a masking pass over dx behind it (14.7 us per head of the production model)
+    const bf16_t *mask;
+    float m_alpha, m_vmax;
 };
 
 constexpr int PW_U = 4;      // 16-pixel groups in flight per wave
@@ -1111,6 +1115,7 @@ __global__ void __launch_bounds__(256) pw_fwd_kernel(PwParams P) {
 }
 
 // dx (pix, 32) = dy (pix, Cout) . W^T: K = Cout zero-padded to 32 (lane groups past Cout carry zeros), two 16-row M tiles
+template <bool MASKED>
 __global__ void __launch_bounds__(256) pw_dgrad_kernel(PwParams P) {
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
     // packed data-gradient weights: [variant][k-group of 8 (2 per 16 output channels, zero-padded past Cout)][32 columns][8];
@@ -1129,6 +1134,7 @@ __global__ void __launch_bounds__(256) pw_dgrad_kernel(PwParams P) {
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
     while (r.g < r.end) {
         uint4 bv[PW_U];
+        uint2 xm[MASKED ? PW_U : 1][2];
 #pragma unroll
         for (int u = 0; u < PW_U; ++u) {
             const int g = r.g + u < r.end ? r.g + u : r.end - 1;
@@ -1140,6 +1146,12 @@ __global__ void __launch_bounds__(256) pw_dgrad_kernel(PwParams P) {
             if (l2) bv[u].y = s32[1];
             if (l3) bv[u].z = s32[2];
             if (l4) bv[u].w = s32[3];
+            if constexpr (MASKED) {
+                // the mask operand at the channels this lane's dx quads cover (4q .. and 16 + 4q .. of pixel n)
+                const bf16_t *xp = P.mask + (unsigned)g * 512u + (unsigned)(n * 32 + q * 4);
+                xm[u][0] = *reinterpret_cast<const uint2 *>(xp);
+                xm[u][1] = *reinterpret_cast<const uint2 *>(xp + 16);
+            }
         }
 #pragma unroll
         for (int u = 0; u < PW_U; ++u) {
@@ -1159,8 +1171,11 @@ __global__ void __launch_bounds__(256) pw_dgrad_kernel(PwParams P) {
                 bf16_t *o_ptr = dst + (unsigned)r.g * 512u;
                 uint2 o;
                 o.x = f2bf2(d0[0], d0[1]); o.y = f2bf2(d0[2], d0[3]);
+                // (the mask multiplies the ROUNDED gradient, like the masking pass it replaces: same bits)
+                if constexpr (MASKED) { o.x = bmask2(o.x, xm[u][0].x, P.m_alpha, P.m_vmax); o.y = bmask2(o.y, xm[u][0].y, P.m_alpha, P.m_vmax); }
                 *reinterpret_cast<uint2 *>(o_ptr) = o;
                 o.x = f2bf2(d1[0], d1[1]); o.y = f2bf2(d1[2], d1[3]);
+                if constexpr (MASKED) { o.x = bmask2(o.x, xm[u][1].x, P.m_alpha, P.m_vmax); o.y = bmask2(o.y, xm[u][1].y, P.m_alpha, P.m_vmax); }
                 *reinterpret_cast<uint2 *>(o_ptr + 16) = o;
                 pw_next(r, gpf);
             }
@@ -1333,7 +1348,8 @@ struct WgradBf16Name { static const char *str() { return "wgrad_bf16_kernel"; } 
 struct WgradMfmaName { static const char *str() { return "wgrad_mfma_kernel"; } };
 struct PwHeadName { static const char *str() { return "pw_head_train_kernel"; } };
 struct PwFwdName { static const char *str() { return "pw_fwd_kernel"; } };
-static const int g_plain_tags[] = {prof_register_tag("pw_dgrad_kernel"), prof_register_tag("wgrad_reduce_batch_kernel")};
+static const int g_plain_tags[] = {prof_register_tag("pw_dgrad_kernel<false>"), prof_register_tag("pw_dgrad_kernel<true>"),
+                                   prof_register_tag("wgrad_reduce_batch_kernel")};
 
 static int dispatch_conv(int dtype, int KS, int vw, const ConvKParams &P, const Work &W, hipStream_t s) {
     if (KS == 3 && P.mode == MODE_HALO && P.edge) {
@@ -1821,11 +1837,18 @@ static int conv_bwd_data_impl(const dlwpcs_conv_desc *d, const void *dy, const v
         Q.in = (const bf16_t *)dy; Q.wpk = (const bf16_t *)wpk; Q.bias = nullptr; Q.out = (bf16_t *)dsrc0;
         Q.ngroups = (long)d->B * 6 * d->N * d->N / 16; Q.groups_per_face = d->N * d->N / 16; Q.Cout = d->Cout;
         int pidx = -1;
-        if (prof_enabled()) { const Work wk = conv_work(d); pidx = prof_begin("pw_dgrad_kernel", wk.flops, wk.bytes, s); }
-        hipLaunchKernelGGL(pw_dgrad_kernel, dim3(pw_grid(Q.ngroups)), dim3(256), 0, s, Q);
+        // pre-masked gradients: act'(m0) inside the launch (the masking pass behind it cost 14.7 us per head of the production model)
+        const bool in_kernel_mask = m0 != nullptr;
+        if (prof_enabled()) {
+            const Work wk = conv_work(d);
+            pidx = prof_begin(in_kernel_mask ? "pw_dgrad_kernel<true>" : "pw_dgrad_kernel<false>", wk.flops, wk.bytes, s);
+        }
+        Q.mask = (const bf16_t *)m0; Q.m_alpha = m_alpha; Q.m_vmax = m_vmax;
+        if (in_kernel_mask) hipLaunchKernelGGL(pw_dgrad_kernel<true>, dim3(pw_grid(Q.ngroups)), dim3(256), 0, s, Q);
+        else hipLaunchKernelGGL(pw_dgrad_kernel<false>, dim3(pw_grid(Q.ngroups)), dim3(256), 0, s, Q);
         if (pidx >= 0) prof_end(pidx, s);
         rc = check_launch("pw_dgrad");
-        return rc ? rc : finish_masks(true, false);
+        return rc ? rc : finish_masks(!in_kernel_mask, false);
     }
     ConvKParams P{};
     // DLWPCS_CONV_REUSE_DZ: the weight-gradient call that ran just before left dz = dy * act'(y) in the workspace

@@ -594,3 +594,28 @@ def test_packed_operands_refreshed_by_the_optimizer_launch():
             os.environ.pop('DLWPCS_OPTIONS', None)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize('B,N,Cout', [(3, 16, 14), (2, 48, 8), (5, 12, 32), (1, 24, 26)])
+def test_pointwise_data_gradient_masks_inside_the_launch(B, N, Cout):
+    """Round 6: the pointwise layer's data gradient with a pre-masked source (dlwpcs_conv_bwd_data_masked on a 1 x 1 layer:
+    pw_dgrad_kernel<true>) multiplies by act'(source) inside the launch -- the rounded gradient times the slope, rounded again:
+    bitwise what the unmasked launch followed by the masking pass gave (the production model's first-step head, 14.7 us per step)."""
+    from DLWP import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(100 * N + Cout)
+    x = (torch.randn(B, 6, N, N, 32, device=dev, generator=g) * 6).to(torch.bfloat16)
+    w = [torch.randn(1, 1, 32, Cout, device=dev, generator=g) * 0.2 for _ in range(2)]
+    b = [torch.randn(Cout, device=dev, generator=g) * 0.1 for _ in range(2)]
+    gy = torch.randn(B, 6, N, N, Cout, device=dev, generator=g).to(torch.bfloat16)
+    grads = []
+    for pm in ((ALPHA, VMAX), None):
+        xi = x.clone().requires_grad_(True)
+        y = ops.cs_conv(xi, w[0], w[1], None, b[0], b[1], None, ksize=1, halo=False, premask0=pm)
+        y.backward(gy)
+        grads.append(xi.grad)
+    ref = masked_ref(grads[1], x)
+    got = _f32(grads[0])
+    assert np.isfinite(got).all() and np.abs(got).max() > 0
+    assert (slope(_f32(x)) == 0).any() and (slope(_f32(x)) == np.float32(ALPHA)).any()
+    assert np.array_equal(got, ref)
