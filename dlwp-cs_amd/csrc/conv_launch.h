@@ -79,7 +79,7 @@ static int launch_conv_cfg(ConvKParams P, const Work &W, hipStream_t s) {
     const int gx_ = 256 / gy_ < 1 ? 1 : 256 / gy_;
     if (MODE == MODE_HALO && !EDGE && KS == 3 && MT == 3 && sizeof(T) == 4 && (tune_bits() & TUNE_CONV_ILV) && (tune_bits() & TUNE_CONV_ILV_FWD) &&
         P.ncol == 1 && P.pool_out == nullptr && gx_ > 1) {
-        static const int c2 = getenv("DLWPCS_ILV_C2") ? atoi(getenv("DLWPCS_ILV_C2")) : 2;       // (fixed cost of a tile in half M-tile rounds)
+        constexpr int c2 = 2;       // fixed cost of a tile in half M-tile rounds (swept 0 .. 4 on the fp32 step and encoder6: flat within 0.4 %)
         long best = ilv_cost(pix, face_pix, P.B, gx_, WM, nullptr, nullptr, false, c2);
         for (int k = MT; k >= 1; --k) {
             const int cand = 32 * WM * k;
